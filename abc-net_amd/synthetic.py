@@ -1,0 +1,67 @@
+"""Synthetic inputs honouring the reference tensor contract (SURVEY.md section 8 row T;
+/root/reference/src/utils.py:80-92,116-228 and src/utils_for_test.py:26-39).
+
+No real data exists offline, so the benchmark and the tests rasterise random
+atoms and bonds with the reference's value sets: centre 1, 3x3 ring 0.8 (centre
+maps) / 0.5 (class maps), omega spread over +-1 bin with wrap-around, rho and
+omega maps in float64 (numpy default in the reference), everything else float32.
+Plain torch CPU ops, seeded; independent of the oracle.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def synthetic_images(batch: int, size: int, seed: int = 7, p: float = 0.1, in_channels: int = 1):
+    """Bernoulli(p) ink in {0,1}, f32 [B,C,S,S] (ink = 1)."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand((batch, in_channels, size, size), generator=g) < p).float()
+
+
+def synthetic_targets(batch: int, h: int, seed: int = 1, n_atoms: int = 30, n_bonds: int = 32):
+    """Returns the 8 target maps in the order of the reference collate_fn
+    (utils.py:300): atom_t[B,1,h,h] f32, atom_types[B,14,h,h] f32,
+    atom_charges[B,3,h,h] f32, atom_hs[B,2,h,h] f32, bond_t[B,1,h,h] f32,
+    bond_types[B,6,60,h,h] f32, bond_rhos[B,60,h,h] f64, bond_omega[B,60,h,h] f64."""
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda hi, n: torch.randint(0, hi, (n,), generator=g).tolist()
+    at = torch.zeros(batch, 1, h, h)
+    aty = torch.zeros(batch, 14, h, h)
+    ach = torch.zeros(batch, 3, h, h)
+    ahs = torch.zeros(batch, 2, h, h)
+    bt = torch.zeros(batch, 1, h, h)
+    bty = torch.zeros(batch, 6, 60, h, h)
+    rho = torch.zeros(batch, 60, h, h, dtype=torch.float64)
+    om = torch.zeros(batch, 60, h, h, dtype=torch.float64)
+    for b in range(batch):
+        xs, ys = ri(h, n_atoms), ri(h, n_atoms)
+        ty, ch, hs = ri(14, n_atoms), ri(3, n_atoms), ri(3, n_atoms)
+        for x, y, t, c, k in zip(xs, ys, ty, ch, hs):
+            x0, y0 = max(x - 1, 0), max(y - 1, 0)
+            at[b, 0, x0:x + 2, y0:y + 2] = 0.8
+            at[b, 0, x, y] = 1
+            aty[b, t, x0:x + 2, y0:y + 2] = 0.5
+            aty[b, t, x, y] = 1
+            ach[b, c, x0:x + 2, y0:y + 2] = 0.5
+            ach[b, c, x, y] = 1
+            if k < 2:  # hs == -1 (unknown) leaves the map empty, utils.py:121
+                ahs[b, k, x0:x + 2, y0:y + 2] = 0.5
+                ahs[b, k, x, y] = 1
+        xs, ys = ri(h, n_bonds), ri(h, n_bonds)
+        tys, oms = ri(6, n_bonds), ri(60, n_bonds)
+        rs = (torch.rand(n_bonds, generator=g, dtype=torch.float64) * 9 + 3).tolist()
+        for x, y, t, o, r in zip(xs, ys, tys, oms, rs):
+            x0, y0 = max(x - 1, 0), max(y - 1, 0)
+            bt[b, 0, x0:x + 2, y0:y + 2] = 0.8
+            bt[b, 0, x, y] = 1
+            bins = [o] if t >= 4 else [o % 30, o % 30 + 30]  # non-stereo bonds mark both directions
+            for ob in bins:
+                for d in (-1, 0, 1):
+                    k = (ob + d) % 60
+                    rho[b, k, x0:x + 2, y0:y + 2] = r
+                    om[b, k, x0:x + 2, y0:y + 2] = 0.8
+                    bty[b, t, k, x0:x + 2, y0:y + 2] = 0.5
+            for ob in bins:
+                om[b, ob, x, y] = 1
+                bty[b, t, ob, x, y] = 1
+    return [at, aty, ach, ahs, bt, bty, rho, om]
