@@ -1,0 +1,175 @@
+"""ctypes binding of libabcnet_hip.so (the C ABI of include/abcnet_hip.h).
+
+This is the reference-side stub in full: plain pointers and sizes go in, an int
+status comes out.  There is NO CPU fallback: when the library is missing or a call
+fails, an exception is raised (the product path must fail loudly).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libabcnet_hip.so")
+
+F32, BF16 = 0, 1
+MAX_TAPS = 49
+
+vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
+
+
+class ActSrc(C.Structure):
+    _fields_ = [("x", vp), ("scale", vp), ("shift", vp), ("slope", vp), ("Hx", i32), ("Wx", i32), ("ldx", i32),
+                ("pool", i32), ("drop_p", f32), ("drop_seed", u32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("src", ActSrc), ("w", vp), ("bias", vp), ("y", vp), ("stats", vp),
+                ("dtype_in", i32), ("dtype_c", i32), ("dtype_out", i32),
+                ("B", i32), ("Hin", i32), ("Win", i32), ("cin_off", i32), ("Cin", i32), ("Hg", i32), ("Wg", i32),
+                ("Hout", i32), ("Wout", i32), ("ldy", i32), ("cout_off", i32), ("Cout", i32), ("Cout_pad", i32),
+                ("stride", i32), ("om", i32), ("oy0", i32), ("ox0", i32), ("ntaps", i32),
+                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("w", vp), ("dst", vp), ("mode", i32), ("dtype_c", i32), ("Cout", i32), ("Cin", i32), ("kh", i32),
+                ("kw", i32), ("py", i32), ("px", i32), ("rows_pad", i32), ("red_pad", i32), ("red_total", i32),
+                ("red_off", i32), ("ck", i32)]
+
+
+class BnFwdDesc(C.Structure):
+    _fields_ = [("partial", vp), ("nblk", i32), ("C", i32), ("count", f64), ("gamma", vp), ("beta", vp),
+                ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp), ("running_mean", vp), ("running_var", vp),
+                ("num_batches_tracked", vp), ("eps", f32), ("momentum", f32)]
+
+
+class ActBwdDesc(C.Structure):
+    _fields_ = [("y_raw", vp), ("ld_y", i32), ("dA_same", vp), ("ld_same", i32), ("dA_pool", vp), ("ld_pool", i32),
+                ("g", vp), ("ld_g", i32), ("partial", vp), ("scale", vp), ("shift", vp), ("slope", vp), ("mean", vp),
+                ("invstd", vp), ("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("cy_off", i32),
+                ("csame_off", i32), ("cpool_off", i32), ("drop_p", f32), ("drop_seed", u32), ("drop_ld", i32)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [("partial", vp), ("nblk", i32), ("C", i32), ("count", f64), ("gamma", vp), ("invstd", vp),
+                ("dgamma", vp), ("dbeta", vp), ("k1", vp), ("k2", vp), ("gscale", vp)]
+
+
+class BnApplyDesc(C.Structure):
+    _fields_ = [("g", vp), ("ld_g", i32), ("y_raw", vp), ("ld_y", i32), ("cy_off", i32), ("mean", vp), ("invstd", vp),
+                ("k1", vp), ("k2", vp), ("gscale", vp), ("dtype", i32), ("C", i32), ("npix", i64)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("p", ActSrc), ("q", ActSrc), ("partial", vp), ("dtype_p", i32), ("dtype_q", i32), ("dtype_c", i32),
+                ("B", i32), ("Hg", i32), ("Wg", i32), ("Hq", i32), ("Wq", i32), ("cp_off", i32), ("Ca", i32),
+                ("cq_off", i32), ("Cb", i32), ("stride", i32), ("ntaps", i32), ("nsplit", i32),
+                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS)]
+
+
+class WgradReduceDesc(C.Structure):
+    _fields_ = [("partial", vp), ("nsplit", i32), ("ntaps", i32), ("Ca", i32), ("Cb", i32), ("Ca_pad", i32),
+                ("Cb_pad", i32), ("dw", vp), ("accumulate", i32)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("logits", vp), ("dlogits", vp), ("ldl", i32), ("t_atom", vp), ("t_types", vp), ("t_charges", vp),
+                ("t_hs", vp), ("t_bond", vp), ("t_btypes", vp), ("t_rho", vp), ("t_omega", vp), ("B", i32), ("h", i32),
+                ("w", i32), ("head_off", i32 * 8), ("partial", vp)]
+
+
+class LossFinDesc(C.Structure):
+    _fields_ = [("partial", vp), ("nblk", i32), ("s", vp), ("ds", vp), ("out", vp), ("chan_scale", vp), ("ldl", i32),
+                ("head_off", i32 * 8), ("head_c", i32 * 8), ("grad_scale", f32)]
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64), ("step", vp), ("lr", f32), ("beta1", f32),
+                ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("grad_scale", f32)]
+
+
+class NmsDesc(C.Structure):
+    _fields_ = [("logits", vp), ("ldl", i32), ("B", i32), ("h", i32), ("w", i32), ("off_atom", i32), ("off_bond", i32),
+                ("off_rho", i32), ("off_omega", i32), ("n_omega", i32), ("atom_mask", vp), ("bond_mask", vp),
+                ("rho_abs", vp), ("omega_mask", vp)]
+
+
+_STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
+            LossDesc, LossFinDesc, AdamDesc, NmsDesc]
+
+# every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
+P = C.POINTER
+SYMBOLS = {
+    "abc_conv_stat_blocks": (C.c_int, [P(ConvDesc)]),
+    "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),
+    "abc_conv_chunk": (C.c_int, [C.c_int, C.c_int]),
+    "abc_pack_conv_weights": (C.c_int, [P(PackDesc), vp]),
+    "abc_bn_finalize_fwd": (C.c_int, [P(BnFwdDesc), vp]),
+    "abc_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, f32, vp]),
+    "abc_act_bwd_blocks": (C.c_int, [P(ActBwdDesc)]),
+    "abc_act_bwd": (C.c_int, [P(ActBwdDesc), vp]),
+    "abc_bn_finalize_bwd": (C.c_int, [P(BnBwdDesc), vp]),
+    "abc_bn_apply_bwd": (C.c_int, [P(BnApplyDesc), vp]),
+    "abc_wgrad_pads": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),
+    "abc_wgrad": (C.c_int, [P(WgradDesc), vp]),
+    "abc_wgrad_reduce": (C.c_int, [P(WgradReduceDesc), vp]),
+    "abc_colsum_blocks": (C.c_int, [i64]),
+    "abc_colsum": (C.c_int, [vp, i32, i64, i32, i32, i32, vp, vp, vp, vp]),
+    "abc_loss_blocks": (C.c_int, [P(LossDesc)]),
+    "abc_loss_fwd_bwd": (C.c_int, [P(LossDesc), vp]),
+    "abc_loss_finalize": (C.c_int, [P(LossFinDesc), vp]),
+    "abc_adam_step": (C.c_int, [P(AdamDesc), vp]),
+    "abc_nms_peaks": (C.c_int, [P(NmsDesc), vp]),
+    "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),
+    "abc_sizeof": (C.c_int, [C.c_int]),
+    "abc_last_error": (C.c_char_p, []),
+    "abc_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+class AbcNetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it is missing or does not match this binding."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AbcNetHipError(
+            "libabcnet_hip.so not found at %s -- build it with ./build_hip.sh (or __graft_entry__.build()); "
+            "abcnet_amd has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    for i, st in enumerate(_STRUCTS):
+        n = lib.abc_sizeof(i)
+        if n != C.sizeof(st):
+            raise AbcNetHipError("struct #%d (%s): binding has %d bytes, library %d" % (i, st.__name__, C.sizeof(st), n))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise AbcNetHipError("%s failed (%d): %s" % (what, rc, load().abc_last_error().decode()))
+
+
+def ptr(t):
+    """raw device/host address of a torch tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def set_taps(desc, taps):
+    desc.ntaps = len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        desc.tap_dy[i] = dy
+        desc.tap_dx[i] = dx

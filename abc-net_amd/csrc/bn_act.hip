@@ -1,0 +1,377 @@
+// BatchNorm statistics finalisation, eval coefficients, and the backward of
+// [BN -> activation -> dropout -> 2x2 max-pool] as two HBM-bound element-wise passes
+// with deterministic two-stage per-channel reductions (per-block f32 partials, f64
+// finalisation; no atomics).
+//
+// Reference: nn.BatchNorm2d / ReLU / LeakyReLU / Dropout / MaxPool2d and their autograd
+// (unet.py:13-17, 30, 67-69 under train.py:94,140).
+#include "common.hpp"
+#include "../../include/abcnet_hip.h"
+#include "capi_util.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ helpers
+__device__ inline double block_sum_f64(double v, double* sm) {
+    // 256 threads
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const abc_bn_fwd_desc d) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < d.nblk; k += 256) {
+        s1 += (double)d.partial[((size_t)k * 2 + 0) * d.C + c];
+        s2 += (double)d.partial[((size_t)k * 2 + 1) * d.C + c];
+    }
+    s1 = block_sum_f64(s1, sm);
+    s2 = block_sum_f64(s2, sm);
+    if (threadIdx.x == 0) {
+        const double mean = s1 / d.count;
+        double var = s2 / d.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)d.eps));
+        const float sc = d.gamma[c] * invstd;
+        d.scale[c] = sc;
+        d.shift[c] = d.beta[c] - (float)mean * sc;
+        d.mean[c] = (float)mean;
+        d.invstd[c] = invstd;
+        if (d.running_mean != nullptr) {
+            const double unb = d.count > 1.0 ? var * d.count / (d.count - 1.0) : var;
+            d.running_mean[c] = (1.f - d.momentum) * d.running_mean[c] + d.momentum * (float)mean;
+            d.running_var[c] = (1.f - d.momentum) * d.running_var[c] + d.momentum * (float)unb;
+            if (c == 0 && d.num_batches_tracked != nullptr) *d.num_batches_tracked += 1;
+        }
+    }
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
+                               float* shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const abc_bn_bwd_desc d) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < d.nblk; k += 256) {
+        s1 += (double)d.partial[((size_t)k * 2 + 0) * d.C + c];
+        s2 += (double)d.partial[((size_t)k * 2 + 1) * d.C + c];
+    }
+    s1 = block_sum_f64(s1, sm);
+    s2 = block_sum_f64(s2, sm);
+    if (threadIdx.x == 0) {
+        if (d.dbeta != nullptr) d.dbeta[c] = (float)s1;
+        if (d.dgamma != nullptr) d.dgamma[c] = (float)s2;
+        d.k1[c] = (float)(s1 / d.count);
+        d.k2[c] = (float)(s2 / d.count);
+        d.gscale[c] = d.gamma[c] * d.invstd[c];
+    }
+}
+
+// ------------------------------------------------------------------ pass 1
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<bf16> { static constexpr int N = 8; };
+
+template <typename T, int N> __device__ inline void ldv(const T* p, float* v) { LoadVec<T, N>::ld(p, v); }
+template <int N> __device__ inline void stv(float* p, const float* v) {
+    f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+    *(f32x4*)p = t;
+}
+template <int N> __device__ inline void stv(bf16* p, const float* v) {
+    bf16x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (bf16)v[j];
+    *(bf16x8*)p = t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const abc_act_bwd_desc d) {
+    constexpr int N = VecOf<T>::N;
+    __shared__ float red[256][2 * N + 1];
+    const int ncv = d.C / N;
+    const bool pooled = d.dA_pool != nullptr;
+    const int Hw = pooled ? d.H / 2 : d.H, Ww = pooled ? d.W / 2 : d.W;  // work grid (windows or pixels)
+    const int64_t nitems = (int64_t)d.B * Hw * Ww * ncv;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int tid = threadIdx.x;
+    const int cv = (int)((blockIdx.x * 256 + tid) % ncv);  // constant per thread: stride % ncv == 0
+    const int c = cv * N;
+    float sc[N], sh[N], sl[N], mu[N], is[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        sc[j] = d.scale[c + j]; sh[j] = d.shift[c + j]; sl[j] = d.slope[c + j]; mu[j] = d.mean[c + j]; is[j] = d.invstd[c + j];
+    }
+    float a1[N], a2[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+    const T* yr = (const T*)d.y_raw;
+    const T* ds = (const T*)d.dA_same;
+    const T* dp = (const T*)d.dA_pool;
+    T* g = (T*)d.g;
+    const float dscale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+
+    for (int64_t it = (int64_t)blockIdx.x * 256 + tid; it < nitems; it += stride) {
+        int64_t pix = it / ncv;
+        const int wx = (int)(pix % Ww); pix /= Ww;
+        const int wy = (int)(pix % Hw);
+        const int b = (int)(pix / Hw);
+        if (!pooled) {
+            const size_t p = ((size_t)b * d.H + wy) * d.W + wx;
+            float x[N], da[N], out[N];
+            ldv<T, N>(yr + p * d.ld_y + d.cy_off + c, x);
+            ldv<T, N>(ds + p * d.ld_same + d.csame_off + c, da);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float y = fmaf(x[j], sc[j], sh[j]);
+                float gg = da[j] * (y > 0.f ? 1.f : sl[j]);
+                if (d.drop_p > 0.f)
+                    gg = abc_drop_keep((uint32_t)(p * d.drop_ld + d.cy_off + c + j), d.drop_seed, d.drop_p) ? gg * dscale : 0.f;
+                out[j] = gg;
+                a1[j] += gg;
+                a2[j] += gg * ((x[j] - mu[j]) * is[j]);
+            }
+            stv<N>(g + p * d.ld_g + c, out);
+        } else {
+            float x[4][N], dpool[N];
+            size_t pq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pq[q] = ((size_t)b * d.H + 2 * wy + (q >> 1)) * d.W + 2 * wx + (q & 1);
+                ldv<T, N>(yr + pq[q] * d.ld_y + d.cy_off + c, x[q]);
+            }
+            ldv<T, N>(dp + (((size_t)b * Hw + wy) * Ww + wx) * d.ld_pool + d.cpool_off + c, dpool);
+            int arg[N];
+            float yv[4][N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float best = 0.f;
+                arg[j] = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float y = fmaf(x[q][j], sc[j], sh[j]);
+                    yv[q][j] = y;
+                    const float av = fmaxf(y, sl[j] * y);
+                    if (q == 0 || av > best) { best = av; arg[j] = q; }  // first maximum wins (torch max_pool2d)
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float da[N], out[N];
+                if (ds != nullptr) ldv<T, N>(ds + pq[q] * d.ld_same + d.csame_off + c, da);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float up = (arg[j] == q) ? dpool[j] : 0.f;
+                    if (ds != nullptr) up += da[j];
+                    const float gg = up * (yv[q][j] > 0.f ? 1.f : sl[j]);
+                    out[j] = gg;
+                    a1[j] += gg;
+                    a2[j] += gg * ((x[q][j] - mu[j]) * is[j]);
+                }
+                stv<N>(g + pq[q] * d.ld_g + c, out);
+            }
+        }
+    }
+    // block reduction per channel: threads with equal (tid % ncv) share a channel vector
+#pragma unroll
+    for (int j = 0; j < N; ++j) { red[tid][j] = a1[j]; red[tid][N + j] = a2[j]; }
+    __syncthreads();
+    for (int cc = tid; cc < d.C; cc += 256) {
+        const int v = cc / N, j = cc % N;
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = v; t < 256; t += ncv) { s1 += red[t][j]; s2 += red[t][N + j]; }
+        d.partial[((size_t)blockIdx.x * 2 + 0) * d.C + cc] = s1;
+        d.partial[((size_t)blockIdx.x * 2 + 1) * d.C + cc] = s2;
+    }
+}
+
+// ------------------------------------------------------------------ pass 2
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const abc_bn_apply_desc d) {
+    constexpr int N = VecOf<T>::N;
+    const int ncv = d.C / N;
+    const int64_t nitems = d.npix * ncv;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    T* g = (T*)d.g;
+    const T* yr = (const T*)d.y_raw;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < nitems; it += stride) {
+        const int64_t p = it / ncv;
+        const int c = (int)(it % ncv) * N;
+        float gv[N], x[N], out[N];
+        ldv<T, N>(g + p * d.ld_g + c, gv);
+        ldv<T, N>(yr + p * d.ld_y + d.cy_off + c, x);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float xh = (x[j] - d.mean[c + j]) * d.invstd[c + j];
+            out[j] = d.gscale[c + j] * (gv[j] - d.k1[c + j] - xh * d.k2[c + j]);
+        }
+        stv<N>(g + p * d.ld_g + c, out);
+    }
+}
+
+// ------------------------------------------------------------------ column sums
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t npix, int ld, int c_off, int C, const float* cs,
+                                                      float* work) {
+    // thread t handles channels t, t+256, ... ; pixels strided over blocks
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t p = blockIdx.x; p < npix; p += gridDim.x) s += (float)x[p * ld + c_off + c];
+        work[(size_t)blockIdx.x * C + c] = s * (cs ? cs[c_off + c] : 1.f);
+    }
+}
+__global__ void colsum_reduce_kernel(const float* work, int nblk, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += (double)work[(size_t)k * C + c];
+    out[c] = (float)s;
+}
+
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// NHWC(f32, strided) <-> NCHW(f32) through a 32x32 LDS transpose tile
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* src, int ld, int c_off, int C, int HW, float* dst) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        tile[k][tx] = (p < HW && c < C) ? src[((size_t)b * HW + p) * ld + c_off + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        if (p < HW && c < C) dst[((size_t)b * C + c) * HW + p] = tile[tx][k];
+    }
+}
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int C, int HW, float* dst, int ld, int c_off) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        tile[k][tx] = (p < HW && c < C) ? src[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        if (p < HW && c < C) dst[((size_t)b * HW + p) * ld + c_off + c] = tile[tx][k];
+    }
+}
+
+static int ew_blocks(int64_t nitems) {
+    int64_t b = (nitems + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int abc_bn_finalize_fwd(const abc_bn_fwd_desc* d, abc_stream_t stream) {
+    if (d->C < 1 || d->nblk < 1) return abc_fail(ABC_EINVAL, "bn_finalize_fwd: empty");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(d->C), dim3(256), 0, (hipStream_t)stream, *d);
+    return abc_check_launch("bn_finalize_fwd");
+}
+
+extern "C" int abc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  float* scale, float* shift, int32_t C, float eps, abc_stream_t stream) {
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(abc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, scale, shift, C, eps);
+    return abc_check_launch("bn_eval_coeffs");
+}
+
+extern "C" int abc_bn_finalize_bwd(const abc_bn_bwd_desc* d, abc_stream_t stream) {
+    if (d->C < 1 || d->nblk < 1) return abc_fail(ABC_EINVAL, "bn_finalize_bwd: empty");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(d->C), dim3(256), 0, (hipStream_t)stream, *d);
+    return abc_check_launch("bn_finalize_bwd");
+}
+
+static int act_bwd_check(const abc_act_bwd_desc* d) {
+    const int N = d->dtype == ABC_BF16 ? 8 : 4;
+    if (d->C % N) return abc_fail(ABC_EINVAL, "act_bwd: C must be a multiple of the vector width");
+    const int ncv = d->C / N;
+    if (ncv > 256 || (256 % ncv)) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: C/vec must divide 256");
+    if (d->dA_pool && ((d->H & 1) || (d->W & 1))) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: pooled dims must be even");
+    if (!d->dA_pool && !d->dA_same) return abc_fail(ABC_EINVAL, "act_bwd: no gradient source");
+    if ((d->ld_y | d->ld_g | d->cy_off) % N) return abc_fail(ABC_EINVAL, "act_bwd: alignment");
+    return ABC_OK;
+}
+
+extern "C" int abc_act_bwd_blocks(const abc_act_bwd_desc* d) {
+    const int N = d->dtype == ABC_BF16 ? 8 : 4;
+    const bool pooled = d->dA_pool != nullptr;
+    const int64_t n = (int64_t)d->B * (pooled ? d->H / 2 : d->H) * (pooled ? d->W / 2 : d->W) * (d->C / N);
+    return ew_blocks(n);
+}
+
+extern "C" int abc_act_bwd(const abc_act_bwd_desc* d, abc_stream_t stream) {
+    int rc = act_bwd_check(d);
+    if (rc) return rc;
+    const int nb = abc_act_bwd_blocks(d);
+    if (d->dtype == ABC_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
+    return abc_check_launch("act_bwd");
+}
+
+extern "C" int abc_bn_apply_bwd(const abc_bn_apply_desc* d, abc_stream_t stream) {
+    const int N = d->dtype == ABC_BF16 ? 8 : 4;
+    if (d->C % N || (d->ld_g | d->ld_y | d->cy_off) % N) return abc_fail(ABC_EINVAL, "bn_apply: alignment");
+    const int nb = ew_blocks(d->npix * (d->C / N));
+    if (d->dtype == ABC_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
+    return abc_check_launch("bn_apply_bwd");
+}
+
+extern "C" int abc_colsum_blocks(int64_t npix) { return (int)(npix < 512 ? (npix < 1 ? 1 : npix) : 512); }
+
+extern "C" int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C,
+                          const float* chan_scale, float* work, float* out, abc_stream_t stream) {
+    const int nb = abc_colsum_blocks(npix);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ABC_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, npix, ld, c_off, C, chan_scale, work);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, npix, ld, c_off, C, chan_scale, work);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(abc_cdiv(C, 256)), dim3(256), 0, st, (const float*)work, nb, C, out);
+    return abc_check_launch("colsum");
+}
+
+extern "C" int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream) {
+    if (n <= 0) return ABC_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+    return abc_check_launch("fill");
+}
+
+extern "C" int abc_nhwc_to_nchw_f32(const float* src, int32_t ld, int32_t c_off, int32_t C, int32_t B, int32_t H, int32_t W,
+                                    float* dst, abc_stream_t stream) {
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(abc_cdiv(HW, 32), abc_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, src,
+                       ld, c_off, C, HW, dst);
+    return abc_check_launch("nhwc_to_nchw");
+}
+
+extern "C" int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int32_t W, float* dst, int32_t ld,
+                                    int32_t c_off, abc_stream_t stream) {
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(abc_cdiv(HW, 32), abc_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, src,
+                       C, HW, dst, ld, c_off);
+    return abc_check_launch("nchw_to_nhwc");
+}

@@ -1,0 +1,192 @@
+// Internal device-side helpers shared by the gfx950 kernels of abcnet_amd.
+// (The public C-ABI is include/abcnet_hip.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define ABC_MAX_TAPS 49
+#define ABC_WAVE 64
+
+__host__ __device__ inline int abc_roundup(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ inline int abc_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// 16-byte fragment of the compute type: 4 x f32 or 8 x bf16.
+template <typename CT> struct Frag;
+template <> struct Frag<float> { typedef f32x4 type; static constexpr int NV = 4; };
+template <> struct Frag<bf16>  { typedef bf16x8 type; static constexpr int NV = 8; };
+
+// One 16-byte K-slice of a 32x32 MFMA tile: lane-half h of the wave holds the same
+// K-slice of A and of B, so any fixed channel permutation inside a chunk is legal.
+__device__ inline void mma16B(f32x16& acc, f32x4 a, f32x4 b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+}
+__device__ inline void mma16B(f32x16& acc, bf16x8 a, bf16x8 b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// activation applied on load: y = scale*x + shift ; out = max(y, slope*y)
+//   slope 0 -> ReLU, 0.01 -> LeakyReLU, 1 -> identity
+__device__ inline float abc_act(float x, float sc, float sh, float sl) {
+    float y = fmaf(x, sc, sh);
+    return fmaxf(y, sl * y);
+}
+
+// Counter-based dropout keep-decision (K7).  idx = element index in the tensor the
+// mask applies to.  Mirrored bit-for-bit by abcnet_amd.dropout.keep_mask (torch int ops)
+// so that the oracle can be driven with the identical mask.
+__host__ __device__ inline bool abc_drop_keep(uint32_t idx, uint32_t seed, float p) {
+    uint32_t h = idx * 0x9E3779B1u ^ seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+// XCD-aware, bijective block remap: blocks with equal (bid % 8) share an XCD (and
+// its L2) under round-robin placement, so give each such group a contiguous range of
+// logical ids.  Placement only affects speed, never results.
+__device__ inline int abc_xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------
+// load NV consecutive channels of InT as floats
+template <typename InT, int NV> struct LoadVec;
+template <> struct LoadVec<float, 4> {
+    __device__ static inline void ld(const float* p, float* v) {
+        f32x4 t = *(const f32x4*)p;
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+};
+template <> struct LoadVec<float, 8> {
+    __device__ static inline void ld(const float* p, float* v) {
+        f32x4 t = *(const f32x4*)p, u = *(const f32x4*)(p + 4);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        v[4] = u[0]; v[5] = u[1]; v[6] = u[2]; v[7] = u[3];
+    }
+};
+template <> struct LoadVec<bf16, 8> {
+    __device__ static inline void ld(const bf16* p, float* v) {
+        bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    }
+};
+template <> struct LoadVec<bf16, 4> {
+    __device__ static inline void ld(const bf16* p, float* v) {
+        bf16x4 t = *(const bf16x4*)p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)t[j];
+    }
+};
+
+// vector load when all NV channels exist, scalar tail (zero-filled) otherwise; the
+// scalar path also serves tensors whose pixel stride breaks 16-byte alignment (C = 1 image)
+template <typename InT, int NV>
+__device__ inline void load_n(const InT* p, float* v, int nval) {
+    if (nval >= NV) {
+        LoadVec<InT, NV>::ld(p, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = (j < nval) ? (float)p[j] : 0.f;
+    }
+}
+
+template <typename CT> __device__ inline typename Frag<CT>::type pack_frag(const float* v);
+template <> __device__ inline f32x4 pack_frag<float>(const float* v) {
+    f32x4 r; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; return r;
+}
+template <> __device__ inline bf16x8 pack_frag<bf16>(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16)v[j];
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Source description of an activation tensor that is consumed "through" the
+// previous layer's BN + activation (+ 2x2 max-pool, + dropout): fusion boundary
+// "producer writes raw conv output + statistics, consumer normalises on load".
+struct ActSrc {
+    const void* x;        // NHWC raw tensor, physical dims [B, Hx, Wx, ldx]
+    const float* scale;   // per channel (absolute channel index in x), or null = identity
+    const float* shift;
+    const float* slope;
+    int Hx, Wx, ldx;
+    int pool;             // 1: logical dims are (Hx/2, Wx/2), value = max over 2x2 of act(x)
+    float drop_p;         // >0: multiply by keep/(1-p), keep from abc_drop_keep(idx, seed, p)
+    uint32_t drop_seed;
+};
+
+// Stage a halo tile [HH][HW] pixels x CK channels (channels c0..c0+CK of src) into LDS in
+// the compute type, pixel (hy,hx) at byte hy*RS + hx*PS.  Logical input coords of halo
+// pixel (0,0) are (iy0, ix0); everything outside [0,Hin)x[0,Win) is zero (conv padding
+// applies to the ACTIVATED tensor).
+template <typename InT, typename CT, int CK>
+__device__ inline void stage_halo(char* sA, int RS, int PS, int HH, int HW, int b, int iy0, int ix0, int Hin, int Win,
+                                  const ActSrc& s, int c0, int tid, int nthreads, int cvalid = 1 << 30) {
+    constexpr int NV = Frag<CT>::NV;
+    constexpr int SEGS = CK / NV;  // 16-byte LDS segments per pixel
+    const int part = tid % SEGS;   // nthreads % SEGS == 0 -> constant per thread
+    const int cch = c0 + part * NV;
+    float sc[NV], sh[NV], sl[NV];
+    const int nval = min(NV, cvalid - part * NV);  // channels beyond the tensor's width are zero-filled
+    const bool chan_ok = nval > 0;
+    const bool has_t = (s.scale != nullptr) && chan_ok;
+    if (has_t) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool ok = j < nval;
+            sc[j] = ok ? s.scale[cch + j] : 0.f; sh[j] = ok ? s.shift[cch + j] : 0.f; sl[j] = ok ? s.slope[cch + j] : 0.f;
+        }
+    }
+    const InT* xb = (const InT*)s.x;
+    const float dscale = (s.drop_p > 0.f) ? 1.0f / (1.0f - s.drop_p) : 1.0f;
+    const int total = HH * HW * SEGS;
+    for (int sidx = tid; sidx < total; sidx += nthreads) {
+        const int pix = sidx / SEGS;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        float v[NV];
+        if (chan_ok && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+            if (!s.pool) {
+                const size_t off = ((size_t)(b * s.Hx + iy) * s.Wx + ix) * s.ldx + cch;
+                load_n<InT, NV>(xb + off, v, nval);
+                if (has_t) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) v[j] = abc_act(v[j], sc[j], sh[j], sl[j]);
+                }
+                if (s.drop_p > 0.f) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        v[j] = abc_drop_keep((uint32_t)(off + j), s.drop_seed, s.drop_p) ? v[j] * dscale : 0.f;
+                }
+            } else {
+                float t[NV];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t off = ((size_t)(b * s.Hx + 2 * iy + (q >> 1)) * s.Wx + 2 * ix + (q & 1)) * s.ldx + cch;
+                    load_n<InT, NV>(xb + off, t, nval);
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        float y = has_t ? abc_act(t[j], sc[j], sh[j], sl[j]) : t[j];
+                        v[j] = (q == 0) ? y : fmaxf(v[j], y);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = 0.f;
+        }
+        *(typename Frag<CT>::type*)(sA + hy * RS + hx * PS + part * 16) = pack_frag<CT>(v);
+    }
+}

@@ -1,0 +1,238 @@
+// Fused activation + 8-term loss + d(loss)/d(logits) in one pass over the logits
+// and the targets (reference: src/train.py:95-137, K9 of SURVEY.md).
+//
+// One thread per quarter-resolution pixel.  Logits/dlogits are NHWC f32 (one 2 KB row
+// per pixel, walked sequentially by its thread); targets are the reference's NCHW maps
+// (coalesced across the wave, since adjacent lanes are adjacent pixels).  rho/omega
+// targets are float64 as in the reference (utils.py:91-92).
+// Normalisers are global sums, so the kernel writes the gradient of each term's
+// NUMERATOR; abc_loss_finalize turns the partial sums into the 8 terms, the
+// uncertainty-weighted total (train.py:127-137), ds, and a per-channel factor
+// weight_i/denominator_i which the heads' backward applies on load.
+#include "common.hpp"
+#include "../../include/abcnet_hip.h"
+#include "capi_util.hpp"
+
+namespace {
+
+constexpr float LO = 1e-5f, HI = 1.f - 1e-5f;
+
+__device__ inline float sigm(float z) { return 1.f / (1.f + expf(-z)); }
+
+// penalty-reduced focal on one sigmoid channel (train.py:107-108): returns the loss
+// value, writes dL/dz.  `w` multiplies both (omega's per-pixel weight, train.py:124).
+__device__ inline float center_focal(float z, float t, float w, float* dz) {
+    const float ps = sigm(z);
+    const bool inside = (ps >= LO) && (ps <= HI);
+    const float p = fminf(fmaxf(ps, LO), HI);
+    const float q = 1.f - p;
+    const float lp = logf(p), lq = logf(q);
+    const float pos = (t == 1.f) ? 1.f : 0.f;
+    const float neg = (1.f - t) * (1.f - t); const float neg4 = neg * neg;
+    const float loss = -pos * q * q * lp - neg4 * p * p * lq;
+    // dL/dp
+    const float dLp = -pos * (-2.f * q * lp + q * q / p) - neg4 * (2.f * p * lq - p * p / q);
+    *dz = inside ? w * dLp * ps * (1.f - ps) : 0.f;
+    return w * loss;
+}
+
+// focal cross-entropy over a K-way softmax (train.py:109,111,114,119); z/t/dz are
+// register arrays.  Returns the numerator contribution, adds sum(t) to *den.
+template <int K>
+__device__ inline float class_focal(const float* z, const float* t, const float* wk, float* dz, float* den) {
+    float m = z[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) m = fmaxf(m, z[k]);
+    float e[K], se = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { e[k] = expf(z[k] - m); se += e[k]; }
+    const float inv = 1.f / se;
+    float loss = 0.f, dot = 0.f, a[K], q[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        q[k] = e[k] * inv;
+        a[k] = 0.f;
+        *den += t[k];
+        if (t[k] != 0.f) {
+            const bool inside = (q[k] >= LO) && (q[k] <= HI);
+            const float p = fminf(fmaxf(q[k], LO), HI);
+            const float om = 1.f - p;
+            const float lp = logf(p);
+            const float w = wk ? wk[k] : 1.f;
+            loss += -w * t[k] * om * om * lp;
+            if (inside) a[k] = -w * t[k] * (-2.f * om * lp + om * om / p);
+        }
+        dot += a[k] * q[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) dz[k] = q[k] * (a[k] - dot);
+    return loss;
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__constant__ float c_type_w[14] = {1.f, 0.1f, 0.1f, 0.1f, 1.f, 1.f, 1.f, 1.f, 1.f, 10.f, 10.f, 10.f, 10.f, 10.f};  // train.py:16
+
+__global__ __launch_bounds__(256) void loss_kernel(const abc_loss_desc d) {
+    __shared__ double sm[4][16];
+    const int hw = d.h * d.w;
+    const int64_t npix = (int64_t)d.B * hw;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double num[8], den[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { num[i] = 0.0; den[i] = 0.0; }
+    if (p < npix) {
+        const int b = (int)(p / hw), yx = (int)(p % hw);
+        const float* L = d.logits + p * d.ldl;
+        float* D = d.dlogits + p * d.ldl;
+        // ---- head 0: atom centre
+        {
+            const float t = d.t_atom[(size_t)b * hw + yx];
+            float dz;
+            num[0] = center_focal(L[d.head_off[0]], t, 1.f, &dz);
+            den[0] = (t == 1.f) ? 1.0 : 0.0;
+            D[d.head_off[0]] = dz;
+        }
+        // ---- head 1: atom types (14-way softmax, class weights)
+        {
+            float z[14], t[14], dz[14], dn = 0.f;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) { z[k] = L[d.head_off[1] + k]; t[k] = d.t_types[((size_t)b * 14 + k) * hw + yx]; }
+            num[1] = class_focal<14>(z, t, c_type_w, dz, &dn);
+            den[1] = dn;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) D[d.head_off[1] + k] = dz[k];
+        }
+        // ---- head 2: charges (3-way)
+        {
+            float z[3], t[3], dz[3], dn = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { z[k] = L[d.head_off[2] + k]; t[k] = d.t_charges[((size_t)b * 3 + k) * hw + yx]; }
+            num[2] = class_focal<3>(z, t, nullptr, dz, &dn);
+            den[2] = dn;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) D[d.head_off[2] + k] = dz[k];
+        }
+        // ---- head 3: hydrogens (2-way)
+        {
+            float z[2], t[2], dz[2], dn = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { z[k] = L[d.head_off[3] + k]; t[k] = d.t_hs[((size_t)b * 2 + k) * hw + yx]; }
+            num[3] = class_focal<2>(z, t, nullptr, dz, &dn);
+            den[3] = dn;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) D[d.head_off[3] + k] = dz[k];
+        }
+        // ---- head 4: bond centre
+        {
+            const float t = d.t_bond[(size_t)b * hw + yx];
+            float dz;
+            num[4] = center_focal(L[d.head_off[4]], t, 1.f, &dz);
+            den[4] = (t == 1.f) ? 1.0 : 0.0;
+            D[d.head_off[4]] = dz;
+        }
+        // ---- omega per-pixel weight = sum over the 60 bins of the omega target (train.py:124)
+        double wpix = 0.0;
+        for (int o = 0; o < 60; ++o) wpix += d.t_omega[((size_t)b * 60 + o) * hw + yx];
+        den[7] = wpix;
+        // ---- heads 5,6,7 per omega bin
+        double n5 = 0.0, n6 = 0.0, n7 = 0.0, d5 = 0.0;
+        for (int o = 0; o < 60; ++o) {
+            float z[6], t[6], dz[6], dn = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                z[k] = L[d.head_off[5] + k * 60 + o];
+                t[k] = d.t_btypes[(((size_t)b * 6 + k) * 60 + o) * hw + yx];
+            }
+            n5 += class_focal<6>(z, t, nullptr, dz, &dn);
+            d5 += dn;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) D[d.head_off[5] + k * 60 + o] = dz[k];
+            // rho: |abs(pred) - rho| * sum_types(t)   (train.py:105,121), f64 like the reference
+            {
+                const float zr = L[d.head_off[6] + o];
+                const double tr = d.t_rho[((size_t)b * 60 + o) * hw + yx];
+                const double diff = (double)fabsf(zr) - tr;
+                n6 += fabs(diff) * (double)dn;
+                const float sg = (diff > 0.0) ? 1.f : ((diff < 0.0) ? -1.f : 0.f);
+                const float sz = (zr > 0.f) ? 1.f : ((zr < 0.f) ? -1.f : 0.f);
+                D[d.head_off[6] + o] = sg * sz * dn;
+            }
+            // omega: focal per bin weighted by wpix (train.py:124-125)
+            {
+                const float to = (float)d.t_omega[((size_t)b * 60 + o) * hw + yx];
+                float dz7;
+                n7 += center_focal(L[d.head_off[7] + o], to, (float)wpix, &dz7);
+                D[d.head_off[7] + o] = dz7;
+            }
+        }
+        num[5] = n5; den[5] = d5; num[6] = n6; den[6] = d5; num[7] = n7;
+    }
+    // ---- block reduction of the 16 sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double a = wave_sum(num[i]), bsum = wave_sum(den[i]);
+        if (lane == 0) { sm[wave][i] = a; sm[wave][8 + i] = bsum; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16)
+        d.partial[(size_t)blockIdx.x * 16 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const abc_loss_fin_desc d) {
+    __shared__ double tot[16];
+    __shared__ float cscale[8];
+    const int t = threadIdx.x;
+    if (t < 16) {
+        double s = 0.0;
+        for (int k = 0; k < d.nblk; ++k) s += d.partial[(size_t)k * 16 + t];
+        tot[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+        // head -> index into s and the factor in front of exp(-s)   (train.py:127-135)
+        const int sidx[8] = {0, 2, 3, 9, 1, 4, 6, 7};
+        const double fac[8] = {1, 1, 1, 1, 1, 1, 0.5, 1};
+        double total = 0.0;
+        for (int i = 0; i < 10; ++i) d.ds[i] = 0.f;
+        for (int i = 0; i < 8; ++i) {
+            const double den = tot[8 + i] + (i == 3 ? 0.1 : 0.0);  // atom_hs: +0.1 (train.py:114)
+            const double term = tot[i] / den;
+            const double sv = (double)d.s[sidx[i]];
+            const double wgt = fac[i] * exp(-sv) + sv;
+            d.out[1 + i] = wgt * term;
+            d.out[9 + i] = term;
+            total += wgt * term;
+            d.ds[sidx[i]] = (float)(term * (1.0 - fac[i] * exp(-sv)) * (double)d.grad_scale);
+            cscale[i] = (float)(wgt / den * (double)d.grad_scale);
+        }
+        d.out[0] = total;
+    }
+    __syncthreads();
+    for (int c = t; c < d.ldl; c += 64) {
+        float v = 0.f;
+        for (int i = 0; i < 8; ++i)
+            if (c >= d.head_off[i] && c < d.head_off[i] + d.head_c[i]) v = cscale[i];
+        d.chan_scale[c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int abc_loss_blocks(const abc_loss_desc* d) { return abc_cdiv(d->B * d->h * d->w, 256); }
+
+extern "C" int abc_loss_fwd_bwd(const abc_loss_desc* d, abc_stream_t stream) {
+    if (d->B < 1 || d->h < 1 || d->w < 1) return abc_fail(ABC_EINVAL, "loss: empty");
+    hipLaunchKernelGGL(loss_kernel, dim3(abc_loss_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d);
+    return abc_check_launch("loss_fwd_bwd");
+}
+
+extern "C" int abc_loss_finalize(const abc_loss_fin_desc* d, abc_stream_t stream) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *d);
+    return abc_check_launch("loss_finalize");
+}

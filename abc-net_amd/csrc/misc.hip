@@ -1,0 +1,185 @@
+// Weight repacking, fused Adam, inference NMS, and the C-ABI error plumbing.
+#include "common.hpp"
+#include "../../include/abcnet_hip.h"
+#include "capi_util.hpp"
+#include <string.h>
+
+// ------------------------------------------------------------------ error text
+static thread_local char g_err[256] = "";
+int abc_fail(int code, const char* msg) {
+    strncpy(g_err, msg, sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+    return code;
+}
+int abc_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return ABC_ELAUNCH;
+    }
+    return ABC_OK;
+}
+extern "C" const char* abc_last_error(void) { return g_err; }
+extern "C" int abc_version(void) { return 100; }
+
+namespace {
+
+// ------------------------------------------------------------------ weight packing
+// dst[t][chunk][row][k], element type CT; see abc_pack_desc in the public header.
+template <typename CT>
+__global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunks) {
+    // nchunks = chunks of THIS weight; it lands at chunk offset red_off/CK of a dst with red_total/CK chunks
+    const int nch_total = d.red_total / CK, ch_off = d.red_off / CK;
+    const int64_t total = (int64_t)ntaps * nchunks * d.rows_pad * CK;
+    CT* dst = (CT*)d.dst;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % CK);
+        int64_t r = i / CK;
+        const int n = (int)(r % d.rows_pad); r /= d.rows_pad;
+        const int c = (int)(r % nchunks);
+        const int t = (int)(r / nchunks);
+        const int rc = c * CK + k;
+        float v = 0.f;
+        if (d.mode == 0) {  // Conv2d forward: row = cout, reduce over cin
+            if (n < d.Cout && rc < d.Cin) v = d.w[((size_t)n * d.Cin + rc) * ntaps + t];
+        } else if (d.mode == 1) {  // Conv2d dgrad: row = cin, reduce over cout (host mirrors the tap offsets)
+            if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)rc * d.Cin + n) * ntaps + t];
+        } else if (d.mode == 2) {  // ConvTranspose2d forward, output parity (py,px): row = cout, reduce over cin
+            const int nx = d.px ? 2 : 1;
+            const int iy = t / nx, ix = t % nx;
+            const int ky = d.py ? (iy == 0 ? 0 : 2) : 1;
+            const int kx = d.px ? (ix == 0 ? 0 : 2) : 1;
+            if (n < d.Cout && rc < d.Cin) v = d.w[(((size_t)rc * d.Cout + n) * 3 + ky) * 3 + kx];
+        } else {  // ConvTranspose2d dgrad: row = cin, reduce over cout, 9 taps
+            if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
+        }
+        dst[(((size_t)t * nch_total + ch_off + c) * d.rows_pad + n) * CK + k] = (CT)v;
+    }
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ void step_inc_kernel(int64_t* step) { *step += 1; }
+
+__global__ __launch_bounds__(256) void adam_kernel(const abc_adam_desc d) {
+    const double t = (double)*d.step;
+    const float bc1 = (float)(1.0 - pow((double)d.beta1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)d.beta2, t));
+    const float step_size = d.lr / bc1;
+    const int64_t n4 = d.n / 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 p = ((f32x4*)d.p)[i], g = ((const f32x4*)d.g)[i], m = ((f32x4*)d.m)[i], v = ((f32x4*)d.v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = g[j] * d.grad_scale + d.weight_decay * p[j];
+            m[j] = m[j] + (gg - m[j]) * (1.f - d.beta1);
+            v[j] = v[j] * d.beta2 + (1.f - d.beta2) * gg * gg;
+            p[j] -= step_size * m[j] / (sqrtf(v[j]) / bc2s + d.eps);
+        }
+        ((f32x4*)d.p)[i] = p; ((f32x4*)d.m)[i] = m; ((f32x4*)d.v)[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = n4 * 4 + threadIdx.x; i < d.n; i += 256) {
+            const float gg = d.g[i] * d.grad_scale + d.weight_decay * d.p[i];
+            const float m = d.m[i] + (gg - d.m[i]) * (1.f - d.beta1);
+            const float v = d.v[i] * d.beta2 + (1.f - d.beta2) * gg * gg;
+            d.m[i] = m; d.v[i] = v;
+            d.p[i] -= step_size * m / (sqrtf(v) / bc2s + d.eps);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ NMS (img2smiles2.py:61-79)
+__global__ __launch_bounds__(256) void nms_kernel(const abc_nms_desc d) {
+    const int hw = d.h * d.w;
+    const int64_t npix = (int64_t)d.B * hw;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const int b = (int)(p / hw), yx = (int)(p % hw);
+    const int y = yx / d.w, x = yx % d.w;
+    const float* L = d.logits + p * d.ldl;
+    // 3x3 local maximum with -inf padding, logit > -1
+    for (int which = 0; which < 2; ++which) {
+        const int off = which ? d.off_bond : d.off_atom;
+        const float v = L[off];
+        float m = v;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < d.h && xx >= 0 && xx < d.w)
+                    m = fmaxf(m, d.logits[((size_t)b * hw + yy * d.w + xx) * d.ldl + off]);
+            }
+        float* o = which ? d.bond_mask : d.atom_mask;
+        o[(size_t)b * hw + yx] = (m == v && v > -1.f) ? 1.f : 0.f;
+    }
+    const int n = d.n_omega;
+    for (int k = 0; k < n; ++k) {
+        d.rho_abs[((size_t)b * n + k) * hw + yx] = fabsf(L[d.off_rho + k]);
+        const float v = L[d.off_omega + k];
+        const float l = L[d.off_omega + (k + n - 1) % n], r = L[d.off_omega + (k + 1) % n];
+        const float m = fmaxf(v, fmaxf(l, r));
+        d.omega_mask[((size_t)b * n + k) * hw + yx] = (m == v && v > -1.f) ? 1.f : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream) {
+    int ntaps, red;
+    switch (d->mode) {
+        case 0: ntaps = d->kh * d->kw; red = d->Cin; break;
+        case 1: ntaps = d->kh * d->kw; red = d->Cout; break;
+        case 2: ntaps = (d->py ? 2 : 1) * (d->px ? 2 : 1); red = d->Cin; break;
+        case 3: ntaps = 9; red = d->Cout; break;
+        default: return abc_fail(ABC_EINVAL, "pack: mode");
+    }
+    const int CK = d->ck;
+    if (CK != abc_conv_chunk(d->dtype_c, d->red_total)) return abc_fail(ABC_EINVAL, "pack: ck does not match red_total");
+    if (d->red_pad % CK || d->red_pad < red || d->red_off % CK || d->red_off + d->red_pad > abc_roundup(d->red_total, CK))
+        return abc_fail(ABC_EINVAL, "pack: red_pad/red_off");
+    const int nchunks = d->red_pad / CK;
+    const int64_t total = (int64_t)ntaps * nchunks * d->rows_pad * CK;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    if (d->dtype_c == ABC_BF16) hipLaunchKernelGGL(pack_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, CK, ntaps, nchunks);
+    else hipLaunchKernelGGL(pack_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, CK, ntaps, nchunks);
+    return abc_check_launch("pack_conv_weights");
+}
+
+extern "C" int abc_adam_step(const abc_adam_desc* d, abc_stream_t stream) {
+    if (d->n < 1) return abc_fail(ABC_EINVAL, "adam: empty");
+    if (((uintptr_t)d->p | (uintptr_t)d->g | (uintptr_t)d->m | (uintptr_t)d->v) & 15) return abc_fail(ABC_EINVAL, "adam: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, d->step);
+    int64_t nb = (d->n / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, *d);
+    return abc_check_launch("adam_step");
+}
+
+extern "C" int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream) {
+    const int64_t npix = (int64_t)d->B * d->h * d->w;
+    hipLaunchKernelGGL(nms_kernel, dim3((int)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    return abc_check_launch("nms_peaks");
+}
+
+// sizeof() of every descriptor, so that the host binding can verify its mirror structs
+extern "C" int abc_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(abc_act_src);
+        case 1: return (int)sizeof(abc_conv_desc);
+        case 2: return (int)sizeof(abc_pack_desc);
+        case 3: return (int)sizeof(abc_bn_fwd_desc);
+        case 4: return (int)sizeof(abc_act_bwd_desc);
+        case 5: return (int)sizeof(abc_bn_bwd_desc);
+        case 6: return (int)sizeof(abc_bn_apply_desc);
+        case 7: return (int)sizeof(abc_wgrad_desc);
+        case 8: return (int)sizeof(abc_wgrad_reduce_desc);
+        case 9: return (int)sizeof(abc_loss_desc);
+        case 10: return (int)sizeof(abc_loss_fin_desc);
+        case 11: return (int)sizeof(abc_adam_desc);
+        case 12: return (int)sizeof(abc_nms_desc);
+        default: return -1;
+    }
+}

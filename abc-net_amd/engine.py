@@ -1,0 +1,526 @@
+"""Launch plan of the U-Net hot path on one MI355X.
+
+The engine lowers the topology of the reference networks (unet.py:100-119,
+unet2.py:152-173) to a static list of C-ABI calls into libabcnet_hip.so for a fixed
+(batch, height, width, dtype): weight packing, forward, backward.  All activations
+are NHWC in HBM; every conv writes its RAW output plus BatchNorm partial statistics
+and every consumer applies BN + activation (+pool, +dropout) on load, so an
+activation is written once and read once per consumer.  The skip concatenations are
+never materialised by a copy: the encoder conv and the transposed conv write the two
+channel halves of one buffer in place (unet.py:51-59).
+
+PyTorch is used here only to own device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import arch
+
+BN_EPS = 1e-5
+BN_MOM = 0.1
+LDL = 544  # logits row stride: 512 aligned channels + slack for padded K-chunks of the last head
+
+
+def head_offsets(heads):
+    """channel offset of each head inside a logits row, 4-aligned (16-byte) so the loss kernel's rows stay aligned"""
+    offs, o = [], 0
+    for h in heads:
+        offs.append(o)
+        o += (h + 3) // 4 * 4
+    if o + 32 > LDL:
+        raise ValueError("heads do not fit the logits row (%d > %d)" % (o + 32, LDL))
+    return offs
+
+
+def taps_square(k):
+    p = (k - 1) // 2
+    return [(ky - p, kx - p) for ky in range(k) for kx in range(k)]
+
+
+def taps_mirror(taps):
+    return [(-dy, -dx) for dy, dx in taps]
+
+
+def convT_phase_taps(py, px):
+    """input offsets of the taps of output parity (py,px) of ConvTranspose2d(k3,s2) after the
+    crop of the first row/col (unet.py:51-57); order matches abc_pack_conv_weights mode 2"""
+    ys = [0] if py == 0 else [1, 0]  # py=1: ky=0 -> iy=a+1, ky=2 -> iy=a
+    xs = [0] if px == 0 else [1, 0]
+    return [(dy, dx) for dy in ys for dx in xs]
+
+
+TAPS_CONVT_DGRAD = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+
+
+class Src:
+    """an activation as a consumer sees it: raw tensor + on-load transform"""
+
+    def __init__(self, t, dt, H, W, ld, coff, C, coef=None, pool=False, drop_p=0.0, drop_seed=0, producer=None):
+        self.t, self.dt, self.H, self.W, self.ld, self.coff, self.C = t, dt, H, W, ld, coff, C
+        self.coef, self.pool, self.drop_p, self.drop_seed, self.producer = coef, pool, drop_p, drop_seed, producer
+
+    def lh(self):  # logical dims
+        return (self.H // 2, self.W // 2) if self.pool else (self.H, self.W)
+
+    def fill(self, a: L.ActSrc):
+        a.x = self.t.data_ptr()
+        if self.coef is not None:
+            a.scale, a.shift, a.slope = (c.data_ptr() for c in self.coef)
+        else:
+            a.scale = a.shift = a.slope = None
+        a.Hx, a.Wx, a.ldx, a.pool = self.H, self.W, self.ld, 1 if self.pool else 0
+        a.drop_p, a.drop_seed = self.drop_p, self.drop_seed
+
+
+class Rec:
+    """one conv (+BN) layer: what forward produced and what backward needs"""
+
+    def __init__(self, **kw):
+        self.grad_same = None  # (tensor, ld, coff): grad wrt the activated output, full resolution
+        self.grad_pool = None  # (tensor, ld, coff): grad wrt the pooled activated output
+        self.__dict__.update(kw)
+
+
+class Engine:
+    def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
+                 dropout_p=0.2, device="cuda"):
+        if variant != "unet":
+            raise NotImplementedError("variant %r is not lowered yet" % variant)
+        if H % 32 or W % 32:
+            raise ValueError("H and W must be multiples of 32 (got %dx%d)" % (H, W))
+        if in_channels != 1:
+            raise NotImplementedError("in_channels != 1")
+        self.lib = L.load()
+        self.variant, self.heads, self.B, self.H, self.W = variant, list(heads), B, H, W
+        self.train = train
+        self.dt = L.BF16 if dtype == "bf16" else L.F32
+        self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.dev = device
+        self.params, self.grads, self.buffers, self.counters = params, grads, buffers, counters
+        self.lay_p, self.lay_b, self.lay_c = layout
+        self.drop_p = dropout_p if (train and variant == "unet") else 0.0
+        self.drop_seed = 0x1234ABCD
+        self.head_off = head_offsets(self.heads)
+        self.keep = []  # ctypes descriptors and tensors referenced by raw pointer
+        self.pack_ops, self.fwd_ops, self.bwd_ops = [], [], []
+        self.recs = []
+        self._ws_need = 0
+        self._ws_users = []
+        self._colsum_need = 0
+        self._colsum_users = []
+        self._build()
+
+    # ------------------------------------------------------------------ memory helpers
+    def P(self, name):
+        off, n = self.lay_p[name]
+        return self.params.data_ptr() + 4 * off
+
+    def G(self, name):
+        off, n = self.lay_p[name]
+        return self.grads.data_ptr() + 4 * off
+
+    def Bf(self, name):
+        off, n = self.lay_b[name]
+        return self.buffers.data_ptr() + 4 * off
+
+    def Cn(self, name):
+        return self.counters.data_ptr() + 8 * self.lay_c[name]
+
+    def new(self, shape, dtype=None, fill=0.0):
+        t = torch.full(shape, fill, dtype=dtype or self.tdt, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def act_buf(self, H, W, C):
+        t = self.new((self.B, H, W, C))
+        coef = (self.new((C,), torch.float32, 1.0), self.new((C,), torch.float32, 0.0), self.new((C,), torch.float32, 1.0))
+        return t, coef
+
+    # ------------------------------------------------------------------ op emitters
+    def _emit(self, ops, fn, desc, what, writes=()):
+        """writes = names of parameters whose GRADIENT is final once this op has run (bucketed all-reduce)"""
+        self.keep.append(desc)
+        ref = C.byref(desc)
+        ops.append((fn, ref, what, tuple(writes)))
+
+    def emit_pack(self, wname, dst, mode, Cout, Cin, k, rows_pad, red_real, red_total=None, red_off=0, py=0, px=0):
+        d = L.PackDesc()
+        d.w, d.dst, d.mode, d.dtype_c = self.P(wname), dst.data_ptr(), mode, self.dt
+        d.Cout, d.Cin, d.kh, d.kw, d.py, d.px = Cout, Cin, k, k, py, px
+        total = red_real if red_total is None else red_total
+        ck = self.lib.abc_conv_chunk(self.dt, total)
+        d.rows_pad, d.red_pad, d.red_total, d.red_off, d.ck = rows_pad, -(-red_real // ck) * ck, total, red_off, ck
+        self._emit(self.pack_ops, self.lib.abc_pack_conv_weights, d, "pack " + wname)
+
+    def packed(self, ntaps, red, rows_pad):
+        ck = self.lib.abc_conv_chunk(self.dt, red)
+        return self.new((ntaps * (-(-red // ck)) * rows_pad * ck,))
+
+    def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
+                  grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv"):
+        d = L.ConvDesc()
+        src.fill(d.src)
+        d.w, d.bias, d.y = w.data_ptr(), bias, y.data_ptr()
+        d.stats = None
+        d.dtype_in, d.dtype_c, d.dtype_out = src.dt, self.dt, y_dt
+        lh, lw = src.lh()
+        d.B, d.Hin, d.Win = self.B, lh, lw
+        d.cin_off = src.coff if cin_off is None else cin_off
+        d.Cin = src.C if Cin is None else Cin
+        gh, gw = grid if grid is not None else (Hout, Wout)
+        d.Hg, d.Wg, d.Hout, d.Wout, d.ldy, d.cout_off, d.Cout, d.Cout_pad = gh, gw, Hout, Wout, ldy, cout_off, Cout, -(-Cout // 32) * 32
+        d.stride, d.om, d.oy0, d.ox0 = stride, om, oy0, ox0
+        L.set_taps(d, taps)
+        nblk = self.lib.abc_conv_stat_blocks(C.byref(d))
+        st = None
+        if stats:
+            st = self.new((nblk, 2, Cout), torch.float32)
+            d.stats = st.data_ptr()
+        self._emit(ops, self.lib.abc_conv_fwd, d, what)
+        return st, nblk
+
+    def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None):
+        dw_ptr = self.G(wname)
+        d = L.WgradDesc()
+        p.fill(d.p)
+        q.fill(d.q)
+        d.dtype_p, d.dtype_q, d.dtype_c = p.dt, q.dt, self.dt
+        gh, gw = p.lh()
+        qh, qw = q.lh()
+        d.B, d.Hg, d.Wg, d.Hq, d.Wq = self.B, gh, gw, qh, qw
+        d.cp_off = p.coff if cp_off is None else cp_off
+        d.cq_off = q.coff if cq_off is None else cq_off
+        d.Ca, d.Cb, d.stride = Ca, Cb, stride
+        L.set_taps(d, taps)
+        ca_pad, cb_pad = L.i32(), L.i32()
+        L.check(self.lib.abc_wgrad_pads(C.byref(d), C.byref(ca_pad), C.byref(cb_pad)), "wgrad_pads")
+        ca_pad, cb_pad = ca_pad.value, cb_pad.value
+        wide = stride == 1 and (-(-Ca // 32) * 32) % 64 == 0 and (-(-Cb // 32) * 32) % 64 == 0
+        cw = 64 if wide else 32
+        ngroups = -(-len(taps) // 9)
+        npatch = self.B * (-(-gh // 8)) * (-(-gw // 16))
+        nsplit = max(1, min(npatch, 768 // ((ca_pad // cw) * (cb_pad // cw) * ngroups)))
+        d.nsplit = nsplit
+        need = nsplit * len(taps) * ca_pad * cb_pad
+        self._ws_need = max(self._ws_need, need)
+        r = L.WgradReduceDesc()
+        r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = nsplit, len(taps), Ca, Cb, ca_pad, cb_pad, dw_ptr, 0
+        self._ws_users += [d, r]
+        self._emit(ops, self.lib.abc_wgrad, d, what)
+        self._emit(ops, self.lib.abc_wgrad_reduce, r, what + " reduce", writes=(wname,) if wname else ())
+
+    def emit_colsum(self, ops, t, dt, npix, ld, c_off, Cn, chan_scale, bname, what):
+        out_ptr = self.G(bname)
+        nb = self.lib.abc_colsum_blocks(npix)
+        self._colsum_need = max(self._colsum_need, nb * Cn)
+        args = [t.data_ptr(), dt, npix, ld, c_off, Cn, None if chan_scale is None else chan_scale.data_ptr(), None, out_ptr]
+        self._colsum_users.append(args)
+        lib = self.lib
+
+        def fn(_ref, stream, a=args):
+            return lib.abc_colsum(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], stream)
+
+        ops.append((fn, None, what, (bname,)))
+
+    # ------------------------------------------------------------------ layers
+    def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None):
+        """conv (+bias) -> raw output into dst=(tensor, coef, H, W, ld, coff); BN stats/coefficients"""
+        yt, coef, H, W, ld, coff = dst
+        cin = src.C
+        taps = taps_square(k)
+        rows_pad = -(-cout // 32) * 32
+        wf = self.packed(len(taps), cin, rows_pad)
+        self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin)
+        stats, nblk = self.emit_conv(self.fwd_ops, src, wf, self.P(cname + ".bias"), yt, self.dt, H, W, ld, coff, cout, taps,
+                                     stats=self.train, what="fwd " + cname)
+        rec = Rec(kind="conv", cname=cname, bname=bname, src=src, cin=cin, cout=cout, k=k, taps=taps, y=yt, H=H, W=W, ld=ld,
+                  coff=coff, coef=coef, slope=slope)
+        sc, sh, sl = coef
+        sl[coff:coff + cout] = slope
+        rec.scale, rec.shift, rec.slopes = sc[coff:coff + cout], sh[coff:coff + cout], sl[coff:coff + cout]
+        rec.mean, rec.invstd = self.new((cout,), torch.float32), self.new((cout,), torch.float32, 1.0)
+        if self.train:
+            d = L.BnFwdDesc()
+            d.partial, d.nblk, d.C, d.count = stats.data_ptr(), nblk, cout, float(self.B * H * W)
+            d.gamma, d.beta = self.P(bname + ".weight"), self.P(bname + ".bias")
+            d.scale, d.shift, d.mean, d.invstd = rec.scale.data_ptr(), rec.shift.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr()
+            d.running_mean, d.running_var = self.Bf(bname + ".running_mean"), self.Bf(bname + ".running_var")
+            d.num_batches_tracked = self.Cn(bname + ".num_batches_tracked")
+            d.eps, d.momentum = BN_EPS, BN_MOM
+            self._emit(self.fwd_ops, self.lib.abc_bn_finalize_fwd, d, "bn " + bname)
+        else:
+            lib = self.lib
+            a = (self.P(bname + ".weight"), self.P(bname + ".bias"), self.Bf(bname + ".running_mean"),
+                 self.Bf(bname + ".running_var"), rec.scale.data_ptr(), rec.shift.data_ptr(), cout, BN_EPS)
+            self.fwd_ops.append((lambda _r, st, a=a: lib.abc_bn_eval_coeffs(*a, st), None, "bn-eval " + bname, ()))
+        self.recs.append(rec)
+        out = Src(yt, self.dt, H, W, ld, coff, cout, coef=coef, producer=rec)
+        return rec, out
+
+    def double_conv(self, prefix, src, cout, k, dst_b=None):
+        H, W = src.lh()
+        ta, ca = self.act_buf(H, W, cout)
+        p = prefix + ".double_conv"
+        _, a = self.conv_bn(p + ".0", p + ".1", src, cout, k, (ta, ca, H, W, cout, 0), 0.0)
+        if dst_b is None:
+            tb, cb = self.act_buf(H, W, cout)
+            dst_b = (tb, cb, H, W, cout, 0)
+        _, b = self.conv_bn(p + ".3", p + ".4", a, cout, k, dst_b, 0.0)
+        return b
+
+    def pooled(self, s: Src):
+        return Src(s.t, s.dt, s.H, s.W, s.ld, s.coff, s.C, coef=s.coef, pool=True, producer=s.producer)
+
+    def up(self, name, low: Src, cat, cat_coef, Hs, Ws, Ctot, cout):
+        """ConvTranspose2d(Ctot -> Ctot/2, k3, s2) of `low` into cat[..., Ctot/2:], then DoubleConv(Ctot -> cout)"""
+        half = Ctot // 2
+        cin = low.C
+        lh, lw = low.lh()
+        assert (2 * lh, 2 * lw) == (Hs, Ws)
+        rows_pad = -(-half // 32) * 32
+        phases = []
+        for py in (0, 1):
+            for px in (0, 1):
+                taps = convT_phase_taps(py, px)
+                wp = self.packed(len(taps), cin, rows_pad)
+                self.emit_pack(name + ".up.weight", wp, 2, half, cin, 3, rows_pad, cin, py=py, px=px)
+                self.emit_conv(self.fwd_ops, low, wp, self.P(name + ".up.bias"), cat, self.dt, Hs, Ws, Ctot, half, half, taps,
+                               grid=(lh, lw), om=2, oy0=py, ox0=px, what="fwd %s.up phase %d%d" % (name, py, px))
+                phases.append(wp)
+        rec = Rec(kind="convT", cname=name + ".up", src=low, cin=cin, cout=half, H=Hs, W=Ws, ld=Ctot, coff=half, y=cat)
+        self.recs.append(rec)
+        cat_src = Src(cat, self.dt, Hs, Ws, Ctot, 0, Ctot, coef=cat_coef, producer=("cat", None))
+        out = self.double_conv(name + ".conv", cat_src, cout, 3)
+        # remember who receives the two halves of d(cat)
+        first = [r for r in self.recs if r.kind == "conv" and r.cname == name + ".conv.double_conv.0"][0]
+        first.cat_upper = rec
+        return out, rec
+
+    # ------------------------------------------------------------------ build
+    def _build(self):
+        B, H, W = self.B, self.H, self.W
+        S = [(H >> i, W >> i) for i in range(6)]
+        self.img = self.new((B, 1, H, W), torch.float32)
+        img_src = Src(self.img, L.F32, H, W, 1, 0, 1)
+        x = self.double_conv("inc1", img_src, 16, 3)
+        x1 = self.double_conv("inc2", x, 16, 3)
+        x2 = self.double_conv("down1.maxpool_conv.1", self.pooled(x1), 32, 3)
+        x = self.double_conv("down2.maxpool_conv.1", self.pooled(x2), 64, 3)
+        cat3, cc3 = self.act_buf(S[2][0], S[2][1], 128)
+        cat2, cc2 = self.act_buf(S[3][0], S[3][1], 256)
+        cat1, cc1 = self.act_buf(S[4][0], S[4][1], 512)
+        x3 = self.double_conv("inc3", x, 64, 3, dst_b=(cat3, cc3, S[2][0], S[2][1], 128, 0))
+        x4 = self.double_conv("down3.maxpool_conv.1", self.pooled(x3), 128, 3, dst_b=(cat2, cc2, S[3][0], S[3][1], 256, 0))
+        x5 = self.double_conv("down4.maxpool_conv.1", self.pooled(x4), 256, 3, dst_b=(cat1, cc1, S[4][0], S[4][1], 512, 0))
+        x6 = self.double_conv("down5.maxpool_conv.1", self.pooled(x5), 512, 3)
+        u, _ = self.up("up1", x6, cat1, cc1, S[4][0], S[4][1], 512, 256)
+        u, _ = self.up("up2", u, cat2, cc2, S[3][0], S[3][1], 256, 128)
+        u, _ = self.up("up3", u, cat3, cc3, S[2][0], S[2][1], 128, 128)
+        u = self.double_conv("dconv1", u, 128, 3)
+        trunk = self.double_conv("dconv2", u, 128, 3)
+        self.trunk = trunk
+        self._build_heads(trunk)
+        if self.train:
+            self._build_backward()
+        # shared workspaces
+        self.ws = self.new((max(self._ws_need, 4),), torch.float32)
+        for d in self._ws_users:
+            d.partial = self.ws.data_ptr()
+        self.cs_ws = self.new((max(self._colsum_need, 4),), torch.float32)
+        for a in self._colsum_users:
+            a[7] = self.cs_ws.data_ptr()
+
+    def _build_heads(self, trunk: Src):
+        h, w = trunk.H, trunk.W
+        nh = len(self.heads)
+        self.h, self.w = h, w
+        self.hfeat, self.hcoef = self.act_buf(h, w, 128 * nh)
+        self.logits = self.new((self.B, h, w, LDL), torch.float32)
+        self.head_recs, self.head2 = [], []
+        for i, hc in enumerate(self.heads):
+            p = "out_modules.%d" % i
+            rec, f = self.conv_bn(p + ".conv1", p + ".bn", trunk, 128, 3, (self.hfeat, self.hcoef, h, w, 128 * nh, 128 * i), 0.01)
+            rec.is_head = True
+            self.head_recs.append(rec)
+            f.drop_p, f.drop_seed = self.drop_p, self.drop_seed
+            rows_pad = -(-hc // 32) * 32
+            w2 = self.packed(1, 128, rows_pad)
+            self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
+            self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits, L.F32, h, w, LDL, self.head_off[i], hc,
+                           [(0, 0)], what="fwd %s.conv2" % p)
+            self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
+
+    # ------------------------------------------------------------------ backward plan
+    def _bn_backward(self, ops, rec, same, pool, drop=None):
+        """act_bwd + bn finalize + apply for rec; returns Src of dY (plain)"""
+        C_ = rec.cout
+        g = self.new((self.B, rec.H, rec.W, C_))
+        d = L.ActBwdDesc()
+        d.y_raw, d.ld_y = rec.y.data_ptr(), rec.ld
+        if same is not None:
+            d.dA_same, d.ld_same, d.csame_off = same[0].data_ptr(), same[1], same[2]
+        if pool is not None:
+            d.dA_pool, d.ld_pool, d.cpool_off = pool[0].data_ptr(), pool[1], pool[2]
+        d.g, d.ld_g = g.data_ptr(), C_
+        d.scale, d.shift, d.slope = rec.scale.data_ptr(), rec.shift.data_ptr(), rec.slopes.data_ptr()
+        d.mean, d.invstd = rec.mean.data_ptr(), rec.invstd.data_ptr()
+        d.dtype, d.B, d.H, d.W, d.C, d.cy_off = self.dt, self.B, rec.H, rec.W, C_, rec.coff
+        if drop is not None:
+            d.drop_p, d.drop_seed, d.drop_ld = drop[0], drop[1], rec.ld
+        nblk = self.lib.abc_act_bwd_blocks(C.byref(d))
+        part = self.new((nblk, 2, C_), torch.float32)
+        d.partial = part.data_ptr()
+        self._emit(ops, self.lib.abc_act_bwd, d, "act_bwd " + rec.bname)
+        k1, k2, gs = (self.new((C_,), torch.float32) for _ in range(3))
+        f = L.BnBwdDesc()
+        f.partial, f.nblk, f.C, f.count = part.data_ptr(), nblk, C_, float(self.B * rec.H * rec.W)
+        f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
+        f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
+        f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
+        a = L.BnApplyDesc()
+        a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = g.data_ptr(), C_, rec.y.data_ptr(), rec.ld, rec.coff
+        a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
+        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname)
+        return Src(g, self.dt, rec.H, rec.W, C_, 0, C_)
+
+    def _conv_backward(self, ops, rec, dY: Src, want_dgrad=True):
+        """wgrad (+ dgrad into a fresh buffer registered with the producer of rec.src)"""
+        self.emit_wgrad(ops, dY, rec.src, rec.cout, rec.cin, rec.taps, 1, rec.cname + ".weight", "wgrad " + rec.cname)
+        prod = rec.src.producer
+        if not want_dgrad or prod is None:
+            return None
+        lh, lw = rec.src.lh()
+        rows_pad = -(-rec.cin // 32) * 32
+        wd = self.packed(len(rec.taps), rec.cout, rows_pad)
+        self.emit_pack(rec.cname + ".weight", wd, 1, rec.cout, rec.cin, rec.k, rows_pad, rec.cout)
+        dsrc = self.new((self.B, lh, lw, rec.cin))
+        self.emit_conv(ops, dY, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, taps_mirror(rec.taps), what="dgrad " + rec.cname)
+        return dsrc
+
+    def _route(self, rec, dsrc):
+        """hand d(src) of `rec` to whoever produced src"""
+        src = rec.src
+        prod = src.producer
+        if isinstance(prod, tuple) and prod[0] == "cat":
+            half = rec.cin // 2
+            up = rec.cat_upper
+            up.grad_out = (dsrc, rec.cin, half)
+            # the skip half belongs to the conv that wrote channels [0:half) of the cat buffer
+            skip = [r for r in self.recs if r.kind == "conv" and r.y is src.t and r.coff == 0][0]
+            skip.grad_same = (dsrc, rec.cin, 0)
+        elif src.pool:
+            prod.grad_pool = (dsrc, rec.cin, 0)
+        else:
+            prod.grad_same = (dsrc, rec.cin, 0)
+
+    def _build_backward(self):
+        ops = self.bwd_ops
+        B, h, w = self.B, self.h, self.w
+        nh = len(self.heads)
+        self.dlogits = self.new((B, h, w, LDL), torch.float32)
+        self.chan_scale = self.new((LDL,), torch.float32, 0.0)
+        one = self.new((LDL,), torch.float32, 1.0)
+        zero = self.new((LDL,), torch.float32, 0.0)
+        dfeat = self.new((B, h, w, 128 * nh))
+        # ---- heads' 1x1 convs
+        for r2 in self.head2:
+            i, hc = r2.idx, r2.cout
+            dl = Src(self.dlogits, L.F32, h, w, LDL, self.head_off[i], hc, coef=(self.chan_scale, zero, one))
+            self.emit_wgrad(ops, dl, r2.src, hc, 128, [(0, 0)], 1, r2.cname + ".weight", "wgrad " + r2.cname)
+            self.emit_colsum(ops, self.dlogits, L.F32, B * h * w, LDL, self.head_off[i], hc, self.chan_scale,
+                             r2.cname + ".bias", "dbias " + r2.cname)
+            wd = self.packed(1, hc, 128)
+            self.emit_pack(r2.cname + ".weight", wd, 1, hc, 128, 1, 128, hc)
+            self.emit_conv(ops, dl, wd, None, dfeat, self.dt, h, w, 128 * nh, 128 * i, 128, [(0, 0)], what="dgrad " + r2.cname)
+        # ---- heads' BN + conv1: per-head BN backward, ONE data-gradient conv over the 8x128 concatenated channels
+        taps = taps_square(3)
+        dyh = self.new((B, h, w, 128 * nh))
+        wd_all = self.packed(9, 128 * nh, 128)
+        for i, rec in enumerate(self.head_recs):
+            drop = (self.drop_p, self.drop_seed) if self.drop_p > 0 else None
+            dY = self._bn_backward_into(ops, rec, (dfeat, 128 * nh, 128 * i), dyh, 128 * nh, 128 * i, drop)
+            self.emit_wgrad(ops, dY, rec.src, 128, 128, taps, 1, rec.cname + ".weight", "wgrad " + rec.cname)
+            self.emit_pack(rec.cname + ".weight", wd_all, 1, 128, 128, 3, 128, 128, red_total=128 * nh, red_off=128 * i)
+        dtrunk = self.new((B, h, w, 128))
+        dy_all = Src(dyh, self.dt, h, w, 128 * nh, 0, 128 * nh)
+        self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
+        self.trunk.producer.grad_same = (dtrunk, 128, 0)
+        # ---- trunk, decoder, encoder in reverse
+        body = [r for r in self.recs if not getattr(r, "is_head", False)]
+        for rec in reversed(body):
+            if rec.kind == "conv":
+                dY = self._bn_backward(ops, rec, rec.grad_same, rec.grad_pool)
+                dsrc = self._conv_backward(ops, rec, dY)
+                if dsrc is not None:
+                    self._route(rec, dsrc)
+            else:  # transposed conv
+                dcat, ld, coff = rec.grad_out
+                hs, ws = rec.H, rec.W
+                dOut = Src(dcat, self.dt, hs, ws, ld, coff, rec.cout)
+                self.emit_colsum(ops, dcat, self.dt, B * hs * ws, ld, coff, rec.cout, None, rec.cname + ".bias",
+                                 "dbias " + rec.cname)
+                self.emit_wgrad(ops, rec.src, dOut, rec.cin, rec.cout, TAPS_CONVT_DGRAD, 2, rec.cname + ".weight",
+                                "wgrad " + rec.cname)
+                lh, lw = rec.src.lh()
+                rows_pad = -(-rec.cin // 32) * 32
+                wd = self.packed(9, rec.cout, rows_pad)
+                self.emit_pack(rec.cname + ".weight", wd, 3, rec.cout, rec.cin, 3, rows_pad, rec.cout)
+                dsrc = self.new((B, lh, lw, rec.cin))
+                self.emit_conv(ops, dOut, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, TAPS_CONVT_DGRAD, stride=2,
+                               what="dgrad " + rec.cname)
+                rec.src.producer.grad_same = (dsrc, rec.cin, 0)
+
+    def _bn_backward_into(self, ops, rec, same, gbuf, ld_g, g_off, drop):
+        """as _bn_backward, but G/dY live in a channel slice of a shared buffer (the heads)"""
+        C_ = rec.cout
+        esz = gbuf.element_size()
+        gptr = gbuf.data_ptr() + g_off * esz
+        d = L.ActBwdDesc()
+        d.y_raw, d.ld_y = rec.y.data_ptr(), rec.ld
+        d.dA_same, d.ld_same, d.csame_off = same[0].data_ptr(), same[1], same[2]
+        d.g, d.ld_g = gptr, ld_g
+        d.scale, d.shift, d.slope = rec.scale.data_ptr(), rec.shift.data_ptr(), rec.slopes.data_ptr()
+        d.mean, d.invstd = rec.mean.data_ptr(), rec.invstd.data_ptr()
+        d.dtype, d.B, d.H, d.W, d.C, d.cy_off = self.dt, self.B, rec.H, rec.W, C_, rec.coff
+        if drop is not None:
+            d.drop_p, d.drop_seed, d.drop_ld = drop[0], drop[1], rec.ld
+        nblk = self.lib.abc_act_bwd_blocks(C.byref(d))
+        part = self.new((nblk, 2, C_), torch.float32)
+        d.partial = part.data_ptr()
+        self._emit(ops, self.lib.abc_act_bwd, d, "act_bwd " + rec.bname)
+        k1, k2, gs = (self.new((C_,), torch.float32) for _ in range(3))
+        f = L.BnBwdDesc()
+        f.partial, f.nblk, f.C, f.count = part.data_ptr(), nblk, C_, float(self.B * rec.H * rec.W)
+        f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
+        f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
+        f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
+        a = L.BnApplyDesc()
+        a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = gptr, ld_g, rec.y.data_ptr(), rec.ld, rec.coff
+        a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
+        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname)
+        return Src(gbuf, self.dt, rec.H, rec.W, ld_g, g_off, C_)
+
+    # ------------------------------------------------------------------ execution
+    @staticmethod
+    def _run(ops, stream):
+        for fn, ref, what, _w in ops:
+            rc = fn(ref, stream)
+            if rc != 0:
+                L.check(rc, what)
+
+    def run_pack(self, stream):
+        self._run(self.pack_ops, stream)
+
+    def run_forward(self, stream):
+        self._run(self.fwd_ops, stream)
+
+    def run_backward(self, stream):
+        self._run(self.bwd_ops, stream)

@@ -1,0 +1,97 @@
+"""Thin host wrappers over single C-ABI kernels used outside the engine's static plan:
+fused loss (train.py:95-137), inference NMS (img2smiles2.py:61-79), fused Adam (train.py:55,141)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .engine import LDL
+
+HEAD_NAMES = ["atom_t", "atom_types", "atom_charges", "atom_hs", "bond_t", "bond_types", "bond_rhos", "bond_omega"]
+
+
+class FusedLoss:
+    """activation + 8-term loss + dlogits for fixed shapes; targets are read from the given (static) tensors"""
+
+    def __init__(self, eng, targets, s_ptr, ds_ptr, grad_scale=1.0):
+        lib = eng.lib
+        self.eng, self.lib = eng, lib
+        self.targets = targets  # keep alive
+        exp = [(eng.B, 1), (eng.B, 14), (eng.B, 3), (eng.B, 2), (eng.B, 1), (eng.B, 6, 60), (eng.B, 60), (eng.B, 60)]
+        dts = [torch.float32] * 6 + [torch.float64] * 2
+        for t, e, dt in zip(targets, exp, dts):
+            if tuple(t.shape) != tuple(e) + (eng.h, eng.w) or t.dtype != dt or not t.is_contiguous():
+                raise ValueError("target %s %s does not match the contract %s %s" % (tuple(t.shape), t.dtype, e, dt))
+        if eng.heads != [1, 14, 3, 2, 1, 360, 60, 60]:
+            raise ValueError("the fused loss is defined for heads [1,14,3,2,1,360,60,60] (train.py:47)")
+        d = L.LossDesc()
+        d.logits, d.dlogits, d.ldl = eng.logits.data_ptr(), eng.dlogits.data_ptr(), LDL
+        (d.t_atom, d.t_types, d.t_charges, d.t_hs, d.t_bond, d.t_btypes, d.t_rho, d.t_omega) = (t.data_ptr() for t in targets)
+        d.B, d.h, d.w = eng.B, eng.h, eng.w
+        for i in range(8):
+            d.head_off[i] = eng.head_off[i]
+        self.nblk = lib.abc_loss_blocks(C.byref(d))
+        self.partial = torch.zeros((self.nblk, 16), dtype=torch.float64, device=eng.logits.device)
+        d.partial = self.partial.data_ptr()
+        self.out = torch.zeros(17, dtype=torch.float64, device=eng.logits.device)
+        f = L.LossFinDesc()
+        f.partial, f.nblk, f.s, f.ds, f.out = self.partial.data_ptr(), self.nblk, s_ptr, ds_ptr, self.out.data_ptr()
+        f.chan_scale, f.ldl = eng.chan_scale.data_ptr(), LDL
+        for i in range(8):
+            f.head_off[i] = eng.head_off[i]
+            f.head_c[i] = eng.heads[i]
+        f.grad_scale = grad_scale
+        self.d, self.f = d, f
+
+    def run(self, stream):
+        L.check(self.lib.abc_loss_fwd_bwd(C.byref(self.d), stream), "loss_fwd_bwd")
+        L.check(self.lib.abc_loss_finalize(C.byref(self.f), stream), "loss_finalize")
+
+    def result(self):
+        """dict: total + weighted terms + raw terms (device sync)"""
+        o = self.out.cpu()
+        r = {"total": o[0].item()}
+        for i, n in enumerate(HEAD_NAMES):
+            r[n] = o[1 + i].item()
+            r["raw_" + n] = o[9 + i].item()
+        return r
+
+
+def nms_peaks(eng, logits):
+    """(atom_mask[B,1,h,w], bond_mask[B,1,h,w], |rho|[B,60,h,w], omega_mask[B,60,h,w]) as NCHW f32"""
+    B, h, w = eng.B, eng.h, eng.w
+    dev = logits.device
+    am = torch.empty((B, 1, h, w), dtype=torch.float32, device=dev)
+    bm = torch.empty((B, 1, h, w), dtype=torch.float32, device=dev)
+    rho = torch.empty((B, 60, h, w), dtype=torch.float32, device=dev)
+    om = torch.empty((B, 60, h, w), dtype=torch.float32, device=dev)
+    d = L.NmsDesc()
+    d.logits, d.ldl, d.B, d.h, d.w = logits.data_ptr(), logits.shape[-1], B, h, w
+    d.off_atom, d.off_bond, d.off_rho, d.off_omega, d.n_omega = eng.head_off[0], eng.head_off[4], eng.head_off[6], eng.head_off[7], 60
+    d.atom_mask, d.bond_mask, d.rho_abs, d.omega_mask = am.data_ptr(), bm.data_ptr(), rho.data_ptr(), om.data_ptr()
+    L.check(eng.lib.abc_nms_peaks(C.byref(d), torch.cuda.current_stream().cuda_stream), "nms_peaks")
+    return am, bm, rho, om
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr, weight_decay) over the flat arena as one kernel (train.py:55).  Re-create it to
+    reset the moments, as the reference does at the learning-rate drop (train.py:84-85)."""
+
+    def __init__(self, params, grads, lr=2.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8, grad_scale=1.0):
+        self.lib = L.load()
+        self.p, self.g = params, grads
+        self.m = torch.zeros_like(params)
+        self.v = torch.zeros_like(params)
+        self.step_t = torch.zeros(1, dtype=torch.int64, device=params.device)
+        d = L.AdamDesc()
+        d.p, d.g, d.m, d.v, d.n = params.data_ptr(), grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), params.numel()
+        d.step = self.step_t.data_ptr()
+        d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.grad_scale = lr, betas[0], betas[1], eps, weight_decay, grad_scale
+        self.d = d
+
+    def step(self, stream=None):
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        L.check(self.lib.abc_adam_step(C.byref(self.d), stream), "adam_step")

@@ -1,0 +1,144 @@
+"""Training-step harness: the hot loop of /root/reference/src/train.py:83-141 (and its DDP
+form, multi_gpu_train.py:72-119) on the HIP kernels.
+
+One step = pack weights -> forward -> fused activation+loss+dlogits -> backward ->
+(bucketed gradient all-reduce over RCCL, overlapped with backward) -> fused Adam.
+No host synchronisation inside the step; the loss value stays on the device until asked for.
+The static launch plan is replayed from hipGraphs: one graph per segment between two
+all-reduce launch points (a single graph when world size is 1).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import distributed as D
+from .ops import FusedAdam, FusedLoss
+
+
+class Trainer:
+    def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
+                 process_group=None, device=None):
+        if not torch.cuda.is_available():
+            raise L.AbcNetHipError("Trainer needs an MI355X; abcnet_amd has no CPU fallback")
+        self.model = model
+        dev = device or next(model.parameters()).device
+        self.dev = dev
+        model.train()
+        x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
+        self.eng = model._engine_for(x0, True)
+        eng = self.eng
+        self.world = torch.distributed.get_world_size(process_group) if torch.distributed.is_initialized() else 1
+        self.group = process_group
+        h, w = eng.h, eng.w
+        B = batch
+        shapes = [(B, 1, h, w), (B, 14, h, w), (B, 3, h, w), (B, 2, h, w), (B, 1, h, w), (B, 6, 60, h, w), (B, 60, h, w), (B, 60, h, w)]
+        dts = [torch.float32] * 6 + [torch.float64] * 2
+        self.targets = [torch.zeros(s, dtype=dt, device=dev) for s, dt in zip(shapes, dts)]
+        off_s, _ = model._lay_p["s"]
+        self.loss = FusedLoss(eng, self.targets, model._flat.data.data_ptr() + 4 * off_s, model._flat_grad.data_ptr() + 4 * off_s,
+                              grad_scale=1.0 / self.world)
+        self.lr, self.wd = lr, weight_decay
+        self.opt = FusedAdam(model._flat.data, model._flat_grad, lr=lr, weight_decay=weight_decay)
+        # ---- gradient buckets: which backward op finalises which parameter
+        names = list(model._lay_p.keys())
+        sizes = [model._lay_p[n][1] for n in names]
+        ready = {n: -1 for n in names}
+        for j, (_fn, _ref, _what, writes) in enumerate(eng.bwd_ops):
+            for n in writes:
+                ready[n] = max(ready[n], j)
+        self.buckets = D.plan_buckets([ready[n] for n in names], sizes, int(bucket_mb * (1 << 20) / 4))
+        self.reducer = D.GradReducer(model._flat_grad, self.buckets, process_group)
+        self.use_graph = use_graph
+        self._graphs = None
+        self._segments = self._plan_segments()
+        self.steps = 0
+
+    # ------------------------------------------------------------------ data
+    def load_batch(self, imgs, targets):
+        """copy a batch into the static input buffers (what a loader's H2D copy would target directly)"""
+        self.eng.img.copy_(imgs.reshape(self.eng.img.shape), non_blocking=True)
+        for dst, src in zip(self.targets, targets):
+            dst.copy_(src, non_blocking=True)
+
+    def reset_optimizer(self, lr):
+        """train.py:84-85: a NEW Adam (moments reset) at the learning-rate drop"""
+        self.lr = lr
+        self.opt = FusedAdam(self.model._flat.data, self.model._flat_grad, lr=lr, weight_decay=self.wd)
+        self._graphs = None
+
+    # ------------------------------------------------------------------ plan
+    def _plan_segments(self):
+        """list of segments; a segment = list of callables(stream); after segment k the buckets in
+        self._seg_buckets[k] are complete and their all-reduce is launched"""
+        eng = self.eng
+        pre = [eng.run_pack, eng.run_forward, self.loss.run]
+        cut = sorted(set(b[2] for b in self.buckets)) if self.world > 1 else []
+        segs, seg_b = [], []
+        cur = list(pre)
+        start = 0
+        ops = eng.bwd_ops
+        early = [b for b in self.buckets if b[2] < 0]
+        for c in [c for c in cut if c >= 0]:
+            chunk = ops[start:c + 1]
+            cur.append(lambda st, chunk=chunk: eng._run(chunk, st))
+            segs.append(cur)
+            seg_b.append([b for b in self.buckets if b[2] == c])
+            cur = []
+            start = c + 1
+        tail = ops[start:]
+        if tail:
+            cur.append(lambda st, chunk=tail: eng._run(chunk, st))
+        segs.append(cur)
+        seg_b.append([])
+        self._early = early
+        self._seg_buckets = seg_b
+        return segs
+
+    def _run_segment(self, k):
+        st = torch.cuda.current_stream().cuda_stream
+        for fn in self._segments[k]:
+            fn(st)
+
+    def _capture(self):
+        graphs = []
+        for k in range(len(self._segments)):
+            if not self._segments[k]:
+                graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_segment(k)
+            graphs.append(g)
+        gopt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gopt):
+            self.opt.step()
+        self._graphs = (graphs, gopt)
+
+    # ------------------------------------------------------------------ step
+    def step(self):
+        """one optimisation step on the batch currently in the static buffers"""
+        if self.use_graph and self._graphs is None and self.steps >= 1:
+            torch.cuda.synchronize()
+            self._capture()
+        graphs = self._graphs
+        for k in range(len(self._segments)):
+            if graphs is not None:
+                if graphs[0][k] is not None:
+                    graphs[0][k].replay()
+            else:
+                self._run_segment(k)
+            if k == 0:
+                for lo, hi, _ in self._early:
+                    self.reducer.bucket_ready(lo, hi)
+            for lo, hi, _ in self._seg_buckets[k]:
+                self.reducer.bucket_ready(lo, hi)
+        self.reducer.finish()
+        if graphs is not None:
+            graphs[1].replay()
+        else:
+            self.opt.step()
+        self.steps += 1
+
+    def loss_value(self):
+        return self.loss.result()

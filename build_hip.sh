@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libabcnet_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")/abc-net_amd/csrc"
+OUT=../libabcnet_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+[ -n "$ABC_RESOURCE_USAGE" ] && FLAGS="$FLAGS -Rpass-analysis=kernel-resource-usage"
+OBJS=""
+pids=""
+for f in conv_igemm wgrad bn_act loss misc; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.hpp -nt $f.o ] || [ ../../include/abcnet_hip.h -nt $f.o ]; then
+    hipcc $FLAGS -c $f.hip -o $f.o &
+    pids="$pids $!"
+  fi
+  OBJS="$OBJS $f.o"
+done
+for p in $pids; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+echo "built $(readlink -f $OUT)"

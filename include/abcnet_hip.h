@@ -1,0 +1,249 @@
+/* abcnet_hip.h -- C ABI of libabcnet_hip.so: the MI355X (gfx950) kernels behind
+ * ABC-Net's U-Net hot path.
+ *
+ * The reference (zhang-xuan1314/ABC-Net) has NO native interface: every FLOP of
+ * the path runs inside torch ops.  Each entry point
+ * below therefore names the reference *torch call site* it replaces (file:line
+ * under /root/reference).  The binding a maintainer adds is the ctypes stub in
+ * INTEGRATION.md; abc-net_amd/_lib.py is that stub in full.
+ *
+ * Conventions
+ *  - plain pointers and sizes only: device pointers are raw HBM addresses owned by
+ *    the caller (torch tensors stay owned by torch); nothing is retained past a call;
+ *  - every function enqueues on the given hipStream_t, never allocates, never
+ *    synchronises (graph-capture safe), and returns 0 on success or a negative
+ *    abc_status (abc_last_error() gives text); no exceptions cross the boundary;
+ *  - activations are NHWC with an explicit pixel stride (ld*, in elements) and a
+ *    channel offset, so concat buffers are written/read in place (unet.py:51-59);
+ *  - dtype codes: 0 = float32, 1 = bfloat16.  Accumulation is always float32.
+ *  - one host thread per GPU/process (mirrors mp.spawn, multi_gpu_train.py:36).
+ */
+#ifndef ABCNET_HIP_H
+#define ABCNET_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* abc_stream_t; /* hipStream_t */
+
+enum abc_status { ABC_OK = 0, ABC_EINVAL = -1, ABC_EUNSUPPORTED = -2, ABC_ELAUNCH = -3 };
+enum abc_dtype { ABC_F32 = 0, ABC_BF16 = 1 };
+#define ABC_MAX_TAPS_C 49
+
+/* A raw (pre-BatchNorm) activation tensor consumed through its BN affine +
+ * activation, optional 2x2 max-pool and optional dropout, all applied ON LOAD:
+ *   v = max(y, slope*y), y = scale[c]*x + shift[c]      (BN+ReLU: unet.py:13-17,
+ *                                                         BN+LeakyReLU: unet.py:67-68)
+ *   pool: max over the 2x2 window of v                   (nn.MaxPool2d(2): unet.py:30)
+ *   dropout: v * keep/(1-p)                              (nn.Dropout(0.2): unet.py:69)
+ * scale == NULL means identity.  Coefficient arrays are indexed by the absolute
+ * channel inside x (so a concat buffer carries one array for both halves). */
+typedef struct abc_act_src {
+    const void* x;
+    const float* scale;
+    const float* shift;
+    const float* slope;
+    int32_t Hx, Wx, ldx; /* physical dims / pixel stride of x */
+    int32_t pool;
+    float drop_p;
+    uint32_t drop_seed;
+} abc_act_src;
+
+/* Generic tap-list convolution as implicit GEMM on MFMA.  One descriptor covers
+ *   nn.Conv2d 3x3/5x5/1x1 forward   (unet.py:12,15,66,70; unet2.py:56,59,66)
+ *   its data gradient               (autograd of the same, train.py:140)
+ *   nn.ConvTranspose2d(k3,s2) forward as 4 output-parity phases, written straight
+ *   into the concat buffer with the crop of unet.py:51-57 folded in (unet.py:44)
+ *   and its data gradient (stride-2 gather).
+ * out[b, g*om+o0, cout_off+n] = bias[n] + sum_t sum_c  W[t][c][n] * in[b, g*stride + d_t, cin_off+c]
+ * Weights are pre-packed by abc_pack_conv_weights as [tap][Cin/CK][Cout_pad][CK]. */
+typedef struct abc_conv_desc {
+    abc_act_src src;
+    const void* w;
+    const float* bias; /* [Cout] or NULL */
+    void* y;
+    float* stats;      /* NULL, or per-block partial (sum, sumsq) [nblk][2][Cout] of the f32 outputs */
+    int32_t dtype_in, dtype_c, dtype_out;
+    int32_t B, Hin, Win; /* logical input dims (after the optional pool) */
+    int32_t cin_off, Cin; /* real channel count; padded to the K-chunk (16, or 32 for bf16 when Cin%32==0)
+                             with zeros on load, so the 1-channel image (unet.py:83) goes through here too */
+    int32_t Hg, Wg;       /* output grid iterated by the kernel */
+    int32_t Hout, Wout, ldy, cout_off, Cout, Cout_pad;
+    int32_t stride, om, oy0, ox0;
+    int32_t ntaps;
+    int8_t tap_dy[ABC_MAX_TAPS_C];
+    int8_t tap_dx[ABC_MAX_TAPS_C];
+} abc_conv_desc;
+
+/* number of per-block stat partials abc_conv_fwd writes for this descriptor */
+int abc_conv_stat_blocks(const abc_conv_desc* d);
+int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream);
+
+/* channels per K-chunk used by the packed weight layout for (compute dtype, Cin) */
+int abc_conv_chunk(int dtype_c, int Cin);
+
+/* Repack master f32 weights into the layout abc_conv_fwd / abc_wgrad consume.
+ *   mode 0: Conv2d weight [Cout][Cin][kh][kw] -> forward packing   (taps = kh*kw)
+ *   mode 1: Conv2d weight -> data-gradient packing (roles of Cin/Cout swapped, taps mirrored)
+ *   mode 2: ConvTranspose2d weight [Cin][Cout][3][3] -> one forward parity phase (py,px)
+ *   mode 3: ConvTranspose2d weight -> data-gradient packing (stride-2 gather, 9 taps)
+ * Rows beyond the real channel counts are zero.  dst element type = dtype_c. */
+typedef struct abc_pack_desc {
+    const float* w; void* dst;
+    int32_t mode, dtype_c, Cout, Cin, kh, kw, py, px;
+    int32_t rows_pad;  /* padded row count of dst (Cout_pad of the consuming conv) */
+    int32_t red_pad;   /* padded reduction-channel count of THIS weight (multiple of CK) */
+    int32_t red_total; /* reduction-channel count of the whole dst (>= red_off + red_pad): several weights
+                          may be packed side by side along the reduction axis (the 8 heads' conv1 data
+                          gradient is ONE conv over the concatenated 8x128 channels) */
+    int32_t red_off;   /* where this weight's reduction channels start in dst (multiple of CK) */
+    int32_t ck;        /* K-chunk of dst: abc_conv_chunk(dtype_c, red_total) */
+} abc_pack_desc;
+int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream);
+
+/* BatchNorm2d, training mode (unet.py:13,16,67): reduce the conv's stat partials
+ * in f64, write the on-load coefficients (scale, shift) for consumers, keep
+ * (mean, invstd) for backward, update running stats with momentum 0.1 / unbiased
+ * variance and bump num_batches_tracked. */
+typedef struct abc_bn_fwd_desc {
+    const float* partial; int32_t nblk; int32_t C; double count;
+    const float* gamma; const float* beta;
+    float* scale; float* shift; float* mean; float* invstd;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    float eps, momentum;
+} abc_bn_fwd_desc;
+int abc_bn_finalize_fwd(const abc_bn_fwd_desc* d, abc_stream_t stream);
+/* eval mode: coefficients from running stats (model.eval(): img2smiles2.py:49) */
+int abc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float* scale, float* shift, int32_t C, float eps, abc_stream_t stream);
+
+/* Backward of [BN -> act -> (dropout) -> (maxpool)] in two passes (autograd of
+ * unet.py:13-17,30,67-69):
+ *   pass 1 (abc_act_bwd): G = (dA_same + unpool(dA_pooled)) * act'(y) * dropout;
+ *           per-block partials of sum(G), sum(G*xhat)
+ *   abc_bn_finalize_bwd: dgamma, dbeta (into the gradient arena) and k1=mean(G), k2=mean(G*xhat)
+ *   pass 2 (abc_bn_apply_bwd): dY = gamma*invstd*(G - k1 - xhat*k2)   (in place on G) */
+typedef struct abc_act_bwd_desc {
+    const void* y_raw; int32_t ld_y;        /* raw conv output [B,H,W,*] */
+    const void* dA_same; int32_t ld_same;   /* grad wrt activated tensor at full res, or NULL */
+    const void* dA_pool; int32_t ld_pool;   /* grad wrt pooled activated tensor [B,H/2,W/2,*], or NULL */
+    void* g; int32_t ld_g;                  /* out [B,H,W,C] */
+    float* partial;                         /* [nblk][2][C] */
+    const float* scale; const float* shift; const float* slope; const float* mean; const float* invstd;
+    int32_t dtype, B, H, W, C, cy_off, csame_off, cpool_off;
+    float drop_p; uint32_t drop_seed; int32_t drop_ld; /* dropout index = pixel*drop_ld + cy_off + c */
+} abc_act_bwd_desc;
+int abc_act_bwd_blocks(const abc_act_bwd_desc* d);
+int abc_act_bwd(const abc_act_bwd_desc* d, abc_stream_t stream);
+typedef struct abc_bn_bwd_desc {
+    const float* partial; int32_t nblk; int32_t C; double count;
+    const float* gamma; const float* invstd;
+    float* dgamma; float* dbeta; float* k1; float* k2; float* gscale; /* gscale = gamma*invstd */
+} abc_bn_bwd_desc;
+int abc_bn_finalize_bwd(const abc_bn_bwd_desc* d, abc_stream_t stream);
+typedef struct abc_bn_apply_desc {
+    void* g; int32_t ld_g; const void* y_raw; int32_t ld_y; int32_t cy_off;
+    const float* mean; const float* invstd; const float* k1; const float* k2; const float* gscale;
+    int32_t dtype, C; int64_t npix;
+} abc_bn_apply_desc;
+int abc_bn_apply_bwd(const abc_bn_apply_desc* d, abc_stream_t stream);
+
+/* Weight gradient of a tap-list convolution (autograd of unet.py:12,15,44,66,70):
+ *   dW[t][a][b] = sum_p P[p][a] * Q[stride*p + d_t][b]
+ * regular conv: P = dY (a = cout), Q = activated input (b = cin), stride 1
+ * transposed conv: P = activated input (a = cin), Q = dOut (b = cout), stride 2
+ * Two stages: split-K partial slabs, then abc_wgrad_reduce sums the slabs and
+ * writes the reference layout [a][b][taps] into the f32 gradient arena. */
+typedef struct abc_wgrad_desc {
+    abc_act_src p;  /* un-shifted operand */
+    abc_act_src q;  /* shifted operand (halo) */
+    float* partial; /* [nsplit][ntaps][Ca_pad][Cb_pad] */
+    int32_t dtype_p, dtype_q, dtype_c;
+    int32_t B, Hg, Wg;  /* grid of p */
+    int32_t Hq, Wq;     /* logical dims of q */
+    int32_t cp_off, Ca, cq_off, Cb;
+    int32_t stride, ntaps, nsplit;
+    int8_t tap_dy[ABC_MAX_TAPS_C];
+    int8_t tap_dx[ABC_MAX_TAPS_C];
+} abc_wgrad_desc;
+int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad);
+int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream);
+typedef struct abc_wgrad_reduce_desc {
+    const float* partial; int32_t nsplit, ntaps, Ca, Cb, Ca_pad, Cb_pad;
+    float* dw;    /* [Ca][Cb][ntaps] */
+    int32_t accumulate; /* 1: add to dw instead of overwrite */
+} abc_wgrad_reduce_desc;
+int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream);
+
+/* Per-channel column sums of an NHWC tensor (bias gradients of convs that do not
+ * feed a BN: unet.py:44 up.bias, unet.py:70 conv2.bias), optional per-channel scale. */
+int abc_colsum_blocks(int64_t npix);
+int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C,
+               const float* chan_scale, float* work /* [abc_colsum_blocks(npix)][C] */, float* out, abc_stream_t stream);
+
+/* Fused activation + loss + dlogits (train.py:95-137).  Logits and dlogits are
+ * NHWC f32 [B,h,w,ldl] with the 8 heads at channel offsets head_off[i];
+ * targets are the reference's NCHW tensors (utils.py:254-300), rho/omega f64.
+ * Writes the UNNORMALISED per-term gradient d(numerator_i)/d(logit) and per-block
+ * partials of the 8 numerators + 8 denominators; abc_loss_finalize reduces them,
+ * forms the 8 terms, the uncertainty weighting with s (train.py:127-135), the
+ * total, ds, and the per-channel factor chan_scale[c] = weight_i/denominator_i that
+ * the heads' backward applies on load. */
+typedef struct abc_loss_desc {
+    const float* logits; float* dlogits; int32_t ldl;
+    const float* t_atom; const float* t_types; const float* t_charges; const float* t_hs; const float* t_bond;
+    const float* t_btypes; const double* t_rho; const double* t_omega;
+    int32_t B, h, w;
+    int32_t head_off[8];
+    double* partial; /* [nblk][16] */
+} abc_loss_desc;
+int abc_loss_blocks(const abc_loss_desc* d);
+int abc_loss_fwd_bwd(const abc_loss_desc* d, abc_stream_t stream);
+typedef struct abc_loss_fin_desc {
+    const double* partial; int32_t nblk;
+    const float* s; float* ds;         /* [10] */
+    double* out;                       /* [0]=total, [1+i]=weighted term of head i, [9+i]=raw term of head i
+                                          (head order of unet.forward: atom_t, types, charges, hs, bond_t, btypes, rho, omega) */
+    float* chan_scale; int32_t ldl;    /* [ldl] */
+    int32_t head_off[8]; int32_t head_c[8];
+    float grad_scale;                  /* multiplies dlogits scale (1/world for DDP mean) */
+} abc_loss_fin_desc;
+int abc_loss_finalize(const abc_loss_fin_desc* d, abc_stream_t stream);
+
+/* torch.optim.Adam step over a flat f32 arena (train.py:55,141): L2 decay into the
+ * gradient, bias correction from the device-side step counter. */
+typedef struct abc_adam_desc {
+    float* p; const float* g; float* m; float* v; int64_t n;
+    int64_t* step; /* device scalar, incremented by the kernel */
+    float lr, beta1, beta2, eps, weight_decay, grad_scale;
+} abc_adam_desc;
+int abc_adam_step(const abc_adam_desc* d, abc_stream_t stream);
+
+/* Inference NMS (img2smiles2.py:61-79) on NHWC f32 logits: atom/bond 3x3 peak
+ * masks, |rho|, circular 3-tap omega peak mask; outputs NCHW f32 like the reference. */
+typedef struct abc_nms_desc {
+    const float* logits; int32_t ldl; int32_t B, h, w;
+    int32_t off_atom, off_bond, off_rho, off_omega, n_omega;
+    float* atom_mask; float* bond_mask; float* rho_abs; float* omega_mask;
+} abc_nms_desc;
+int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream);
+
+/* layout conversion at the drop-in boundary (forward() returns NCHW f32 maps: unet.py:119) */
+int abc_nhwc_to_nchw_f32(const float* src, int32_t ld, int32_t c_off, int32_t C, int32_t B, int32_t H, int32_t W,
+                         float* dst, abc_stream_t stream);
+int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int32_t W, float* dst, int32_t ld,
+                         int32_t c_off, abc_stream_t stream);
+int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream);
+
+/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12):
+ * lets a foreign-language binding check its mirror structs at load time */
+int abc_sizeof(int which);
+const char* abc_last_error(void);
+int abc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,274 @@
+"""GPU parity tests, kernel level: every HIP kernel of the path against plain torch-CPU fp32
+ops of the same arithmetic (the same ATen ops the reference model dispatches), through the
+C ABI.  Tolerances: fp32 mode 1e-4 relative-to-max (exact-f32 MFMA, different summation
+order only); bf16 mode 3e-2 (operands rounded to 8 significant bits)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import abcnet_amd  # noqa: E402,F401
+from abcnet_amd import _lib as L  # noqa: E402
+from abcnet_amd.engine import TAPS_CONVT_DGRAD, convT_phase_taps, taps_mirror, taps_square  # noqa: E402
+
+import hiputil as U  # noqa: E402
+
+DTS = [L.F32, L.BF16]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return L.load()
+
+
+def q(x, dt):
+    """round a CPU f32 tensor to the storage dtype (so that the reference sees what the kernel sees)"""
+    return x.to(U.tdt(dt)).float()
+
+
+def act(x, sc, sh, sl):
+    y = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    return torch.maximum(y, sl.view(1, -1, 1, 1) * y)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [
+    dict(Cin=16, Cout=16, k=3, H=24, W=40),
+    dict(Cin=32, Cout=64, k=3, H=32, W=32, pool=True),
+    dict(Cin=64, Cout=128, k=3, H=16, W=16, coef=True),
+    dict(Cin=1, Cout=16, k=3, H=40, W=24, img=True),
+    dict(Cin=128, Cout=14, k=1, H=16, W=16, coef=True, f32out=True),
+    dict(Cin=32, Cout=32, k=5, H=24, W=24, coef=True),
+    dict(Cin=256, Cout=96, k=3, H=8, W=8),
+])
+def test_conv_forward(lib, dt, case):
+    g = torch.Generator().manual_seed(3)
+    B, Cin, Cout, k, H, W = 2, case["Cin"], case["Cout"], case["k"], case["H"], case["W"]
+    pool = case.get("pool", False)
+    img = case.get("img", False)
+    dt_in = L.F32 if img else dt
+    x = torch.randn((B, Cin, H, W), generator=g)
+    x = x if img else q(x, dt)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    coef = None
+    xin = x
+    if case.get("coef") or pool:
+        sc = torch.rand(Cin, generator=g) * 2 - 0.6
+        sh = torch.randn(Cin, generator=g) * 0.3
+        sl = torch.tensor([0.0, 0.01, 1.0])[torch.randint(0, 3, (Cin,), generator=g)]
+        coef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
+        xin = act(x, sc, sh, sl)
+    if pool:
+        xin = F.max_pool2d(xin, 2)
+    Ho, Wo = xin.shape[2:]
+    ref = F.conv2d(q(xin, dt), q(w, dt), b, padding=(k - 1) // 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(U.tdt(dt_in)).to(U.DEV)
+    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, k, -(-Cout // 32) * 32, Cin)
+    out_dt = L.F32 if case.get("f32out") else dt
+    y, st = U.conv(lib, xd, dt_in, dt, B, H, W, Cin, 0, Cin, wp, b.to(U.DEV), Cout, taps_square(k), Ho, Wo, coef=coef, pool=pool,
+                   out_dt=out_dt, stats=True)
+    torch.cuda.synchronize()
+    got = U.to_nchw(y)
+    assert U.relerr(got, ref) < U.tol(dt), U.relerr(got, ref)
+    # BatchNorm partial statistics of the f32 conv outputs
+    s = st.double().sum(0).cpu()
+    n = B * Ho * Wo
+    np.testing.assert_allclose(s[0] / n, ref.double().mean((0, 2, 3)), atol=U.tol(dt, 1e-4, 2e-2))
+    np.testing.assert_allclose(s[1] / n, (ref.double() ** 2).mean((0, 2, 3)), rtol=U.tol(dt, 1e-4, 3e-2), atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_transpose_into_concat(lib, dt):
+    """4 parity phases == ConvTranspose2d(k3,s2) + crop of first row/col, written at a channel offset"""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, n = 2, 64, 12
+    half = Cin // 2
+    x = q(torch.randn((B, Cin, n, n), generator=g), dt)
+    w = torch.randn((Cin, half, 3, 3), generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(half, generator=g)
+    ref = F.conv_transpose2d(x, q(w, dt), b, stride=2)[:, :, 1:, 1:]
+    cat = torch.full((B, 2 * n, 2 * n, Cin), 7.0, dtype=U.tdt(dt), device=U.DEV)
+    xd = U.nhwc(x, dt)
+    for py in (0, 1):
+        for px in (0, 1):
+            wp = U.pack(lib, w.to(U.DEV), 2, dt, half, Cin, 3, half, Cin, py=py, px=px)
+            U.conv(lib, xd, dt, dt, B, n, n, Cin, 0, Cin, wp, b.to(U.DEV), half, convT_phase_taps(py, px), 2 * n, 2 * n, ldy=Cin,
+                   cout_off=half, grid=(n, n), om=2, oy0=py, ox0=px, out=cat)
+    torch.cuda.synchronize()
+    got = U.to_nchw(cat)
+    assert U.relerr(got[:, half:], ref) < U.tol(dt)
+    assert torch.all(got[:, :half] == 7.0)  # the skip half is untouched
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [dict(Cin=32, Cout=64, k=3), dict(Cin=16, Cout=16, k=3), dict(Cin=64, Cout=8, k=1),
+                                  dict(Cin=32, Cout=32, k=5)])
+def test_conv_dgrad(lib, dt, case):
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Cin, Cout, k = 2, 16, 24, case["Cin"], case["Cout"], case["k"]
+    x = torch.randn((B, Cin, H, W), generator=g, requires_grad=True)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    dy = q(torch.randn((B, Cout, H, W), generator=g), dt)
+    F.conv2d(x, q(w, dt), None, padding=(k - 1) // 2).backward(dy)
+    wd = U.pack(lib, w.to(U.DEV), 1, dt, Cout, Cin, k, -(-Cin // 32) * 32, Cout)
+    dx, _ = U.conv(lib, U.nhwc(dy, dt), dt, dt, B, H, W, Cout, 0, Cout, wd, None, Cin, taps_mirror(taps_square(k)), H, W)
+    torch.cuda.synchronize()
+    assert U.relerr(U.to_nchw(dx), x.grad) < U.tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_conv_transpose_dgrad_wgrad(lib, dt):
+    g = torch.Generator().manual_seed(9)
+    B, Cin, n = 2, 64, 12
+    half = Cin // 2
+    x = q(torch.randn((B, Cin, n, n), generator=g), dt).requires_grad_(True)
+    w = q(torch.randn((Cin, half, 3, 3), generator=g) / (Cin * 9) ** 0.5, dt).requires_grad_(True)
+    dout = q(torch.randn((B, half, 2 * n, 2 * n), generator=g), dt)
+    F.conv_transpose2d(x, w, None, stride=2)[:, :, 1:, 1:].backward(dout)
+    # gradient arrives inside a concat-gradient buffer at channel offset `half`
+    dcat = torch.zeros((B, 2 * n, 2 * n, Cin), dtype=U.tdt(dt), device=U.DEV)
+    dcat[..., half:] = U.nhwc(dout, dt)
+    wd = U.pack(lib, w.detach().to(U.DEV), 3, dt, half, Cin, 3, Cin, half)
+    dx, _ = U.conv(lib, dcat, dt, dt, B, 2 * n, 2 * n, Cin, half, half, wd, None, Cin, TAPS_CONVT_DGRAD, n, n, stride=2)
+    dw = U.wgrad(lib, U.nhwc(x.detach(), dt), dt, n, n, Cin, 0, Cin, None, dcat, dt, 2 * n, 2 * n, Cin, half, half, None, False, dt, B,
+                 TAPS_CONVT_DGRAD, stride=2)
+    torch.cuda.synchronize()
+    assert U.relerr(U.to_nchw(dx), x.grad) < U.tol(dt)
+    assert U.relerr(dw.cpu().view(Cin, half, 3, 3), w.grad) < U.tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [dict(Cin=64, Cout=128, k=3), dict(Cin=16, Cout=16, k=3), dict(Cin=32, Cout=64, k=3, pool=True),
+                                  dict(Cin=1, Cout=16, k=3, img=True), dict(Cin=128, Cout=14, k=1, f32dy=True),
+                                  dict(Cin=32, Cout=32, k=5)])
+def test_conv_wgrad(lib, dt, case):
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout, k = 2, 24, 40, case["Cin"], case["Cout"], case["k"]
+    pool, img = case.get("pool", False), case.get("img", False)
+    Hx, Wx = (2 * H, 2 * W) if pool else (H, W)
+    dt_q = L.F32 if img else dt
+    x = torch.randn((B, Cin, Hx, Wx), generator=g)
+    x = x if img else q(x, dt)
+    sc = torch.rand(Cin, generator=g) * 2 - 0.6
+    sh = torch.randn(Cin, generator=g) * 0.3
+    sl = torch.tensor([0.0, 0.01, 1.0])[torch.randint(0, 3, (Cin,), generator=g)]
+    coef = None if img else tuple(t.to(U.DEV) for t in (sc, sh, sl))
+    a = x if img else act(x, sc, sh, sl)
+    if pool:
+        a = F.max_pool2d(a, 2)
+    w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    dt_p = L.F32 if case.get("f32dy") else dt
+    dy = torch.randn((B, Cout, H, W), generator=g)
+    dy = dy if case.get("f32dy") else q(dy, dt)
+    F.conv2d(q(a, dt), w, None, padding=(k - 1) // 2).backward(q(dy, dt))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(U.tdt(dt_q)).to(U.DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(U.tdt(dt_p)).to(U.DEV)
+    dw = U.wgrad(lib, dyd, dt_p, H, W, Cout, 0, Cout, None, xd, dt_q, Hx, Wx, Cin, 0, Cin, coef, pool, dt, B, taps_square(k))
+    torch.cuda.synchronize()
+    assert U.relerr(dw.cpu().view(Cout, Cin, k, k), w.grad) < U.tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("pooled,same", [(False, True), (True, False), (True, True)])
+def test_bn_act_pool_backward(lib, dt, pooled, same):
+    """conv stats -> BN finalize (fwd), then act_bwd + bn_finalize_bwd + bn_apply_bwd == autograd of
+    batch_norm(train) -> relu/leaky -> (maxpool) with up to two gradient sources"""
+    g = torch.Generator().manual_seed(13)
+    B, Cc, H, W = 2, 32, 16, 24
+    y = q(torch.randn((B, Cc, H, W), generator=g) * 1.5 + 0.3, dt).requires_grad_(True)
+    gamma = (torch.rand(Cc, generator=g) * 2 - 0.5).requires_grad_(True)
+    beta = (torch.randn(Cc, generator=g) * 0.3).requires_grad_(True)
+    slope = 0.01
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    z = F.leaky_relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5), slope)
+    loss = 0
+    d_same = q(torch.randn((B, Cc, H, W), generator=g), dt)
+    d_pool = q(torch.randn((B, Cc, H // 2, W // 2), generator=g), dt)
+    if same:
+        loss = loss + (z * d_same).sum()
+    if pooled:
+        loss = loss + (F.max_pool2d(z, 2) * d_pool).sum()
+    loss.backward()
+    # ---- device: statistics straight from y (as the conv epilogue would deliver them)
+    yd = U.nhwc(y.detach(), dt)
+    yf = y.detach().double()
+    part = torch.stack([yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))]).float().view(1, 2, Cc).to(U.DEV)
+    f32 = lambda n, v=0.0: torch.full((n,), v, dtype=torch.float32, device=U.DEV)
+    scale, shift, mean, invstd, rmd, rvd = f32(Cc), f32(Cc), f32(Cc), f32(Cc), f32(Cc), f32(Cc, 1.0)
+    nbt = torch.zeros(1, dtype=torch.int64, device=U.DEV)
+    gd, bd = gamma.detach().to(U.DEV), beta.detach().to(U.DEV)
+    d = L.BnFwdDesc()
+    d.partial, d.nblk, d.C, d.count = part.data_ptr(), 1, Cc, float(B * H * W)
+    d.gamma, d.beta, d.scale, d.shift, d.mean, d.invstd = (t.data_ptr() for t in (gd, bd, scale, shift, mean, invstd))
+    d.running_mean, d.running_var, d.num_batches_tracked, d.eps, d.momentum = rmd.data_ptr(), rvd.data_ptr(), nbt.data_ptr(), 1e-5, 0.1
+    L.check(lib.abc_bn_finalize_fwd(C.byref(d), U.stream()), "bn_fwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(rmd.cpu(), rm, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu(), rv, rtol=1e-5, atol=1e-6)
+    assert nbt.item() == 1
+    slopes = f32(Cc, slope)
+    a = L.ActBwdDesc()
+    gbuf = torch.zeros((B, H, W, Cc), dtype=U.tdt(dt), device=U.DEV)
+    a.y_raw, a.ld_y, a.g, a.ld_g = yd.data_ptr(), Cc, gbuf.data_ptr(), Cc
+    ds_d, dp_d = U.nhwc(d_same, dt), U.nhwc(d_pool, dt)
+    if same:
+        a.dA_same, a.ld_same = ds_d.data_ptr(), Cc
+    if pooled:
+        a.dA_pool, a.ld_pool = dp_d.data_ptr(), Cc
+    a.scale, a.shift, a.slope, a.mean, a.invstd = (t.data_ptr() for t in (scale, shift, slopes, mean, invstd))
+    a.dtype, a.B, a.H, a.W, a.C = dt, B, H, W, Cc
+    nblk = lib.abc_act_bwd_blocks(C.byref(a))
+    p2 = torch.zeros((nblk, 2, Cc), dtype=torch.float32, device=U.DEV)
+    a.partial = p2.data_ptr()
+    L.check(lib.abc_act_bwd(C.byref(a), U.stream()), "act_bwd")
+    dgam, dbet, k1, k2, gs = f32(Cc), f32(Cc), f32(Cc), f32(Cc), f32(Cc)
+    f = L.BnBwdDesc()
+    f.partial, f.nblk, f.C, f.count, f.gamma, f.invstd = p2.data_ptr(), nblk, Cc, float(B * H * W), gd.data_ptr(), invstd.data_ptr()
+    f.dgamma, f.dbeta, f.k1, f.k2, f.gscale = (t.data_ptr() for t in (dgam, dbet, k1, k2, gs))
+    L.check(lib.abc_bn_finalize_bwd(C.byref(f), U.stream()), "bn_bwd")
+    ap = L.BnApplyDesc()
+    ap.g, ap.ld_g, ap.y_raw, ap.ld_y = gbuf.data_ptr(), Cc, yd.data_ptr(), Cc
+    ap.mean, ap.invstd, ap.k1, ap.k2, ap.gscale = (t.data_ptr() for t in (mean, invstd, k1, k2, gs))
+    ap.dtype, ap.C, ap.npix = dt, Cc, B * H * W
+    L.check(lib.abc_bn_apply_bwd(C.byref(ap), U.stream()), "bn_apply")
+    torch.cuda.synchronize()
+    t = U.tol(dt, 1e-4, 3e-2)
+    assert U.relerr(dgam.cpu(), gamma.grad) < t
+    assert U.relerr(dbet.cpu(), beta.grad) < t
+    assert U.relerr(U.to_nchw(gbuf), y.grad) < t
+
+
+def test_adam_matches_oracle(lib, golden_dir):
+    from oracle import adam_oracle
+    from abcnet_amd.ops import FusedAdam
+    gold = np.load(golden_dir + "/adam.npz")
+    p = torch.from_numpy(gold["p0"].copy()).to(U.DEV)
+    gr = torch.zeros_like(p)
+    opt = FusedAdam(p, gr)
+    pc, m, v = torch.from_numpy(gold["p0"].copy()), torch.zeros(p.numel()), torch.zeros(p.numel())
+    for it in range(3):
+        gr.copy_(torch.from_numpy(gold["g%d" % it]))
+        opt.step()
+        adam_oracle.adam_step(pc, torch.from_numpy(gold["g%d" % it]), m, v, it + 1)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p.cpu().numpy(), gold["p%d" % (it + 1)], rtol=2e-6, atol=2e-7)  # torch.optim.Adam
+        np.testing.assert_allclose(p.cpu().numpy(), pc.numpy(), rtol=2e-6, atol=2e-7)              # oracle
+
+
+def test_layout_roundtrip(lib):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((3, 37, 9, 11), generator=g)
+    xd = x.to(U.DEV)
+    nh = torch.zeros((3, 9, 11, 64), dtype=torch.float32, device=U.DEV)
+    L.check(lib.abc_nchw_to_nhwc_f32(xd.data_ptr(), 37, 3, 9, 11, nh.data_ptr(), 64, 5, U.stream()), "to_nhwc")
+    back = torch.zeros_like(xd)
+    L.check(lib.abc_nhwc_to_nchw_f32(nh.data_ptr(), 64, 5, 37, 3, 9, 11, back.data_ptr(), U.stream()), "to_nchw")
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), x)
+    assert torch.equal(nh[..., 5:42].cpu(), x.permute(0, 2, 3, 1))
