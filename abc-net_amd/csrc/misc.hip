@@ -29,7 +29,7 @@ namespace {
 template <typename CT>
 __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunks) {
     // nchunks = chunks of THIS weight; it lands at chunk offset red_off/CK of a dst with red_total/CK chunks
-    const int nch_total = d.red_total / CK, ch_off = d.red_off / CK;
+    const int nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
     const int64_t total = (int64_t)ntaps * nchunks * d.rows_pad * CK;
     CT* dst = (CT*)d.dst;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
