@@ -83,25 +83,31 @@ def test_forward_bf16_bound():
         assert worst < bound, (mode, worst)
 
 
-def _oracle_grads(x, targets, dropout_masks=None):
-    sd = uo.clone_state(uo.filled_state("unet", 1, HEADS, seed=0), requires_grad=True)
-    preds = uo.forward("unet", sd, x, train=True, dropout_masks=dropout_masks)
-    total, weighted, terms = loss_oracle.abc_loss(preds, targets, sd["s"])
+def _oracle_grads(x, targets, dropout_masks=None, dtype=torch.float32):
+    sd0 = uo.filled_state("unet", 1, HEADS, seed=0)
+    sd = uo.clone_state({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd0.items()}, requires_grad=True)
+    dm = None if dropout_masks is None else [m.to(dtype) for m in dropout_masks]
+    preds = uo.forward("unet", sd, x.to(dtype), train=True, dropout_masks=dm)
+    total, weighted, terms = loss_oracle.abc_loss(preds, [t.to(dtype) for t in targets], sd["s"])
     total.backward()
     return sd, total, weighted, preds
 
 
-def _check_grads(get_grad, sd, rtol):
+def _check_grads(get_grad, sd32, sd64):
+    """Gradient parity bar.  ReLU / max-pool decisions flip on 1e-7 perturbations, so the reference's OWN
+    fp32 gradients differ from its fp64 gradients by up to ~1e-2 (relative L2) in the earliest layers
+    (measured: 4e-3..1.5e-2 at inc1/inc2, 1e-6 at the heads).  The HIP fp32 path is therefore held to
+        ||g_hip - g_f64|| <= 2.5 * ||g_cpu32 - g_f64|| + 1e-3 * ||g_f64||      per parameter."""
     bad = []
-    for name, t in sd.items():
+    for name, t in sd64.items():
         if t.grad is None or name.endswith(PRE_BN_BIAS):
             continue
         ref = t.grad.double()
+        floor = (sd32[name].grad.double() - ref).norm().item()
         got = get_grad(name).double().cpu()
-        den = ref.norm().item() + 1e-12
-        e = (got - ref).norm().item() / den
-        if not e < rtol:
-            bad.append((name, e))
+        e = (got - ref).norm().item()
+        if not e <= 2.5 * floor + 1e-3 * ref.norm().item():
+            bad.append((name, e / (ref.norm().item() + 1e-30), floor / (ref.norm().item() + 1e-30)))
     assert not bad, bad[:8]
 
 
@@ -111,6 +117,7 @@ def test_compat_path_autograd_matches_oracle():
     x = synthetic_images(B, S, seed=7)
     tg = synthetic_targets(B, S // 4, seed=1)
     sd, total, _, _ = _oracle_grads(x, tg)
+    sd64 = _oracle_grads(x, tg, dtype=torch.float64)[0]
     m = make_model()
     m.train()
     preds = m(x.to(DEV))
@@ -123,7 +130,7 @@ def test_compat_path_autograd_matches_oracle():
         off, n = m._lay_p[name]
         return flat[off:off + n].view(sd[name].shape)
 
-    _check_grads(get, sd, 3e-3)
+    _check_grads(get, sd, sd64)
 
 
 def test_fused_train_step_matches_oracle():
@@ -138,6 +145,7 @@ def test_fused_train_step_matches_oracle():
     tr = Trainer(m, B, S, S, use_graph=False)
     masks = head_keep_masks(B, S // 4, S // 4, 8, tr.eng.drop_seed, 0.2)
     sd, total, weighted, _ = _oracle_grads(x, tg, dropout_masks=masks)
+    sd64 = _oracle_grads(x, tg, dropout_masks=masks, dtype=torch.float64)[0]
     p0 = m._flat.data.clone()
     tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
     tr.step()
@@ -147,7 +155,7 @@ def test_fused_train_step_matches_oracle():
     for k_or, k_us in (("atom_t", "atom_t"), ("bond_t", "bond_t"), ("atom_types", "atom_types"), ("atom_charges", "atom_charges"),
                        ("bond_types", "bond_types"), ("bond_rhos", "bond_rhos"), ("bond_omega", "bond_omega"), ("atom_hs", "atom_hs")):
         assert abs(res[k_us] - weighted[k_or].item()) < 5e-4 * abs(weighted[k_or].item()) + 1e-6, k_or
-    _check_grads(lambda n: m.grad_of(n), sd, 3e-3)
+    _check_grads(lambda n: m.grad_of(n), sd, sd64)
     # one Adam step from the ORACLE gradients must land where the fused optimiser landed
     worst = 0.0
     for name, t in sd.items():
