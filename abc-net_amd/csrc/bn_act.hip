@@ -222,22 +222,45 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const abc_bn_apply_desc d
 }
 
 // ------------------------------------------------------------------ column sums
+// 256 threads = PL pixel lanes x CW channel lanes (CW = power of two <= 64 covering C or a slice of it);
+// a thread keeps up to 8 channel accumulators (C <= 8*CW = 512), block-level LDS reduce over the pixel lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, int64_t npix, int ld, int c_off, int C, const float* cs,
-                                                      float* work) {
-    // thread t handles channels t, t+256, ... ; pixels strided over blocks
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int64_t p = blockIdx.x; p < npix; p += gridDim.x) s += (float)x[p * ld + c_off + c];
-        work[(size_t)blockIdx.x * C + c] = s * (cs ? cs[c_off + c] : 1.f);
+                                                      float* work, int CW) {
+    __shared__ float red[256];
+    const int PL = 256 / CW;
+    const int cl = threadIdx.x % CW, pl = threadIdx.x / CW;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
+        const T* row = x + p * ld + c_off;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cl + j * CW;
+            if (c < C) acc[j] += (float)row[c];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cl + j * CW;
+        __syncthreads();
+        red[threadIdx.x] = acc[j];
+        __syncthreads();
+        if (pl == 0 && c < C) {
+            float s = 0.f;
+            for (int q = 0; q < PL; ++q) s += red[q * CW + cl];
+            work[(size_t)blockIdx.x * C + c] = s * (cs ? cs[c_off + c] : 1.f);
+        }
     }
 }
-__global__ void colsum_reduce_kernel(const float* work, int nblk, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* work, int nblk, int C, float* out) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += (double)work[(size_t)k * C + c];
-    out[c] = (float)s;
+    for (int k = threadIdx.x; k < nblk; k += 256) s += (double)work[(size_t)k * C + c];
+    s = block_sum_f64(s, sm);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 __global__ void fill_kernel(float* p, float v, int64_t n) {
@@ -340,17 +363,23 @@ extern "C" int abc_bn_apply_bwd(const abc_bn_apply_desc* d, abc_stream_t stream)
     return abc_check_launch("bn_apply_bwd");
 }
 
-extern "C" int abc_colsum_blocks(int64_t npix) { return (int)(npix < 512 ? (npix < 1 ? 1 : npix) : 512); }
+extern "C" int abc_colsum_blocks(int64_t npix) {
+    int64_t b = (npix + 63) / 64;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
 
 extern "C" int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C,
                           const float* chan_scale, float* work, float* out, abc_stream_t stream) {
     const int nb = abc_colsum_blocks(npix);
     hipStream_t st = (hipStream_t)stream;
+    if (C > 512) return abc_fail(ABC_EUNSUPPORTED, "colsum: C > 512");
+    int CW = 1;
+    while (CW < C && CW < 64) CW <<= 1;
     if (dtype == ABC_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, npix, ld, c_off, C, chan_scale, work);
+        hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, npix, ld, c_off, C, chan_scale, work, CW);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, npix, ld, c_off, C, chan_scale, work);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(abc_cdiv(C, 256)), dim3(256), 0, st, (const float*)work, nb, C, out);
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, npix, ld, c_off, C, chan_scale, work, CW);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(C), dim3(256), 0, st, (const float*)work, nb, C, out);
     return abc_check_launch("colsum");
 }
 

@@ -162,18 +162,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const abc_wgrad_reduce_desc d) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d.Ca * d.Cb) return;
-    const int ai = idx / d.Cb, bi = idx - ai * d.Cb;
+// Sum the split-K slabs.  One thread per (tap, a, b) output element; consecutive threads walk
+// b, so every slab read is a coalesced 4-byte stream and the whole reduction is one pass at
+// HBM/L2 speed (slab order fixed -> bitwise reproducible).  Output = reference layout [a][b][tap].
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const abc_wgrad_reduce_desc d) {
+    const int64_t n = (int64_t)d.ntaps * d.Ca * d.Cb;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int bi = (int)(idx % d.Cb);
+    const int ai = (int)((idx / d.Cb) % d.Ca);
+    const int t = (int)(idx / ((int64_t)d.Cb * d.Ca));
     const size_t slab = (size_t)d.Ca_pad * d.Cb_pad;
-    for (int t = 0; t < d.ntaps; ++t) {
-        float s = 0.f;
-        const float* p = d.partial + (size_t)t * slab + (size_t)ai * d.Cb_pad + bi;
-        for (int k = 0; k < d.nsplit; ++k) s += p[(size_t)k * d.ntaps * slab];
-        float* o = d.dw + (size_t)idx * d.ntaps + t;
-        *o = d.accumulate ? (*o + s) : s;
+    const float* p = d.partial + (size_t)t * slab + (size_t)ai * d.Cb_pad + bi;
+    const size_t step = (size_t)d.ntaps * slab;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= d.nsplit; k += 4) {
+        s0 += p[(size_t)k * step]; s1 += p[(size_t)(k + 1) * step]; s2 += p[(size_t)(k + 2) * step]; s3 += p[(size_t)(k + 3) * step];
     }
+    for (; k < d.nsplit; ++k) s0 += p[(size_t)k * step];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* o = d.dw + ((size_t)ai * d.Cb + bi) * d.ntaps + t;
+    *o = d.accumulate ? (*o + s) : s;
 }
 
 struct WGeom { int CW, dy_min, dx_min, HH, HW, PSW, sP_bytes, lds, tgw, ngroups, nta, ntb, npatch, tiles_x, tiles_y; };
@@ -270,7 +280,7 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
 }
 
 extern "C" int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream) {
-    const int n = d->Ca * d->Cb;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(abc_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    const int64_t n = (int64_t)d->ntaps * d->Ca * d->Cb;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
     return abc_check_launch("wgrad_reduce");
 }

@@ -141,11 +141,18 @@ class Engine:
         return t, coef
 
     # ------------------------------------------------------------------ op emitters
-    def _emit(self, ops, fn, desc, what, writes=()):
-        """writes = names of parameters whose GRADIENT is final once this op has run (bucketed all-reduce)"""
+    def _emit(self, ops, fn, desc, what, writes=(), meta=None):
+        """writes = names of parameters whose GRADIENT is final once this op has run (bucketed all-reduce);
+        meta = {kernel, flops, bytes}: algorithmic work of this launch (for the roofline report)"""
         self.keep.append(desc)
         ref = C.byref(desc)
-        ops.append((fn, ref, what, tuple(writes)))
+        ops.append((fn, ref, what, tuple(writes), meta or {"kernel": what.split(" ")[0], "flops": 0, "bytes": 0}))
+
+    def _dn(self, dt):
+        return "bf16" if dt == L.BF16 else "f32"
+
+    def _esz(self, dt):
+        return 2 if dt == L.BF16 else 4
 
     def emit_pack(self, wname, dst, mode, Cout, Cin, k, rows_pad, red_real, red_total=None, red_off=0, py=0, px=0):
         d = L.PackDesc()
@@ -180,7 +187,15 @@ class Engine:
         if stats:
             st = self.new((nblk, 2, Cout), torch.float32)
             d.stats = st.data_ptr()
-        self._emit(ops, self.lib.abc_conv_fwd, d, what)
+        cp = -(-Cout // 32) * 32
+        bn = 128 if cp % 128 == 0 else (64 if cp % 64 == 0 else 32)
+        ck = self.lib.abc_conv_chunk(self.dt, d.Cin)
+        npx = self.B * gh * gw
+        in_px = self.B * lh * lw * (4 if src.pool else 1)
+        meta = {"kernel": "conv_igemm<%s,%s,%s,CK%d,BN%d,S%d>" % (self._dn(src.dt), self._dn(self.dt), self._dn(y_dt), ck, bn, stride),
+                "flops": 2.0 * npx * Cout * len(taps) * d.Cin,
+                "bytes": float(in_px * d.Cin * self._esz(src.dt) + npx * Cout * self._esz(y_dt))}
+        self._emit(ops, self.lib.abc_conv_fwd, d, what, meta=meta)
         return st, nblk
 
     def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None):
@@ -203,15 +218,19 @@ class Engine:
         cw = 64 if wide else 32
         ngroups = -(-len(taps) // 9)
         npatch = self.B * (-(-gh // 8)) * (-(-gw // 16))
-        nsplit = max(1, min(npatch, 768 // ((ca_pad // cw) * (cb_pad // cw) * ngroups)))
+        nsplit = max(1, min(npatch, 512 // ((ca_pad // cw) * (cb_pad // cw) * ngroups)))
         d.nsplit = nsplit
         need = nsplit * len(taps) * ca_pad * cb_pad
         self._ws_need = max(self._ws_need, need)
         r = L.WgradReduceDesc()
         r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = nsplit, len(taps), Ca, Cb, ca_pad, cb_pad, dw_ptr, 0
         self._ws_users += [d, r]
-        self._emit(ops, self.lib.abc_wgrad, d, what)
-        self._emit(ops, self.lib.abc_wgrad_reduce, r, what + " reduce", writes=(wname,) if wname else ())
+        meta = {"kernel": "wgrad<%s,%s,%s,CW%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), cw, stride),
+                "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
+                "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt))}
+        self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
+        self._emit(ops, self.lib.abc_wgrad_reduce, r, what + " reduce", writes=(wname,) if wname else (),
+                   meta={"kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)})
 
     def emit_colsum(self, ops, t, dt, npix, ld, c_off, Cn, chan_scale, bname, what):
         out_ptr = self.G(bname)
@@ -224,7 +243,7 @@ class Engine:
         def fn(_ref, stream, a=args):
             return lib.abc_colsum(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], stream)
 
-        ops.append((fn, None, what, (bname,)))
+        ops.append((fn, None, what, (bname,), {"kernel": "colsum", "flops": 0, "bytes": float(npix * Cn * self._esz(dt))}))
 
     # ------------------------------------------------------------------ layers
     def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None):
@@ -256,7 +275,7 @@ class Engine:
             lib = self.lib
             a = (self.P(bname + ".weight"), self.P(bname + ".bias"), self.Bf(bname + ".running_mean"),
                  self.Bf(bname + ".running_var"), rec.scale.data_ptr(), rec.shift.data_ptr(), cout, BN_EPS)
-            self.fwd_ops.append((lambda _r, st, a=a: lib.abc_bn_eval_coeffs(*a, st), None, "bn-eval " + bname, ()))
+            self.fwd_ops.append((lambda _r, st, a=a: lib.abc_bn_eval_coeffs(*a, st), None, "bn-eval " + bname, (), {"kernel": "bn_eval", "flops": 0, "bytes": 0}))
         self.recs.append(rec)
         out = Src(yt, self.dt, H, W, ld, coff, cout, coef=coef, producer=rec)
         return rec, out
@@ -374,7 +393,9 @@ class Engine:
         nblk = self.lib.abc_act_bwd_blocks(C.byref(d))
         part = self.new((nblk, 2, C_), torch.float32)
         d.partial = part.data_ptr()
-        self._emit(ops, self.lib.abc_act_bwd, d, "act_bwd " + rec.bname)
+        nsrc = (1 if d.dA_same else 0) + (0.25 if d.dA_pool else 0)
+        self._emit(ops, self.lib.abc_act_bwd, d, "act_bwd " + rec.bname,
+                   meta={"kernel": "act_bwd", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * (2 + nsrc))})
         k1, k2, gs = (self.new((C_,), torch.float32) for _ in range(3))
         f = L.BnBwdDesc()
         f.partial, f.nblk, f.C, f.count = part.data_ptr(), nblk, C_, float(self.B * rec.H * rec.W)
@@ -386,7 +407,8 @@ class Engine:
         a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = g.data_ptr(), C_, rec.y.data_ptr(), rec.ld, rec.coff
         a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
         a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
-        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname)
+        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
+                   meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
         return Src(g, self.dt, rec.H, rec.W, C_, 0, C_)
 
     def _conv_backward(self, ops, rec, dY: Src, want_dgrad=True):
@@ -493,7 +515,9 @@ class Engine:
         nblk = self.lib.abc_act_bwd_blocks(C.byref(d))
         part = self.new((nblk, 2, C_), torch.float32)
         d.partial = part.data_ptr()
-        self._emit(ops, self.lib.abc_act_bwd, d, "act_bwd " + rec.bname)
+        nsrc = (1 if d.dA_same else 0) + (0.25 if d.dA_pool else 0)
+        self._emit(ops, self.lib.abc_act_bwd, d, "act_bwd " + rec.bname,
+                   meta={"kernel": "act_bwd", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * (2 + nsrc))})
         k1, k2, gs = (self.new((C_,), torch.float32) for _ in range(3))
         f = L.BnBwdDesc()
         f.partial, f.nblk, f.C, f.count = part.data_ptr(), nblk, C_, float(self.B * rec.H * rec.W)
@@ -505,13 +529,14 @@ class Engine:
         a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = gptr, ld_g, rec.y.data_ptr(), rec.ld, rec.coff
         a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
         a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
-        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname)
+        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
+                   meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
         return Src(gbuf, self.dt, rec.H, rec.W, ld_g, g_off, C_)
 
     # ------------------------------------------------------------------ execution
     @staticmethod
     def _run(ops, stream):
-        for fn, ref, what, _w in ops:
+        for fn, ref, what, _w, _m in ops:
             rc = fn(ref, stream)
             if rc != 0:
                 L.check(rc, what)

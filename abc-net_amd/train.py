@@ -44,7 +44,7 @@ class Trainer:
         names = list(model._lay_p.keys())
         sizes = [model._lay_p[n][1] for n in names]
         ready = {n: -1 for n in names}
-        for j, (_fn, _ref, _what, writes) in enumerate(eng.bwd_ops):
+        for j, (_fn, _ref, _what, writes, _meta) in enumerate(eng.bwd_ops):
             for n in writes:
                 ready[n] = max(ready[n], j)
         self.buckets = D.plan_buckets([ready[n] for n in names], sizes, int(bucket_mb * (1 << 20) / 4))
@@ -142,3 +142,48 @@ class Trainer:
 
     def loss_value(self):
         return self.loss.result()
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, iters=3):
+        """Eager (no graph) steps with a HIP event pair around EVERY launch, recorded on the stream the
+        kernels are launched on.  Returns {kernel: {calls, ms, flops, bytes}} per step (averaged)."""
+        eng = self.eng
+        stream = torch.cuda.current_stream()
+        st = stream.cuda_stream
+        groups = [eng.pack_ops, eng.fwd_ops, None, eng.bwd_ops]
+        acc = {}
+        for _ in range(iters):
+            marks = []
+            for ops in groups:
+                if ops is None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    self.loss.run(st)
+                    e1.record(stream)
+                    marks.append(("loss_fwd_bwd+finalize", 0.0, float(eng.B * eng.h * eng.w * (544 * 4 * 2 + 381 * 4 + 120 * 8)), e0, e1))
+                    continue
+                for fn, ref, what, _w, meta in ops:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    rc = fn(ref, st)
+                    e1.record(stream)
+                    if rc != 0:
+                        L.check(rc, what)
+                    marks.append((meta["kernel"], meta["flops"], meta["bytes"], e0, e1))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            self.opt.step(st)
+            e1.record(stream)
+            marks.append(("adam", 0.0, float(self.model._flat.numel() * 28), e0, e1))
+            torch.cuda.synchronize()
+            for k, fl, by, a, b in marks:
+                r = acc.setdefault(k, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                r["calls"] += 1
+                r["ms"] += a.elapsed_time(b)
+                r["flops"] += fl
+                r["bytes"] += by
+        for r in acc.values():
+            for f in ("calls", "ms", "flops", "bytes"):
+                r[f] /= iters
+        self.steps += iters
+        return acc

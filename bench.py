@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): training images/sec of unet.py at 384x384, bf16, batch 16 per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = pack weights + forward + fused loss + backward + gradient all-reduce (N>1) + fused Adam on one
+batch of synthetic inputs already resident in HBM (data: Bernoulli ink images + rasterised random
+atoms/bonds honouring the reference tensor contract; random-init weights of the reference architecture).
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     -- the dominant kernel's achieved TFLOP/s (algorithmic flops / HIP-event time, measured live)
+  cpu_baseline -- the oracle (CPU restatement of the reference path) timed on this host, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
+MFMA_PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md
+HBM_PEAK = 8000.0  # GB/s
+
+
+def cpu_baseline(size, seconds_budget=25.0):
+    """oracle = torch-CPU restatement of the reference train step (bitwise-pinned to the reference import);
+    bounded sample: fwd+loss+bwd of batch 4 at the benchmark resolution, median of up to 3 timed iterations"""
+    from abcnet_amd.synthetic import synthetic_images, synthetic_targets
+    from oracle import loss_oracle
+    from oracle import unet_oracle as uo
+    B = 4
+    x = synthetic_images(B, size, seed=7)
+    tg = synthetic_targets(B, size // 4, seed=1)
+    sd0 = uo.filled_state("unet", 1, HEADS, seed=0)
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        sd = uo.clone_state(sd0, requires_grad=True)
+        t0 = time.time()
+        preds = uo.forward("unet", sd, x, train=True)
+        total, _, _ = loss_oracle.abc_loss(preds, tg, sd["s"])
+        total.backward()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and times:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle fwd+loss+bwd (no optimiser), fp32, batch %d at %dx%d, median of %d warm iterations" % (B, size, size, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=384)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import abcnet_amd  # noqa: F401
+    from abcnet_amd import distributed as D
+    from abcnet_amd.synthetic import synthetic_images, synthetic_targets
+    from abcnet_amd.train import Trainer
+    from abcnet_amd.unet import UNet
+
+    if world > 1:
+        D.init_process_group(rank=rank, world_size=world)
+
+    model = UNet(1, HEADS, dtype=a.dtype)
+    model.reset_parameters(seed=1234)  # identical random init on every rank (and re-broadcast below)
+    model = model.to(dev)
+    if world > 1:
+        D.broadcast_parameters(model._flat.data, model._flat_buf)
+    tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph)
+    # each rank owns its shard of the synthetic stream (weak scaling: batch 16 per GPU)
+    imgs = synthetic_images(a.batch, a.size, seed=7 + rank)
+    tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
+    tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
+    torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    loss = tr.loss_value()["total"]
+
+    out = {
+        "metric": "training images/sec (384x384, b16/GPU)", "value": round(world * a.batch * a.steps / el, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "unet.py train step (pack+fwd+fused loss+bwd+allreduce+Adam), %dx%d, batch %d/GPU, dropout 0.2" % (a.size, a.size, a.batch),
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph},
+        "final_loss": round(loss, 4),
+    }
+
+    if rank == 0 and not a.no_profile:
+        prof = tr.profile(iters=3)
+        tot = sum(r["ms"] for r in prof.values())
+        dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
+        r = prof[dom]
+        ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK[a.dtype], "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": None,
+                           "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
+                           "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
+        out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        out["eager_step_ms_sum_of_kernels"] = round(tot, 3)
+        flops_step = sum(v["flops"] for v in prof.values())
+        bytes_step = sum(v["bytes"] for v in prof.values())
+        out["whole_step"] = {"algorithmic_tflop": round(flops_step / 1e12, 3), "algorithmic_gb": round(bytes_step / 1e9, 3),
+                             "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK[a.dtype], 4),
+                             "hbm_frac": round(bytes_step / (el / a.steps) / 1e9 / HBM_PEAK, 4)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.size)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
