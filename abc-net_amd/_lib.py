@@ -20,7 +20,7 @@ vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_
 
 class ActSrc(C.Structure):
     _fields_ = [("x", vp), ("scale", vp), ("shift", vp), ("slope", vp), ("Hx", i32), ("Wx", i32), ("ldx", i32),
-                ("pool", i32), ("drop_p", f32), ("drop_seed", u32)]
+                ("pool", i32), ("drop_p", f32), ("drop_seed", u32), ("planar", i32), ("ctot", i32)]
 
 
 class ConvDesc(C.Structure):
@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("B", i32), ("Hin", i32), ("Win", i32), ("cin_off", i32), ("Cin", i32), ("Hg", i32), ("Wg", i32),
                 ("Hout", i32), ("Wout", i32), ("ldy", i32), ("cout_off", i32), ("Cout", i32), ("Cout_pad", i32),
                 ("stride", i32), ("om", i32), ("oy0", i32), ("ox0", i32), ("ntaps", i32),
-                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS)]
+                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("planar_out", i32), ("ctot_out", i32)]
 
 
 class PackDesc(C.Structure):
@@ -74,14 +74,14 @@ class WgradReduceDesc(C.Structure):
 
 
 class LossDesc(C.Structure):
-    _fields_ = [("logits", vp), ("dlogits", vp), ("ldl", i32), ("t_atom", vp), ("t_types", vp), ("t_charges", vp),
+    _fields_ = [("logits", vp * 8), ("dlogits", vp * 8), ("t_atom", vp), ("t_types", vp), ("t_charges", vp),
                 ("t_hs", vp), ("t_bond", vp), ("t_btypes", vp), ("t_rho", vp), ("t_omega", vp), ("B", i32), ("h", i32),
-                ("w", i32), ("head_off", i32 * 8), ("partial", vp)]
+                ("w", i32), ("partial", vp)]
 
 
 class LossFinDesc(C.Structure):
-    _fields_ = [("partial", vp), ("nblk", i32), ("s", vp), ("ds", vp), ("out", vp), ("chan_scale", vp), ("ldl", i32),
-                ("head_off", i32 * 8), ("head_c", i32 * 8), ("grad_scale", f32)]
+    _fields_ = [("partial", vp), ("nblk", i32), ("s", vp), ("ds", vp), ("out", vp), ("chan_scale", vp), ("nchan", i32),
+                ("chan_off", i32 * 8), ("head_c", i32 * 8), ("grad_scale", f32)]
 
 
 class AdamDesc(C.Structure):
@@ -90,9 +90,8 @@ class AdamDesc(C.Structure):
 
 
 class NmsDesc(C.Structure):
-    _fields_ = [("logits", vp), ("ldl", i32), ("B", i32), ("h", i32), ("w", i32), ("off_atom", i32), ("off_bond", i32),
-                ("off_rho", i32), ("off_omega", i32), ("n_omega", i32), ("atom_mask", vp), ("bond_mask", vp),
-                ("rho_abs", vp), ("omega_mask", vp)]
+    _fields_ = [("atom", vp), ("bond", vp), ("rho", vp), ("omega", vp), ("B", i32), ("h", i32), ("w", i32),
+                ("n_omega", i32), ("atom_mask", vp), ("bond_mask", vp), ("rho_abs", vp), ("omega_mask", vp)]
 
 
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
@@ -121,6 +120,8 @@ SYMBOLS = {
     "abc_loss_finalize": (C.c_int, [P(LossFinDesc), vp]),
     "abc_adam_step": (C.c_int, [P(AdamDesc), vp]),
     "abc_nms_peaks": (C.c_int, [P(NmsDesc), vp]),
+    "abc_plane_sum": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "abc_plane_sum_work": (C.c_int, [i32]),
     "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),

@@ -125,6 +125,8 @@ struct ActSrc {
     int pool;             // 1: logical dims are (Hx/2, Wx/2), value = max over 2x2 of act(x)
     float drop_p;         // >0: multiply by keep/(1-p), keep from abc_drop_keep(idx, seed, p)
     uint32_t drop_seed;
+    int planar;           // 1: x is f32 channel-planar [B][ctot][Hx][Wx] (NCHW head maps); no pool / dropout
+    int ctot;
 };
 
 // Stage a halo tile [HH][HW] pixels x CK channels (channels c0..c0+CK of src) into LDS in
@@ -158,7 +160,17 @@ __device__ inline void stage_halo(char* sA, int RS, int PS, int HH, int HW, int 
         const int iy = iy0 + hy, ix = ix0 + hx;
         float v[NV];
         if (chan_ok && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
-            if (!s.pool) {
+            if (s.planar) {
+                // consecutive threads of a wave = consecutive channel segments of consecutive pixels: per j the
+                // wave reads SEGS planes x (64/SEGS) adjacent pixels, i.e. 64..128-byte runs
+                const float* xp = (const float*)s.x + ((size_t)(b * s.ctot + cch) * s.Hx + iy) * s.Wx + ix;
+                const size_t plane = (size_t)s.Hx * s.Wx;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    float t = (j < nval) ? xp[j * plane] : 0.f;
+                    v[j] = has_t ? abc_act(t, sc[j], sh[j], sl[j]) : t;
+                }
+            } else if (!s.pool) {
                 const size_t off = ((size_t)(b * s.Hx + iy) * s.Wx + ix) * s.ldx + cch;
                 load_n<InT, NV>(xb + off, v, nval);
                 if (has_t) {

@@ -30,7 +30,7 @@ struct ConvK {
     int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad;
     int om, oy0, ox0;
     int ntaps, tg, dy_min, dx_min, HH, HW, RS;
-    int tiles_x, tiles_y, nblocks_n, sB_off, tap_off;
+    int tiles_x, tiles_y, nblocks_n, sB_off, tap_off, planar_out, ctot_out;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
@@ -149,6 +149,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
                 if (nvalid && gy < a.Hg && gx < a.Wg) {
                     const float v = acc[i][j][k] + bv;
                     s1[j] += v; s2[j] += v * v;
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (a.planar_out) {
+                            // NCHW: registers k..k+3 of a lane are 4 consecutive x of one plane -> one 16-byte store
+                            const size_t o = ((size_t)(b * a.ctot_out + a.cout_off + n) * a.Hout + gy) * a.Wout + gx;
+                            if ((k & 3) == 0 && gx + 3 < a.Wg && (a.Wout & 3) == 0) {
+                                f32x4 t;
+                                t[0] = v; t[1] = acc[i][j][k + 1] + bv; t[2] = acc[i][j][k + 2] + bv; t[3] = acc[i][j][k + 3] + bv;
+                                *(f32x4*)((float*)a.y + o) = t;
+                            } else if (!(gx - (k & 3) + 3 < a.Wg && (a.Wout & 3) == 0)) {
+                                ((float*)a.y)[o] = v;
+                            }
+                            continue;
+                        }
+                    }
                     const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy
                                      + a.cout_off + n;
                     yo[o] = (OutT)v;
@@ -268,12 +282,18 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     if (d->src.pool && (d->src.Hx / 2 != d->Hin || d->src.Wx / 2 != d->Win))
         return abc_fail(ABC_EINVAL, "conv: pooled dims mismatch");
     if (!d->src.pool && (d->src.Hx != d->Hin || d->src.Wx != d->Win)) return abc_fail(ABC_EINVAL, "conv: dims mismatch");
-    if (d->Cin % 16 == 0 && ((d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4)) % 16 || (d->cin_off % 8)))
+    if (!d->src.planar && d->Cin % 16 == 0 && ((d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4)) % 16 || (d->cin_off % 8)))
         return abc_fail(ABC_EINVAL, "conv: input stride/offset must keep 16-byte alignment");
     ConvK k;
     k.src.x = d->src.x; k.src.scale = d->src.scale; k.src.shift = d->src.shift; k.src.slope = d->src.slope;
     k.src.Hx = d->src.Hx; k.src.Wx = d->src.Wx; k.src.ldx = d->src.ldx; k.src.pool = d->src.pool;
     k.src.drop_p = d->src.drop_p; k.src.drop_seed = d->src.drop_seed;
+    k.src.planar = d->src.planar; k.src.ctot = d->src.ctot;
+    k.planar_out = d->planar_out; k.ctot_out = d->ctot_out;
+    if (d->src.planar && (d->dtype_in != ABC_F32 || d->src.pool || d->src.drop_p > 0.f))
+        return abc_fail(ABC_EUNSUPPORTED, "conv: planar input must be f32 without pool/dropout");
+    if (d->planar_out && (d->dtype_out != ABC_F32 || d->om != 1 || d->oy0 || d->ox0))
+        return abc_fail(ABC_EUNSUPPORTED, "conv: planar output must be f32, unit output stride");
     k.w = d->w; k.bias = d->bias; k.y = d->y; k.stats = d->stats;
     k.B = d->B; k.Hin = d->Hin; k.Win = d->Win; k.cin_off = d->cin_off; k.Cin = d->Cin; k.nchunks = abc_cdiv(d->Cin, g.CK);
     k.Hg = d->Hg; k.Wg = d->Wg; k.Hout = d->Hout; k.Wout = d->Wout; k.ldy = d->ldy; k.cout_off = d->cout_off;

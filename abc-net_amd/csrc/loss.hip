@@ -1,10 +1,10 @@
 // Fused activation + 8-term loss + d(loss)/d(logits) in one pass over the logits
 // and the targets (reference: src/train.py:95-137, K9 of SURVEY.md).
 //
-// One thread per quarter-resolution pixel.  Logits/dlogits are NHWC f32 (one 2 KB row
-// per pixel, walked sequentially by its thread); targets are the reference's NCHW maps
-// (coalesced across the wave, since adjacent lanes are adjacent pixels).  rho/omega
-// targets are float64 as in the reference (utils.py:91-92).
+// One thread per quarter-resolution pixel.  Logits, dlogits and targets are all NCHW planes
+// (the reference's own interface layout), so adjacent lanes = adjacent pixels and every load
+// and store of the kernel is a coalesced 256-byte wave access.  rho/omega targets are float64
+// as in the reference (utils.py:91-92).
 // Normalisers are global sums, so the kernel writes the gradient of each term's
 // NUMERATOR; abc_loss_finalize turns the partial sums into the 8 terms, the
 // uncertainty-weighted total (train.py:127-137), ds, and a per-channel factor
@@ -87,89 +87,87 @@ __global__ __launch_bounds__(256) void loss_kernel(const abc_loss_desc d) {
     for (int i = 0; i < 8; ++i) { num[i] = 0.0; den[i] = 0.0; }
     if (p < npix) {
         const int b = (int)(p / hw), yx = (int)(p % hw);
-        const float* L = d.logits + p * d.ldl;
-        float* D = d.dlogits + p * d.ldl;
+        // plane (b, c) of a head with C channels: base + (b*C + c)*hw + yx
+#define PL(ptr, C, c) (ptr)[((size_t)b * (C) + (c)) * hw + yx]
         // ---- head 0: atom centre
         {
-            const float t = d.t_atom[(size_t)b * hw + yx];
+            const float t = PL(d.t_atom, 1, 0);
             float dz;
-            num[0] = center_focal(L[d.head_off[0]], t, 1.f, &dz);
+            num[0] = center_focal(PL(d.logits[0], 1, 0), t, 1.f, &dz);
             den[0] = (t == 1.f) ? 1.0 : 0.0;
-            D[d.head_off[0]] = dz;
+            PL(d.dlogits[0], 1, 0) = dz;
         }
         // ---- head 1: atom types (14-way softmax, class weights)
         {
             float z[14], t[14], dz[14], dn = 0.f;
 #pragma unroll
-            for (int k = 0; k < 14; ++k) { z[k] = L[d.head_off[1] + k]; t[k] = d.t_types[((size_t)b * 14 + k) * hw + yx]; }
+            for (int k = 0; k < 14; ++k) { z[k] = PL(d.logits[1], 14, k); t[k] = PL(d.t_types, 14, k); }
             num[1] = class_focal<14>(z, t, c_type_w, dz, &dn);
             den[1] = dn;
 #pragma unroll
-            for (int k = 0; k < 14; ++k) D[d.head_off[1] + k] = dz[k];
+            for (int k = 0; k < 14; ++k) PL(d.dlogits[1], 14, k) = dz[k];
         }
         // ---- head 2: charges (3-way)
         {
             float z[3], t[3], dz[3], dn = 0.f;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { z[k] = L[d.head_off[2] + k]; t[k] = d.t_charges[((size_t)b * 3 + k) * hw + yx]; }
+            for (int k = 0; k < 3; ++k) { z[k] = PL(d.logits[2], 3, k); t[k] = PL(d.t_charges, 3, k); }
             num[2] = class_focal<3>(z, t, nullptr, dz, &dn);
             den[2] = dn;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) D[d.head_off[2] + k] = dz[k];
+            for (int k = 0; k < 3; ++k) PL(d.dlogits[2], 3, k) = dz[k];
         }
         // ---- head 3: hydrogens (2-way)
         {
             float z[2], t[2], dz[2], dn = 0.f;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { z[k] = L[d.head_off[3] + k]; t[k] = d.t_hs[((size_t)b * 2 + k) * hw + yx]; }
+            for (int k = 0; k < 2; ++k) { z[k] = PL(d.logits[3], 2, k); t[k] = PL(d.t_hs, 2, k); }
             num[3] = class_focal<2>(z, t, nullptr, dz, &dn);
             den[3] = dn;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) D[d.head_off[3] + k] = dz[k];
+            for (int k = 0; k < 2; ++k) PL(d.dlogits[3], 2, k) = dz[k];
         }
         // ---- head 4: bond centre
         {
-            const float t = d.t_bond[(size_t)b * hw + yx];
+            const float t = PL(d.t_bond, 1, 0);
             float dz;
-            num[4] = center_focal(L[d.head_off[4]], t, 1.f, &dz);
+            num[4] = center_focal(PL(d.logits[4], 1, 0), t, 1.f, &dz);
             den[4] = (t == 1.f) ? 1.0 : 0.0;
-            D[d.head_off[4]] = dz;
+            PL(d.dlogits[4], 1, 0) = dz;
         }
         // ---- omega per-pixel weight = sum over the 60 bins of the omega target (train.py:124)
         double wpix = 0.0;
-        for (int o = 0; o < 60; ++o) wpix += d.t_omega[((size_t)b * 60 + o) * hw + yx];
+        for (int o = 0; o < 60; ++o) wpix += PL(d.t_omega, 60, o);
         den[7] = wpix;
-        // ---- heads 5,6,7 per omega bin
+        // ---- heads 5,6,7 per omega bin; bond-type channel = type*60 + omega (train.py:101 view)
         double n5 = 0.0, n6 = 0.0, n7 = 0.0, d5 = 0.0;
         for (int o = 0; o < 60; ++o) {
             float z[6], t[6], dz[6], dn = 0.f;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                z[k] = L[d.head_off[5] + k * 60 + o];
-                t[k] = d.t_btypes[(((size_t)b * 6 + k) * 60 + o) * hw + yx];
-            }
+            for (int k = 0; k < 6; ++k) { z[k] = PL(d.logits[5], 360, k * 60 + o); t[k] = PL(d.t_btypes, 360, k * 60 + o); }
             n5 += class_focal<6>(z, t, nullptr, dz, &dn);
             d5 += dn;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) D[d.head_off[5] + k * 60 + o] = dz[k];
+            for (int k = 0; k < 6; ++k) PL(d.dlogits[5], 360, k * 60 + o) = dz[k];
             // rho: |abs(pred) - rho| * sum_types(t)   (train.py:105,121), f64 like the reference
             {
-                const float zr = L[d.head_off[6] + o];
-                const double tr = d.t_rho[((size_t)b * 60 + o) * hw + yx];
+                const float zr = PL(d.logits[6], 60, o);
+                const double tr = PL(d.t_rho, 60, o);
                 const double diff = (double)fabsf(zr) - tr;
                 n6 += fabs(diff) * (double)dn;
                 const float sg = (diff > 0.0) ? 1.f : ((diff < 0.0) ? -1.f : 0.f);
                 const float sz = (zr > 0.f) ? 1.f : ((zr < 0.f) ? -1.f : 0.f);
-                D[d.head_off[6] + o] = sg * sz * dn;
+                PL(d.dlogits[6], 60, o) = sg * sz * dn;
             }
             // omega: focal per bin weighted by wpix (train.py:124-125)
             {
-                const float to = (float)d.t_omega[((size_t)b * 60 + o) * hw + yx];
+                const float to = (float)PL(d.t_omega, 60, o);
                 float dz7;
-                n7 += center_focal(L[d.head_off[7] + o], to, (float)wpix, &dz7);
-                D[d.head_off[7] + o] = dz7;
+                n7 += center_focal(PL(d.logits[7], 60, o), to, (float)wpix, &dz7);
+                PL(d.dlogits[7], 60, o) = dz7;
             }
         }
+#undef PL
         num[5] = n5; den[5] = d5; num[6] = n6; den[6] = d5; num[7] = n7;
     }
     // ---- block reduction of the 16 sums
@@ -188,10 +186,14 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const abc_loss_fin_de
     __shared__ double tot[16];
     __shared__ float cscale[8];
     const int t = threadIdx.x;
-    if (t < 16) {
+    {
+        // 4 lanes per sum, fixed order -> reproducible
+        const int which = t & 15, part = t >> 4;
         double s = 0.0;
-        for (int k = 0; k < d.nblk; ++k) s += d.partial[(size_t)k * 16 + t];
-        tot[t] = s;
+        for (int k = part; k < d.nblk; k += 4) s += d.partial[(size_t)k * 16 + which];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (t < 16) tot[t] = s;
     }
     __syncthreads();
     if (t == 0) {
@@ -214,10 +216,10 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const abc_loss_fin_de
         d.out[0] = total;
     }
     __syncthreads();
-    for (int c = t; c < d.ldl; c += 64) {
+    for (int c = t; c < d.nchan; c += 64) {
         float v = 0.f;
         for (int i = 0; i < 8; ++i)
-            if (c >= d.head_off[i] && c < d.head_off[i] + d.head_c[i]) v = cscale[i];
+            if (c >= d.chan_off[i] && c < d.chan_off[i] + d.head_c[i]) v = cscale[i];
         d.chan_scale[c] = v;
     }
 }

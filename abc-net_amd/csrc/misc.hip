@@ -97,29 +97,59 @@ __global__ __launch_bounds__(256) void nms_kernel(const abc_nms_desc d) {
     if (p >= npix) return;
     const int b = (int)(p / hw), yx = (int)(p % hw);
     const int y = yx / d.w, x = yx % d.w;
-    const float* L = d.logits + p * d.ldl;
     // 3x3 local maximum with -inf padding, logit > -1
     for (int which = 0; which < 2; ++which) {
-        const int off = which ? d.off_bond : d.off_atom;
-        const float v = L[off];
+        const float* L = (which ? d.bond : d.atom) + (size_t)b * hw;
+        const float v = L[yx];
         float m = v;
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int yy = y + dy, xx = x + dx;
-                if (yy >= 0 && yy < d.h && xx >= 0 && xx < d.w)
-                    m = fmaxf(m, d.logits[((size_t)b * hw + yy * d.w + xx) * d.ldl + off]);
+                if (yy >= 0 && yy < d.h && xx >= 0 && xx < d.w) m = fmaxf(m, L[yy * d.w + xx]);
             }
         float* o = which ? d.bond_mask : d.atom_mask;
         o[(size_t)b * hw + yx] = (m == v && v > -1.f) ? 1.f : 0.f;
     }
     const int n = d.n_omega;
+    const float* R = d.rho + (size_t)b * n * hw + yx;
+    const float* O = d.omega + (size_t)b * n * hw + yx;
+    float prev = O[(size_t)(n - 1) * hw], cur = O[0];
+    const float first = cur;
     for (int k = 0; k < n; ++k) {
-        d.rho_abs[((size_t)b * n + k) * hw + yx] = fabsf(L[d.off_rho + k]);
-        const float v = L[d.off_omega + k];
-        const float l = L[d.off_omega + (k + n - 1) % n], r = L[d.off_omega + (k + 1) % n];
-        const float m = fmaxf(v, fmaxf(l, r));
-        d.omega_mask[((size_t)b * n + k) * hw + yx] = (m == v && v > -1.f) ? 1.f : 0.f;
+        const float nxt = (k + 1 < n) ? O[(size_t)(k + 1) * hw] : first;
+        d.rho_abs[((size_t)b * n + k) * hw + yx] = fabsf(R[(size_t)k * hw]);
+        const float m = fmaxf(cur, fmaxf(prev, nxt));
+        d.omega_mask[((size_t)b * n + k) * hw + yx] = (m == cur && cur > -1.f) ? 1.f : 0.f;
+        prev = cur; cur = nxt;
     }
+}
+
+// per-channel sum over batch and pixels of planar [B][C][HW] f32: grid (C, NCH) partials, then a tiny reduce
+constexpr int PS_CHUNKS = 64;
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* x, int B, int C, int HW, float* work) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x, ch = blockIdx.y;
+    const int64_t n = (int64_t)B * HW;
+    const int64_t per = (n + PS_CHUNKS - 1) / PS_CHUNKS;
+    const int64_t lo = ch * per, hi = (lo + per < n) ? lo + per : n;
+    double s = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int b = (int)(i / HW);
+        const int p = (int)(i - (int64_t)b * HW);
+        s += (double)x[((size_t)b * C + c) * HW + p];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) work[(size_t)c * PS_CHUNKS + ch] = (float)(sm[0] + sm[1] + sm[2] + sm[3]);
+}
+__global__ void plane_sum_reduce_kernel(const float* work, int C, const float* cs, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < PS_CHUNKS; ++k) s += (double)work[(size_t)c * PS_CHUNKS + k];
+    out[c] = (float)(s * (double)(cs ? cs[c] : 1.f));
 }
 
 }  // namespace
@@ -156,6 +186,17 @@ extern "C" int abc_adam_step(const abc_adam_desc* d, abc_stream_t stream) {
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, *d);
     return abc_check_launch("adam_step");
+}
+
+extern "C" int abc_plane_sum_work(int32_t C) { return C * PS_CHUNKS; }
+
+extern "C" int abc_plane_sum(const float* x, int32_t B, int32_t C, int32_t HW, const float* chan_scale, float* work, float* out,
+                             abc_stream_t stream) {
+    if (C < 1) return abc_fail(ABC_EINVAL, "plane_sum: empty");
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(C, PS_CHUNKS), dim3(256), 0, (hipStream_t)stream, x, B, C, HW, work);
+    hipLaunchKernelGGL(plane_sum_reduce_kernel, dim3(abc_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)work, C,
+                       chan_scale, out);
+    return abc_check_launch("plane_sum");
 }
 
 extern "C" int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream) {

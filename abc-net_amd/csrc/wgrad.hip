@@ -255,7 +255,7 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     WgK k;
     auto cp = [](ActSrc& o, const abc_act_src& i) {
         o.x = i.x; o.scale = i.scale; o.shift = i.shift; o.slope = i.slope; o.Hx = i.Hx; o.Wx = i.Wx; o.ldx = i.ldx;
-        o.pool = i.pool; o.drop_p = i.drop_p; o.drop_seed = i.drop_seed;
+        o.pool = i.pool; o.drop_p = i.drop_p; o.drop_seed = i.drop_seed; o.planar = i.planar; o.ctot = i.ctot;
     };
     cp(k.p, d->p); cp(k.q, d->q);
     const int php = d->p.pool ? d->p.Hx / 2 : d->p.Hx, pwp = d->p.pool ? d->p.Wx / 2 : d->p.Wx;

@@ -22,17 +22,12 @@ from . import arch
 
 BN_EPS = 1e-5
 BN_MOM = 0.1
-LDL = 544  # logits row stride: 512 aligned channels + slack for padded K-chunks of the last head
-
-
 def head_offsets(heads):
-    """channel offset of each head inside a logits row, 4-aligned (16-byte) so the loss kernel's rows stay aligned"""
+    """offset of each head inside the flat per-channel loss-scale array"""
     offs, o = [], 0
     for h in heads:
         offs.append(o)
-        o += (h + 3) // 4 * 4
-    if o + 32 > LDL:
-        raise ValueError("heads do not fit the logits row (%d > %d)" % (o + 32, LDL))
+        o += h
     return offs
 
 
@@ -59,15 +54,17 @@ TAPS_CONVT_DGRAD = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 class Src:
     """an activation as a consumer sees it: raw tensor + on-load transform"""
 
-    def __init__(self, t, dt, H, W, ld, coff, C, coef=None, pool=False, drop_p=0.0, drop_seed=0, producer=None):
+    def __init__(self, t, dt, H, W, ld, coff, C, coef=None, pool=False, drop_p=0.0, drop_seed=0, producer=None, planar=False):
         self.t, self.dt, self.H, self.W, self.ld, self.coff, self.C = t, dt, H, W, ld, coff, C
         self.coef, self.pool, self.drop_p, self.drop_seed, self.producer = coef, pool, drop_p, drop_seed, producer
+        self.planar = planar  # NCHW f32 [B][C][H][W] (head maps / their gradients)
 
     def lh(self):  # logical dims
         return (self.H // 2, self.W // 2) if self.pool else (self.H, self.W)
 
     def fill(self, a: L.ActSrc):
         a.x = self.t.data_ptr()
+        a.planar, a.ctot = (1, self.C) if self.planar else (0, 0)
         if self.coef is not None:
             a.scale, a.shift, a.slope = (c.data_ptr() for c in self.coef)
         else:
@@ -168,7 +165,7 @@ class Engine:
         return self.new((ntaps * (-(-red // ck)) * rows_pad * ck,))
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
-                  grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv"):
+                  grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False):
         d = L.ConvDesc()
         src.fill(d.src)
         d.w, d.bias, d.y = w.data_ptr(), bias, y.data_ptr()
@@ -181,6 +178,7 @@ class Engine:
         gh, gw = grid if grid is not None else (Hout, Wout)
         d.Hg, d.Wg, d.Hout, d.Wout, d.ldy, d.cout_off, d.Cout, d.Cout_pad = gh, gw, Hout, Wout, ldy, cout_off, Cout, -(-Cout // 32) * 32
         d.stride, d.om, d.oy0, d.ox0 = stride, om, oy0, ox0
+        d.planar_out, d.ctot_out = (1, Cout) if planar_out else (0, 0)
         L.set_taps(d, taps)
         nblk = self.lib.abc_conv_stat_blocks(C.byref(d))
         st = None
@@ -358,7 +356,8 @@ class Engine:
         nh = len(self.heads)
         self.h, self.w = h, w
         self.hfeat, self.hcoef = self.act_buf(h, w, 128 * nh)
-        self.logits = self.new((self.B, h, w, LDL), torch.float32)
+        # the list forward() returns: one contiguous NCHW f32 map per head (unet.py:119), written directly
+        self.logits = [self.new((self.B, hc, h, w), torch.float32) for hc in self.heads]
         self.head_recs, self.head2 = [], []
         for i, hc in enumerate(self.heads):
             p = "out_modules.%d" % i
@@ -369,8 +368,8 @@ class Engine:
             rows_pad = -(-hc // 32) * 32
             w2 = self.packed(1, 128, rows_pad)
             self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
-            self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits, L.F32, h, w, LDL, self.head_off[i], hc,
-                           [(0, 0)], what="fwd %s.conv2" % p)
+            self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
+                           [(0, 0)], what="fwd %s.conv2" % p, planar_out=True)
             self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
 
     # ------------------------------------------------------------------ backward plan
@@ -445,18 +444,23 @@ class Engine:
         ops = self.bwd_ops
         B, h, w = self.B, self.h, self.w
         nh = len(self.heads)
-        self.dlogits = self.new((B, h, w, LDL), torch.float32)
-        self.chan_scale = self.new((LDL,), torch.float32, 0.0)
-        one = self.new((LDL,), torch.float32, 1.0)
-        zero = self.new((LDL,), torch.float32, 0.0)
+        self.dlogits = [self.new((B, hc, h, w), torch.float32) for hc in self.heads]
+        nchan = sum(self.heads)
+        self.chan_scale = self.new((nchan,), torch.float32, 0.0)
+        one = self.new((max(self.heads),), torch.float32, 1.0)
+        zero = self.new((max(self.heads),), torch.float32, 0.0)
         dfeat = self.new((B, h, w, 128 * nh))
         # ---- heads' 1x1 convs
         for r2 in self.head2:
             i, hc = r2.idx, r2.cout
-            dl = Src(self.dlogits, L.F32, h, w, LDL, self.head_off[i], hc, coef=(self.chan_scale, zero, one))
+            cs = self.chan_scale[self.head_off[i]:self.head_off[i] + hc]
+            dl = Src(self.dlogits[i], L.F32, h, w, 0, 0, hc, coef=(cs, zero, one), planar=True)
             self.emit_wgrad(ops, dl, r2.src, hc, 128, [(0, 0)], 1, r2.cname + ".weight", "wgrad " + r2.cname)
-            self.emit_colsum(ops, self.dlogits, L.F32, B * h * w, LDL, self.head_off[i], hc, self.chan_scale,
-                             r2.cname + ".bias", "dbias " + r2.cname)
+            lib = self.lib
+            psw = self.new((lib.abc_plane_sum_work(hc),), torch.float32)
+            a = (self.dlogits[i].data_ptr(), B, hc, h * w, cs.data_ptr(), psw.data_ptr(), self.G(r2.cname + ".bias"))
+            ops.append((lambda _r, st, a=a: lib.abc_plane_sum(*a, st), None, "dbias " + r2.cname, (r2.cname + ".bias",),
+                        {"kernel": "plane_sum", "flops": 0, "bytes": float(B * hc * h * w * 4)}))
             wd = self.packed(1, hc, 128)
             self.emit_pack(r2.cname + ".weight", wd, 1, hc, 128, 1, 128, hc)
             self.emit_conv(ops, dl, wd, None, dfeat, self.dt, h, w, 128 * nh, 128 * i, 128, [(0, 0)], what="dgrad " + r2.cname)

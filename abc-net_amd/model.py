@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import arch
-from .engine import Engine, LDL, head_offsets
+from .engine import Engine
 
 
 def _kaiming_uniform_(t, fan_in, gen=None):
@@ -59,14 +59,12 @@ class _UNetFn(torch.autograd.Function):
             raise RuntimeError("backward through an eval-mode forward is not supported")
         st = torch.cuda.current_stream().cuda_stream
         lib = eng.lib
-        # d(loss)/d(logits) arrives as NCHW f32 per head; scatter into the NHWC dlogits rows
+        # d(loss)/d(logits) arrives as the NCHW f32 maps the kernels consume directly: plain copies
         for i, g in enumerate(gouts):
-            hc = eng.heads[i]
             if g is None:
-                g = torch.zeros((eng.B, hc, eng.h, eng.w), dtype=torch.float32, device=eng.dlogits.device)
-            g = g.contiguous().float()
-            L.check(lib.abc_nchw_to_nhwc_f32(g.data_ptr(), hc, eng.B, eng.h, eng.w, eng.dlogits.data_ptr(), LDL,
-                                            eng.head_off[i], st), "nchw_to_nhwc")
+                eng.dlogits[i].zero_()
+            else:
+                eng.dlogits[i].copy_(g)
         eng.chan_scale.fill_(1.0)
         eng.run_backward(st)
         return None, None, model._flat_grad.clone()
@@ -205,13 +203,9 @@ class UNetBase(nn.Module):
         return eng
 
     def _export_logits(self, eng, st):
-        outs = []
-        for i, hc in enumerate(eng.heads):
-            o = torch.empty((eng.B, hc, eng.h, eng.w), dtype=torch.float32, device=eng.logits.device)
-            L.check(eng.lib.abc_nhwc_to_nchw_f32(eng.logits.data_ptr(), LDL, eng.head_off[i], hc, eng.B, eng.h, eng.w,
-                                                o.data_ptr(), st), "nhwc_to_nchw")
-            outs.append(o)
-        return outs
+        # the kernels already wrote the reference's NCHW f32 maps; hand out copies because the engine
+        # reuses its buffers on the next call (the reference returns fresh tensors)
+        return [t.clone() for t in eng.logits]
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:
@@ -227,7 +221,7 @@ class UNetBase(nn.Module):
 
     # ------------------------------------------------------------------ fast path
     def forward_logits(self, x):
-        """NHWC f32 logits [B,h,w,LDL] (heads at engine.head_off) without the NCHW export"""
+        """the engine's own NCHW f32 head maps (valid until the next call), no copies"""
         eng = self._engine_for(x, self.training)
         st = torch.cuda.current_stream().cuda_stream
         eng.img.copy_(x.reshape(eng.img.shape))
@@ -237,6 +231,6 @@ class UNetBase(nn.Module):
 
     def nms(self, x):
         """inference prologue of img2smiles2.py:56-79: forward + peak NMS, heat-map only"""
-        logits, eng = self.forward_logits(x)
+        lg, eng = self.forward_logits(x)
         from .ops import nms_peaks
-        return nms_peaks(eng, logits)
+        return nms_peaks(lg[0], lg[4], lg[6], lg[7])

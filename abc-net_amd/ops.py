@@ -7,7 +7,6 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .engine import LDL
 
 HEAD_NAMES = ["atom_t", "atom_types", "atom_charges", "atom_hs", "bond_t", "bond_types", "bond_rhos", "bond_omega"]
 
@@ -27,20 +26,20 @@ class FusedLoss:
         if eng.heads != [1, 14, 3, 2, 1, 360, 60, 60]:
             raise ValueError("the fused loss is defined for heads [1,14,3,2,1,360,60,60] (train.py:47)")
         d = L.LossDesc()
-        d.logits, d.dlogits, d.ldl = eng.logits.data_ptr(), eng.dlogits.data_ptr(), LDL
+        for i in range(8):
+            d.logits[i], d.dlogits[i] = eng.logits[i].data_ptr(), eng.dlogits[i].data_ptr()
         (d.t_atom, d.t_types, d.t_charges, d.t_hs, d.t_bond, d.t_btypes, d.t_rho, d.t_omega) = (t.data_ptr() for t in targets)
         d.B, d.h, d.w = eng.B, eng.h, eng.w
-        for i in range(8):
-            d.head_off[i] = eng.head_off[i]
         self.nblk = lib.abc_loss_blocks(C.byref(d))
-        self.partial = torch.zeros((self.nblk, 16), dtype=torch.float64, device=eng.logits.device)
+        dev = eng.logits[0].device
+        self.partial = torch.zeros((self.nblk, 16), dtype=torch.float64, device=dev)
         d.partial = self.partial.data_ptr()
-        self.out = torch.zeros(17, dtype=torch.float64, device=eng.logits.device)
+        self.out = torch.zeros(17, dtype=torch.float64, device=dev)
         f = L.LossFinDesc()
         f.partial, f.nblk, f.s, f.ds, f.out = self.partial.data_ptr(), self.nblk, s_ptr, ds_ptr, self.out.data_ptr()
-        f.chan_scale, f.ldl = eng.chan_scale.data_ptr(), LDL
+        f.chan_scale, f.nchan = eng.chan_scale.data_ptr(), eng.chan_scale.numel()
         for i in range(8):
-            f.head_off[i] = eng.head_off[i]
+            f.chan_off[i] = eng.head_off[i]
             f.head_c[i] = eng.heads[i]
         f.grad_scale = grad_scale
         self.d, self.f = d, f
@@ -59,20 +58,21 @@ class FusedLoss:
         return r
 
 
-def nms_peaks(eng, logits):
-    """(atom_mask[B,1,h,w], bond_mask[B,1,h,w], |rho|[B,60,h,w], omega_mask[B,60,h,w]) as NCHW f32"""
-    B, h, w = eng.B, eng.h, eng.w
-    dev = logits.device
-    am = torch.empty((B, 1, h, w), dtype=torch.float32, device=dev)
-    bm = torch.empty((B, 1, h, w), dtype=torch.float32, device=dev)
-    rho = torch.empty((B, 60, h, w), dtype=torch.float32, device=dev)
-    om = torch.empty((B, 60, h, w), dtype=torch.float32, device=dev)
+def nms_peaks(atom, bond, rho, omega):
+    """img2smiles2.py:61-79 on the NCHW f32 head maps: (atom_mask[B,1,h,w], bond_mask[B,1,h,w],
+    |rho|[B,60,h,w], omega_mask[B,60,h,w])"""
+    lib = L.load()
+    B, n, h, w = omega.shape
+    for t in (atom, bond, rho, omega):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise L.AbcNetHipError("nms_peaks wants contiguous f32 device tensors (no CPU fallback)")
+    am, bm, r, om = torch.empty_like(atom), torch.empty_like(bond), torch.empty_like(rho), torch.empty_like(omega)
     d = L.NmsDesc()
-    d.logits, d.ldl, d.B, d.h, d.w = logits.data_ptr(), logits.shape[-1], B, h, w
-    d.off_atom, d.off_bond, d.off_rho, d.off_omega, d.n_omega = eng.head_off[0], eng.head_off[4], eng.head_off[6], eng.head_off[7], 60
-    d.atom_mask, d.bond_mask, d.rho_abs, d.omega_mask = am.data_ptr(), bm.data_ptr(), rho.data_ptr(), om.data_ptr()
-    L.check(eng.lib.abc_nms_peaks(C.byref(d), torch.cuda.current_stream().cuda_stream), "nms_peaks")
-    return am, bm, rho, om
+    d.atom, d.bond, d.rho, d.omega = atom.data_ptr(), bond.data_ptr(), rho.data_ptr(), omega.data_ptr()
+    d.B, d.h, d.w, d.n_omega = B, h, w, n
+    d.atom_mask, d.bond_mask, d.rho_abs, d.omega_mask = am.data_ptr(), bm.data_ptr(), r.data_ptr(), om.data_ptr()
+    L.check(lib.abc_nms_peaks(C.byref(d), torch.cuda.current_stream().cuda_stream), "nms_peaks")
+    return am, bm, r, om
 
 
 class FusedAdam:

@@ -160,7 +160,7 @@ class Trainer:
                     e0.record(stream)
                     self.loss.run(st)
                     e1.record(stream)
-                    marks.append(("loss_fwd_bwd+finalize", 0.0, float(eng.B * eng.h * eng.w * (544 * 4 * 2 + 381 * 4 + 120 * 8)), e0, e1))
+                    marks.append(("loss_fwd_bwd+finalize", 0.0, float(eng.B * eng.h * eng.w * (501 * 4 * 2 + 381 * 4 + 120 * 8)), e0, e1))
                     continue
                 for fn, ref, what, _w, meta in ops:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

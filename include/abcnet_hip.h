@@ -49,6 +49,9 @@ typedef struct abc_act_src {
     int32_t pool;
     float drop_p;
     uint32_t drop_seed;
+    int32_t planar;      /* 1: x is channel-planar f32 [B][ctot][Hx][Wx] (the reference's NCHW head maps and
+                            their gradients, unet.py:119); ldx is ignored, no pool/dropout */
+    int32_t ctot;
 } abc_act_src;
 
 /* Generic tap-list convolution as implicit GEMM on MFMA.  One descriptor covers
@@ -75,6 +78,9 @@ typedef struct abc_conv_desc {
     int32_t ntaps;
     int8_t tap_dy[ABC_MAX_TAPS_C];
     int8_t tap_dx[ABC_MAX_TAPS_C];
+    int32_t planar_out;  /* 1: y is channel-planar f32 [B][ctot_out][Hout][Wout] (NCHW logits written directly by
+                            the heads' 1x1 conv: the list forward() returns needs no layout pass); ldy ignored */
+    int32_t ctot_out;
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
@@ -183,20 +189,19 @@ int abc_colsum_blocks(int64_t npix);
 int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C,
                const float* chan_scale, float* work /* [abc_colsum_blocks(npix)][C] */, float* out, abc_stream_t stream);
 
-/* Fused activation + loss + dlogits (train.py:95-137).  Logits and dlogits are
- * NHWC f32 [B,h,w,ldl] with the 8 heads at channel offsets head_off[i];
- * targets are the reference's NCHW tensors (utils.py:254-300), rho/omega f64.
+/* Fused activation + loss + dlogits (train.py:95-137).  Logits and dlogits are the 8 NCHW f32
+ * head maps of unet.forward (unet.py:119), targets the reference's NCHW tensors
+ * (utils.py:254-300; rho/omega f64): one thread per pixel, every access coalesced.
  * Writes the UNNORMALISED per-term gradient d(numerator_i)/d(logit) and per-block
  * partials of the 8 numerators + 8 denominators; abc_loss_finalize reduces them,
  * forms the 8 terms, the uncertainty weighting with s (train.py:127-135), the
- * total, ds, and the per-channel factor chan_scale[c] = weight_i/denominator_i that
- * the heads' backward applies on load. */
+ * total, ds, and head_scale[i] = weight_i/denominator_i, replicated per channel into
+ * chan_scale (head i at chan_off[i]) which the heads' backward applies on load. */
 typedef struct abc_loss_desc {
-    const float* logits; float* dlogits; int32_t ldl;
+    const float* logits[8]; float* dlogits[8];
     const float* t_atom; const float* t_types; const float* t_charges; const float* t_hs; const float* t_bond;
     const float* t_btypes; const double* t_rho; const double* t_omega;
     int32_t B, h, w;
-    int32_t head_off[8];
     double* partial; /* [nblk][16] */
 } abc_loss_desc;
 int abc_loss_blocks(const abc_loss_desc* d);
@@ -206,11 +211,17 @@ typedef struct abc_loss_fin_desc {
     const float* s; float* ds;         /* [10] */
     double* out;                       /* [0]=total, [1+i]=weighted term of head i, [9+i]=raw term of head i
                                           (head order of unet.forward: atom_t, types, charges, hs, bond_t, btypes, rho, omega) */
-    float* chan_scale; int32_t ldl;    /* [ldl] */
-    int32_t head_off[8]; int32_t head_c[8];
-    float grad_scale;                  /* multiplies dlogits scale (1/world for DDP mean) */
+    float* chan_scale; int32_t nchan;  /* [nchan] */
+    int32_t chan_off[8]; int32_t head_c[8];
+    float grad_scale;                  /* multiplies the scales (1/world for the DDP gradient mean) */
 } abc_loss_fin_desc;
 int abc_loss_finalize(const abc_loss_fin_desc* d, abc_stream_t stream);
+
+/* per-channel sum over batch and pixels of a planar f32 tensor [B][C][HW], times chan_scale[c]:
+ * bias gradient of the heads' 1x1 convs (unet.py:70) from the NCHW dlogits */
+int abc_plane_sum_work(int32_t C); /* floats of workspace */
+int abc_plane_sum(const float* x, int32_t B, int32_t C, int32_t HW, const float* chan_scale, float* work, float* out,
+                  abc_stream_t stream);
 
 /* torch.optim.Adam step over a flat f32 arena (train.py:55,141): L2 decay into the
  * gradient, bias correction from the device-side step counter. */
@@ -221,16 +232,16 @@ typedef struct abc_adam_desc {
 } abc_adam_desc;
 int abc_adam_step(const abc_adam_desc* d, abc_stream_t stream);
 
-/* Inference NMS (img2smiles2.py:61-79) on NHWC f32 logits: atom/bond 3x3 peak
- * masks, |rho|, circular 3-tap omega peak mask; outputs NCHW f32 like the reference. */
+/* Inference NMS (img2smiles2.py:61-79) on the NCHW f32 head maps: atom/bond 3x3 peak
+ * masks (logit > -1), |rho|, circular 3-tap omega peak mask; outputs NCHW f32 like the reference. */
 typedef struct abc_nms_desc {
-    const float* logits; int32_t ldl; int32_t B, h, w;
-    int32_t off_atom, off_bond, off_rho, off_omega, n_omega;
+    const float* atom; const float* bond; const float* rho; const float* omega;
+    int32_t B, h, w, n_omega;
     float* atom_mask; float* bond_mask; float* rho_abs; float* omega_mask;
 } abc_nms_desc;
 int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream);
 
-/* layout conversion at the drop-in boundary (forward() returns NCHW f32 maps: unet.py:119) */
+/* layout conversion helpers (multi-channel NCHW input images -> NHWC) */
 int abc_nhwc_to_nchw_f32(const float* src, int32_t ld, int32_t c_off, int32_t C, int32_t B, int32_t H, int32_t W,
                          float* dst, abc_stream_t stream);
 int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int32_t W, float* dst, int32_t ld,

@@ -47,13 +47,16 @@ def pack(lib, w, mode, dt, Cout, Cin, k, rows_pad, red_real, py=0, px=0):
 
 
 def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, Hout, Wout, ldy=None, cout_off=0, coef=None,
-         pool=False, stride=1, grid=None, om=1, oy0=0, ox0=0, out=None, out_dt=None, stats=False, drop_p=0.0, drop_seed=0):
+         pool=False, stride=1, grid=None, om=1, oy0=0, ox0=0, out=None, out_dt=None, stats=False, drop_p=0.0, drop_seed=0,
+         planar_in=0, planar_out=False):
     out_dt = dt if out_dt is None else out_dt
     ldy = Cout if ldy is None else ldy
     if out is None:
-        out = torch.zeros((B, Hout, Wout, ldy), dtype=tdt(out_dt), device=DEV)
+        out = torch.zeros((B, Cout, Hout, Wout) if planar_out else (B, Hout, Wout, ldy), dtype=tdt(out_dt), device=DEV)
     d = L.ConvDesc()
     fill_src(d.src, x, Hx, Wx, ldx, coef, pool, drop_p, drop_seed)
+    d.src.planar, d.src.ctot = (1, planar_in) if planar_in else (0, 0)
+    d.planar_out, d.ctot_out = (1, Cout) if planar_out else (0, 0)
     d.w, d.bias, d.y = wp.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr()
     d.dtype_in, d.dtype_c, d.dtype_out = dt_in, dt, out_dt
     d.B, d.Hin, d.Win = B, (Hx // 2 if pool else Hx), (Wx // 2 if pool else Wx)

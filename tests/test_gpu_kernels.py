@@ -84,6 +84,74 @@ def test_conv_forward(lib, dt, case):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Cout,W", [(14, 32), (60, 24), (1, 20), (360, 18)])
+def test_head_conv1x1_writes_nchw(lib, dt, Cout, W):
+    """heads' 1x1 conv (unet.py:70): BN+LeakyReLU+dropout on load, channel-offset input, NCHW f32 output"""
+    from abcnet_amd.dropout import keep_mask
+    g = torch.Generator().manual_seed(31)
+    B, H, ld, coff, Cin = 2, 16, 256, 128, 128
+    x = q(torch.randn((B, ld, H, W), generator=g), dt)
+    w = torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    sc, sh = torch.rand(ld, generator=g) * 2 - 0.6, torch.randn(ld, generator=g) * 0.3
+    sl = torch.full((ld,), 0.01)
+    p_drop, seed = 0.2, 777
+    idx = (torch.arange(B * H * W).view(B, H, W, 1) * ld + torch.arange(ld).view(1, 1, 1, ld))
+    keep = keep_mask(idx, seed, p_drop).permute(0, 3, 1, 2).float()
+    a = act(x, sc, sh, sl) * keep / (1 - p_drop)
+    ref = F.conv2d(q(a[:, coff:coff + Cin], dt), q(w, dt), b)
+    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, 1, -(-Cout // 32) * 32, Cin)
+    coef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
+    y, _ = U.conv(lib, U.nhwc(x, dt), dt, dt, B, H, W, ld, coff, Cin, wp, b.to(U.DEV), Cout, [(0, 0)], H, W, coef=coef, out_dt=L.F32,
+                  drop_p=p_drop, drop_seed=seed, planar_out=True)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (B, Cout, H, W)
+    assert U.relerr(y.cpu(), ref) < U.tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("Cn", [14, 60, 1, 360])
+def test_head_conv1x1_backward_from_nchw(lib, dt, Cn):
+    """data and weight gradient of the heads' 1x1 conv, reading NCHW f32 dlogits with a per-channel scale"""
+    g = torch.Generator().manual_seed(33)
+    B, H, W, Cin = 2, 16, 24, 128
+    f = q(torch.randn((B, Cin, H, W), generator=g), dt).requires_grad_(True)
+    w = q(torch.randn((Cn, Cin, 1, 1), generator=g) / Cin ** 0.5, dt).requires_grad_(True)
+    dl = torch.randn((B, Cn, H, W), generator=g)
+    scale = 0.37
+    F.conv2d(f, w).backward(q(dl * scale, dt))
+    dld = dl.to(U.DEV).contiguous()
+    cs = (torch.full((Cn,), scale), torch.zeros(Cn), torch.ones(Cn))
+    cs = tuple(t.to(U.DEV) for t in cs)
+    wd = U.pack(lib, w.detach().to(U.DEV), 1, dt, Cn, Cin, 1, Cin, Cn)
+    dx, _ = U.conv(lib, dld, L.F32, dt, B, H, W, 0, 0, Cn, wd, None, Cin, [(0, 0)], H, W, coef=cs, planar_in=Cn)
+    d = L.WgradDesc()
+    U.fill_src(d.p, dld, H, W, 0, cs)
+    d.p.planar, d.p.ctot = 1, Cn
+    fd = U.nhwc(f.detach(), dt)
+    U.fill_src(d.q, fd, H, W, Cin)
+    d.dtype_p, d.dtype_q, d.dtype_c = L.F32, dt, dt
+    d.B, d.Hg, d.Wg, d.Hq, d.Wq, d.Ca, d.Cb, d.stride, d.nsplit = B, H, W, H, W, Cn, Cin, 1, 2
+    L.set_taps(d, [(0, 0)])
+    ca, cb = L.i32(), L.i32()
+    L.check(lib.abc_wgrad_pads(C.byref(d), C.byref(ca), C.byref(cb)), "pads")
+    part = torch.zeros(2 * ca.value * cb.value, dtype=torch.float32, device=U.DEV)
+    d.partial = part.data_ptr()
+    L.check(lib.abc_wgrad(C.byref(d), U.stream()), "wgrad")
+    dw = torch.zeros((Cn, Cin, 1), dtype=torch.float32, device=U.DEV)
+    r = L.WgradReduceDesc()
+    r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), 2, 1, Cn, Cin, ca.value, cb.value, dw.data_ptr(), 0
+    L.check(lib.abc_wgrad_reduce(C.byref(r), U.stream()), "reduce")
+    db = torch.zeros(Cn, device=U.DEV)
+    psw = torch.zeros(lib.abc_plane_sum_work(Cn), device=U.DEV)
+    L.check(lib.abc_plane_sum(dld.data_ptr(), B, Cn, H * W, cs[0].data_ptr(), psw.data_ptr(), db.data_ptr(), U.stream()), "plane_sum")
+    torch.cuda.synchronize()
+    assert U.relerr(U.to_nchw(dx), f.grad) < U.tol(dt)
+    assert U.relerr(dw.cpu().view(Cn, Cin, 1, 1), w.grad) < U.tol(dt)
+    np.testing.assert_allclose(db.cpu(), (dl * scale).sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_conv_transpose_into_concat(lib, dt):
     """4 parity phases == ConvTranspose2d(k3,s2) + crop of first row/col, written at a channel offset"""
     g = torch.Generator().manual_seed(5)

@@ -170,7 +170,7 @@ def test_fused_train_step_matches_oracle():
 
 def test_fused_loss_matches_golden(golden_dir):
     """loss kernel alone on the seeded logits/targets of tests/golden/loss_128.npz"""
-    from abcnet_amd.engine import LDL, head_offsets
+    from abcnet_amd.engine import head_offsets
     from abcnet_amd.ops import FusedLoss
     gold = np.load(os.path.join(golden_dir, "loss_128.npz"))
     g = torch.Generator().manual_seed(11)
@@ -183,11 +183,9 @@ def test_fused_loss_matches_golden(golden_dir):
 
     e = E()
     e.lib, e.B, e.h, e.w, e.heads, e.head_off = L.load(), 2, 128, 128, HEADS, head_offsets(HEADS)
-    e.logits = torch.zeros((2, 128, 128, LDL), device=DEV)
-    e.dlogits = torch.zeros_like(e.logits)
-    e.chan_scale = torch.zeros(LDL, device=DEV)
-    for i, p in enumerate(preds):
-        e.logits[..., e.head_off[i]:e.head_off[i] + HEADS[i]] = p.permute(0, 2, 3, 1).to(DEV)
+    e.logits = [p.to(DEV).contiguous() for p in preds]
+    e.dlogits = [torch.zeros_like(t) for t in e.logits]
+    e.chan_scale = torch.zeros(sum(HEADS), device=DEV)
     sdev, ds = s.to(DEV), torch.zeros(10, device=DEV)
     fl = FusedLoss(e, [t.to(DEV) for t in tg], sdev.data_ptr(), ds.data_ptr())
     fl.run(torch.cuda.current_stream().cuda_stream)
@@ -196,7 +194,7 @@ def test_fused_loss_matches_golden(golden_dir):
     assert abs(r["total"] - gold["loss"].item()) < 1e-5 * abs(gold["loss"].item())
     np.testing.assert_allclose(ds.cpu().double().numpy(), gold["ds"], rtol=1e-4, atol=1e-7)
     for i, c in enumerate(HEADS):
-        gl = (e.dlogits[..., e.head_off[i]:e.head_off[i] + c] * e.chan_scale[e.head_off[i]]).permute(0, 3, 1, 2).contiguous().cpu()
+        gl = (e.dlogits[i] * e.chan_scale[e.head_off[i]]).cpu()
         f = gl.reshape(-1)
         step = max(f.numel() // 1031, 1)
         np.testing.assert_allclose(f[::step][:1031].double().numpy(), gold["dlogit%d_sample" % i], rtol=2e-3, atol=1e-7)
@@ -204,7 +202,6 @@ def test_fused_loss_matches_golden(golden_dir):
 
 
 def test_nms_matches_golden(golden_dir):
-    from abcnet_amd.engine import LDL, head_offsets
     from abcnet_amd.ops import nms_peaks
     gold = np.load(os.path.join(golden_dir, "nms_128.npz"))
     g = torch.Generator().manual_seed(13)
@@ -213,22 +210,28 @@ def test_nms_matches_golden(golden_dir):
     rho = torch.randn((2, 60, 128, 128), generator=g) * 3
     _ = torch.randn((2, 360, 128, 128), generator=g)
     om = torch.round(torch.randn((2, 60, 128, 128), generator=g) * 4) / 4
-
-    class E:
-        pass
-
-    e = E()
-    e.lib, e.B, e.h, e.w, e.head_off = L.load(), 2, 128, 128, head_offsets(HEADS)
-    logits = torch.zeros((2, 128, 128, LDL), device=DEV)
-    for i, t in ((0, a), (4, b), (6, rho), (7, om)):
-        logits[..., e.head_off[i]:e.head_off[i] + t.shape[1]] = t.permute(0, 2, 3, 1).to(DEV)
-    am, bm, r, omm = nms_peaks(e, logits)
+    am, bm, r, omm = nms_peaks(a.to(DEV), b.to(DEV), rho.to(DEV), om.to(DEV))
     torch.cuda.synchronize()
     assert np.array_equal(np.packbits(am.cpu().numpy().astype(np.uint8)), gold["atom_mask"])
     assert np.array_equal(np.packbits(bm.cpu().numpy().astype(np.uint8)), gold["bond_mask"])
     assert np.array_equal(np.packbits(omm.cpu().numpy().astype(np.uint8)), gold["omega_mask"])
     ra, rb, rr, ro = nms_oracle.nms(a, b, rho, om)
     assert torch.equal(r.cpu(), rr) and torch.equal(am.cpu(), ra) and torch.equal(omm.cpu(), ro)
+
+
+def test_inference_prologue_matches_oracle():
+    """img2smiles2.py:42-79 end to end: eval forward + NMS on the HIP path vs oracle forward + oracle NMS.
+    Peak masks are decisions on logits that differ by ~1e-5, so allow a handful of flips."""
+    x = synthetic_images(2, 128, seed=7)
+    m = make_model()
+    m.eval()
+    with torch.no_grad():
+        am, bm, r, om = m.nms(x.to(DEV))
+        ref = uo.forward("unet", uo.filled_state("unet", 1, HEADS, seed=0), x, train=False)
+    ra, rb, rr, ro = nms_oracle.nms(ref[0], ref[4], ref[6], ref[7])
+    assert (am.cpu() != ra).sum().item() <= 2 and (bm.cpu() != rb).sum().item() <= 2
+    assert (om.cpu() != ro).float().mean().item() < 1e-3
+    assert (r.cpu() - rr).abs().max().item() < 1e-3
 
 
 def test_state_dict_roundtrip_and_module_prefix():
