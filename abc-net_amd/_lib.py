@@ -103,6 +103,7 @@ SYMBOLS = {
     "abc_conv_stat_blocks": (C.c_int, [P(ConvDesc)]),
     "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),
     "abc_conv_chunk": (C.c_int, [C.c_int, C.c_int]),
+    "abc_conv_tile": (C.c_int, [P(ConvDesc), P(i32), P(i32), P(i32)]),
     "abc_pack_conv_weights": (C.c_int, [P(PackDesc), vp]),
     "abc_bn_finalize_fwd": (C.c_int, [P(BnFwdDesc), vp]),
     "abc_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, f32, vp]),

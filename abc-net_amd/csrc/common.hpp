@@ -202,3 +202,92 @@ __device__ inline void stage_halo(char* sA, int RS, int PS, int HH, int HW, int 
         *(typename Frag<CT>::type*)(sA + hy * RS + hx * PS + part * 16) = pack_frag<CT>(v);
     }
 }
+
+// ---------------------------------------------------------------------------
+// Split-phase halo staging (cdna_hip_programming.md T14: issue the global loads early, transform and
+// write LDS late, so HBM/L2 latency hides under the MFMA block in between).  Fast path only:
+// NHWC source, no pool, no dropout, all NV channels of every segment present.
+template <typename InT, int NV> struct RawVec;
+template <> struct RawVec<bf16, 8> {
+    bf16x8 v;
+    __device__ inline void ld(const bf16* p) { v = *(const bf16x8*)p; }
+    __device__ inline void zero() { for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f; }
+    __device__ inline void get(float* o) const { for (int j = 0; j < 8; ++j) o[j] = (float)v[j]; }
+};
+template <> struct RawVec<float, 4> {
+    f32x4 v;
+    __device__ inline void ld(const float* p) { v = *(const f32x4*)p; }
+    __device__ inline void zero() { v[0] = v[1] = v[2] = v[3] = 0.f; }
+    __device__ inline void get(float* o) const { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+};
+template <> struct RawVec<float, 8> {
+    f32x4 a, b;
+    __device__ inline void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    __device__ inline void zero() { a[0] = a[1] = a[2] = a[3] = 0.f; b = a; }
+    __device__ inline void get(float* o) const {
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    }
+};
+
+template <typename InT, typename CT, int CK, int NMAX, int NTHR>
+struct HaloPrefetch {
+    static constexpr int NV = Frag<CT>::NV;
+    static constexpr int SEGS = CK / NV;
+    RawVec<InT, NV> raw[NMAX];
+    unsigned inb;  // bit i: item i is inside the image
+
+    // issue the loads of chunk starting at absolute channel c0
+    __device__ inline void issue(int HH, int HW, int b, int iy0, int ix0, int Hin, int Win, const ActSrc& s, int c0, int tid) {
+        const int part = tid % SEGS;
+        const int cch = c0 + part * NV;
+        const int total = HH * HW * SEGS;
+        const InT* xb = (const InT*)s.x;
+        inb = 0;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {
+            const int sidx = tid + i * NTHR;
+            if (sidx < total) {
+                const int pix = sidx / SEGS;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+                    raw[i].ld(xb + ((size_t)(b * s.Hx + iy) * s.Wx + ix) * s.ldx + cch);
+                    inb |= 1u << i;
+                }
+            }
+        }
+    }
+    // transform + write to LDS.  lcoef = LDS table [3][cstride] of (scale, shift, slope) indexed by the channel
+    // RELATIVE to the conv's first input channel (crel0 = first channel of this chunk), or null = identity
+    __device__ inline void commit(char* sA, int RS, int PS, int HH, int HW, const float* lcoef, int cstride, int crel0, int tid) {
+        const int part = tid % SEGS;
+        const int cch = crel0 + part * NV;
+        const int total = HH * HW * SEGS;
+        float sc[NV], sh[NV], sl[NV];
+        const bool has_t = lcoef != nullptr;
+        if (has_t) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { sc[j] = lcoef[cch + j]; sh[j] = lcoef[cstride + cch + j]; sl[j] = lcoef[2 * cstride + cch + j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {
+            const int sidx = tid + i * NTHR;
+            if (sidx < total) {
+                const int pix = sidx / SEGS;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                float v[NV];
+                if (inb & (1u << i)) {
+                    raw[i].get(v);
+                    if (has_t) {
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) v[j] = abc_act(v[j], sc[j], sh[j], sl[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) v[j] = 0.f;
+                }
+                *(typename Frag<CT>::type*)(sA + hy * RS + hx * PS + part * 16) = pack_frag<CT>(v);
+            }
+        }
+    }
+};

@@ -1,24 +1,32 @@
 // Generic tap-list convolution as implicit GEMM on the gfx950 matrix cores.
 //
-// GEMM view: M = output pixels (8x16 spatial patch of one image per workgroup),
-// N = output channels (BN per workgroup), K = taps x input channels, walked as
-// [Cin chunk of 64 B][tap].  Per chunk the activated input halo tile is staged ONCE
-// in LDS (previous layer's BN + activation (+pool, +dropout) applied on the way in)
-// and reused by every tap; the weight slices of TG taps are staged beside it.
+// GEMM view: M = output pixels (a (2*MT) x 16 spatial patch of one image per workgroup: 128 or
+// 256 pixels), N = output channels (BN per workgroup), K = taps x input channels, walked as
+// [Cin chunk of 64 B][tap group].  Per chunk the activated input halo tile is staged ONCE in LDS
+// (previous layer's BN + activation (+pool, +dropout) applied on the way in) and reused by every
+// tap; the weight slices of a tap group (<= TG taps) sit beside it, double-buffered.
 // A wave computes TM x TN tiles of 32x32 with v_mfma_f32_32x32x16_bf16 (bf16 mode) or
 // v_mfma_f32_32x32x2_f32 (exact-f32 parity mode): lane-half h of the wave owns bytes
-// [32h, 32h+32) of each pixel's/row's 64-byte chunk for BOTH operands, so one LDS image
-// serves both dtypes and fragment reads are plain ds_read_b128.
+// [32h, 32h+32) of each pixel's/row's 64-byte chunk for BOTH operands, so one LDS image serves
+// both dtypes and fragment reads are plain ds_read_b128.
 //
-// LDS images: pixel stride PS = chunk bytes + 16, A row stride a multiple of 256 B:
-// every ds_read_b128 lane group then covers 16 distinct 16-byte slots (conflict-free).
+// Software pipeline (cdna_hip_programming.md T14): the global loads of stage s+1 (weights, and the
+// next chunk's halo when s+1 opens a chunk) are ISSUED before the MFMA block of stage s and
+// COMMITTED to LDS after it, so L2/HBM latency hides under the matrix work; one barrier per stage.
+//
+// LDS images: pixel stride PS = chunk bytes + 16, A row stride a multiple of 256 B: every
+// ds_read_b128 lane group then covers 16 distinct 16-byte slots (conflict-free).
 //
 // Reference ops covered: see include/abcnet_hip.h (abc_conv_desc).
 #include "common.hpp"
 #include "../../include/abcnet_hip.h"
 #include "capi_util.hpp"
+#include <stdlib.h>
 
 namespace {
+
+constexpr int NTHR = 512;  // 8 waves per workgroup, one workgroup per CU (2 waves per SIMD)
+constexpr int NA_MAX = 4;  // halo segments a thread may prefetch (fast path)
 
 struct ConvK {
     ActSrc src;
@@ -29,13 +37,13 @@ struct ConvK {
     int B, Hin, Win, cin_off, Cin, nchunks;
     int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad;
     int om, oy0, ox0;
-    int ntaps, tg, dy_min, dx_min, HH, HW, RS;
-    int tiles_x, tiles_y, nblocks_n, sB_off, tap_off, planar_out, ctot_out;
+    int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS;
+    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
     constexpr int LHB = CKB / 2;
@@ -44,15 +52,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
     constexpr int SEGS = CKB / 16;
     constexpr int NT = BN / 32;
     constexpr int WN = (NT >= 2) ? 2 : 1;
-    constexpr int WM = 4 / WN;
-    constexpr int TM = 4 / WM;
+    constexpr int WM = 8 / WN;
+    constexpr int TM = MT / WM;
     constexpr int TN = NT / WN;
+    static_assert(TM >= 1 && TM * WM == MT, "tile/wave layout");
+    constexpr int TGMAX = 3;
+    constexpr int NB = (TGMAX * BN * SEGS + NTHR - 1) / NTHR;  // weight segments a thread prefetches per stage
     typedef typename Frag<CT>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* sB = smem + a.sB_off;
+    char* sA = smem;                 // a_bufs buffers of sA_bytes
+    char* sB = smem + a.sB_off;      // 2 buffers of sB_bytes
     int* sTap = (int*)(smem + a.tap_off);
+    float* sCoef = (float*)(smem + a.coef_off);  // [3][cstride]: scale, shift, slope of the conv's input channels
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -67,10 +79,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
     const int tx_i = id % a.tiles_x; id /= a.tiles_x;
     const int ty_i = id % a.tiles_y; id /= a.tiles_y;
     const int b = id;
-    const int gy0 = ty_i * 8, gx0 = tx_i * 16;
+    const int gy0 = ty_i * (2 * MT), gx0 = tx_i * 16;
     const int n0 = nb * BN;
 
     if (tid < a.ntaps) sTap[tid] = a.ty[tid] * a.RS + a.tx[tid] * PS;
+    const bool has_coef = a.src.scale != nullptr;
+    if (has_coef && a.fast_a) {
+        for (int i = tid; i < a.Cin; i += NTHR) {
+            sCoef[i] = a.src.scale[a.cin_off + i];
+            sCoef[a.cstride + i] = a.src.shift[a.cin_off + i];
+            sCoef[2 * a.cstride + i] = a.src.slope[a.cin_off + i];
+        }
+    }
+    const float* lcoef = has_coef ? sCoef : nullptr;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -91,81 +112,184 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 
     const CT* wp = (const CT*)a.w;
     const int iy0 = gy0 * STRIDE + a.dy_min, ix0 = gx0 * STRIDE + a.dx_min;
+    const int nstages = a.nchunks * a.ngroups;
 
-    for (int c = 0; c < a.nchunks; ++c) {
-        __syncthreads();  // everyone done with the previous chunk's A and B
-        stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off + c * CK, tid, 256,
-                                a.Cin - c * CK);
-        for (int t0 = 0; t0 < a.ntaps; t0 += a.tg) {
-            if (t0 > 0) __syncthreads();  // B of the previous tap group consumed
-            const int tcnt = min(a.tg, a.ntaps - t0);
-            // ---- stage B: tcnt x BN rows of CKB bytes (contiguous per tap in the packed layout)
-            for (int s = tid; s < tcnt * BN * SEGS; s += 256) {
+    frag_t breg[NB];
+    HaloPrefetch<InT, CT, CK, NA_MAX, NTHR> apre;
+
+    // weights of stage (c, g): tcnt x BN rows of CKB bytes, contiguous per tap in the packed layout
+    auto b_issue = [&](int c, int g) {
+        const int t0 = g * a.tg;
+        const int tcnt = min(a.tg, a.ntaps - t0);
+        const int total = tcnt * BN * SEGS;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int s = tid + i * NTHR;
+            if (s < total) {
                 const int tl = s / (BN * SEGS);
                 const int rem = s - tl * (BN * SEGS);
                 const int row = rem / SEGS, part = rem - row * SEGS;
-                const CT* g = wp + ((size_t)((t0 + tl) * a.nchunks + c) * a.Cout_pad + n0 + row) * CK + part * NV;
-                *(frag_t*)(sB + (tl * BN + row) * PS + part * 16) = *(const frag_t*)g;
+                breg[i] = *(const frag_t*)(wp + ((size_t)((t0 + tl) * a.nchunks + c) * a.Cout_pad + n0 + row) * CK + part * NV);
             }
-            __syncthreads();
-            // ---- MFMA over the staged taps
-            for (int tl = 0; tl < tcnt; ++tl) {
+        }
+    };
+    auto b_commit = [&](int g, char* dst) {
+        const int t0 = g * a.tg;
+        const int tcnt = min(a.tg, a.ntaps - t0);
+        const int total = tcnt * BN * SEGS;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int s = tid + i * NTHR;
+            if (s < total) {
+                const int tl = s / (BN * SEGS);
+                const int rem = s - tl * (BN * SEGS);
+                const int row = rem / SEGS, part = rem - row * SEGS;
+                *(frag_t*)(dst + (tl * BN + row) * PS + part * 16) = breg[i];
+            }
+        }
+    };
+
+    // ---- prologue: chunk 0 halo + stage 0 weights
+    b_issue(0, 0);
+    if (a.fast_a) {
+        apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
+        __syncthreads();  // coefficient table visible
+        apre.commit(sA, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, 0, tid);
+    } else {
+        stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid, NTHR, a.Cin);
+    }
+    b_commit(0, sB);
+    __syncthreads();
+
+    int c = 0, g = 0;
+    for (int s = 0; s < nstages; ++s) {
+        int gn = g + 1, cn = c;
+        if (gn == a.ngroups) { gn = 0; cn = c + 1; }
+        const bool has_next = (s + 1 < nstages);
+        const bool new_chunk = has_next && (gn == 0);
+        if (has_next && !(a.dbg & 1)) b_issue(cn, gn);
+        if (new_chunk && a.fast_a && !(a.dbg & 2))
+            apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off + cn * CK, tid);
+
+        // ---- MFMA over the taps of this stage
+        {
+            const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
+            const char* sBc = sB + (s & 1) * a.sB_bytes;
+            const int t0 = g * a.tg;
+            const int tcnt = min(a.tg, a.ntaps - t0);
+            for (int tl = 0; tl < ((a.dbg & 4) ? 0 : tcnt); ++tl) {
                 const int aoff = sTap[t0 + tl];
                 const int boff = tl * BN * PS;
-                frag_t fa[TM][NR], fb[TN][NR];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int q = 0; q < NR; ++q) {
+                    frag_t fa[TM], fb[TN];
 #pragma unroll
-                    for (int q = 0; q < NR; ++q) fa[i][q] = *(const frag_t*)(sA + aBase[i] + aoff + q * 16);
+                    for (int i = 0; i < TM; ++i) fa[i] = *(const frag_t*)(sAc + aBase[i] + aoff + q * 16);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < NR; ++q) fb[j][q] = *(const frag_t*)(sB + bBase[j] + boff + q * 16);
-#pragma unroll
-                for (int q = 0; q < NR; ++q)
+                    for (int j = 0; j < TN; ++j) fb[j] = *(const frag_t*)(sBc + bBase[j] + boff + q * 16);
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa[i][q], fb[j][q]);
+                        for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa[i], fb[j]);
+                }
             }
         }
+
+        if (has_next && !(a.dbg & 8)) b_commit(gn, sB + ((s + 1) & 1) * a.sB_bytes);
+        if (new_chunk) {
+            if (a.a_bufs == 2) {
+                // the other halo buffer was last read in chunk c-1: free since the barrier that ended it
+                if (!(a.dbg & 16)) apre.commit(sA + (cn & 1) * a.sA_bytes, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, cn * CK, tid);
+            } else {
+                __syncthreads();  // every wave is done reading this chunk's halo
+                if (a.fast_a) apre.commit(sA, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, cn * CK, tid);
+                else
+                    stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off + cn * CK, tid, NTHR,
+                                            a.Cin - cn * CK);
+            }
+        }
+        __syncthreads();
+        c = cn; g = gn;
     }
 
-    // ---- epilogue: bias, statistics of the f32 values, store
+    // ---- epilogue: bias, statistics of the f32 values, store.
+    // NHWC outputs go through a per-wave LDS transpose (32 pixels x TN*32 channels at a time) so that every
+    // global store is 16 bytes of consecutive channels of one pixel (a lane of the accumulator layout holds ONE
+    // channel of 16 pixels: storing from registers would be 2-/4-byte scattered stores, issue-bound).
     OutT* yo = (OutT*)a.y;
     float s1[TN], s2[TN];
+    float bv[TN];
+    bool nval[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         s1[j] = 0.f; s2[j] = 0.f;
         const int n = n0 + (wn * TN + j) * 32 + r;
-        const bool nvalid = n < a.Cout;
-        const float bv = (a.bias != nullptr && nvalid) ? a.bias[n] : 0.f;
+        nval[j] = n < a.Cout;
+        bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
+    }
+    const bool planar = (sizeof(OutT) == 4) && a.planar_out;
+    if (!planar) {
+        constexpr int TW = TN * 32;                       // channels of this wave's tile row
+        constexpr int ROWB = TW * (int)sizeof(OutT) + 16;  // padded LDS row (bytes)
+        constexpr int EV = 16 / (int)sizeof(OutT);         // elements per 16-byte store
+        constexpr int SEG_PER_ROW = TW / EV;
+        __syncthreads();  // main-loop LDS reads finished
+        char* stg = smem + wave * (32 * ROWB);
+        const int cbase = n0 + wn * TW;  // first channel of the wave's tile row
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
+                    const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
+                    const float v = acc[i][j][k] + bv[j];
+                    if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; }
+                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)v;
+                }
+            }
+            __syncthreads();
+            // 32 rows x SEG_PER_ROW 16-byte segments, 64 lanes
+#pragma unroll
+            for (int e = lane; e < 32 * SEG_PER_ROW; e += 64) {
+                const int rit = e / SEG_PER_ROW, sg = e - rit * SEG_PER_ROW;
                 const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
-                if (nvalid && gy < a.Hg && gx < a.Wg) {
-                    const float v = acc[i][j][k] + bv;
-                    s1[j] += v; s2[j] += v * v;
-                    if constexpr (sizeof(OutT) == 4) {
-                        if (a.planar_out) {
-                            // NCHW: registers k..k+3 of a lane are 4 consecutive x of one plane -> one 16-byte store
-                            const size_t o = ((size_t)(b * a.ctot_out + a.cout_off + n) * a.Hout + gy) * a.Wout + gx;
-                            if ((k & 3) == 0 && gx + 3 < a.Wg && (a.Wout & 3) == 0) {
-                                f32x4 t;
-                                t[0] = v; t[1] = acc[i][j][k + 1] + bv; t[2] = acc[i][j][k + 2] + bv; t[3] = acc[i][j][k + 3] + bv;
-                                *(f32x4*)((float*)a.y + o) = t;
-                            } else if (!(gx - (k & 3) + 3 < a.Wg && (a.Wout & 3) == 0)) {
-                                ((float*)a.y)[o] = v;
-                            }
-                            continue;
+                const int cch = cbase + sg * EV;
+                if (gy < a.Hg && gx < a.Wg && cch < a.Cout) {
+                    const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cch;
+                    if (cch + EV <= a.Cout && ((a.ldy | (a.cout_off + cch)) % EV) == 0) {
+                        *(f32x4*)(yo + o) = *(const f32x4*)(stg + rit * ROWB + sg * 16);
+                    } else {
+                        for (int q = 0; q < EV && cch + q < a.Cout; ++q) yo[o + q] = *(const OutT*)(stg + rit * ROWB + sg * 16 + q * (int)sizeof(OutT));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + r;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
+                    const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
+                    if (nval[j] && gy < a.Hg && gx < a.Wg) {
+                        const float v = acc[i][j][k] + bv[j];
+                        s1[j] += v; s2[j] += v * v;
+                        // NCHW: registers k..k+3 of a lane are 4 consecutive x of one plane -> one 16-byte store
+                        const size_t o = ((size_t)(b * a.ctot_out + a.cout_off + n) * a.Hout + gy) * a.Wout + gx;
+                        if ((k & 3) == 0 && gx + 3 < a.Wg && (a.Wout & 3) == 0) {
+                            f32x4 t;
+                            t[0] = v; t[1] = acc[i][j][k + 1] + bv[j]; t[2] = acc[i][j][k + 2] + bv[j]; t[3] = acc[i][j][k + 3] + bv[j];
+                            *(f32x4*)((float*)a.y + o) = t;
+                        } else if (!(gx - (k & 3) + 3 < a.Wg && (a.Wout & 3) == 0)) {
+                            ((float*)a.y)[o] = v;
                         }
                     }
-                    const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy
-                                     + a.cout_off + n;
-                    yo[o] = (OutT)v;
                 }
             }
         }
@@ -195,7 +319,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK a) {
 }
 
 struct Geom {
-    int CK, BN, dy_min, dx_min, HH, HW, PS, RS, tg, sA_bytes, sB_bytes, tap_off, lds, tiles_x, tiles_y, nbn, grid;
+    int CK, BN, MT, dy_min, dx_min, HH, HW, PS, RS, tg, ngroups, sA_bytes, a_bufs, sB_bytes, tap_off, coef_off, cstride, lds, tiles_x,
+        tiles_y, nbn, grid, fast_a;
 };
 
 static int conv_geom(const abc_conv_desc* d, Geom* g) {
@@ -206,60 +331,79 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
     if (g->CK <= 0) return abc_fail(ABC_EINVAL, "conv: Cin must be positive");
     if (d->Cout_pad % 32 || d->Cout_pad < d->Cout) return abc_fail(ABC_EINVAL, "conv: Cout_pad must be a multiple of 32 >= Cout");
     g->BN = (d->Cout_pad % 128 == 0) ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
+    g->nbn = d->Cout_pad / g->BN;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
     for (int t = 0; t < d->ntaps; ++t) {
         dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
         dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
     }
     g->dy_min = dymin; g->dx_min = dxmin;
-    g->HH = 7 * d->stride + (dymax - dymin) + 1;
+    // patch height: 16 rows (256 pixels) halves the weight re-staging per output pixel; 8 rows where the taller
+    // patch would waste rows or (stride 2) blow up the halo image.  BN = 32 needs 8 m-tiles to feed 8 waves.
+    const int t16 = abc_cdiv(d->Hg, 16) * 16, t8 = abc_cdiv(d->Hg, 8) * 8;
+    g->MT = (g->BN == 32 || (d->stride == 1 && t16 == t8)) ? 8 : 4;
+    const int prow = 2 * g->MT;
+    g->HH = (prow - 1) * d->stride + (dymax - dymin) + 1;
     g->HW = 15 * d->stride + (dxmax - dxmin) + 1;
     const int CKB = g->CK * csz;
     g->PS = CKB + 16;
     g->RS = abc_roundup(g->HW * g->PS, 256);
     g->sA_bytes = abc_roundup(g->HH * g->RS, 256);
-    // taps per weight stage: keep the B image <= ~40 KB so that 2-3 workgroups fit a CU
-    int tg = 40960 / (g->BN * g->PS);
-    if (tg < 1) tg = 1;
+    const int segs = CKB / 16;
+    g->fast_a = (!d->src.pool && !d->src.planar && d->src.drop_p <= 0.f && d->Cin % g->CK == 0 &&
+                 abc_cdiv(g->HH * g->HW * segs, NTHR) <= NA_MAX) ? 1 : 0;
+    g->cstride = abc_roundup(d->Cin, 4);
+    const int coef_bytes = abc_roundup(3 * g->cstride * 4, 256);
+    // one workgroup per CU: spend the LDS on double buffers (halo when it is prefetched, weights always)
+    const int budget = 156 * 1024 - coef_bytes - 256;
+    g->a_bufs = (g->fast_a && 2 * g->sA_bytes + 2 * g->BN * g->PS <= budget) ? 2 : 1;
+    int tg = (budget - g->a_bufs * g->sA_bytes) / 2 / (g->BN * g->PS);
+    if (tg < 1) return abc_fail(ABC_EUNSUPPORTED, "conv: LDS tile too large");
+    if (tg > 3) tg = 3;
     if (tg > d->ntaps) tg = d->ntaps;
-    // balance the groups
-    const int ngroups = abc_cdiv(d->ntaps, tg);
-    tg = abc_cdiv(d->ntaps, ngroups);
-    g->tg = tg;
-    g->sB_bytes = abc_roundup(tg * g->BN * g->PS, 256);
-    g->tap_off = g->sA_bytes + g->sB_bytes;
-    g->lds = g->tap_off + 256;
-    if (g->lds < 4 * 2 * 128 * 4 + 256) g->lds = 4 * 2 * 128 * 4 + 256;
+    g->ngroups = abc_cdiv(d->ntaps, tg);
+    g->tg = abc_cdiv(d->ntaps, g->ngroups);
+    g->sB_bytes = abc_roundup(g->tg * g->BN * g->PS, 256);
+    g->tap_off = g->a_bufs * g->sA_bytes + 2 * g->sB_bytes;
+    g->coef_off = g->tap_off + 256;
+    g->lds = g->coef_off + coef_bytes;
+    if (g->lds < 72 * 1024) g->lds = 72 * 1024;  // epilogue transpose staging: 8 waves x 32 rows x 272 B
     if (g->lds > 160 * 1024) return abc_fail(ABC_EUNSUPPORTED, "conv: LDS tile too large");
     g->tiles_x = abc_cdiv(d->Wg, 16);
-    g->tiles_y = abc_cdiv(d->Hg, 8);
-    g->nbn = d->Cout_pad / g->BN;
+    g->tiles_y = abc_cdiv(d->Hg, prow);
     g->grid = g->nbn * g->tiles_x * g->tiles_y * d->B;
     return ABC_OK;
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
 static int launch_inst(const ConvK& k, const Geom& g, hipStream_t st) {
-    auto fn = conv_igemm_kernel<InT, CT, OutT, CK, BN, STRIDE>;
+    auto fn = conv_igemm_kernel<InT, CT, OutT, CK, BN, STRIDE, MT>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(fn, dim3(g.grid), dim3(256), g.lds, st, k);
+    hipLaunchKernelGGL(fn, dim3(g.grid), dim3(NTHR), g.lds, st, k);
     return abc_check_launch("conv_igemm");
+}
+
+template <typename InT, typename CT, typename OutT, int CK, int BN>
+static int launch_mt(const ConvK& k, const Geom& g, int stride, hipStream_t st) {
+    if constexpr (BN == 32) {  // 8 waves need 8 m-tiles when there is a single n-tile
+        return stride == 2 ? launch_inst<InT, CT, OutT, CK, BN, 2, 8>(k, g, st) : launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st);
+    } else {
+        if (stride == 2) return launch_inst<InT, CT, OutT, CK, BN, 2, 4>(k, g, st);
+        return g.MT == 8 ? launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st) : launch_inst<InT, CT, OutT, CK, BN, 1, 4>(k, g, st);
+    }
 }
 
 template <typename InT, typename CT, typename OutT, int CK>
 static int launch_bn(const ConvK& k, const Geom& g, int stride, hipStream_t st) {
-#define ABC_L(BN_)                                                                        \
-    (stride == 1 ? launch_inst<InT, CT, OutT, CK, BN_, 1>(k, g, st) : launch_inst<InT, CT, OutT, CK, BN_, 2>(k, g, st))
     switch (g.BN) {
-        case 128: return ABC_L(128);
-        case 64: return ABC_L(64);
-        default: return ABC_L(32);
+        case 128: return launch_mt<InT, CT, OutT, CK, 128>(k, g, stride, st);
+        case 64: return launch_mt<InT, CT, OutT, CK, 64>(k, g, stride, st);
+        default: return launch_mt<InT, CT, OutT, CK, 32>(k, g, stride, st);
     }
-#undef ABC_L
 }
 
 }  // namespace
@@ -271,8 +415,18 @@ extern "C" int abc_conv_chunk(int dtype_c, int Cin) {
     return 16;
 }
 
+extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, int32_t* ck) {
+    Geom g;
+    int rc = conv_geom(d, &g);
+    if (rc) return rc;
+    *bn = g.BN; *mt = g.MT; *ck = g.CK;
+    return ABC_OK;
+}
+
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
-    return abc_cdiv(d->Wg, 16) * abc_cdiv(d->Hg, 8) * d->B;
+    Geom g;
+    if (conv_geom(d, &g)) return -1;
+    return g.tiles_x * g.tiles_y * d->B;
 }
 
 extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
@@ -298,8 +452,11 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     k.B = d->B; k.Hin = d->Hin; k.Win = d->Win; k.cin_off = d->cin_off; k.Cin = d->Cin; k.nchunks = abc_cdiv(d->Cin, g.CK);
     k.Hg = d->Hg; k.Wg = d->Wg; k.Hout = d->Hout; k.Wout = d->Wout; k.ldy = d->ldy; k.cout_off = d->cout_off;
     k.Cout = d->Cout; k.Cout_pad = d->Cout_pad; k.om = d->om; k.oy0 = d->oy0; k.ox0 = d->ox0;
-    k.ntaps = d->ntaps; k.tg = g.tg; k.dy_min = g.dy_min; k.dx_min = g.dx_min; k.HH = g.HH; k.HW = g.HW; k.RS = g.RS;
-    k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y; k.nblocks_n = g.nbn; k.sB_off = g.sA_bytes; k.tap_off = g.tap_off;
+    k.ntaps = d->ntaps; k.tg = g.tg; k.ngroups = g.ngroups; k.dy_min = g.dy_min; k.dx_min = g.dx_min; k.HH = g.HH; k.HW = g.HW; k.RS = g.RS;
+    k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y; k.nblocks_n = g.nbn; k.sA_bytes = g.sA_bytes; k.a_bufs = g.a_bufs;
+    k.sB_off = g.a_bufs * g.sA_bytes; k.coef_off = g.coef_off; k.cstride = g.cstride;
+    k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a;
+    { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     for (int t = 0; t < d->ntaps; ++t) {
         k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);
         k.tx[t] = (int8_t)(d->tap_dx[t] - g.dx_min);

@@ -185,12 +185,12 @@ class Engine:
         if stats:
             st = self.new((nblk, 2, Cout), torch.float32)
             d.stats = st.data_ptr()
-        cp = -(-Cout // 32) * 32
-        bn = 128 if cp % 128 == 0 else (64 if cp % 64 == 0 else 32)
-        ck = self.lib.abc_conv_chunk(self.dt, d.Cin)
+        bn_, mt_, ck_ = L.i32(), L.i32(), L.i32()
+        L.check(self.lib.abc_conv_tile(C.byref(d), C.byref(bn_), C.byref(mt_), C.byref(ck_)), "conv_tile")
+        bn, mt, ck = bn_.value, mt_.value, ck_.value
         npx = self.B * gh * gw
         in_px = self.B * lh * lw * (4 if src.pool else 1)
-        meta = {"kernel": "conv_igemm<%s,%s,%s,CK%d,BN%d,S%d>" % (self._dn(src.dt), self._dn(self.dt), self._dn(y_dt), ck, bn, stride),
+        meta = {"kernel": "conv_igemm<%s,%s,%s,CK%d,BN%d,S%d,MT%d>" % (self._dn(src.dt), self._dn(self.dt), self._dn(y_dt), ck, bn, stride, mt),
                 "flops": 2.0 * npx * Cout * len(taps) * d.Cin,
                 "bytes": float(in_px * d.Cin * self._esz(src.dt) + npx * Cout * self._esz(y_dt))}
         self._emit(ops, self.lib.abc_conv_fwd, d, what, meta=meta)

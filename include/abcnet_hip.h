@@ -86,6 +86,8 @@ typedef struct abc_conv_desc {
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
 int abc_conv_stat_blocks(const abc_conv_desc* d);
 int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream);
+/* tile the launcher picks for this descriptor: BN output channels x (2*mt x 16) pixels per workgroup, K-chunk ck */
+int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, int32_t* ck);
 
 /* channels per K-chunk used by the packed weight layout for (compute dtype, Cin) */
 int abc_conv_chunk(int dtype_c, int Cin);
