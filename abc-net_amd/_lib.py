@@ -112,6 +112,8 @@ SYMBOLS = {
     "abc_bn_finalize_bwd": (C.c_int, [P(BnBwdDesc), vp]),
     "abc_bn_apply_bwd": (C.c_int, [P(BnApplyDesc), vp]),
     "abc_wgrad_pads": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),
+    "abc_wgrad_blocks": (C.c_int, [P(WgradDesc)]),
+    "abc_wgrad_tile": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),
     "abc_wgrad": (C.c_int, [P(WgradDesc), vp]),
     "abc_wgrad_reduce": (C.c_int, [P(WgradReduceDesc), vp]),
     "abc_colsum_blocks": (C.c_int, [i64]),

@@ -237,10 +237,11 @@ struct HaloPrefetch {
     unsigned inb;  // bit i: item i is inside the image
 
     // issue the loads of chunk starting at absolute channel c0
-    __device__ inline void issue(int HH, int HW, int b, int iy0, int ix0, int Hin, int Win, const ActSrc& s, int c0, int tid) {
+    __device__ inline void issue(int HH, int HW, int b, int iy0, int ix0, int Hin, int Win, const ActSrc& s, int c0, int tid,
+                                 int cvalid = 1 << 30) {
         const int part = tid % SEGS;
         const int cch = c0 + part * NV;
-        const int total = HH * HW * SEGS;
+        const int total = (part * NV < cvalid) ? HH * HW * SEGS : 0;  // segments past the tensor's width stay zero
         const InT* xb = (const InT*)s.x;
         inb = 0;
 #pragma unroll
@@ -259,12 +260,13 @@ struct HaloPrefetch {
     }
     // transform + write to LDS.  lcoef = LDS table [3][cstride] of (scale, shift, slope) indexed by the channel
     // RELATIVE to the conv's first input channel (crel0 = first channel of this chunk), or null = identity
-    __device__ inline void commit(char* sA, int RS, int PS, int HH, int HW, const float* lcoef, int cstride, int crel0, int tid) {
+    __device__ inline void commit(char* sA, int RS, int PS, int HH, int HW, const float* lcoef, int cstride, int crel0, int tid,
+                                  int cvalid = 1 << 30) {
         const int part = tid % SEGS;
         const int cch = crel0 + part * NV;
         const int total = HH * HW * SEGS;
         float sc[NV], sh[NV], sl[NV];
-        const bool has_t = lcoef != nullptr;
+        const bool has_t = lcoef != nullptr && (part * NV < cvalid);
         if (has_t) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) { sc[j] = lcoef[cch + j]; sh[j] = lcoef[cstride + cch + j]; sl[j] = lcoef[2 * cstride + cch + j]; }

@@ -43,7 +43,7 @@ struct ConvK {
 };
 
 template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
+__global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(const ConvK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
     constexpr int LHB = CKB / 2;
@@ -367,7 +367,12 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
     g->tap_off = g->a_bufs * g->sA_bytes + 2 * g->sB_bytes;
     g->coef_off = g->tap_off + 256;
     g->lds = g->coef_off + coef_bytes;
-    if (g->lds < 72 * 1024) g->lds = 72 * 1024;  // epilogue transpose staging: 8 waves x 32 rows x 272 B
+    {   // epilogue transpose staging: 8 waves x 32 rows x (TN*32 channels + 16 B pad)
+        const int tn = (g->BN / 32 >= 2) ? g->BN / 64 : 1;
+        const int osz = d->dtype_out == ABC_BF16 ? 2 : 4;
+        const int stg = 8 * 32 * (tn * 32 * osz + 16) + 8 * 2 * 128 * 4;
+        if (g->lds < stg) g->lds = stg;
+    }
     if (g->lds > 160 * 1024) return abc_fail(ABC_EUNSUPPORTED, "conv: LDS tile too large");
     g->tiles_x = abc_cdiv(d->Wg, 16);
     g->tiles_y = abc_cdiv(d->Hg, prow);

@@ -2,15 +2,21 @@
 //
 //   dW[t][a][b] = sum over pixels p of  P[p][a] * Q[stride*p + d_t][b]
 //
-// GEMM view per tap: M = a-channels, N = b-channels, K = pixels (split-K over 8x16
-// spatial patches across workgroups; every workgroup writes its own f32 slab and
-// abc_wgrad_reduce sums the slabs in a fixed order -> bitwise reproducible, no atomics).
-// Both operands have the reduction index (pixel) as the SLOW memory axis (NHWC), so
-// the [pixel][channel] LDS images are read column-wise: in bf16 mode with the
-// hardware-transposing ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group),
-// in exact-f32 mode with plain ds_read_b32 (v_mfma_f32_32x32x2_f32 wants one value per lane).
-// One K-step = one 16-pixel row segment of the patch; the un-shifted operand's
-// fragment is read once per K-step and reused by all taps.
+// GEMM view per tap: M = a-channels, N = b-channels, K = pixels (split-K over 8x16 spatial
+// patches across workgroups; every workgroup writes its own f32 slab and abc_wgrad_reduce sums
+// the slabs in a fixed order -> bitwise reproducible, no atomics).
+// Both operands have the reduction index (pixel) as the SLOW memory axis (NHWC), so the
+// [pixel][channel] LDS images are read column-wise: in bf16 mode with the hardware-transposing
+// ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group), in exact-f32 mode with plain
+// ds_read_b32 (v_mfma_f32_32x32x2_f32 wants one value per lane).  One K-step = one 16-pixel row
+// segment of the patch; the un-shifted operand's fragment is read once per K-step and reused by
+// all taps.
+//
+// Workgroup = 8 waves (one per CU, two per SIMD) arranged AT x BT x RS: AT*BT 32x32 output tile
+// pairs (every wave keeps all <= 9 taps of its pair: 144 accumulator VGPRs) and RS-way split of the
+// patch rows (folded through LDS at the end).  Patches are double-buffered in LDS and the next patch's
+// global loads are issued before / committed after the MFMA block (split-phase, T14), with the
+// BatchNorm coefficients of both operands held in an LDS table.
 //
 // Reference ops covered: autograd of nn.Conv2d / nn.ConvTranspose2d weights
 // (unet.py:12,15,44,66,70 under loss.backward(), train.py:140).
@@ -20,7 +26,9 @@
 
 namespace {
 
-constexpr int MAXT = 9;  // taps per workgroup (accumulator budget: 9 x 16 VGPRs)
+constexpr int MAXT_FAST = 9;  // taps per workgroup (accumulator budget: 9 x 16 VGPRs)
+constexpr int MAXT_SLOW = 5;  // the general loader needs the registers: fewer taps per workgroup, more tap groups
+constexpr int WTHR = 512;  // 8 waves
 
 struct WgK {
     ActSrc p, q;
@@ -28,7 +36,7 @@ struct WgK {
     int B, Hg, Wg, Hq, Wq;
     int cp_off, Ca, cq_off, Cb, Ca_pad, Cb_pad;
     int ntaps, tgw, nsplit, npatch, tiles_x, tiles_y;
-    int dy_min, dx_min, HH, HW, PSW, sQ_off, nta, ntb;
+    int dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, nta, ntb, fast_p, fast_q, nbuf;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
@@ -40,12 +48,27 @@ __device__ inline bf16x8 tr_read8(const char* base0, const char* base1) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename PT, typename QT, typename CT, int CW, int STRIDE>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgK a) {
-    constexpr bool WIDE = (CW == 64);
+// general (pool / dropout / planar / ragged-tail) loader kept out of line: inlined next to the accumulators and the
+// prefetch registers it makes the register allocator spill inside the MFMA loop
+template <typename T, typename CT, int CW>
+__device__ inline void stage_slow(char* dst, int RS, int PS, int HH, int HW, int b, int iy0, int ix0, int Hin, int Win,
+                                                     const ActSrc* s, int c0, int tid, int cvalid) {
+    stage_halo<T, CT, CW>(dst, RS, PS, HH, HW, b, iy0, ix0, Hin, Win, *s, c0, tid, WTHR, cvalid);
+}
+
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM>
+__global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
+    constexpr int MAXT = FAST ? MAXT_FAST : MAXT_SLOW;
+    constexpr int RSPLIT = 8 / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
+    constexpr int PROWS = 8 * PM;           // patch rows (x 16 columns)
+    constexpr int ROWS = PROWS / RSPLIT;    // patch rows per wave
+    constexpr int CWP = AT * 32, CWQ = BT * 32;
+    constexpr int NPF_P = (PROWS * 16 * (CWP / Frag<CT>::NV) + WTHR - 1) / WTHR;
+    constexpr int NPF_Q = (PM > 1) ? 5 : ((sizeof(CT) == 2) ? 4 : 6);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sP = smem;
-    char* sQ = smem + a.sQ_off;
+    const int buf_bytes = a.sP_bytes + a.sQ_bytes;
+    float* sCoefP = (float*)(smem + a.coef_off);
+    float* sCoefQ = sCoefP + 3 * a.cstrP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -56,9 +79,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK a) {
     const int t0 = blockIdx.y * a.tgw;
     const int tcnt = min(a.tgw, a.ntaps - t0);
 
-    const int ai = WIDE ? (wave >> 1) : 0, bi = WIDE ? (wave & 1) : 0;
-    const int row_lo = WIDE ? 0 : 2 * wave, row_hi = WIDE ? 8 : 2 * wave + 2;
-    const int PSW = a.PSW;
+    const int pair = wave / RSPLIT, rs = wave % RSPLIT;
+    const int ai = pair / BT, bi = pair % BT;
+    const int row_lo = rs * ROWS;
+    const int PSWP = a.PSWP, PSWQ = a.PSWQ;
+    const int ca0 = at * CWP, cb0 = bt * CWQ;          // first channel of the workgroup's a / b range
+    const int cvalP = a.Ca - ca0, cvalQ = a.Cb - cb0;  // valid channels from there
+
+    // ---- BatchNorm coefficient tables of both operands (relative channel index)
+    // FAST: both operands are plain NHWC tensors -> split-phase prefetch; otherwise (pool / dropout / planar /
+    // ragged channel tail on either operand) both are staged synchronously by the general loader.  Two separate
+    // instantiations: inlining the general loader next to the prefetch registers makes the allocator spill.
+    const bool coefP = FAST && a.p.scale != nullptr, coefQ = FAST && a.q.scale != nullptr;
+    if (coefP)
+        for (int i = tid; i < min(CWP, cvalP); i += WTHR) {
+            sCoefP[i] = a.p.scale[a.cp_off + ca0 + i]; sCoefP[a.cstrP + i] = a.p.shift[a.cp_off + ca0 + i];
+            sCoefP[2 * a.cstrP + i] = a.p.slope[a.cp_off + ca0 + i];
+        }
+    if (coefQ)
+        for (int i = tid; i < min(CWQ, cvalQ); i += WTHR) {
+            sCoefQ[i] = a.q.scale[a.cq_off + cb0 + i]; sCoefQ[a.cstrQ + i] = a.q.shift[a.cq_off + cb0 + i];
+            sCoefQ[2 * a.cstrQ + i] = a.q.slope[a.cq_off + cb0 + i];
+        }
 
     f32x16 acc[MAXT];
 #pragma unroll
@@ -68,7 +110,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK a) {
 
     int tapoff[MAXT];  // LDS byte offset of each tap inside the Q halo
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) tapoff[t] = (t < tcnt) ? (a.ty[t0 + t] * a.HW + a.tx[t0 + t]) * PSW : 0;
+    for (int t = 0; t < MAXT; ++t) tapoff[t] = (t < tcnt) ? (a.ty[t0 + t] * a.HW + a.tx[t0 + t]) * PSWQ : 0;
 
     // per-lane channel byte offsets inside a pixel
     int pch, qch;
@@ -81,78 +123,112 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK a) {
         qch = (bi * 32 + r) * 4;
     }
 
-    for (int patch = split; patch < a.npatch; patch += a.nsplit) {
+    HaloPrefetch<PT, CT, CWP, FAST ? NPF_P : 1, WTHR> pp;
+    HaloPrefetch<QT, CT, CWQ, FAST ? NPF_Q : 1, WTHR> pq;
+
+    auto patch_origin = [&](int patch, int& b, int& gy0, int& gx0) {
         int pid = patch;
         const int tx_i = pid % a.tiles_x; pid /= a.tiles_x;
         const int ty_i = pid % a.tiles_y; pid /= a.tiles_y;
-        const int b = pid;
-        const int gy0 = ty_i * 8, gx0 = tx_i * 16;
-        __syncthreads();
-        stage_halo<PT, CT, CW>(sP, 16 * PSW, PSW, 8, 16, b, gy0, gx0, a.Hg, a.Wg, a.p, a.cp_off + at * CW, tid, 256,
-                               a.Ca - at * CW);
-        stage_halo<QT, CT, CW>(sQ, a.HW * PSW, PSW, a.HH, a.HW, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min,
-                               a.Hq, a.Wq, a.q, a.cq_off + bt * CW, tid, 256, a.Cb - bt * CW);
-        __syncthreads();
-        for (int row = row_lo; row < row_hi; ++row) {
-            if constexpr (sizeof(CT) == 2) {
-                // lane supplies the address of pixel k = 8h + 4q + ((lane&15)>>2), 4 channels
-                const int kq = 8 * h + ((lane & 15) >> 2);
-                const char* pa = sP + (row * 16 + kq) * PSW + pch;
-                const bf16x8 fa = tr_read8(pa, pa + 4 * PSW);
-                const char* qb = sQ + ((row * STRIDE) * a.HW + kq * STRIDE) * PSW + qch;
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) {
-                    if (t < tcnt) {
-                        const bf16x8 fb = tr_read8(qb + tapoff[t], qb + tapoff[t] + 4 * STRIDE * PSW);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll 2
-                for (int s = 0; s < 8; ++s) {
-                    const int k = 2 * s + h;
-                    const float fa = *(const float*)(sP + (row * 16 + k) * PSW + pch);
-                    const char* qb = sQ + ((row * STRIDE) * a.HW + k * STRIDE) * PSW + qch;
+        b = pid; gy0 = ty_i * PROWS; gx0 = tx_i * 16;
+    };
+    auto issue = [&](int patch) {
+        int b, gy0, gx0;
+        patch_origin(patch, b, gy0, gx0);
+        if constexpr (FAST) {
+            pp.issue(PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, a.p, a.cp_off + ca0, tid, cvalP);
+            pq.issue(a.HH, a.HW, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.Hq, a.Wq, a.q, a.cq_off + cb0, tid, cvalQ);
+        }
+    };
+    auto commit = [&](int patch, char* buf) {
+        int b, gy0, gx0;
+        patch_origin(patch, b, gy0, gx0);
+        char* sP = buf;
+        char* sQ = buf + a.sP_bytes;
+        if constexpr (FAST) {
+            pp.commit(sP, 16 * PSWP, PSWP, PROWS, 16, coefP ? sCoefP : nullptr, a.cstrP, 0, tid, cvalP);
+            pq.commit(sQ, a.HW * PSWQ, PSWQ, a.HH, a.HW, coefQ ? sCoefQ : nullptr, a.cstrQ, 0, tid, cvalQ);
+        } else {
+            stage_slow<PT, CT, CWP>(sP, 16 * PSWP, PSWP, PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, &a.p, a.cp_off + ca0, tid, cvalP);
+            stage_slow<QT, CT, CWQ>(sQ, a.HW * PSWQ, PSWQ, a.HH, a.HW, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.Hq, a.Wq,
+                                    &a.q, a.cq_off + cb0, tid, cvalQ);
+        }
+    };
+
+    __syncthreads();  // coefficient tables visible
+    // it = -1 is the prologue (stage the first patch, no compute): one call site for issue / commit
+    int patch = split - a.nsplit;
+    for (int it = -1; it < 0 || patch < a.npatch; ++it, patch += a.nsplit) {
+        const int next = patch + a.nsplit;
+        const bool has_next = next < a.npatch;
+        if (has_next) issue(next);
+        if (it >= 0) {
+            const char* sP = smem + ((a.nbuf == 2) ? (it & 1) * buf_bytes : 0);
+            const char* sQ = sP + a.sP_bytes;
+#pragma unroll 1
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int row = row_lo + rr;
+                if constexpr (sizeof(CT) == 2) {
+                    // lane supplies the address of pixel k = 8h + 4q + ((lane&15)>>2), 4 channels
+                    const int kq = 8 * h + ((lane & 15) >> 2);
+                    const char* pa = sP + (row * 16 + kq) * PSWP + pch;
+                    const bf16x8 fa = tr_read8(pa, pa + 4 * PSWP);
+                    const char* qb = sQ + ((row * STRIDE) * a.HW + kq * STRIDE) * PSWQ + qch;
 #pragma unroll
                     for (int t = 0; t < MAXT; ++t) {
                         if (t < tcnt) {
-                            const float fb = *(const float*)(qb + tapoff[t]);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
+                            const bf16x8 fb = tr_read8(qb + tapoff[t], qb + tapoff[t] + 4 * STRIDE * PSWQ);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll 2
+                    for (int s = 0; s < 8; ++s) {
+                        const int k = 2 * s + h;
+                        const float fa = *(const float*)(sP + (row * 16 + k) * PSWP + pch);
+                        const char* qb = sQ + ((row * STRIDE) * a.HW + k * STRIDE) * PSWQ + qch;
+#pragma unroll
+                        for (int t = 0; t < MAXT; ++t) {
+                            if (t < tcnt) {
+                                const float fb = *(const float*)(qb + tapoff[t]);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
+            if (a.nbuf == 1) __syncthreads();  // single buffer: everyone is done reading before it is refilled
         }
+        if (has_next) commit(next, smem + ((a.nbuf == 2) ? ((it + 1) & 1) * buf_bytes : 0));
+        __syncthreads();
     }
 
-    if constexpr (!WIDE) {
-        // the 4 waves hold partial sums over different patch rows: fold into wave 0
-        float* red = (float*)smem;  // [3][16][64]
+    if constexpr (RSPLIT > 1) {
+        // the RSPLIT waves of a tile pair hold partial sums over different patch rows: fold into rs == 0
+        float* red = (float*)smem;  // [8 waves][16][64] per tap round
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             if (t < tcnt) {
                 __syncthreads();
-                if (wave > 0) {
+                if (rs > 0) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) red[((wave - 1) * 16 + k) * 64 + lane] = acc[t][k];
+                    for (int k = 0; k < 16; ++k) red[(wave * 16 + k) * 64 + lane] = acc[t][k];
                 }
                 __syncthreads();
-                if (wave == 0) {
+                if (rs == 0) {
+                    for (int w = 1; w < RSPLIT; ++w)
 #pragma unroll
-                    for (int w = 0; w < 3; ++w)
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) acc[t][k] += red[(w * 16 + k) * 64 + lane];
+                        for (int k = 0; k < 16; ++k) acc[t][k] += red[((wave + w) * 16 + k) * 64 + lane];
                 }
             }
         }
-        if (wave != 0) return;
+        if (rs != 0) return;
     }
 
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         if (t < tcnt) {
-            float* out = a.partial + ((size_t)(split * a.ntaps + t0 + t) * a.Ca_pad + at * CW + ai * 32) * a.Cb_pad
-                         + bt * CW + bi * 32 + r;
+            float* out = a.partial + ((size_t)(split * a.ntaps + t0 + t) * a.Ca_pad + ca0 + ai * 32) * a.Cb_pad + cb0 + bi * 32 + r;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int arow = (k & 3) + 8 * (k >> 2) + 4 * h;
@@ -186,54 +262,107 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const abc_wgrad_reduc
     *o = d.accumulate ? (*o + s) : s;
 }
 
-struct WGeom { int CW, dy_min, dx_min, HH, HW, PSW, sP_bytes, lds, tgw, ngroups, nta, ntb, npatch, tiles_x, tiles_y; };
+struct WGeom {
+    int AT, BT, dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, lds, tgw, ngroups, nta, ntb, npatch,
+        tiles_x, tiles_y, fast_p, fast_q, nbuf, PM;
+};
 
-static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
-    if (d->ntaps < 1 || d->ntaps > ABC_MAX_TAPS) return abc_fail(ABC_EINVAL, "wgrad: ntaps");
-    if (d->stride != 1 && d->stride != 2) return abc_fail(ABC_EUNSUPPORTED, "wgrad: stride");
+static int psw_for(int cw, int csz) {
+    // bf16: the 64-byte column blocks of 4 consecutive pixels must fall on distinct quarters of the 256-byte bank row
+    if (csz == 2) return cw == 32 ? 64 : (cw == 64 ? 192 : 320);
+    return cw * 4;
+}
+
+static bool fast_ok(const abc_act_src& s, int csz_c, int cvalid_min) {
+    const int nv = 16 / csz_c;
+    return !s.pool && !s.planar && s.drop_p <= 0.f && (cvalid_min % nv) == 0;
+}
+
+static int wgeom_pm(const abc_wgrad_desc* d, WGeom* g, int pm) {
     const int csz = d->dtype_c == ABC_BF16 ? 2 : 4;
-    const int ca32 = abc_roundup(d->Ca, 32), cb32 = abc_roundup(d->Cb, 32);
-    g->CW = (d->stride == 1 && ca32 % 64 == 0 && cb32 % 64 == 0) ? 64 : 32;
+    const int cwp = g->AT * 32, cwq = g->BT * 32;
+    g->PM = pm;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
     for (int t = 0; t < d->ntaps; ++t) {
         dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
         dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
     }
     g->dy_min = dymin; g->dx_min = dxmin;
-    g->HH = 7 * d->stride + (dymax - dymin) + 1;
+    g->HH = (8 * pm - 1) * d->stride + (dymax - dymin) + 1;
     g->HW = 15 * d->stride + (dxmax - dxmin) + 1;
-    // bf16: 4 consecutive pixels' 64-byte column blocks must fall on distinct bank quarters
-    if (csz == 2) g->PSW = (g->CW == 32) ? 64 : 192;
-    else g->PSW = g->CW * 4;
-    g->sP_bytes = abc_roundup(128 * g->PSW, 256);
-    g->lds = g->sP_bytes + abc_roundup(g->HH * g->HW * g->PSW, 256);
-    if (g->lds < 3 * 16 * 64 * 4) g->lds = 3 * 16 * 64 * 4;
+    g->PSWP = psw_for(cwp, csz); g->PSWQ = psw_for(cwq, csz);
+    g->sP_bytes = abc_roundup(128 * pm * g->PSWP, 256);
+    g->sQ_bytes = abc_roundup(g->HH * g->HW * g->PSWQ, 256);
+    g->cstrP = cwp; g->cstrQ = cwq;
+    const int coef_bytes = 3 * (cwp + cwq) * 4 + 256;
+    g->nbuf = (2 * (g->sP_bytes + g->sQ_bytes) + coef_bytes <= 160 * 1024) ? 2 : 1;
+    g->coef_off = g->nbuf * (g->sP_bytes + g->sQ_bytes);
+    g->lds = g->coef_off + coef_bytes;
+    if (g->lds < 8 * 16 * 64 * 4) g->lds = 8 * 16 * 64 * 4;
     if (g->lds > 160 * 1024) return abc_fail(ABC_EUNSUPPORTED, "wgrad: LDS tile too large");
-    g->ngroups = abc_cdiv(d->ntaps, MAXT);
-    g->tgw = abc_cdiv(d->ntaps, g->ngroups);
-    g->nta = abc_cdiv(d->Ca, g->CW); g->ntb = abc_cdiv(d->Cb, g->CW);
-    g->tiles_x = abc_cdiv(d->Wg, 16); g->tiles_y = abc_cdiv(d->Hg, 8);
+    g->nta = abc_cdiv(d->Ca, cwp); g->ntb = abc_cdiv(d->Cb, cwq);
+    g->tiles_x = abc_cdiv(d->Wg, 16); g->tiles_y = abc_cdiv(d->Hg, 8 * pm);
     g->npatch = g->tiles_x * g->tiles_y * d->B;
+    // prefetch fast path: plain NHWC source whose channel count in the LAST tile is a whole number of 16-byte segments
+    const int lastP = d->Ca - (g->nta - 1) * cwp, lastQ = d->Cb - (g->ntb - 1) * cwq;
+    const int segq = cwq / (16 / csz);
+    g->fast_p = fast_ok(d->p, csz, lastP) ? 1 : 0;
+    g->fast_q = (fast_ok(d->q, csz, lastQ) && abc_cdiv(g->HH * g->HW * segq, WTHR) <= (pm > 1 ? 5 : (csz == 2 ? 4 : 6))) ? 1 : 0;
+    g->ngroups = abc_cdiv(d->ntaps, (g->fast_p && g->fast_q) ? MAXT_FAST : MAXT_SLOW);
+    g->tgw = abc_cdiv(d->ntaps, g->ngroups);
     return ABC_OK;
 }
 
-template <typename PT, typename QT, typename CT, int CW, int STRIDE>
-static int wlaunch(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
-    auto fn = wgrad_kernel<PT, QT, CT, CW, STRIDE>;
+static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
+    if (d->ntaps < 1 || d->ntaps > ABC_MAX_TAPS) return abc_fail(ABC_EINVAL, "wgrad: ntaps");
+    if (d->stride != 1 && d->stride != 2) return abc_fail(ABC_EUNSUPPORTED, "wgrad: stride");
+    const int csz = d->dtype_c == ABC_BF16 ? 2 : 4;
+    const int ta = abc_cdiv(d->Ca, 32), tb = abc_cdiv(d->Cb, 32);
+    // 32x32 tile pairs per workgroup (one pair per wave, the remaining waves split the patch rows).  Ragged channel
+    // tails are fine (zero-filled): wide tiles are what keeps the operands from being re-staged per pair.
+    if (d->stride == 1 && csz == 2 && ta >= 3 && tb >= 2) { g->AT = 4; g->BT = 2; }
+    else if (d->stride == 1 && ta >= 2 && tb >= 2) { g->AT = 2; g->BT = 2; }
+    else if (d->stride == 1 && csz == 2 && ta == 1 && tb >= 4) { g->AT = 1; g->BT = 4; }
+    else { g->AT = 1; g->BT = 1; }
+    // narrow layers (one tile pair, 8-way row split) take 32-row patches when both operands can be prefetched:
+    // 4 K-steps per wave between barriers instead of 1
+    if (g->AT == 1 && g->BT == 1 && d->stride == 1 && csz == 2 && d->Hg % 32 == 0) {
+        int rc = wgeom_pm(d, g, 4);
+        if (rc == ABC_OK && g->fast_p && g->fast_q) return ABC_OK;
+    }
+    return wgeom_pm(d, g, 1);
+}
+
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM = 1>
+static int wlaunch2(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
+    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(256), g.lds, st, k);
+    hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(WTHR), g.lds, st, k);
     return abc_check_launch("wgrad");
+}
+
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE>
+static int wlaunch(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
+    return (g.fast_p && g.fast_q) ? wlaunch2<PT, QT, CT, AT, BT, STRIDE, true>(k, g, nsplit, st)
+                                  : wlaunch2<PT, QT, CT, AT, BT, STRIDE, false>(k, g, nsplit, st);
 }
 
 template <typename PT, typename QT, typename CT>
 static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipStream_t st) {
-    if (g.CW == 64) return wlaunch<PT, QT, CT, 64, 1>(k, g, nsplit, st);
-    if (stride == 1) return wlaunch<PT, QT, CT, 32, 1>(k, g, nsplit, st);
-    return wlaunch<PT, QT, CT, 32, 2>(k, g, nsplit, st);
+    if constexpr (sizeof(CT) == 2) {
+        if (g.AT == 4) return wlaunch<PT, QT, CT, 4, 2, 1>(k, g, nsplit, st);
+    }
+    if (g.AT == 2) return wlaunch<PT, QT, CT, 2, 2, 1>(k, g, nsplit, st);
+    if constexpr (sizeof(CT) == 2) {
+        if (g.BT == 4) return wlaunch<PT, QT, CT, 1, 4, 1>(k, g, nsplit, st);
+        if (g.PM == 4) return wlaunch2<PT, QT, CT, 1, 1, 1, true, 4>(k, g, nsplit, st);
+    }
+    if (stride == 1) return wlaunch<PT, QT, CT, 1, 1, 1>(k, g, nsplit, st);
+    return wlaunch<PT, QT, CT, 1, 1, 2>(k, g, nsplit, st);
 }
 
 }  // namespace
@@ -242,9 +371,23 @@ extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t*
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
-    *ca_pad = g.nta * g.CW;
-    *cb_pad = g.ntb * g.CW;
+    *ca_pad = g.nta * g.AT * 32;
+    *cb_pad = g.ntb * g.BT * 32;
     return ABC_OK;
+}
+
+extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt) {
+    WGeom g;
+    int rc = wgeom(d, &g);
+    if (rc) return rc;
+    *at = g.AT; *bt = g.BT;
+    return ABC_OK;
+}
+
+extern "C" int abc_wgrad_blocks(const abc_wgrad_desc* d) {
+    WGeom g;
+    if (wgeom(d, &g)) return -1;
+    return g.nta * g.ntb * g.ngroups;
 }
 
 extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
@@ -263,10 +406,11 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     if (php != d->Hg || pwp != d->Wg || qhp != d->Hq || qwp != d->Wq) return abc_fail(ABC_EINVAL, "wgrad: dims mismatch");
     k.partial = d->partial; k.B = d->B; k.Hg = d->Hg; k.Wg = d->Wg; k.Hq = d->Hq; k.Wq = d->Wq;
     k.cp_off = d->cp_off; k.Ca = d->Ca; k.cq_off = d->cq_off; k.Cb = d->Cb;
-    k.Ca_pad = g.nta * g.CW; k.Cb_pad = g.ntb * g.CW;
+    k.Ca_pad = g.nta * g.AT * 32; k.Cb_pad = g.ntb * g.BT * 32;
     k.ntaps = d->ntaps; k.tgw = g.tgw; k.nsplit = d->nsplit; k.npatch = g.npatch; k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y;
-    k.dy_min = g.dy_min; k.dx_min = g.dx_min; k.HH = g.HH; k.HW = g.HW; k.PSW = g.PSW; k.sQ_off = g.sP_bytes;
-    k.nta = g.nta; k.ntb = g.ntb;
+    k.dy_min = g.dy_min; k.dx_min = g.dx_min; k.HH = g.HH; k.HW = g.HW; k.PSWP = g.PSWP; k.PSWQ = g.PSWQ;
+    k.sP_bytes = g.sP_bytes; k.sQ_bytes = g.sQ_bytes; k.coef_off = g.coef_off; k.cstrP = g.cstrP; k.cstrQ = g.cstrQ;
+    k.nta = g.nta; k.ntb = g.ntb; k.fast_p = g.fast_p; k.fast_q = g.fast_q; k.nbuf = g.nbuf;
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min); k.tx[t] = (int8_t)(d->tap_dx[t] - g.dx_min); }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype_c == ABC_F32) {

@@ -212,18 +212,19 @@ class Engine:
         ca_pad, cb_pad = L.i32(), L.i32()
         L.check(self.lib.abc_wgrad_pads(C.byref(d), C.byref(ca_pad), C.byref(cb_pad)), "wgrad_pads")
         ca_pad, cb_pad = ca_pad.value, cb_pad.value
-        wide = stride == 1 and (-(-Ca // 32) * 32) % 64 == 0 and (-(-Cb // 32) * 32) % 64 == 0
-        cw = 64 if wide else 32
-        ngroups = -(-len(taps) // 9)
+        per_split = self.lib.abc_wgrad_blocks(C.byref(d))
         npatch = self.B * (-(-gh // 8)) * (-(-gw // 16))
-        nsplit = max(1, min(npatch, 512 // ((ca_pad // cw) * (cb_pad // cw) * ngroups)))
+        # one 8-wave workgroup per CU: aim at ~2 rounds of 256 workgroups, at least 2 patches per workgroup
+        nsplit = max(1, min(max(1, npatch // 2), 512 // per_split))
         d.nsplit = nsplit
         need = nsplit * len(taps) * ca_pad * cb_pad
         self._ws_need = max(self._ws_need, need)
         r = L.WgradReduceDesc()
         r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = nsplit, len(taps), Ca, Cb, ca_pad, cb_pad, dw_ptr, 0
         self._ws_users += [d, r]
-        meta = {"kernel": "wgrad<%s,%s,%s,CW%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), cw, stride),
+        at_, bt_ = L.i32(), L.i32()
+        L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
+        meta = {"kernel": "wgrad<%s,%s,%s,%dx%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), at_.value, bt_.value, stride),
                 "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
                 "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt))}
         self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)

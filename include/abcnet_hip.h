@@ -177,6 +177,8 @@ typedef struct abc_wgrad_desc {
     int8_t tap_dx[ABC_MAX_TAPS_C];
 } abc_wgrad_desc;
 int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad);
+int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt); /* 32x32 tile pairs per workgroup: at x bt */
+int abc_wgrad_blocks(const abc_wgrad_desc* d); /* workgroups per split: choose nsplit so that blocks*nsplit fills the GPU */
 int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream);
 typedef struct abc_wgrad_reduce_desc {
     const float* partial; int32_t nsplit, ntaps, Ca, Cb, Ca_pad, Cb_pad;
