@@ -1,0 +1,174 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/abcnet_hip.h declares, the ctypes
+mirror structs match the library, and the host-side logic (architecture table, plan builder, bucket planner,
+sampler, dropout mirror, gloo gradient reducer at world size 2) behaves.  No kernel is launched here."""
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+import abcnet_amd  # noqa: F401
+from abcnet_amd import _lib as L
+from abcnet_amd import arch
+from abcnet_amd import distributed as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()  # raises on a missing symbol or a struct-size mismatch
+    hdr = open(os.path.join(ROOT, "include", "abcnet_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(abc_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "library does not export %s" % name
+        assert name in L.SYMBOLS, "binding does not cover %s" % name
+    assert set(L.SYMBOLS) <= declared | {"abc_sizeof"}
+
+
+def test_status_and_error_text_without_gpu():
+    lib = L.load()
+    assert lib.abc_version() >= 100
+    assert lib.abc_conv_chunk(L.BF16, 128) == 32 and lib.abc_conv_chunk(L.BF16, 16) == 16 and lib.abc_conv_chunk(L.F32, 1) == 16
+    d = L.ConvDesc()
+    d.ntaps = 0
+    assert lib.abc_conv_stat_blocks(d) == -1  # invalid descriptor is refused on the host, nothing is launched
+    assert b"ntaps" in lib.abc_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.AbcNetHipError):
+        L.load()
+
+
+@pytest.mark.parametrize("variant,n,nparam", [("unet", 261, 10698575), ("unet2", 353, 11177340)])
+def test_arch_table_counts(variant, n, nparam):
+    t = arch.state_table(variant, 1, HEADS)
+    assert len(t) == n
+    assert sum(arch.numel(s) for _, s, r in t if r == "param") == nparam
+
+
+def test_engine_plan_builds_without_gpu():
+    """the static launch plan (descriptor construction + host-side geometry queries) needs no device"""
+    from abcnet_amd.engine import Engine
+    from abcnet_amd.unet import UNet
+    m = UNet(1, HEADS)
+    m._flat_grad = torch.zeros_like(m._flat.data)
+    lay = (m._lay_p, m._lay_b, m._lay_c)
+    ev = Engine("unet", 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, lay, 2, 64, 64, "bf16", False, device="cpu")
+    tr = Engine("unet", 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, lay, 2, 64, 64, "fp32", True, device="cpu")
+    assert len(ev.bwd_ops) == 0 and len(ev.fwd_ops) == len(tr.fwd_ops) > 80 and len(tr.bwd_ops) > 200
+    # every learnable tensor except the conv biases in front of a BatchNorm (exactly-zero gradient) and s
+    # (written by the loss kernel) is finalised by some backward op
+    written = set(w for op in tr.bwd_ops for w in op[3])
+    missing = [n for n in m._lay_p if n not in written]
+    assert missing[0] == "s" and all(n.endswith(("double_conv.0.bias", "double_conv.3.bias", "conv1.bias")) for n in missing[1:])
+    # algorithmic forward flops of the plan == the survey's figure for unet @ 64x64 scaled (52.86 GF @ 384^2 per image)
+    flops = sum(op[4]["flops"] for op in tr.fwd_ops)
+    per_img_384 = flops / 2 * (384 / 64) ** 2
+    assert abs(per_img_384 - 52.86e9) / 52.86e9 < 0.02
+
+
+def test_non_multiple_of_32_is_refused():
+    from abcnet_amd.engine import Engine
+    from abcnet_amd.unet import UNet
+    m = UNet(1, HEADS)
+    m._flat_grad = torch.zeros_like(m._flat.data)
+    with pytest.raises(ValueError):
+        Engine("unet", 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, (m._lay_p, m._lay_b, m._lay_c), 1, 100, 96,
+               "fp32", False, device="cpu")
+
+
+def test_bucket_plan_covers_arena_once_in_ready_order():
+    sizes = [10, 400, 5, 300, 300, 7, 1000, 50]
+    ready = [-1, 70, 70, 40, 30, 30, 10, 5]
+    b = D.plan_buckets(ready, sizes, 500)
+    covered = sorted((lo, hi) for lo, hi, _ in b)
+    assert covered[0][0] == 0 and covered[-1][1] == sum(sizes)
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+    assert [r for _, _, r in b] == sorted(r for _, _, r in b)
+    # the arena's tail (heads, produced first by backward) forms the earliest bucket
+    assert b[0][1] == sum(sizes)
+
+
+def test_sampler_matches_torch_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    ds = list(range(103))
+    for world in (2, 8):
+        for rank in range(world):
+            s = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=0)
+            s.set_epoch(3)
+            assert list(iter(s)) == D.sampler_indices(len(ds), world, rank, epoch=3, seed=0)
+
+
+def test_dropout_mirror_matches_device_hash_definition():
+    """abcnet_amd.dropout.keep_mask must equal the C definition (common.hpp: abc_drop_keep), checked on a Python
+    big-int transcription of the same arithmetic"""
+    from abcnet_amd.dropout import keep_mask
+
+    def ref(idx, seed, p):
+        M = 0xFFFFFFFF
+        h = ((idx * 0x9E3779B1) & M) ^ seed
+        h ^= h >> 16
+        h = (h * 0x85EBCA6B) & M
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & M
+        h ^= h >> 16
+        return (h >> 8) * (1.0 / 16777216.0) >= p
+
+    idx = torch.tensor([0, 1, 2, 12345, 2 ** 20 + 7, 150994943], dtype=torch.int64)
+    got = keep_mask(idx, 0x1234ABCD, 0.2).tolist()
+    assert got == [ref(int(i), 0x1234ABCD, 0.2) for i in idx]
+    big = keep_mask(torch.arange(1 << 16, dtype=torch.int64), 99, 0.2).float().mean().item()
+    assert abs(big - 0.8) < 0.01
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    D.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    sizes = [10, 4000, 5, 3000, 3000, 7, 10000, 50]
+    ready = [-1, 70, 70, 40, 30, 30, 10, 5]
+    g = torch.randn(sum(sizes))
+    mine = g.clone()
+    buckets = D.plan_buckets(ready, sizes, 5000)
+    red = D.GradReducer(g, buckets)
+    # emulate the backward plan: after op j the buckets that became final are launched (async), in ready order
+    for j in range(0, 80):
+        red.after_op(j)
+    for lo, hi, r in buckets:
+        if r < 0:
+            red.bucket_ready(lo, hi)
+    red.finish()
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    want = sum(gathered)
+    # parameters: rank 0 wins (DDP constructor semantics)
+    p = torch.full((17,), float(rank))
+    D.broadcast_parameters(p)
+    # scalar loss for logging (multi_gpu_train.py:116)
+    lm = D.reduce_mean(torch.tensor([float(rank + 1)]), world)
+    q.put((rank, torch.allclose(g, want, atol=1e-6), p.sum().item(), lm.item()))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_bucketed_allreduce_and_broadcast():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29640 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert [r[0] for r in res] == [0, 1]
+    assert all(r[1] for r in res), "bucketed all-reduce != sum over ranks"
+    assert all(r[2] == 0.0 for r in res), "rank 0 parameters must win the broadcast"
+    assert all(abs(r[3] - 1.5) < 1e-6 for r in res)
