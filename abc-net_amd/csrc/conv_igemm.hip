@@ -38,12 +38,12 @@ struct ConvK {
     int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad;
     int om, oy0, ox0;
     int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS;
-    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg;
+    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
 template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
-__global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(const ConvK a) {
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
     constexpr int LHB = CKB / 2;
@@ -51,11 +51,11 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
     constexpr int NV = Frag<CT>::NV;
     constexpr int SEGS = CKB / 16;
     constexpr int NT = BN / 32;
-    constexpr int WN = (NT >= 2) ? 2 : 1;
+    constexpr int WN = (MT == 6) ? 4 : ((NT >= 2) ? 2 : 1);  // MT = 6 (12-row patch): 2 x 4 waves of 3 x 1 tiles
     constexpr int WM = 8 / WN;
     constexpr int TM = MT / WM;
     constexpr int TN = NT / WN;
-    static_assert(TM >= 1 && TM * WM == MT, "tile/wave layout");
+    static_assert(TM >= 1 && TM * WM == MT && TN >= 1 && TN * WN == NT, "tile/wave layout");
     constexpr int TGMAX = 3;
     constexpr int NB = (TGMAX * BN * SEGS + NTHR - 1) / NTHR;  // weight segments a thread prefetches per stage
     typedef typename Frag<CT>::type frag_t;
@@ -71,16 +71,23 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    // ---- block -> (n-block, patch, image); n-block fastest so neighbours share the halo in L2
-    const int nwg = gridDim.x;
-    int id = abc_xcd_remap(blockIdx.x, nwg);
-    const int nb = id % a.nblocks_n; id /= a.nblocks_n;
-    const int mblock = id;
-    const int tx_i = id % a.tiles_x; id /= a.tiles_x;
-    const int ty_i = id % a.tiles_y; id /= a.tiles_y;
-    const int b = id;
-    const int gy0 = ty_i * (2 * MT), gx0 = tx_i * 16;
-    const int n0 = nb * BN;
+    // ---- persistent workgroup: tiles id, id + gridDim.x, ...; tile -> (n-block, patch, image), n-block fastest so
+    // that neighbouring workgroups share the halo in L2.  The next tile's first halo chunk and weight stage are
+    // prefetched into registers before the epilogue of the current tile and committed after it.
+    const int ntiles = a.ntiles;
+    int tile = abc_xcd_remap(blockIdx.x, gridDim.x);
+    int nb, mblock, b, gy0, gx0, n0, iy0, ix0;
+    auto decode = [&](int id) {
+        nb = id % a.nblocks_n; id /= a.nblocks_n;
+        mblock = id;
+        const int tx_i = id % a.tiles_x; id /= a.tiles_x;
+        const int ty_i = id % a.tiles_y; id /= a.tiles_y;
+        b = id;
+        gy0 = ty_i * (2 * MT); gx0 = tx_i * 16;
+        n0 = nb * BN;
+        iy0 = gy0 * STRIDE + a.dy_min; ix0 = gx0 * STRIDE + a.dx_min;
+    };
+    decode(tile);
 
     if (tid < a.ntaps) sTap[tid] = a.ty[tid] * a.RS + a.tx[tid] * PS;
     const bool has_coef = a.src.scale != nullptr;
@@ -94,13 +101,6 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
     const float* lcoef = has_coef ? sCoef : nullptr;
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-
     int aBase[TM], bBase[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
     for (int j = 0; j < TN; ++j) bBase[j] = ((wn * TN + j) * 32 + r) * PS + h * LHB;
 
     const CT* wp = (const CT*)a.w;
-    const int iy0 = gy0 * STRIDE + a.dy_min, ix0 = gx0 * STRIDE + a.dx_min;
     const int nstages = a.nchunks * a.ngroups;
 
     frag_t breg[NB];
@@ -149,16 +148,22 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
         }
     };
 
-    // ---- prologue: chunk 0 halo + stage 0 weights
+    // ---- first tile: chunk 0 halo + stage 0 weights
     b_issue(0, 0);
-    if (a.fast_a) {
-        apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
-        __syncthreads();  // coefficient table visible
-        apre.commit(sA, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, 0, tid);
-    } else {
-        stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid, NTHR, a.Cin);
-    }
+    if (a.fast_a) apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
+    __syncthreads();  // coefficient table + tap offsets visible
+
+  for (;;) {
+    // ---- commit the prefetched first stage of this tile
+    if (a.fast_a) apre.commit(sA, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, 0, tid);
+    else stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid, NTHR, a.Cin);
     b_commit(0, sB);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
     __syncthreads();
 
     int c = 0, g = 0;
@@ -212,6 +217,16 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
         c = cn; g = gn;
     }
 
+    // ---- current tile's output coordinates (the prefetch below re-decodes for the next tile)
+    const int cur_b = b, cur_gy0 = gy0, cur_gx0 = gx0, cur_n0 = n0, cur_mblock = mblock;
+    const int next_tile = tile + gridDim.x;
+    const bool more = next_tile < ntiles;
+    if (more) {
+        decode(next_tile);
+        b_issue(0, 0);
+        if (a.fast_a) apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
+    }
+
     // ---- epilogue: bias, statistics of the f32 values, store.
     // NHWC outputs go through a per-wave LDS transpose (32 pixels x TN*32 channels at a time) so that every
     // global store is 16 bytes of consecutive channels of one pixel (a lane of the accumulator layout holds ONE
@@ -223,19 +238,20 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         s1[j] = 0.f; s2[j] = 0.f;
-        const int n = n0 + (wn * TN + j) * 32 + r;
+        const int n = cur_n0 + (wn * TN + j) * 32 + r;
         nval[j] = n < a.Cout;
         bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
     }
     const bool planar = (sizeof(OutT) == 4) && a.planar_out;
-    if (!planar) {
+    if (a.dbg & 64) {
+    } else if (!planar) {
         constexpr int TW = TN * 32;                       // channels of this wave's tile row
         constexpr int ROWB = TW * (int)sizeof(OutT) + 16;  // padded LDS row (bytes)
         constexpr int EV = 16 / (int)sizeof(OutT);         // elements per 16-byte store
         constexpr int SEG_PER_ROW = TW / EV;
         __syncthreads();  // main-loop LDS reads finished
         char* stg = smem + wave * (32 * ROWB);
-        const int cbase = n0 + wn * TW;  // first channel of the wave's tile row
+        const int cbase = cur_n0 + wn * TW;  // first channel of the wave's tile row
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
-                    const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
+                    const int gy = cur_gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = cur_gx0 + (rit & 15);
                     const float v = acc[i][j][k] + bv[j];
                     if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; }
                     *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)v;
@@ -254,10 +270,10 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
 #pragma unroll
             for (int e = lane; e < 32 * SEG_PER_ROW; e += 64) {
                 const int rit = e / SEG_PER_ROW, sg = e - rit * SEG_PER_ROW;
-                const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
+                const int gy = cur_gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = cur_gx0 + (rit & 15);
                 const int cch = cbase + sg * EV;
                 if (gy < a.Hg && gx < a.Wg && cch < a.Cout) {
-                    const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cch;
+                    const size_t o = ((size_t)(cur_b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cch;
                     if (cch + EV <= a.Cout && ((a.ldy | (a.cout_off + cch)) % EV) == 0) {
                         *(f32x4*)(yo + o) = *(const f32x4*)(stg + rit * ROWB + sg * 16);
                     } else {
@@ -270,18 +286,18 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
     } else {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + r;
+            const int n = cur_n0 + (wn * TN + j) * 32 + r;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
-                    const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
+                    const int gy = cur_gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = cur_gx0 + (rit & 15);
                     if (nval[j] && gy < a.Hg && gx < a.Wg) {
                         const float v = acc[i][j][k] + bv[j];
                         s1[j] += v; s2[j] += v * v;
                         // NCHW: registers k..k+3 of a lane are 4 consecutive x of one plane -> one 16-byte store
-                        const size_t o = ((size_t)(b * a.ctot_out + a.cout_off + n) * a.Hout + gy) * a.Wout + gx;
+                        const size_t o = ((size_t)(cur_b * a.ctot_out + a.cout_off + n) * a.Hout + gy) * a.Wout + gx;
                         if ((k & 3) == 0 && gx + 3 < a.Wg && (a.Wout & 3) == 0) {
                             f32x4 t;
                             t[0] = v; t[1] = acc[i][j][k + 1] + bv[j]; t[2] = acc[i][j][k + 2] + bv[j]; t[3] = acc[i][j][k + 3] + bv[j];
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
             }
         }
     }
-    if (a.stats != nullptr) {
+    if (a.stats != nullptr && !(a.dbg & 128)) {
         __syncthreads();  // LDS reuse
         float* red = (float*)smem;  // [WM][2][BN]
 #pragma unroll
@@ -308,14 +324,18 @@ __global__ __launch_bounds__(512, (BN == 32) ? 4 : 2) void conv_igemm_kernel(con
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < a.Cout) {
+        if (tid < BN && cur_n0 + tid < a.Cout) {
             float v1 = 0.f, v2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { v1 += red[(w * 2 + 0) * BN + tid]; v2 += red[(w * 2 + 1) * BN + tid]; }
-            a.stats[((size_t)mblock * 2 + 0) * a.Cout + n0 + tid] = v1;
-            a.stats[((size_t)mblock * 2 + 1) * a.Cout + n0 + tid] = v2;
+            a.stats[((size_t)cur_mblock * 2 + 0) * a.Cout + cur_n0 + tid] = v1;
+            a.stats[((size_t)cur_mblock * 2 + 1) * a.Cout + cur_n0 + tid] = v2;
         }
     }
+    if (!more) break;
+    tile = next_tile;
+    __syncthreads();  // epilogue staging / statistics scratch in LDS is free again
+  }
 }
 
 struct Geom {
@@ -338,10 +358,25 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
         dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
     }
     g->dy_min = dymin; g->dx_min = dxmin;
-    // patch height: 16 rows (256 pixels) halves the weight re-staging per output pixel; 8 rows where the taller
-    // patch would waste rows or (stride 2) blow up the halo image.  BN = 32 needs 8 m-tiles to feed 8 waves.
-    const int t16 = abc_cdiv(d->Hg, 16) * 16, t8 = abc_cdiv(d->Hg, 8) * 8;
-    g->MT = (g->BN == 32 || (d->stride == 1 && t16 == t8)) ? 8 : 4;
+    // patch height (2*MT rows x 16 columns).  Taller patches re-stage the weights less often per output pixel; the
+    // persistent grid runs ceil(tiles/256) rounds, so pick the height with the least rounds x tile-work (ties: taller).
+    // MT = 6 exists for BN = 128 only (2 x 4 wave layout); BN = 32 needs 8 m-tiles to feed 8 waves; stride 2 keeps
+    // the halo image small with MT = 4.
+    {
+        int best = -1;
+        long best_cost = 0;
+        const int cand[3] = {8, 6, 4};
+        for (int ci = 0; ci < 3; ++ci) {
+            const int mt = cand[ci];
+            if (g->BN == 32 && mt != 8) continue;
+            if (mt == 6 && (g->BN != 128 || d->stride != 1)) continue;
+            if (d->stride == 2 && g->BN != 32 && mt != 4) continue;
+            const long tiles = (long)g->nbn * abc_cdiv(d->Wg, 16) * abc_cdiv(d->Hg, 2 * mt) * d->B;
+            const long cost = ((tiles + 255) / 256) * mt;
+            if (best < 0 || cost < best_cost) { best = mt; best_cost = cost; }
+        }
+        g->MT = best;
+    }
     const int prow = 2 * g->MT;
     g->HH = (prow - 1) * d->stride + (dymax - dymin) + 1;
     g->HW = 15 * d->stride + (dxmax - dxmin) + 1;
@@ -388,7 +423,9 @@ static int launch_inst(const ConvK& k, const Geom& g, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(fn, dim3(g.grid), dim3(NTHR), g.lds, st, k);
+    // persistent: one workgroup per CU walks the tiles
+    const int nwg = g.grid < 256 ? g.grid : 256;
+    hipLaunchKernelGGL(fn, dim3(nwg), dim3(NTHR), g.lds, st, k);
     return abc_check_launch("conv_igemm");
 }
 
@@ -398,6 +435,9 @@ static int launch_mt(const ConvK& k, const Geom& g, int stride, hipStream_t st) 
         return stride == 2 ? launch_inst<InT, CT, OutT, CK, BN, 2, 8>(k, g, st) : launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st);
     } else {
         if (stride == 2) return launch_inst<InT, CT, OutT, CK, BN, 2, 4>(k, g, st);
+        if constexpr (BN == 128) {
+            if (g.MT == 6) return launch_inst<InT, CT, OutT, CK, BN, 1, 6>(k, g, st);
+        }
         return g.MT == 8 ? launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st) : launch_inst<InT, CT, OutT, CK, BN, 1, 4>(k, g, st);
     }
 }
@@ -460,7 +500,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     k.ntaps = d->ntaps; k.tg = g.tg; k.ngroups = g.ngroups; k.dy_min = g.dy_min; k.dx_min = g.dx_min; k.HH = g.HH; k.HW = g.HW; k.RS = g.RS;
     k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y; k.nblocks_n = g.nbn; k.sA_bytes = g.sA_bytes; k.a_bufs = g.a_bufs;
     k.sB_off = g.a_bufs * g.sA_bytes; k.coef_off = g.coef_off; k.cstride = g.cstride;
-    k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a;
+    k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a; k.ntiles = g.grid;
     { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     for (int t = 0; t < d->ntaps; ++t) {
         k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);

@@ -214,8 +214,8 @@ class Engine:
         ca_pad, cb_pad = ca_pad.value, cb_pad.value
         per_split = self.lib.abc_wgrad_blocks(C.byref(d))
         npatch = self.B * (-(-gh // 8)) * (-(-gw // 16))
-        # one 8-wave workgroup per CU: aim at ~2 rounds of 256 workgroups, at least 2 patches per workgroup
-        nsplit = max(1, min(max(1, npatch // 2), 512 // per_split))
+        # one 8-wave workgroup per CU is resident: a single round of ~256 workgroups keeps the split-K slabs small
+        nsplit = max(1, min(max(1, npatch // 2), 256 // per_split))
         d.nsplit = nsplit
         need = nsplit * len(taps) * ca_pad * cb_pad
         self._ws_need = max(self._ws_need, need)
