@@ -105,6 +105,9 @@ SYMBOLS = {
     "abc_conv_chunk": (C.c_int, [C.c_int, C.c_int]),
     "abc_conv_tile": (C.c_int, [P(ConvDesc), P(i32), P(i32), P(i32)]),
     "abc_pack_conv_weights": (C.c_int, [P(PackDesc), vp]),
+    "abc_pack_item_bytes": (C.c_int, []),
+    "abc_pack_item_fill": (i64, [vp, P(PackDesc), i64]),
+    "abc_pack_batch": (C.c_int, [vp, i32, i64, vp]),
     "abc_bn_finalize_fwd": (C.c_int, [P(BnFwdDesc), vp]),
     "abc_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, f32, vp]),
     "abc_act_bwd_blocks": (C.c_int, [P(ActBwdDesc)]),

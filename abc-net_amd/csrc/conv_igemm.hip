@@ -38,7 +38,7 @@ struct ConvK {
     int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad;
     int om, oy0, ox0;
     int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS;
-    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles;
+    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles, b_static, stg_off;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
@@ -57,7 +57,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     constexpr int TN = NT / WN;
     static_assert(TM >= 1 && TM * WM == MT && TN >= 1 && TN * WN == NT, "tile/wave layout");
     constexpr int TGMAX = 3;
-    constexpr int NB = (TGMAX * BN * SEGS + NTHR - 1) / NTHR;  // weight segments a thread prefetches per stage
+    // weight segments a thread prefetches per stage; narrow layers (BN = 32) may hold ALL taps of their single chunk
+    // resident in LDS for the whole persistent loop (b_static), loaded in one go
+    constexpr int NB = (BN == 32) ? 3 : (TGMAX * BN * SEGS + NTHR - 1) / NTHR;
     typedef typename Frag<CT>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,11 +155,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     if (a.fast_a) apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
     __syncthreads();  // coefficient table + tap offsets visible
 
+  bool first_tile = true;
   for (;;) {
     // ---- commit the prefetched first stage of this tile
     if (a.fast_a) apre.commit(sA, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, 0, tid);
     else stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid, NTHR, a.Cin);
-    b_commit(0, sB);
+    if (!a.b_static || first_tile) b_commit(0, sB);
+    first_tile = false;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -165,6 +169,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
     __syncthreads();
+    // this tile's output coordinates; the next tile (if any) is decoded and its first stage prefetched at the
+    // LAST stage of the main loop, before that stage's MFMA block
+    const int cur_b = b, cur_gy0 = gy0, cur_gx0 = gx0, cur_n0 = n0, cur_mblock = mblock;
+    const int next_tile = tile + gridDim.x;
+    const bool more = next_tile < ntiles;
 
     int c = 0, g = 0;
     for (int s = 0; s < nstages; ++s) {
@@ -173,6 +182,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
         const bool has_next = (s + 1 < nstages);
         const bool new_chunk = has_next && (gn == 0);
         if (has_next && !(a.dbg & 1)) b_issue(cn, gn);
+        if (s == nstages - 1 && more) {
+            decode(next_tile);
+            if (!a.b_static) b_issue(0, 0);
+            if (a.fast_a) apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
+        }
         if (new_chunk && a.fast_a && !(a.dbg & 2))
             apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off + cn * CK, tid);
 
@@ -217,16 +231,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
         c = cn; g = gn;
     }
 
-    // ---- current tile's output coordinates (the prefetch below re-decodes for the next tile)
-    const int cur_b = b, cur_gy0 = gy0, cur_gx0 = gx0, cur_n0 = n0, cur_mblock = mblock;
-    const int next_tile = tile + gridDim.x;
-    const bool more = next_tile < ntiles;
-    if (more) {
-        decode(next_tile);
-        b_issue(0, 0);
-        if (a.fast_a) apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
-    }
-
     // ---- epilogue: bias, statistics of the f32 values, store.
     // NHWC outputs go through a per-wave LDS transpose (32 pixels x TN*32 channels at a time) so that every
     // global store is 16 bytes of consecutive channels of one pixel (a lane of the accumulator layout holds ONE
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
         constexpr int EV = 16 / (int)sizeof(OutT);         // elements per 16-byte store
         constexpr int SEG_PER_ROW = TW / EV;
         __syncthreads();  // main-loop LDS reads finished
-        char* stg = smem + wave * (32 * ROWB);
+        char* stg = smem + a.stg_off + wave * (32 * ROWB);
         const int cbase = cur_n0 + wn * TW;  // first channel of the wave's tile row
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     }
     if (a.stats != nullptr && !(a.dbg & 128)) {
         __syncthreads();  // LDS reuse
-        float* red = (float*)smem;  // [WM][2][BN]
+        float* red = (float*)(smem + a.stg_off);  // [WM][2][BN]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float v1 = s1[j] + __shfl_xor(s1[j], 32);
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
 
 struct Geom {
     int CK, BN, MT, dy_min, dx_min, HH, HW, PS, RS, tg, ngroups, sA_bytes, a_bufs, sB_bytes, tap_off, coef_off, cstride, lds, tiles_x,
-        tiles_y, nbn, grid, fast_a;
+        tiles_y, nbn, grid, fast_a, b_static, stg_off;
 };
 
 static int conv_geom(const abc_conv_desc* d, Geom* g) {
@@ -396,17 +400,22 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
     if (tg < 1) return abc_fail(ABC_EUNSUPPORTED, "conv: LDS tile too large");
     if (tg > 3) tg = 3;
     if (tg > d->ntaps) tg = d->ntaps;
+    // narrow layers: one chunk, one n-block -> the whole weight set stays in LDS across the persistent tile loop
+    g->b_static = (g->BN == 32 && g->nbn == 1 && abc_cdiv(d->Cin, g->CK) == 1 && d->ntaps * g->BN * segs <= 3 * NTHR) ? 1 : 0;
+    if (g->b_static) tg = d->ntaps;
     g->ngroups = abc_cdiv(d->ntaps, tg);
     g->tg = abc_cdiv(d->ntaps, g->ngroups);
     g->sB_bytes = abc_roundup(g->tg * g->BN * g->PS, 256);
     g->tap_off = g->a_bufs * g->sA_bytes + 2 * g->sB_bytes;
     g->coef_off = g->tap_off + 256;
     g->lds = g->coef_off + coef_bytes;
-    {   // epilogue transpose staging: 8 waves x 32 rows x (TN*32 channels + 16 B pad)
+    {   // epilogue transpose staging: 8 waves x 32 rows x (TN*32 channels + 16 B pad); it aliases the halo/weight
+        // buffers (dead by then) EXCEPT resident weights, which it must not touch
         const int tn = (g->BN / 32 >= 2) ? g->BN / 64 : 1;
         const int osz = d->dtype_out == ABC_BF16 ? 2 : 4;
         const int stg = 8 * 32 * (tn * 32 * osz + 16) + 8 * 2 * 128 * 4;
-        if (g->lds < stg) g->lds = stg;
+        g->stg_off = g->b_static ? abc_roundup(g->lds, 256) : 0;
+        if (g->lds < g->stg_off + stg) g->lds = g->stg_off + stg;
     }
     if (g->lds > 160 * 1024) return abc_fail(ABC_EUNSUPPORTED, "conv: LDS tile too large");
     g->tiles_x = abc_cdiv(d->Wg, 16);
@@ -500,7 +509,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     k.ntaps = d->ntaps; k.tg = g.tg; k.ngroups = g.ngroups; k.dy_min = g.dy_min; k.dx_min = g.dx_min; k.HH = g.HH; k.HW = g.HW; k.RS = g.RS;
     k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y; k.nblocks_n = g.nbn; k.sA_bytes = g.sA_bytes; k.a_bufs = g.a_bufs;
     k.sB_off = g.a_bufs * g.sA_bytes; k.coef_off = g.coef_off; k.cstride = g.cstride;
-    k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a; k.ntiles = g.grid;
+    k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a; k.ntiles = g.grid; k.b_static = g.b_static; k.stg_off = g.stg_off;
     { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     for (int t = 0; t < d->ntaps; ++t) {
         k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);

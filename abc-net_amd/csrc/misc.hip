@@ -57,6 +57,45 @@ __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunk
     }
 }
 
+// batched form: one launch over a device-resident table of descriptors (the plan packs ~100 small weights per step)
+struct PackItem { abc_pack_desc d; int32_t CK, ntaps, nchunks, is_bf16; int64_t first; };
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackItem* items, int nitems, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        // binary search for the item whose [first, next.first) contains i
+        int lo = 0, hi = nitems - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (items[mid].first <= i) lo = mid; else hi = mid - 1;
+        }
+        const PackItem& it = items[lo];
+        const abc_pack_desc& d = it.d;
+        const int CK = it.CK, ntaps = it.ntaps, nchunks = it.nchunks;
+        int64_t r = i - it.first;
+        const int k = (int)(r % CK); r /= CK;
+        const int n = (int)(r % d.rows_pad); r /= d.rows_pad;
+        const int c = (int)(r % nchunks);
+        const int t = (int)(r / nchunks);
+        const int rc = c * CK + k;
+        float v = 0.f;
+        if (d.mode == 0) {
+            if (n < d.Cout && rc < d.Cin) v = d.w[((size_t)n * d.Cin + rc) * ntaps + t];
+        } else if (d.mode == 1) {
+            if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)rc * d.Cin + n) * ntaps + t];
+        } else if (d.mode == 2) {
+            const int nx = d.px ? 2 : 1;
+            const int iy = t / nx, ix = t % nx;
+            const int ky = d.py ? (iy == 0 ? 0 : 2) : 1;
+            const int kx = d.px ? (ix == 0 ? 0 : 2) : 1;
+            if (n < d.Cout && rc < d.Cin) v = d.w[(((size_t)rc * d.Cout + n) * 3 + ky) * 3 + kx];
+        } else {
+            if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
+        }
+        const int nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
+        const size_t o = (((size_t)t * nch_total + ch_off + c) * d.rows_pad + n) * CK + k;
+        if (it.is_bf16) ((bf16*)d.dst)[o] = (bf16)v; else ((float*)d.dst)[o] = v;
+    }
+}
+
 // ------------------------------------------------------------------ Adam
 __global__ void step_inc_kernel(int64_t* step) { *step += 1; }
 
@@ -174,6 +213,39 @@ extern "C" int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream
     if (d->dtype_c == ABC_BF16) hipLaunchKernelGGL(pack_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, CK, ntaps, nchunks);
     else hipLaunchKernelGGL(pack_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, CK, ntaps, nchunks);
     return abc_check_launch("pack_conv_weights");
+}
+
+static int pack_shape(const abc_pack_desc* d, int* ntaps, int* red) {
+    switch (d->mode) {
+        case 0: *ntaps = d->kh * d->kw; *red = d->Cin; return 0;
+        case 1: *ntaps = d->kh * d->kw; *red = d->Cout; return 0;
+        case 2: *ntaps = (d->py ? 2 : 1) * (d->px ? 2 : 1); *red = d->Cin; return 0;
+        case 3: *ntaps = 9; *red = d->Cout; return 0;
+        default: return -1;
+    }
+}
+
+extern "C" int abc_pack_item_bytes(void) { return (int)sizeof(PackItem); }
+
+// host: fill one table entry (plain host memory, later copied to the device by the caller); returns the
+// number of destination elements this entry covers, or <0
+extern "C" int64_t abc_pack_item_fill(void* item, const abc_pack_desc* d, int64_t first) {
+    int ntaps, red;
+    if (pack_shape(d, &ntaps, &red)) { abc_fail(ABC_EINVAL, "pack: mode"); return -1; }
+    const int CK = d->ck;
+    if (CK != abc_conv_chunk(d->dtype_c, d->red_total) || d->red_pad % CK || d->red_pad < red || d->red_off % CK ||
+        d->red_off + d->red_pad > abc_roundup(d->red_total, CK)) { abc_fail(ABC_EINVAL, "pack: red_pad/red_off/ck"); return -1; }
+    PackItem* it = (PackItem*)item;
+    it->d = *d; it->CK = CK; it->ntaps = ntaps; it->nchunks = d->red_pad / CK; it->is_bf16 = d->dtype_c == ABC_BF16; it->first = first;
+    return (int64_t)ntaps * it->nchunks * d->rows_pad * CK;
+}
+
+extern "C" int abc_pack_batch(const void* items_dev, int32_t nitems, int64_t total, abc_stream_t stream) {
+    if (nitems < 1 || total < 1) return abc_fail(ABC_EINVAL, "pack_batch: empty");
+    int64_t nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_dev, nitems, total);
+    return abc_check_launch("pack_batch");
 }
 
 extern "C" int abc_adam_step(const abc_adam_desc* d, abc_stream_t stream) {

@@ -104,6 +104,7 @@ class Engine:
         self.head_off = head_offsets(self.heads)
         self.keep = []  # ctypes descriptors and tensors referenced by raw pointer
         self.pack_ops, self.fwd_ops, self.bwd_ops = [], [], []
+        self._pack_descs = []
         self.recs = []
         self._ws_need = 0
         self._ws_users = []
@@ -158,7 +159,8 @@ class Engine:
         total = red_real if red_total is None else red_total
         ck = self.lib.abc_conv_chunk(self.dt, total)
         d.rows_pad, d.red_pad, d.red_total, d.red_off, d.ck = rows_pad, -(-red_real // ck) * ck, total, red_off, ck
-        self._emit(self.pack_ops, self.lib.abc_pack_conv_weights, d, "pack " + wname)
+        self.keep.append(d)
+        self._pack_descs.append(d)
 
     def packed(self, ntaps, red, rows_pad):
         ck = self.lib.abc_conv_chunk(self.dt, red)
@@ -344,6 +346,21 @@ class Engine:
         self._build_heads(trunk)
         if self.train:
             self._build_backward()
+        # all weight re-packing of a step as ONE table-driven launch
+        lib = self.lib
+        isz = lib.abc_pack_item_bytes()
+        host = (C.c_char * (isz * len(self._pack_descs)))()
+        first = 0
+        for i, pd in enumerate(self._pack_descs):
+            n = lib.abc_pack_item_fill(C.addressof(host) + i * isz, C.byref(pd), first)
+            if n < 0:
+                L.check(-1, "pack_item_fill")
+            first += n
+        table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.dev)
+        self.keep.append(table)
+        a = (table.data_ptr(), len(self._pack_descs), first)
+        self.pack_ops.append((lambda _r, st, a=a: lib.abc_pack_batch(a[0], a[1], a[2], st), None, "pack weights", (),
+                              {"kernel": "pack_batch", "flops": 0, "bytes": float(first * (2 if self.dt == L.BF16 else 4) + first * 4)}))
         # shared workspaces
         self.ws = self.new((max(self._ws_need, 4),), torch.float32)
         for d in self._ws_users:

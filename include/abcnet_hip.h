@@ -110,6 +110,11 @@ typedef struct abc_pack_desc {
     int32_t ck;        /* K-chunk of dst: abc_conv_chunk(dtype_c, red_total) */
 } abc_pack_desc;
 int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream);
+/* batched form: the caller builds a table of abc_pack_item_bytes()-sized entries with abc_pack_item_fill (host
+ * memory, `first` = running element offset), copies it to the device once, and packs all weights of a step in ONE launch */
+int abc_pack_item_bytes(void);
+int64_t abc_pack_item_fill(void* item, const abc_pack_desc* d, int64_t first);
+int abc_pack_batch(const void* items_dev, int32_t nitems, int64_t total, abc_stream_t stream);
 
 /* BatchNorm2d, training mode (unet.py:13,16,67): reduce the conv's stat partials
  * in f64, write the on-load coefficients (scale, shift) for consumers, keep

@@ -20,7 +20,7 @@ HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
 def test_library_exports_every_declared_symbol():
     lib = L.load()  # raises on a missing symbol or a struct-size mismatch
     hdr = open(os.path.join(ROOT, "include", "abcnet_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(abc_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(abc_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     for name in sorted(declared):
         assert hasattr(lib, name), "library does not export %s" % name

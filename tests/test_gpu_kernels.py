@@ -45,6 +45,12 @@ def act(x, sc, sh, sl):
     dict(Cin=128, Cout=14, k=1, H=16, W=16, coef=True, f32out=True),
     dict(Cin=32, Cout=32, k=5, H=24, W=24, coef=True),
     dict(Cin=256, Cout=96, k=3, H=8, W=8),
+    # > 256 tiles: every persistent workgroup walks several tiles (cross-tile prefetch, resident weights on the
+    # narrow layers, general loader for the image / pooled inputs)
+    dict(Cin=1, Cout=16, k=3, H=128, W=384, img=True),
+    dict(Cin=16, Cout=32, k=3, H=256, W=384, pool=True),
+    dict(Cin=16, Cout=16, k=3, H=192, W=256, coef=True),
+    dict(Cin=128, Cout=128, k=3, H=96, W=192, coef=True),
 ])
 def test_conv_forward(lib, dt, case):
     g = torch.Generator().manual_seed(3)
