@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("B", i32), ("Hin", i32), ("Win", i32), ("cin_off", i32), ("Cin", i32), ("Hg", i32), ("Wg", i32),
                 ("Hout", i32), ("Wout", i32), ("ldy", i32), ("cout_off", i32), ("Cout", i32), ("Cout_pad", i32),
                 ("stride", i32), ("om", i32), ("oy0", i32), ("ox0", i32), ("ntaps", i32),
-                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("planar_out", i32), ("ctot_out", i32)]
+                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("stats_rows", i32), ("accumulate", i32),
+                ("planar_out", i32), ("ctot_out", i32)]
 
 
 class PackDesc(C.Structure):
@@ -39,7 +40,7 @@ class PackDesc(C.Structure):
 
 
 class BnFwdDesc(C.Structure):
-    _fields_ = [("partial", vp), ("nblk", i32), ("C", i32), ("count", f64), ("gamma", vp), ("beta", vp),
+    _fields_ = [("partial", vp), ("nblk", i32), ("C", i32), ("count", f64), ("rows", i32), ("gamma", vp), ("beta", vp),
                 ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp), ("running_mean", vp), ("running_var", vp),
                 ("num_batches_tracked", vp), ("eps", f32), ("momentum", f32)]
 
@@ -94,8 +95,29 @@ class NmsDesc(C.Structure):
                 ("n_omega", i32), ("atom_mask", vp), ("bond_mask", vp), ("rho_abs", vp), ("omega_mask", vp)]
 
 
+class CbamChannelDesc(C.Structure):
+    _fields_ = [("partial", vp), ("tiles_per_img", i32), ("B", i32), ("C", i32), ("mid", i32), ("HW", f64), ("scale", vp),
+                ("shift", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("ca", vp), ("avgz", vp), ("maxz", vp),
+                ("hid_avg", vp), ("hid_max", vp), ("dw1", vp), ("db1", vp), ("dw2", vp), ("db2", vp), ("d_avgz", vp),
+                ("d_maxz", vp)]
+
+
+class CbamPixDesc(C.Structure):
+    _fields_ = [("y", vp), ("ld_y", i32), ("cy_off", i32), ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp),
+                ("ca", vp), ("maxz", vp), ("d_avgz", vp), ("d_maxz", vp), ("sa", vp), ("st", vp), ("amax", vp), ("du", vp),
+                ("dst", vp), ("res", vp), ("ld_res", i32), ("cres_off", i32), ("res_pool", i32), ("out", vp), ("ld_out", i32),
+                ("cout_off", i32), ("d_same", vp), ("ld_same", i32), ("csame_off", i32), ("d_pool", vp), ("ld_pool", i32),
+                ("cpool_off", i32), ("g", vp), ("ld_g", i32), ("dz", vp), ("ld_dz", i32), ("partial", vp), ("dtype", i32),
+                ("B", i32), ("H", i32), ("W", i32), ("C", i32)]
+
+
+class CbamConv7Desc(C.Structure):
+    _fields_ = [("st", vp), ("w7", vp), ("b7", vp), ("sa", vp), ("du", vp), ("dst", vp), ("dw_partial", vp), ("dw7", vp),
+                ("db7", vp), ("B", i32), ("H", i32), ("W", i32)]
+
+
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
-            LossDesc, LossFinDesc, AdamDesc, NmsDesc]
+            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc]
 
 # every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
@@ -128,6 +150,19 @@ SYMBOLS = {
     "abc_nms_peaks": (C.c_int, [P(NmsDesc), vp]),
     "abc_plane_sum": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "abc_plane_sum_work": (C.c_int, [i32]),
+    "abc_cbam_channel_fwd": (C.c_int, [P(CbamChannelDesc), vp]),
+    "abc_cbam_channel_bwd": (C.c_int, [P(CbamChannelDesc), vp]),
+    "abc_cbam_spatial_stats": (C.c_int, [P(CbamPixDesc), vp]),
+    "abc_cbam_apply_fwd": (C.c_int, [P(CbamPixDesc), vp]),
+    "abc_cbam_bwd1": (C.c_int, [P(CbamPixDesc), vp]),
+    "abc_cbam_bwd2_blocks": (C.c_int, [P(CbamPixDesc)]),
+    "abc_cbam_bwd2": (C.c_int, [P(CbamPixDesc), vp]),
+    "abc_cbam_bwd3_blocks": (C.c_int, [P(CbamPixDesc)]),
+    "abc_cbam_bwd3": (C.c_int, [P(CbamPixDesc), vp]),
+    "abc_cbam_conv7_fwd": (C.c_int, [P(CbamConv7Desc), vp]),
+    "abc_cbam_conv7_blocks": (C.c_int, [P(CbamConv7Desc)]),
+    "abc_cbam_conv7_bwd": (C.c_int, [P(CbamConv7Desc), vp]),
+    "abc_add_into": (C.c_int, [vp, i32, i32, vp, i32, i32, i32, i64, i32, vp]),
     "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),

@@ -26,10 +26,11 @@ __device__ inline double block_sum_f64(double v, double* sm) {
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const abc_bn_fwd_desc d) {
     __shared__ double sm[4];
     const int c = blockIdx.x;
+    const int rows = d.rows == 4 ? 4 : 2;
     double s1 = 0.0, s2 = 0.0;
     for (int k = threadIdx.x; k < d.nblk; k += 256) {
-        s1 += (double)d.partial[((size_t)k * 2 + 0) * d.C + c];
-        s2 += (double)d.partial[((size_t)k * 2 + 1) * d.C + c];
+        s1 += (double)d.partial[((size_t)k * rows + 0) * d.C + c];
+        s2 += (double)d.partial[((size_t)k * rows + 1) * d.C + c];
     }
     s1 = block_sum_f64(s1, sm);
     s2 = block_sum_f64(s2, sm);

@@ -38,7 +38,7 @@ struct ConvK {
     int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad;
     int om, oy0, ox0;
     int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS;
-    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles, b_static, stg_off;
+    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles, b_static, stg_off, stats_rows, accumulate;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
@@ -236,12 +236,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     // global store is 16 bytes of consecutive channels of one pixel (a lane of the accumulator layout holds ONE
     // channel of 16 pixels: storing from registers would be 2-/4-byte scattered stores, issue-bound).
     OutT* yo = (OutT*)a.y;
-    float s1[TN], s2[TN];
+    float s1[TN], s2[TN], smx[TN], smn[TN];
     float bv[TN];
     bool nval[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        s1[j] = 0.f; s2[j] = 0.f;
+        s1[j] = 0.f; s2[j] = 0.f; smx[j] = -3.0e38f; smn[j] = 3.0e38f;
         const int n = cur_n0 + (wn * TN + j) * 32 + r;
         nval[j] = n < a.Cout;
         bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
                     const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
                     const int gy = cur_gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = cur_gx0 + (rit & 15);
                     const float v = acc[i][j][k] + bv[j];
-                    if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; }
+                    if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
                     *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)v;
                 }
             }
@@ -278,7 +278,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
                 const int cch = cbase + sg * EV;
                 if (gy < a.Hg && gx < a.Wg && cch < a.Cout) {
                     const size_t o = ((size_t)(cur_b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cch;
-                    if (cch + EV <= a.Cout && ((a.ldy | (a.cout_off + cch)) % EV) == 0) {
+                    if (a.accumulate) {
+                        for (int q = 0; q < EV && cch + q < a.Cout; ++q)
+                            yo[o + q] = (OutT)((float)yo[o + q] + (float)*(const OutT*)(stg + rit * ROWB + sg * 16 + q * (int)sizeof(OutT)));
+                    } else if (cch + EV <= a.Cout && ((a.ldy | (a.cout_off + cch)) % EV) == 0) {
                         *(f32x4*)(yo + o) = *(const f32x4*)(stg + rit * ROWB + sg * 16);
                     } else {
                         for (int q = 0; q < EV && cch + q < a.Cout; ++q) yo[o + q] = *(const OutT*)(stg + rit * ROWB + sg * 16 + q * (int)sizeof(OutT));
@@ -316,24 +319,36 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     }
     if (a.stats != nullptr && !(a.dbg & 128)) {
         __syncthreads();  // LDS reuse
-        float* red = (float*)(smem + a.stg_off);  // [WM][2][BN]
+        float* red = (float*)(smem + a.stg_off);  // [WM][4][BN]
+        const int rows = a.stats_rows == 4 ? 4 : 2;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float v1 = s1[j] + __shfl_xor(s1[j], 32);
             float v2 = s2[j] + __shfl_xor(s2[j], 32);
+            float v3 = fmaxf(smx[j], __shfl_xor(smx[j], 32));
+            float v4 = fminf(smn[j], __shfl_xor(smn[j], 32));
             if (h == 0) {
                 const int nl = (wn * TN + j) * 32 + r;
-                red[(wm * 2 + 0) * BN + nl] = v1;
-                red[(wm * 2 + 1) * BN + nl] = v2;
+                red[(wm * 4 + 0) * BN + nl] = v1;
+                red[(wm * 4 + 1) * BN + nl] = v2;
+                red[(wm * 4 + 2) * BN + nl] = v3;
+                red[(wm * 4 + 3) * BN + nl] = v4;
             }
         }
         __syncthreads();
         if (tid < BN && cur_n0 + tid < a.Cout) {
-            float v1 = 0.f, v2 = 0.f;
+            float v1 = 0.f, v2 = 0.f, v3 = -3.0e38f, v4 = 3.0e38f;
 #pragma unroll
-            for (int w = 0; w < WM; ++w) { v1 += red[(w * 2 + 0) * BN + tid]; v2 += red[(w * 2 + 1) * BN + tid]; }
-            a.stats[((size_t)cur_mblock * 2 + 0) * a.Cout + cur_n0 + tid] = v1;
-            a.stats[((size_t)cur_mblock * 2 + 1) * a.Cout + cur_n0 + tid] = v2;
+            for (int w = 0; w < WM; ++w) {
+                v1 += red[(w * 4 + 0) * BN + tid]; v2 += red[(w * 4 + 1) * BN + tid];
+                v3 = fmaxf(v3, red[(w * 4 + 2) * BN + tid]); v4 = fminf(v4, red[(w * 4 + 3) * BN + tid]);
+            }
+            a.stats[((size_t)cur_mblock * rows + 0) * a.Cout + cur_n0 + tid] = v1;
+            a.stats[((size_t)cur_mblock * rows + 1) * a.Cout + cur_n0 + tid] = v2;
+            if (rows == 4) {
+                a.stats[((size_t)cur_mblock * rows + 2) * a.Cout + cur_n0 + tid] = v3;
+                a.stats[((size_t)cur_mblock * rows + 3) * a.Cout + cur_n0 + tid] = v4;
+            }
         }
     }
     if (!more) break;
@@ -413,7 +428,7 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
         // buffers (dead by then) EXCEPT resident weights, which it must not touch
         const int tn = (g->BN / 32 >= 2) ? g->BN / 64 : 1;
         const int osz = d->dtype_out == ABC_BF16 ? 2 : 4;
-        const int stg = 8 * 32 * (tn * 32 * osz + 16) + 8 * 2 * 128 * 4;
+        const int stg = 8 * 32 * (tn * 32 * osz + 16) + 8 * 4 * 128 * 4;
         g->stg_off = g->b_static ? abc_roundup(g->lds, 256) : 0;
         if (g->lds < g->stg_off + stg) g->lds = g->stg_off + stg;
     }
@@ -510,6 +525,8 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y; k.nblocks_n = g.nbn; k.sA_bytes = g.sA_bytes; k.a_bufs = g.a_bufs;
     k.sB_off = g.a_bufs * g.sA_bytes; k.coef_off = g.coef_off; k.cstride = g.cstride;
     k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a; k.ntiles = g.grid; k.b_static = g.b_static; k.stg_off = g.stg_off;
+    k.stats_rows = d->stats_rows; k.accumulate = d->accumulate;
+    if (d->accumulate && d->planar_out) return abc_fail(ABC_EUNSUPPORTED, "conv: accumulate needs an NHWC output");
     { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     for (int t = 0; t < d->ntaps; ++t) {
         k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);

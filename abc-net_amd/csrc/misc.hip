@@ -293,6 +293,9 @@ extern "C" int abc_sizeof(int which) {
         case 10: return (int)sizeof(abc_loss_fin_desc);
         case 11: return (int)sizeof(abc_adam_desc);
         case 12: return (int)sizeof(abc_nms_desc);
+        case 13: return (int)sizeof(abc_cbam_channel_desc);
+        case 14: return (int)sizeof(abc_cbam_pix_desc);
+        case 15: return (int)sizeof(abc_cbam_conv7_desc);
         default: return -1;
     }
 }

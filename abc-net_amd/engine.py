@@ -85,8 +85,8 @@ class Rec:
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda"):
-        if variant != "unet":
-            raise NotImplementedError("variant %r is not lowered yet" % variant)
+        if variant not in ("unet", "unet2"):
+            raise NotImplementedError("variant %r" % variant)
         if H % 32 or W % 32:
             raise ValueError("H and W must be multiples of 32 (got %dx%d)" % (H, W))
         if in_channels != 1:
@@ -167,7 +167,8 @@ class Engine:
         return self.new((ntaps * (-(-red // ck)) * rows_pad * ck,))
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
-                  grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False):
+                  grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
+                  accumulate=False):
         d = L.ConvDesc()
         src.fill(d.src)
         d.w, d.bias, d.y = w.data_ptr(), bias, y.data_ptr()
@@ -181,11 +182,12 @@ class Engine:
         d.Hg, d.Wg, d.Hout, d.Wout, d.ldy, d.cout_off, d.Cout, d.Cout_pad = gh, gw, Hout, Wout, ldy, cout_off, Cout, -(-Cout // 32) * 32
         d.stride, d.om, d.oy0, d.ox0 = stride, om, oy0, ox0
         d.planar_out, d.ctot_out = (1, Cout) if planar_out else (0, 0)
+        d.stats_rows, d.accumulate = stats_rows, 1 if accumulate else 0
         L.set_taps(d, taps)
         nblk = self.lib.abc_conv_stat_blocks(C.byref(d))
         st = None
         if stats:
-            st = self.new((nblk, 2, Cout), torch.float32)
+            st = self.new((nblk, stats_rows, Cout), torch.float32)
             d.stats = st.data_ptr()
         bn_, mt_, ck_ = L.i32(), L.i32(), L.i32()
         L.check(self.lib.abc_conv_tile(C.byref(d), C.byref(bn_), C.byref(mt_), C.byref(ck_)), "conv_tile")
@@ -247,7 +249,7 @@ class Engine:
         ops.append((fn, None, what, (bname,), {"kernel": "colsum", "flops": 0, "bytes": float(npix * Cn * self._esz(dt))}))
 
     # ------------------------------------------------------------------ layers
-    def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None):
+    def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None, stats_rows=2, force_stats=False):
         """conv (+bias) -> raw output into dst=(tensor, coef, H, W, ld, coff); BN stats/coefficients"""
         yt, coef, H, W, ld, coff = dst
         cin = src.C
@@ -256,7 +258,7 @@ class Engine:
         wf = self.packed(len(taps), cin, rows_pad)
         self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin)
         stats, nblk = self.emit_conv(self.fwd_ops, src, wf, self.P(cname + ".bias"), yt, self.dt, H, W, ld, coff, cout, taps,
-                                     stats=self.train, what="fwd " + cname)
+                                     stats=self.train or force_stats, what="fwd " + cname, stats_rows=stats_rows)
         rec = Rec(kind="conv", cname=cname, bname=bname, src=src, cin=cin, cout=cout, k=k, taps=taps, y=yt, H=H, W=W, ld=ld,
                   coff=coff, coef=coef, slope=slope)
         sc, sh, sl = coef
@@ -265,7 +267,7 @@ class Engine:
         rec.mean, rec.invstd = self.new((cout,), torch.float32), self.new((cout,), torch.float32, 1.0)
         if self.train:
             d = L.BnFwdDesc()
-            d.partial, d.nblk, d.C, d.count = stats.data_ptr(), nblk, cout, float(self.B * H * W)
+            d.partial, d.nblk, d.C, d.count, d.rows = stats.data_ptr(), nblk, cout, float(self.B * H * W), stats_rows
             d.gamma, d.beta = self.P(bname + ".weight"), self.P(bname + ".bias")
             d.scale, d.shift, d.mean, d.invstd = rec.scale.data_ptr(), rec.shift.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr()
             d.running_mean, d.running_var = self.Bf(bname + ".running_mean"), self.Bf(bname + ".running_var")
@@ -277,6 +279,7 @@ class Engine:
             a = (self.P(bname + ".weight"), self.P(bname + ".bias"), self.Bf(bname + ".running_mean"),
                  self.Bf(bname + ".running_var"), rec.scale.data_ptr(), rec.shift.data_ptr(), cout, BN_EPS)
             self.fwd_ops.append((lambda _r, st, a=a: lib.abc_bn_eval_coeffs(*a, st), None, "bn-eval " + bname, (), {"kernel": "bn_eval", "flops": 0, "bytes": 0}))
+        rec.stats, rec.nblk = stats, nblk
         self.recs.append(rec)
         out = Src(yt, self.dt, H, W, ld, coff, cout, coef=coef, producer=rec)
         return rec, out
@@ -295,7 +298,7 @@ class Engine:
     def pooled(self, s: Src):
         return Src(s.t, s.dt, s.H, s.W, s.ld, s.coff, s.C, coef=s.coef, pool=True, producer=s.producer)
 
-    def up(self, name, low: Src, cat, cat_coef, Hs, Ws, Ctot, cout):
+    def up(self, name, low: Src, cat, cat_coef, Hs, Ws, Ctot, cout, skip_producer=None):
         """ConvTranspose2d(Ctot -> Ctot/2, k3, s2) of `low` into cat[..., Ctot/2:], then DoubleConv(Ctot -> cout)"""
         half = Ctot // 2
         cin = low.C
@@ -314,6 +317,11 @@ class Engine:
         rec = Rec(kind="convT", cname=name + ".up", src=low, cin=cin, cout=half, H=Hs, W=Ws, ld=Ctot, coff=half, y=cat)
         self.recs.append(rec)
         cat_src = Src(cat, self.dt, Hs, Ws, Ctot, 0, Ctot, coef=cat_coef, producer=("cat", None))
+        if self.variant == "unet2":
+            cat_src.cat = (skip_producer, rec)
+            self.units2.append(("convT", rec))
+            out = self.block2(name + ".conv", cat_src, cout, 3)
+            return out, rec
         out = self.double_conv(name + ".conv", cat_src, cout, 3)
         # remember who receives the two halves of d(cat)
         first = [r for r in self.recs if r.kind == "conv" and r.cname == name + ".conv.double_conv.0"][0]
@@ -322,6 +330,8 @@ class Engine:
 
     # ------------------------------------------------------------------ build
     def _build(self):
+        if self.variant == "unet2":
+            return self._build2()
         B, H, W = self.B, self.H, self.W
         S = [(H >> i, W >> i) for i in range(6)]
         self.img = self.new((B, 1, H, W), torch.float32)
@@ -346,6 +356,9 @@ class Engine:
         self._build_heads(trunk)
         if self.train:
             self._build_backward()
+        self._finish_build()
+
+    def _finish_build(self):
         # all weight re-packing of a step as ONE table-driven launch
         lib = self.lib
         isz = lib.abc_pack_item_bytes()
@@ -460,6 +473,19 @@ class Engine:
 
     def _build_backward(self):
         ops = self.bwd_ops
+        self._heads_backward(ops)
+        # ---- trunk, decoder, encoder in reverse
+        body = [r for r in self.recs if not getattr(r, "is_head", False)]
+        for rec in reversed(body):
+            if rec.kind == "conv":
+                dY = self._bn_backward(ops, rec, rec.grad_same, rec.grad_pool)
+                dsrc = self._conv_backward(ops, rec, dY)
+                if dsrc is not None:
+                    self._route(rec, dsrc)
+            else:
+                self._convT_backward(ops, rec)
+
+    def _heads_backward(self, ops):
         B, h, w = self.B, self.h, self.w
         nh = len(self.heads)
         self.dlogits = [self.new((B, hc, h, w), torch.float32) for hc in self.heads]
@@ -495,30 +521,23 @@ class Engine:
         dy_all = Src(dyh, self.dt, h, w, 128 * nh, 0, 128 * nh)
         self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
         self.trunk.producer.grad_same = (dtrunk, 128, 0)
-        # ---- trunk, decoder, encoder in reverse
-        body = [r for r in self.recs if not getattr(r, "is_head", False)]
-        for rec in reversed(body):
-            if rec.kind == "conv":
-                dY = self._bn_backward(ops, rec, rec.grad_same, rec.grad_pool)
-                dsrc = self._conv_backward(ops, rec, dY)
-                if dsrc is not None:
-                    self._route(rec, dsrc)
-            else:  # transposed conv
-                dcat, ld, coff = rec.grad_out
-                hs, ws = rec.H, rec.W
-                dOut = Src(dcat, self.dt, hs, ws, ld, coff, rec.cout)
-                self.emit_colsum(ops, dcat, self.dt, B * hs * ws, ld, coff, rec.cout, None, rec.cname + ".bias",
-                                 "dbias " + rec.cname)
-                self.emit_wgrad(ops, rec.src, dOut, rec.cin, rec.cout, TAPS_CONVT_DGRAD, 2, rec.cname + ".weight",
-                                "wgrad " + rec.cname)
-                lh, lw = rec.src.lh()
-                rows_pad = -(-rec.cin // 32) * 32
-                wd = self.packed(9, rec.cout, rows_pad)
-                self.emit_pack(rec.cname + ".weight", wd, 3, rec.cout, rec.cin, 3, rows_pad, rec.cout)
-                dsrc = self.new((B, lh, lw, rec.cin))
-                self.emit_conv(ops, dOut, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, TAPS_CONVT_DGRAD, stride=2,
-                               what="dgrad " + rec.cname)
-                rec.src.producer.grad_same = (dsrc, rec.cin, 0)
+
+    def _convT_backward(self, ops, rec):
+        """ConvTranspose2d(k3,s2) backward: bias (column sums of dOut), weight (stride-2 wgrad), data (stride-2 gather)"""
+        B = self.B
+        dcat, ld, coff = rec.grad_out
+        hs, ws = rec.H, rec.W
+        dOut = Src(dcat, self.dt, hs, ws, ld, coff, rec.cout)
+        self.emit_colsum(ops, dcat, self.dt, B * hs * ws, ld, coff, rec.cout, None, rec.cname + ".bias", "dbias " + rec.cname)
+        self.emit_wgrad(ops, rec.src, dOut, rec.cin, rec.cout, TAPS_CONVT_DGRAD, 2, rec.cname + ".weight", "wgrad " + rec.cname)
+        lh, lw = rec.src.lh()
+        rows_pad = -(-rec.cin // 32) * 32
+        wd = self.packed(9, rec.cout, rows_pad)
+        self.emit_pack(rec.cname + ".weight", wd, 3, rec.cout, rec.cin, 3, rows_pad, rec.cout)
+        dsrc = self.new((B, lh, lw, rec.cin))
+        self.emit_conv(ops, dOut, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, TAPS_CONVT_DGRAD, stride=2,
+                       what="dgrad " + rec.cname)
+        rec.src.producer.grad_same = (dsrc, rec.cin, 0)
 
     def _bn_backward_into(self, ops, rec, same, gbuf, ld_g, g_off, drop):
         """as _bn_backward, but G/dY live in a channel slice of a shared buffer (the heads)"""
@@ -554,6 +573,223 @@ class Engine:
         self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
                    meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
         return Src(gbuf, self.dt, rec.H, rec.W, ld_g, g_off, C_)
+
+    # ------------------------------------------------------------------ unet2 (CBAM + residual, unet2.py)
+    def f32buf(self, *shape, fill=0.0):
+        return self.new(tuple(shape), torch.float32, fill)
+
+    def block2(self, prefix, xin: Src, cout, k, dst=None):
+        """unet2.DoubleConv (unet2.py:49-74): conv-BN-ReLU-conv-BN-CBAM, + residual, ReLU.  The block output is
+        MATERIALISED (one element-wise pass), so its consumers load it with the identity transform."""
+        lib = self.lib
+        H, W = xin.lh()
+        B, cin = self.B, xin.C
+        p = prefix + ".double_conv"
+        t1, c1 = self.act_buf(H, W, cout)
+        rec1, a1 = self.conv_bn(p + ".0", p + ".1", xin, cout, k, (t1, c1, H, W, cout, 0), 0.0)
+        t2, c2 = self.act_buf(H, W, cout)
+        rec2, _ = self.conv_bn(p + ".3", p + ".4", a1, cout, k, (t2, c2, H, W, cout, 0), 1.0, stats_rows=4, force_stats=True)
+        mid = cout // 16
+        m = p + ".5.channel_attention.shared_MLP"
+        blk = Rec(kind="blk2", prefix=prefix, rec1=rec1, rec2=rec2, xin=xin, cin=cin, cout=cout, k=k, H=H, W=W, mid=mid)
+        blk.ca, blk.avgz, blk.maxz = self.f32buf(B, cout), self.f32buf(B, cout), self.f32buf(B, cout)
+        blk.hid_a, blk.hid_m = self.f32buf(B, mid), self.f32buf(B, mid)
+        ch = L.CbamChannelDesc()
+        ch.partial, ch.tiles_per_img, ch.B, ch.C, ch.mid, ch.HW = rec2.stats.data_ptr(), rec2.nblk // B, B, cout, mid, float(H * W)
+        ch.scale, ch.shift = rec2.scale.data_ptr(), rec2.shift.data_ptr()
+        ch.w1, ch.b1, ch.w2, ch.b2 = self.P(m + ".0.weight"), self.P(m + ".0.bias"), self.P(m + ".2.weight"), self.P(m + ".2.bias")
+        ch.ca, ch.avgz, ch.maxz = blk.ca.data_ptr(), blk.avgz.data_ptr(), blk.maxz.data_ptr()
+        ch.hid_avg, ch.hid_max = blk.hid_a.data_ptr(), blk.hid_m.data_ptr()
+        self._emit(self.fwd_ops, lib.abc_cbam_channel_fwd, ch, "cbam_channel " + prefix)
+        blk.st, blk.amax, blk.sa = self.f32buf(B, H, W, 2), self.new((B, H, W), torch.int32), self.f32buf(B, H, W)
+        # residual branch (unet2.py:62-65,72)
+        if cin != cout:
+            tr = self.new((B, H, W, cout))
+            rows_pad = -(-cout // 32) * 32
+            wr = self.packed(1, cin, rows_pad)
+            self.emit_pack(prefix + ".res_conv.weight", wr, 0, cout, cin, 1, rows_pad, cin)
+            self.emit_conv(self.fwd_ops, xin, wr, self.P(prefix + ".res_conv.bias"), tr, self.dt, H, W, cout, 0, cout, [(0, 0)],
+                           what="fwd %s.res_conv" % prefix)
+            res = (tr, cout, 0, 0)
+        else:
+            res = (xin.t, xin.ld, xin.coff, 1 if xin.pool else 0)
+        if dst is None:
+            to = self.new((B, H, W, cout))
+            dst = (to, H, W, cout, 0)
+        to, _, _, ld_o, coff_o = dst
+        blk.out, blk.ld_out, blk.coff_out, blk.res = to, ld_o, coff_o, res
+
+        def pix():
+            d = L.CbamPixDesc()
+            d.y, d.ld_y, d.cy_off = t2.data_ptr(), cout, 0
+            d.scale, d.shift, d.mean, d.invstd = rec2.scale.data_ptr(), rec2.shift.data_ptr(), rec2.mean.data_ptr(), rec2.invstd.data_ptr()
+            d.ca, d.maxz, d.sa, d.st, d.amax = blk.ca.data_ptr(), blk.maxz.data_ptr(), blk.sa.data_ptr(), blk.st.data_ptr(), blk.amax.data_ptr()
+            d.res, d.ld_res, d.cres_off, d.res_pool = res[0].data_ptr(), res[1], res[2], res[3]
+            d.out, d.ld_out, d.cout_off = to.data_ptr(), ld_o, coff_o
+            d.dtype, d.B, d.H, d.W, d.C = self.dt, B, H, W, cout
+            return d
+
+        blk.pix = pix
+        esz = self._esz(self.dt)
+        npx = B * H * W
+        self._emit(self.fwd_ops, lib.abc_cbam_spatial_stats, pix(), "cbam_spatial_stats " + prefix,
+                   meta={"kernel": "cbam_spatial_stats", "flops": 0, "bytes": float(npx * cout * esz)})
+        c7 = L.CbamConv7Desc()
+        sp = p + ".5.spatial_attention.conv2d"
+        c7.st, c7.w7, c7.b7, c7.sa = blk.st.data_ptr(), self.P(sp + ".weight"), self.P(sp + ".bias"), blk.sa.data_ptr()
+        c7.B, c7.H, c7.W = B, H, W
+        self._emit(self.fwd_ops, lib.abc_cbam_conv7_fwd, c7, "cbam_conv7 " + prefix)
+        self._emit(self.fwd_ops, lib.abc_cbam_apply_fwd, pix(), "cbam_apply " + prefix,
+                   meta={"kernel": "cbam_apply", "flops": 0, "bytes": float(npx * cout * esz * 3)})
+        self.units2.append(("blk", blk))
+        return Src(to, self.dt, H, W, ld_o, coff_o, cout, coef=None, producer=blk)
+
+    def _build2(self):
+        B, H, W = self.B, self.H, self.W
+        S = [(H >> i, W >> i) for i in range(6)]
+        self.units2 = []
+        self.img = self.new((B, 1, H, W), torch.float32)
+        img_src = Src(self.img, L.F32, H, W, 1, 0, 1)
+        x = self.block2("inc1", img_src, 32, 5)
+        x1 = self.block2("inc2", x, 32, 5)
+        x2 = self.block2("down1.maxpool_conv.1", self.pooled(x1), 32, 3)
+        x = self.block2("down2.maxpool_conv.1", self.pooled(x2), 64, 3)
+        cat3, cc3 = self.act_buf(S[2][0], S[2][1], 128)
+        cat2, cc2 = self.act_buf(S[3][0], S[3][1], 256)
+        cat1, cc1 = self.act_buf(S[4][0], S[4][1], 512)
+        x3 = self.block2("inc3", x, 64, 3, dst=(cat3, S[2][0], S[2][1], 128, 0))
+        x4 = self.block2("down3.maxpool_conv.1", self.pooled(x3), 128, 3, dst=(cat2, S[3][0], S[3][1], 256, 0))
+        x5 = self.block2("down4.maxpool_conv.1", self.pooled(x4), 256, 3, dst=(cat1, S[4][0], S[4][1], 512, 0))
+        x6 = self.block2("down5.maxpool_conv.1", self.pooled(x5), 512, 3)
+        u, _ = self.up("up1", x6, cat1, None, S[4][0], S[4][1], 512, 256, skip_producer=x5.producer)
+        u, _ = self.up("up2", u, cat2, None, S[3][0], S[3][1], 256, 128, skip_producer=x4.producer)
+        u, _ = self.up("up3", u, cat3, None, S[2][0], S[2][1], 128, 128, skip_producer=x3.producer)
+        u = self.block2("dconv1", u, 128, 3)
+        trunk = self.block2("dconv2", u, 128, 3)
+        self.trunk = trunk
+        self._build_heads(trunk)
+        if self.train:
+            self._build_backward2()
+        self._finish_build()
+
+    def _build_backward2(self):
+        ops = self.bwd_ops
+        lib = self.lib
+        B = self.B
+        self._heads_backward(ops)  # sets trunk.producer.grad_same
+        for kind, u in reversed(self.units2):
+            if kind == "convT":
+                self._convT_backward(ops, u)
+                continue
+            blk = u
+            H, W, Cc = blk.H, blk.W, blk.cout
+            npx = B * H * W
+            esz = self._esz(self.dt)
+            g = self.new((B, H, W, Cc))
+            dz = self.new((B, H, W, Cc))
+            du, dst = self.f32buf(B, H, W), self.f32buf(B, H, W, 2)
+            d_avgz, d_maxz = self.f32buf(B, Cc), self.f32buf(B, Cc)
+
+            def pix(blk=blk, g=g, dz=dz, du=du, dst=dst, d_avgz=d_avgz, d_maxz=d_maxz):
+                d = blk.pix()
+                d.g, d.ld_g, d.dz, d.ld_dz = g.data_ptr(), Cc, dz.data_ptr(), Cc
+                d.du, d.dst, d.d_avgz, d.d_maxz = du.data_ptr(), dst.data_ptr(), d_avgz.data_ptr(), d_maxz.data_ptr()
+                return d
+
+            d1 = pix()
+            if blk.grad_same is not None:
+                d1.d_same, d1.ld_same, d1.csame_off = blk.grad_same[0].data_ptr(), blk.grad_same[1], blk.grad_same[2]
+            if blk.grad_pool is not None:
+                d1.d_pool, d1.ld_pool, d1.cpool_off = blk.grad_pool[0].data_ptr(), blk.grad_pool[1], blk.grad_pool[2]
+            self._emit(ops, lib.abc_cbam_bwd1, d1, "cbam_bwd1 " + blk.prefix,
+                       meta={"kernel": "cbam_bwd1", "flops": 0, "bytes": float(npx * Cc * esz * 4)})
+            p = blk.prefix + ".double_conv"
+            sp = p + ".5.spatial_attention.conv2d"
+            c7 = L.CbamConv7Desc()
+            c7.st, c7.w7, c7.b7, c7.du, c7.dst = blk.st.data_ptr(), self.P(sp + ".weight"), self.P(sp + ".bias"), du.data_ptr(), dst.data_ptr()
+            c7.B, c7.H, c7.W = B, H, W
+            nb7 = lib.abc_cbam_conv7_blocks(C.byref(c7))
+            part7 = self.f32buf(nb7, 99)
+            c7.dw_partial, c7.dw7, c7.db7 = part7.data_ptr(), self.G(sp + ".weight"), self.G(sp + ".bias")
+            self._emit(ops, lib.abc_cbam_conv7_bwd, c7, "cbam_conv7_bwd " + blk.prefix, writes=(sp + ".weight", sp + ".bias"))
+            d2 = pix()
+            nb2 = lib.abc_cbam_bwd2_blocks(C.byref(d2))
+            part2 = self.f32buf(B, nb2, Cc)
+            d2.partial = part2.data_ptr()
+            self._emit(ops, lib.abc_cbam_bwd2, d2, "cbam_bwd2 " + blk.prefix,
+                       meta={"kernel": "cbam_bwd2", "flops": 0, "bytes": float(npx * Cc * esz * 3)})
+            m = p + ".5.channel_attention.shared_MLP"
+            ch = L.CbamChannelDesc()
+            ch.partial, ch.tiles_per_img, ch.B, ch.C, ch.mid, ch.HW = part2.data_ptr(), nb2, B, Cc, blk.mid, float(H * W)
+            ch.w1, ch.b1, ch.w2, ch.b2 = self.P(m + ".0.weight"), self.P(m + ".0.bias"), self.P(m + ".2.weight"), self.P(m + ".2.bias")
+            ch.ca, ch.avgz, ch.maxz = blk.ca.data_ptr(), blk.avgz.data_ptr(), blk.maxz.data_ptr()
+            ch.hid_avg, ch.hid_max = blk.hid_a.data_ptr(), blk.hid_m.data_ptr()
+            ch.dw1, ch.db1, ch.dw2, ch.db2 = self.G(m + ".0.weight"), self.G(m + ".0.bias"), self.G(m + ".2.weight"), self.G(m + ".2.bias")
+            ch.d_avgz, ch.d_maxz = d_avgz.data_ptr(), d_maxz.data_ptr()
+            self._emit(ops, lib.abc_cbam_channel_bwd, ch, "cbam_channel_bwd " + blk.prefix,
+                       writes=(m + ".0.weight", m + ".0.bias", m + ".2.weight", m + ".2.bias"))
+            d3 = pix()
+            nb3 = lib.abc_cbam_bwd3_blocks(C.byref(d3))
+            part3 = self.f32buf(nb3, 2, Cc)
+            d3.partial = part3.data_ptr()
+            self._emit(ops, lib.abc_cbam_bwd3, d3, "cbam_bwd3 " + blk.prefix,
+                       meta={"kernel": "cbam_bwd3", "flops": 0, "bytes": float(npx * Cc * esz * 3)})
+            # BN2 backward on d_z, then the second conv
+            rec2, rec1 = blk.rec2, blk.rec1
+            dY2 = self._bn_finish(ops, rec2, part3, nb3, dz)
+            dA1 = self._conv_backward(ops, rec2, dY2)
+            rec1.grad_same = (dA1, rec1.cout, 0)
+            dY1 = self._bn_backward(ops, rec1, rec1.grad_same, None)
+            xin = blk.xin
+            has_prod = xin.producer is not None
+            d_x = self._conv_backward(ops, rec1, dY1, want_dgrad=has_prod)
+            gsrc = Src(g, self.dt, H, W, Cc, 0, Cc)
+            if blk.cin != blk.cout:
+                rname = blk.prefix + ".res_conv"
+                self.emit_wgrad(ops, gsrc, xin, blk.cout, blk.cin, [(0, 0)], 1, rname + ".weight", "wgrad " + rname)
+                self.emit_colsum(ops, g, self.dt, npx, Cc, 0, Cc, None, rname + ".bias", "dbias " + rname)
+                if has_prod:
+                    rows_pad = -(-blk.cin // 32) * 32
+                    wd = self.packed(1, blk.cout, rows_pad)
+                    self.emit_pack(rname + ".weight", wd, 1, blk.cout, blk.cin, 1, rows_pad, blk.cout)
+                    self.emit_conv(ops, gsrc, wd, None, d_x, self.dt, H, W, blk.cin, 0, blk.cin, [(0, 0)], what="dgrad " + rname,
+                                   accumulate=True)
+            elif has_prod:
+                a = (d_x.data_ptr(), blk.cin, 0, g.data_ptr(), Cc, 0, Cc, npx, self.dt)
+                ops.append((lambda _r, st, a=a: lib.abc_add_into(*a, st), None, "d_x += g " + blk.prefix, (),
+                            {"kernel": "add_into", "flops": 0, "bytes": float(npx * Cc * esz * 3)}))
+            if has_prod:
+                self._route2(blk, d_x)
+
+    def _route2(self, blk, d_x):
+        src = blk.xin
+        if getattr(src, "cat", None) is not None:
+            skip_prod, up_rec = src.cat
+            half = blk.cin // 2
+            up_rec.grad_out = (d_x, blk.cin, half)
+            skip_prod.grad_same = (d_x, blk.cin, 0)
+        elif src.pool:
+            src.producer.grad_pool = (d_x, blk.cin, 0)
+        else:
+            src.producer.grad_same = (d_x, blk.cin, 0)
+
+    def _bn_finish(self, ops, rec, part, nblk, gbuf):
+        """bn_finalize_bwd + bn_apply for a BN whose G and partials were produced elsewhere (CBAM bwd3)"""
+        C_ = rec.cout
+        k1, k2, gs = (self.new((C_,), torch.float32) for _ in range(3))
+        f = L.BnBwdDesc()
+        f.partial, f.nblk, f.C, f.count = part.data_ptr(), nblk, C_, float(self.B * rec.H * rec.W)
+        f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
+        f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
+        f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
+        a = L.BnApplyDesc()
+        a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = gbuf.data_ptr(), C_, rec.y.data_ptr(), rec.ld, rec.coff
+        a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
+        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
+                   meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
+        return Src(gbuf, self.dt, rec.H, rec.W, C_, 0, C_)
 
     # ------------------------------------------------------------------ execution
     @staticmethod

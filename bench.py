@@ -28,7 +28,7 @@ MFMA_PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.m
 HBM_PEAK = 8000.0  # GB/s
 
 
-def cpu_baseline(size, seconds_budget=25.0):
+def cpu_baseline(size, seconds_budget=25.0, variant="unet"):
     """oracle = torch-CPU restatement of the reference train step (bitwise-pinned to the reference import);
     bounded sample: fwd+loss+bwd of batch 4 at the benchmark resolution, median of up to 3 timed iterations"""
     from abcnet_amd.synthetic import synthetic_images, synthetic_targets
@@ -37,13 +37,13 @@ def cpu_baseline(size, seconds_budget=25.0):
     B = 4
     x = synthetic_images(B, size, seed=7)
     tg = synthetic_targets(B, size // 4, seed=1)
-    sd0 = uo.filled_state("unet", 1, HEADS, seed=0)
+    sd0 = uo.filled_state(variant, 1, HEADS, seed=0)
     times = []
     t_start = time.time()
     for it in range(4):
         sd = uo.clone_state(sd0, requires_grad=True)
         t0 = time.time()
-        preds = uo.forward("unet", sd, x, train=True)
+        preds = uo.forward(variant, sd, x, train=True)
         total, _, _ = loss_oracle.abc_loss(preds, tg, sd["s"])
         total.backward()
         dt = time.time() - t0
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--size", type=int, default=384)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--variant", default="unet", choices=["unet", "unet2"], help="unet.py (headline) or unet2.py (config 3)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -84,7 +85,10 @@ def main():
     from abcnet_amd import distributed as D
     from abcnet_amd.synthetic import synthetic_images, synthetic_targets
     from abcnet_amd.train import Trainer
-    from abcnet_amd.unet import UNet
+    if a.variant == "unet2":
+        from abcnet_amd.unet2 import UNet
+    else:
+        from abcnet_amd.unet import UNet
 
     if world > 1:
         D.init_process_group(rank=rank, world_size=world)
@@ -125,7 +129,7 @@ def main():
         "metric": "training images/sec (384x384, b16/GPU)", "value": round(world * a.batch * a.steps / el, 2), "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": "unet.py train step (pack+fwd+fused loss+bwd+allreduce+Adam), %dx%d, batch %d/GPU, dropout 0.2" % (a.size, a.size, a.batch),
+        "config": {"workload": a.variant + ".py train step (pack+fwd+fused loss+bwd+allreduce+Adam), %dx%d, batch %d/GPU, dropout 0.2" % (a.size, a.size, a.batch),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph},
         "final_loss": round(loss, 4),
     }
@@ -148,7 +152,7 @@ def main():
                              "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK[a.dtype], 4),
                              "hbm_frac": round(bytes_step / (el / a.steps) / 1e9 / HBM_PEAK, 4)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.size)
+        out["cpu_baseline"] = cpu_baseline(a.size, variant=a.variant)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -78,6 +78,10 @@ typedef struct abc_conv_desc {
     int32_t ntaps;
     int8_t tap_dy[ABC_MAX_TAPS_C];
     int8_t tap_dx[ABC_MAX_TAPS_C];
+    int32_t stats_rows;  /* 0/2: stats = [nblk][2][Cout] (sum, sumsq); 4: [nblk][4][Cout] adds (max, min) of the
+                            f32 outputs per workgroup = per-image partials for CBAM's global pools (unet2.py:19-21) */
+    int32_t accumulate;  /* 1: y += result (NHWC only): a second data-gradient summed into the same tensor
+                            (residual branch of unet2.DoubleConv, unet2.py:72) */
     int32_t planar_out;  /* 1: y is channel-planar f32 [B][ctot_out][Hout][Wout] (NCHW logits written directly by
                             the heads' 1x1 conv: the list forward() returns needs no layout pass); ldy ignored */
     int32_t ctot_out;
@@ -122,6 +126,7 @@ int abc_pack_batch(const void* items_dev, int32_t nitems, int64_t total, abc_str
  * variance and bump num_batches_tracked. */
 typedef struct abc_bn_fwd_desc {
     const float* partial; int32_t nblk; int32_t C; double count;
+    int32_t rows; /* rows per workgroup in `partial`: 0/2 or 4 (see abc_conv_desc.stats_rows) */
     const float* gamma; const float* beta;
     float* scale; float* shift; float* mean; float* invstd;
     float* running_mean; float* running_var; int64_t* num_batches_tracked;
@@ -250,6 +255,53 @@ typedef struct abc_nms_desc {
 } abc_nms_desc;
 int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream);
 
+/* ---- unet2: CBAM attention + residual (unet2.py:6-74).  See csrc/cbam.hip for the pass structure. ---- */
+typedef struct abc_cbam_channel_desc { /* ChannelAttentionModule (unet2.py:6-22), one MLP evaluation per image */
+    const float* partial;  /* fwd: conv stats [B*tiles_per_img][4][C] (sum,sumsq,max,min of y2); bwd: [B*tiles_per_img][C] */
+    int32_t tiles_per_img, B, C, mid; double HW;
+    const float* scale; const float* shift;            /* BN2 affine of this block */
+    const float* w1; const float* b1; const float* w2; const float* b2; /* shared_MLP.0 / .2 */
+    float* ca; float* avgz; float* maxz; float* hid_avg; float* hid_max; /* [B][C], [B][C], [B][C], [B][mid] x2 */
+    float* dw1; float* db1; float* dw2; float* db2; float* d_avgz; float* d_maxz; /* backward outputs */
+} abc_cbam_channel_desc;
+int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
+int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
+
+typedef struct abc_cbam_pix_desc { /* per-pixel passes of SpatialAttentionModule / CBAM / residual (unet2.py:24-74) */
+    const void* y; int32_t ld_y, cy_off;               /* raw second-conv output y2 */
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    const float* ca; const float* maxz; const float* d_avgz; const float* d_maxz;
+    const float* sa; float* st; int32_t* amax; float* du; const float* dst;
+    const void* res; int32_t ld_res, cres_off, res_pool; /* residual r (res_pool: 2x2 max of a 2x tensor) */
+    void* out; int32_t ld_out, cout_off;               /* block output relu(sa*ca*z + r) */
+    const void* d_same; int32_t ld_same, csame_off;    /* gradient sources wrt `out` */
+    const void* d_pool; int32_t ld_pool, cpool_off;
+    void* g; int32_t ld_g;                             /* dOut*[out>0] (the residual branch's gradient) */
+    void* dz; int32_t ld_dz;                           /* d_o1, then d_z in place */
+    float* partial;
+    int32_t dtype, B, H, W, C;
+} abc_cbam_pix_desc;
+int abc_cbam_spatial_stats(const abc_cbam_pix_desc* d, abc_stream_t stream); /* y,ca -> st[B,H,W,2], amax */
+int abc_cbam_apply_fwd(const abc_cbam_pix_desc* d, abc_stream_t stream);     /* -> out */
+int abc_cbam_bwd1(const abc_cbam_pix_desc* d, abc_stream_t stream);          /* -> g, du */
+int abc_cbam_bwd2_blocks(const abc_cbam_pix_desc* d);                        /* workgroups per image */
+int abc_cbam_bwd2(const abc_cbam_pix_desc* d, abc_stream_t stream);          /* -> dz = d_o1, partial [B][blocks][C] */
+int abc_cbam_bwd3_blocks(const abc_cbam_pix_desc* d);
+int abc_cbam_bwd3(const abc_cbam_pix_desc* d, abc_stream_t stream);          /* dz -> d_z in place, BN partial [blocks][2][C] */
+
+typedef struct abc_cbam_conv7_desc { /* SpatialAttentionModule.conv2d 7x7 (2->1) + sigmoid (unet2.py:27,34) */
+    const float* st; const float* w7; const float* b7; float* sa;
+    const float* du; float* dst; float* dw_partial; float* dw7; float* db7; /* backward */
+    int32_t B, H, W;
+} abc_cbam_conv7_desc;
+int abc_cbam_conv7_fwd(const abc_cbam_conv7_desc* d, abc_stream_t stream);
+int abc_cbam_conv7_blocks(const abc_cbam_conv7_desc* d); /* dw_partial = [blocks][99] */
+int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream);
+
+/* dst[.., cdst_off + c] += src[.., csrc_off + c] (identity residual gradient, unet2.py:62) */
+int abc_add_into(void* dst, int32_t ld_dst, int32_t cdst_off, const void* src, int32_t ld_src, int32_t csrc_off, int32_t C,
+                 int64_t npix, int32_t dtype, abc_stream_t stream);
+
 /* layout conversion helpers (multi-channel NCHW input images -> NHWC) */
 int abc_nhwc_to_nchw_f32(const float* src, int32_t ld, int32_t c_off, int32_t C, int32_t B, int32_t H, int32_t W,
                          float* dst, abc_stream_t stream);
@@ -257,7 +309,7 @@ int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int3
                          int32_t c_off, abc_stream_t stream);
 int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream);
 
-/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12):
+/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15):
  * lets a foreign-language binding check its mirror structs at load time */
 int abc_sizeof(int which);
 const char* abc_last_error(void);

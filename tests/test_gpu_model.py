@@ -16,6 +16,7 @@ import abcnet_amd  # noqa: E402,F401
 from abcnet_amd import _lib as L  # noqa: E402
 from abcnet_amd.synthetic import synthetic_images, synthetic_targets  # noqa: E402
 from abcnet_amd.unet import UNet  # noqa: E402
+from abcnet_amd.unet2 import UNet as UNet2  # noqa: E402
 from oracle import loss_oracle, nms_oracle  # noqa: E402
 from oracle import unet_oracle as uo  # noqa: E402
 
@@ -24,9 +25,10 @@ DEV = "cuda"
 PRE_BN_BIAS = ("double_conv.0.bias", "double_conv.3.bias", "conv1.bias")
 
 
-def make_model(dtype="fp32", dropout_p=0.0, seed=0):
-    m = UNet(1, HEADS, dtype=dtype, dropout_p=dropout_p)
-    m.load_state_dict(uo.filled_state("unet", 1, HEADS, seed=seed))
+def make_model(dtype="fp32", dropout_p=0.0, seed=0, variant="unet"):
+    cls = UNet if variant == "unet" else UNet2
+    m = cls(1, HEADS, dtype=dtype, dropout_p=dropout_p)
+    m.load_state_dict(uo.filled_state(variant, 1, HEADS, seed=seed))
     return m.to(DEV)
 
 
@@ -83,11 +85,11 @@ def test_forward_bf16_bound():
         assert worst < bound, (mode, worst)
 
 
-def _oracle_grads(x, targets, dropout_masks=None, dtype=torch.float32):
-    sd0 = uo.filled_state("unet", 1, HEADS, seed=0)
+def _oracle_grads(x, targets, dropout_masks=None, dtype=torch.float32, variant="unet"):
+    sd0 = uo.filled_state(variant, 1, HEADS, seed=0)
     sd = uo.clone_state({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd0.items()}, requires_grad=True)
     dm = None if dropout_masks is None else [m.to(dtype) for m in dropout_masks]
-    preds = uo.forward("unet", sd, x.to(dtype), train=True, dropout_masks=dm)
+    preds = uo.forward(variant, sd, x.to(dtype), train=True, dropout_masks=dm)
     total, weighted, terms = loss_oracle.abc_loss(preds, [t.to(dtype) for t in targets], sd["s"])
     total.backward()
     return sd, total, weighted, preds
@@ -253,3 +255,63 @@ def test_fails_loudly_on_cpu_tensor():
     m = UNet(1, HEADS)
     with pytest.raises(L.AbcNetHipError):
         m(torch.zeros(1, 1, 64, 64))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# unet2 (CBAM + residual variant, /root/reference/src/unet2.py) -- BASELINE.json config 3
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_unet2_forward_matches_golden_fp32(mode, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "model_unet2_64.npz"))
+    m = make_model(variant="unet2")
+    m.train(mode == "train")
+    x = synthetic_images(2, 64, seed=7).to(DEV)
+    with torch.no_grad():
+        ys = m(x)
+    for i, y in enumerate(ys):
+        ref = gold["%s_head%d" % (mode, i)]
+        assert tuple(y.shape) == ref.shape
+        err = np.abs(y.cpu().numpy() - ref).max()
+        assert err < 1e-3, (mode, i, err)
+    if mode == "train":
+        sd = m.state_dict()
+        for k in gold.files:
+            if k.startswith("rs_"):
+                np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), gold[k], rtol=1e-4, atol=1e-5)
+
+
+def test_unet2_forward_384_and_bf16_bound(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "model_unet2_384.npz"))
+    x = synthetic_images(2, 384, seed=7)
+    m = make_model(variant="unet2")
+    m.train()
+    with torch.no_grad():
+        ys = m(x.to(DEV))
+    for i, y in enumerate(ys):
+        f = y.cpu().reshape(-1)
+        step = max(f.numel() // 257, 1)
+        np.testing.assert_allclose(f[::step][:257].double().numpy(), gold["train_head%d_sample" % i], atol=1e-3)
+    xb = synthetic_images(2, 128, seed=7)
+    mb = make_model("bf16", variant="unet2")
+    mb.eval()
+    with torch.no_grad():
+        yb = mb(xb.to(DEV))
+        ref = uo.forward("unet2", uo.filled_state("unet2", 1, HEADS, seed=0), xb, train=False)
+    assert max((a.cpu() - b).abs().max().item() for a, b in zip(yb, ref)) < 0.1
+
+
+def test_unet2_fused_train_step_matches_oracle():
+    from abcnet_amd.train import Trainer
+    B, S = 2, 128
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    sd, total, weighted, _ = _oracle_grads(x, tg, variant="unet2")
+    sd64 = _oracle_grads(x, tg, dtype=torch.float64, variant="unet2")[0]
+    m = make_model(variant="unet2")
+    tr = Trainer(m, B, S, S, use_graph=False)
+    tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    res = tr.loss_value()
+    assert abs(res["total"] - total.item()) < 2e-4 * abs(total.item()), (res["total"], total.item())
+    _check_grads(lambda n: m.grad_of(n), sd, sd64)
