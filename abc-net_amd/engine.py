@@ -439,6 +439,7 @@ class Engine:
         a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
         self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
                    meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
+        rec.dY = g
         return Src(g, self.dt, rec.H, rec.W, C_, 0, C_)
 
     def _conv_backward(self, ops, rec, dY: Src, want_dgrad=True):

