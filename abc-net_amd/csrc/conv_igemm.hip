@@ -38,11 +38,12 @@ struct ConvK {
     int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad;
     int om, oy0, ox0;
     int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS;
-    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles, b_static, stg_off, stats_rows, accumulate;
+    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles, b_static, stg_off, stats_rows, accumulate, magic;
+    unsigned bytesA, bytesW;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool FAST>
 __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
 
     if (tid < a.ntaps) sTap[tid] = a.ty[tid] * a.RS + a.tx[tid] * PS;
     const bool has_coef = a.src.scale != nullptr;
-    if (has_coef && a.fast_a) {
+    if (has_coef && FAST) {
         for (int i = tid; i < a.Cin; i += NTHR) {
             sCoef[i] = a.src.scale[a.cin_off + i];
             sCoef[a.cstride + i] = a.src.shift[a.cin_off + i];
@@ -115,50 +116,57 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
     const CT* wp = (const CT*)a.w;
     const int nstages = a.nchunks * a.ngroups;
 
-    frag_t breg[NB];
-    HaloPrefetch<InT, CT, CK, NA_MAX, NTHR> apre;
+    u32x4 breg[NB];
+    // FAST: plain NHWC input -> split-phase prefetch by raw buffer loads; otherwise (pool / dropout / planar / ragged
+    // channel tail) the halo is staged synchronously by the general loader.  Separate instantiations: the general
+    // loader inlined beside the prefetch registers makes the allocator spill, and a scratch reload waits on vmcnt(0).
+    HaloFetch<InT, CT, CK, FAST ? NA_MAX : 1, NTHR> apre;
+    const __amdgpu_buffer_rsrc_t rsA = abc_make_rsrc(a.src.x, a.bytesA), rsW = abc_make_rsrc(a.w, a.bytesW);
+    const HaloGeom gA = {a.HH, a.HW, a.magic, a.Hin, a.Win, a.src.Hx, a.src.Wx, a.src.ldx};
 
     // weights of stage (c, g): tcnt x BN rows of CKB bytes, contiguous per tap in the packed layout
+    // (thread id laundered: per-segment offsets are recomputed per stage instead of being hoisted and spilled)
     auto b_issue = [&](int c, int g) {
         const int t0 = g * a.tg;
         const int tcnt = min(a.tg, a.ntaps - t0);
         const int total = tcnt * BN * SEGS;
+        const int lt = abc_launder(tid);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int s = tid + i * NTHR;
-            if (s < total) {
-                const int tl = s / (BN * SEGS);
-                const int rem = s - tl * (BN * SEGS);
-                const int row = rem / SEGS, part = rem - row * SEGS;
-                breg[i] = *(const frag_t*)(wp + ((size_t)((t0 + tl) * a.nchunks + c) * a.Cout_pad + n0 + row) * CK + part * NV);
-            }
+            const int s = lt + i * NTHR;
+            const int tl = s / (BN * SEGS);
+            const int rem = s - tl * (BN * SEGS);
+            const int row = rem / SEGS, part = rem - row * SEGS;
+            const unsigned off = (unsigned)((((t0 + tl) * a.nchunks + c) * a.Cout_pad + n0 + row) * CK + part * NV) * (unsigned)sizeof(CT);
+            breg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, s < total ? off : 0x80000000u, 0, 0);
         }
     };
     auto b_commit = [&](int g, char* dst) {
         const int t0 = g * a.tg;
         const int tcnt = min(a.tg, a.ntaps - t0);
         const int total = tcnt * BN * SEGS;
+        const int lt = abc_launder(tid);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int s = tid + i * NTHR;
+            const int s = lt + i * NTHR;
             if (s < total) {
                 const int tl = s / (BN * SEGS);
                 const int rem = s - tl * (BN * SEGS);
                 const int row = rem / SEGS, part = rem - row * SEGS;
-                *(frag_t*)(dst + (tl * BN + row) * PS + part * 16) = breg[i];
+                *(u32x4*)(dst + (tl * BN + row) * PS + part * 16) = breg[i];
             }
         }
     };
 
     // ---- first tile: chunk 0 halo + stage 0 weights
     b_issue(0, 0);
-    if (a.fast_a) apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
+    if constexpr (FAST) apre.issue(rsA, gA, b, iy0, ix0, a.cin_off, tid, 1 << 30);
     __syncthreads();  // coefficient table + tap offsets visible
 
   bool first_tile = true;
   for (;;) {
     // ---- commit the prefetched first stage of this tile
-    if (a.fast_a) apre.commit(sA, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, 0, tid);
+    if constexpr (FAST) apre.commit(sA, a.RS, PS, gA, lcoef, a.cstride, tid, 1 << 30);
     else stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid, NTHR, a.Cin);
     if (!a.b_static || first_tile) b_commit(0, sB);
     first_tile = false;
@@ -185,10 +193,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
         if (s == nstages - 1 && more) {
             decode(next_tile);
             if (!a.b_static) b_issue(0, 0);
-            if (a.fast_a) apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off, tid);
+            if constexpr (FAST) apre.issue(rsA, gA, b, iy0, ix0, a.cin_off, tid, 1 << 30);
         }
-        if (new_chunk && a.fast_a && !(a.dbg & 2))
-            apre.issue(a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off + cn * CK, tid);
+        if constexpr (FAST) {
+            if (new_chunk && !(a.dbg & 2)) apre.issue(rsA, gA, b, iy0, ix0, a.cin_off + cn * CK, tid, 1 << 30);
+        }
 
         // ---- MFMA over the taps of this stage
         {
@@ -218,10 +227,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
         if (new_chunk) {
             if (a.a_bufs == 2) {
                 // the other halo buffer was last read in chunk c-1: free since the barrier that ended it
-                if (!(a.dbg & 16)) apre.commit(sA + (cn & 1) * a.sA_bytes, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, cn * CK, tid);
+                if constexpr (FAST) {
+                    if (!(a.dbg & 16)) apre.commit(sA + (cn & 1) * a.sA_bytes, a.RS, PS, gA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid, 1 << 30);
+                }
             } else {
                 __syncthreads();  // every wave is done reading this chunk's halo
-                if (a.fast_a) apre.commit(sA, a.RS, PS, a.HH, a.HW, lcoef, a.cstride, cn * CK, tid);
+                if constexpr (FAST) apre.commit(sA, a.RS, PS, gA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid, 1 << 30);
                 else
                     stage_halo<InT, CT, CK>(sA, a.RS, PS, a.HH, a.HW, b, iy0, ix0, a.Hin, a.Win, a.src, a.cin_off + cn * CK, tid, NTHR,
                                             a.Cin - cn * CK);
@@ -404,8 +415,9 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
     g->RS = abc_roundup(g->HW * g->PS, 256);
     g->sA_bytes = abc_roundup(g->HH * g->RS, 256);
     const int segs = CKB / 16;
-    g->fast_a = (!d->src.pool && !d->src.planar && d->src.drop_p <= 0.f && d->Cin % g->CK == 0 &&
-                 abc_cdiv(g->HH * g->HW * segs, NTHR) <= NA_MAX) ? 1 : 0;
+    const int64_t bytes_a = (int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4);
+    g->fast_a = (!d->src.pool && !d->src.planar && d->src.drop_p <= 0.f && d->Cin % g->CK == 0 && bytes_a < (int64_t(1) << 31) &&
+                 abc_cdiv(g->HH * g->HW * segs, NTHR) <= NA_MAX && g->HH * g->HW * g->HW < 65536) ? 1 : 0;
     g->cstride = abc_roundup(d->Cin, 4);
     const int coef_bytes = abc_roundup(3 * g->cstride * 4, 256);
     // one workgroup per CU: spend the LDS on double buffers (halo when it is prefetched, weights always)
@@ -439,9 +451,9 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
     return ABC_OK;
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
-static int launch_inst(const ConvK& k, const Geom& g, hipStream_t st) {
-    auto fn = conv_igemm_kernel<InT, CT, OutT, CK, BN, STRIDE, MT>;
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool FAST>
+static int launch_fs(const ConvK& k, const Geom& g, hipStream_t st) {
+    auto fn = conv_igemm_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, FAST>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -451,6 +463,11 @@ static int launch_inst(const ConvK& k, const Geom& g, hipStream_t st) {
     const int nwg = g.grid < 256 ? g.grid : 256;
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(NTHR), g.lds, st, k);
     return abc_check_launch("conv_igemm");
+}
+
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+static int launch_inst(const ConvK& k, const Geom& g, hipStream_t st) {
+    return g.fast_a ? launch_fs<InT, CT, OutT, CK, BN, STRIDE, MT, true>(k, g, st) : launch_fs<InT, CT, OutT, CK, BN, STRIDE, MT, false>(k, g, st);
 }
 
 template <typename InT, typename CT, typename OutT, int CK, int BN>
@@ -527,6 +544,9 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a; k.ntiles = g.grid; k.b_static = g.b_static; k.stg_off = g.stg_off;
     k.stats_rows = d->stats_rows; k.accumulate = d->accumulate;
     if (d->accumulate && d->planar_out) return abc_fail(ABC_EUNSUPPORTED, "conv: accumulate needs an NHWC output");
+    k.magic = 65536 / g.HW + 1;
+    k.bytesA = (unsigned)((int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4));
+    k.bytesW = (unsigned)((int64_t)d->ntaps * k.nchunks * d->Cout_pad * g.CK * (d->dtype_c == ABC_BF16 ? 2 : 4));
     { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     for (int t = 0; t < d->ntaps; ++t) {
         k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);

@@ -36,7 +36,8 @@ struct WgK {
     int B, Hg, Wg, Hq, Wq;
     int cp_off, Ca, cq_off, Cb, Ca_pad, Cb_pad;
     int ntaps, tgw, nsplit, npatch, tiles_x, tiles_y;
-    int dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, nta, ntb, fast_p, fast_q, nbuf;
+    int dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, nta, ntb, fast_p, fast_q, nbuf, dbg, magicQ;
+    unsigned bytesP, bytesQ;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
@@ -123,8 +124,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
         qch = (bi * 32 + r) * 4;
     }
 
-    HaloPrefetch<PT, CT, CWP, FAST ? NPF_P : 1, WTHR> pp;
-    HaloPrefetch<QT, CT, CWQ, FAST ? NPF_Q : 1, WTHR> pq;
+    HaloFetch<PT, CT, CWP, FAST ? NPF_P : 1, WTHR> pp;
+    HaloFetch<QT, CT, CWQ, FAST ? NPF_Q : 1, WTHR> pq;
+    const __amdgpu_buffer_rsrc_t rsP = abc_make_rsrc(a.p.x, a.bytesP), rsQ = abc_make_rsrc(a.q.x, a.bytesQ);
+    const HaloGeom gP = {PROWS, 16, 4097, a.Hg, a.Wg, a.p.Hx, a.p.Wx, a.p.ldx};
+    const HaloGeom gQ = {a.HH, a.HW, a.magicQ, a.Hq, a.Wq, a.q.Hx, a.q.Wx, a.q.ldx};
 
     auto patch_origin = [&](int patch, int& b, int& gy0, int& gx0) {
         int pid = patch;
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
         int b, gy0, gx0;
         patch_origin(patch, b, gy0, gx0);
         if constexpr (FAST) {
-            pp.issue(PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, a.p, a.cp_off + ca0, tid, cvalP);
-            pq.issue(a.HH, a.HW, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.Hq, a.Wq, a.q, a.cq_off + cb0, tid, cvalQ);
+            pp.issue(rsP, gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
+            pq.issue(rsQ, gQ, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.cq_off + cb0, tid, cvalQ);
         }
     };
     auto commit = [&](int patch, char* buf) {
@@ -146,8 +150,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
         char* sP = buf;
         char* sQ = buf + a.sP_bytes;
         if constexpr (FAST) {
-            pp.commit(sP, 16 * PSWP, PSWP, PROWS, 16, coefP ? sCoefP : nullptr, a.cstrP, 0, tid, cvalP);
-            pq.commit(sQ, a.HW * PSWQ, PSWQ, a.HH, a.HW, coefQ ? sCoefQ : nullptr, a.cstrQ, 0, tid, cvalQ);
+            pp.commit(sP, 16 * PSWP, PSWP, gP, coefP ? sCoefP : nullptr, a.cstrP, tid, cvalP);
+            pq.commit(sQ, a.HW * PSWQ, PSWQ, gQ, coefQ ? sCoefQ : nullptr, a.cstrQ, tid, cvalQ);
         } else {
             stage_slow<PT, CT, CWP>(sP, 16 * PSWP, PSWP, PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, &a.p, a.cp_off + ca0, tid, cvalP);
             stage_slow<QT, CT, CWQ>(sQ, a.HW * PSWQ, PSWQ, a.HH, a.HW, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.Hq, a.Wq,
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
     for (int it = -1; it < 0 || patch < a.npatch; ++it, patch += a.nsplit) {
         const int next = patch + a.nsplit;
         const bool has_next = next < a.npatch;
-        if (has_next) issue(next);
-        if (it >= 0) {
+        if (has_next && !(a.dbg & 1)) issue(next);
+        if (it >= 0 && !(a.dbg & 4)) {
             const char* sP = smem + ((a.nbuf == 2) ? (it & 1) * buf_bytes : 0);
             const char* sQ = sP + a.sP_bytes;
 #pragma unroll 1
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
             }
             if (a.nbuf == 1) __syncthreads();  // single buffer: everyone is done reading before it is refilled
         }
-        if (has_next) commit(next, smem + ((a.nbuf == 2) ? ((it + 1) & 1) * buf_bytes : 0));
+        if (has_next && !(a.dbg & 2)) commit(next, smem + ((a.nbuf == 2) ? ((it + 1) & 1) * buf_bytes : 0));
         __syncthreads();
     }
 
@@ -273,9 +277,9 @@ static int psw_for(int cw, int csz) {
     return cw * 4;
 }
 
-static bool fast_ok(const abc_act_src& s, int csz_c, int cvalid_min) {
+static bool fast_ok(const abc_act_src& s, int csz_c, int cvalid_min, int64_t bytes) {
     const int nv = 16 / csz_c;
-    return !s.pool && !s.planar && s.drop_p <= 0.f && (cvalid_min % nv) == 0;
+    return !s.pool && !s.planar && s.drop_p <= 0.f && (cvalid_min % nv) == 0 && bytes < (int64_t(1) << 31);
 }
 
 static int wgeom_pm(const abc_wgrad_desc* d, WGeom* g, int pm) {
@@ -306,8 +310,10 @@ static int wgeom_pm(const abc_wgrad_desc* d, WGeom* g, int pm) {
     // prefetch fast path: plain NHWC source whose channel count in the LAST tile is a whole number of 16-byte segments
     const int lastP = d->Ca - (g->nta - 1) * cwp, lastQ = d->Cb - (g->ntb - 1) * cwq;
     const int segq = cwq / (16 / csz);
-    g->fast_p = fast_ok(d->p, csz, lastP) ? 1 : 0;
-    g->fast_q = (fast_ok(d->q, csz, lastQ) && abc_cdiv(g->HH * g->HW * segq, WTHR) <= (pm > 1 ? 5 : (csz == 2 ? 4 : 6))) ? 1 : 0;
+    const int64_t bytesP = (int64_t)d->B * d->p.Hx * d->p.Wx * d->p.ldx * (d->dtype_p == ABC_BF16 ? 2 : 4);
+    const int64_t bytesQ = (int64_t)d->B * d->q.Hx * d->q.Wx * d->q.ldx * (d->dtype_q == ABC_BF16 ? 2 : 4);
+    g->fast_p = (fast_ok(d->p, csz, lastP, bytesP) && g->HH * g->HW * g->HW < 65536) ? 1 : 0;
+    g->fast_q = (fast_ok(d->q, csz, lastQ, bytesQ) && abc_cdiv(g->HH * g->HW * segq, WTHR) <= (pm > 1 ? 5 : (csz == 2 ? 4 : 6))) ? 1 : 0;
     g->ngroups = abc_cdiv(d->ntaps, (g->fast_p && g->fast_q) ? MAXT_FAST : MAXT_SLOW);
     g->tgw = abc_cdiv(d->ntaps, g->ngroups);
     return ABC_OK;
@@ -411,6 +417,10 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     k.dy_min = g.dy_min; k.dx_min = g.dx_min; k.HH = g.HH; k.HW = g.HW; k.PSWP = g.PSWP; k.PSWQ = g.PSWQ;
     k.sP_bytes = g.sP_bytes; k.sQ_bytes = g.sQ_bytes; k.coef_off = g.coef_off; k.cstrP = g.cstrP; k.cstrQ = g.cstrQ;
     k.nta = g.nta; k.ntb = g.ntb; k.fast_p = g.fast_p; k.fast_q = g.fast_q; k.nbuf = g.nbuf;
+    k.magicQ = 65536 / g.HW + 1;
+    k.bytesP = (unsigned)((int64_t)d->B * d->p.Hx * d->p.Wx * d->p.ldx * (d->dtype_p == ABC_BF16 ? 2 : 4));
+    k.bytesQ = (unsigned)((int64_t)d->B * d->q.Hx * d->q.Wx * d->q.ldx * (d->dtype_q == ABC_BF16 ? 2 : 4));
+    { const char* e = getenv("ABC_WGRAD_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min); k.tx[t] = (int8_t)(d->tap_dx[t] - g.dx_min); }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype_c == ABC_F32) {
