@@ -315,6 +315,7 @@ template <typename InT, int NV> struct RawBuf;
 template <> struct RawBuf<bf16, 8> {
     u32x4 v;
     __device__ inline void ld(__amdgpu_buffer_rsrc_t r, unsigned off) { v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+    __device__ inline void ld2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) { v = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0); }
     __device__ inline void get(float* o) const {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(v[j] << 16); o[2 * j + 1] = __uint_as_float(v[j] & 0xFFFF0000u); }
@@ -323,6 +324,7 @@ template <> struct RawBuf<bf16, 8> {
 template <> struct RawBuf<float, 4> {
     u32x4 v;
     __device__ inline void ld(__amdgpu_buffer_rsrc_t r, unsigned off) { v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+    __device__ inline void ld2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) { v = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0); }
     __device__ inline void get(float* o) const {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(v[j]);
@@ -333,6 +335,10 @@ template <> struct RawBuf<float, 8> {
     __device__ inline void ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
         a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
         b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0);
+    }
+    __device__ inline void ld2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        a = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0);
+        b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, soff, 0);
     }
     __device__ inline void get(float* o) const {
 #pragma unroll
@@ -400,6 +406,66 @@ struct HaloFetch {
                     for (int j = 0; j < NV; ++j) v[j] = abc_act(v[j], sc[j], sh[j], sl[j]);
                 }
                 *(typename Frag<CT>::type*)dst = pack_frag<CT>(v);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Halo staging with the per-segment geometry computed ONCE per tile (the kernels that use it are bound by
+// instruction issue, not by registers): voff = byte offset of the segment in chunk 0 (out-of-range marker when the
+// pixel lies outside the image -> the buffer load returns zeros), dst = LDS byte offset.  Per chunk the issue is
+// NMAX buffer loads with the chunk's byte offset in the scalar operand, nothing else.
+template <typename InT, typename CT, int CK, int NMAX, int NTHR>
+struct HaloTile {
+    static constexpr int NV = Frag<CT>::NV;
+    static constexpr int SEGS = CK / NV;
+    RawBuf<InT, NV> raw[NMAX];
+    unsigned voff[NMAX];
+    int dst[NMAX];  // < 0: this thread has no such segment
+
+    __device__ inline void setup(const HaloGeom& g, int RS, int PS, int b, int iy0, int ix0, int c0, int tid) {
+        const int part = tid % SEGS;
+        const int total = g.HH * g.HW * SEGS;
+        const int base = ((b * g.Hx + iy0) * g.Wx + ix0) * g.ldx + c0 + part * NV;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {
+            const int sidx = tid + i * NTHR;
+            const int pix = sidx / SEGS;
+            const int hy = (pix * g.magic) >> 16, hx = pix - hy * g.HW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool have = sidx < total;
+            const bool ok = have & (iy >= 0) & (iy < g.Hin) & (ix >= 0) & (ix < g.Win);
+            voff[i] = ok ? (unsigned)(base + (hy * g.Wx + hx) * g.ldx) * (unsigned)sizeof(InT) : 0x80000000u;
+            dst[i] = have ? hy * RS + hx * PS + part * 16 : -1;
+        }
+    }
+    // coff = byte offset of the chunk's first channel relative to chunk 0
+    __device__ inline void issue(__amdgpu_buffer_rsrc_t rs, unsigned coff) {
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) raw[i].ld2(rs, voff[i], coff);
+    }
+    // lcoef = LDS table [3][cstride] of (scale, shift, slope) at the chunk's first channel, or null
+    __device__ inline void commit(char* sA, const float* lcoef, int cstride, int tid) {
+        const int cch = (tid % SEGS) * NV;
+        float sc[NV], sh[NV], sl[NV];
+        if (lcoef != nullptr) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { sc[j] = lcoef[cch + j]; sh[j] = lcoef[cstride + cch + j]; sl[j] = lcoef[2 * cstride + cch + j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {
+            if (dst[i] >= 0) {
+                if constexpr (sizeof(InT) == sizeof(CT)) {
+                    if (lcoef == nullptr) { *(u32x4*)(sA + dst[i]) = raw[i].v; continue; }
+                }
+                float v[NV];
+                raw[i].get(v);
+                if (lcoef != nullptr && !(voff[i] >> 31)) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) v[j] = abc_act(v[j], sc[j], sh[j], sl[j]);
+                }
+                *(typename Frag<CT>::type*)(sA + dst[i]) = pack_frag<CT>(v);
             }
         }
     }

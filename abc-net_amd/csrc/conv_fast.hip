@@ -1,0 +1,525 @@
+// Tap-list convolution as implicit GEMM, lean form for plain NHWC inputs (the common case: every 3x3 / 1x1 /
+// transposed-phase convolution whose input needs no pooling, dropout or planar read).
+//
+// Same GEMM view and LDS images as conv_igemm.hip (M = a (2*MT) x 16 pixel patch, N = BN output channels,
+// K = [Cin chunk][tap group]; halo staged once per chunk with the previous layer's BN + activation applied on the
+// way in, weight slices of a tap group beside it, double-buffered), but organised for OVERLAP BETWEEN WORKGROUPS:
+//
+//   * 4 waves per workgroup and at most 80 KB of LDS, so TWO workgroups share a CU (2 waves per SIMD, 256 VGPRs
+//     each).  Their phases drift apart, so one workgroup's staging, barriers and epilogue run under the other's
+//     MFMA block.  (Measured on the 8-wave one-per-CU kernel: MFMA 33 us + staging 24 us + epilogue 38 us = 95 us,
+//     i.e. nothing overlapped, because all waves of a CU were always in the same phase.)
+//   * a wave owns TM x TN 32x32 tiles with TN = 2 where BN >= 64... (2 x 2 .. 4 x 2): (TM + TN) ds_read_b128 per
+//     TM * TN MFMAs keeps the LDS pipe under the matrix pipe.
+//   * one tile per workgroup (grid = tiles) unless the whole weight set fits in LDS beside the halo (narrow layers):
+//     then the workgroup is persistent and keeps the weights resident.
+//   * the epilogue transposes through a wave-private LDS region (no workgroup barriers) into 16-byte stores.
+//
+// Reference ops covered: nn.Conv2d forward (unet.py:12,15,66,70), its data gradient, nn.ConvTranspose2d (unet.py:44)
+// as four output-parity phases; see include/abcnet_hip.h (abc_conv_desc).
+#include "common.hpp"
+#include "../../include/abcnet_hip.h"
+#include "capi_util.hpp"
+#include "conv_fast.hpp"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int FT = 256;      // threads per workgroup
+// halo segments a thread may hold (3x3 taps, 64-byte chunks: (2*MT+2) x 18 pixels x 4 segments over 256 threads)
+__host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 6 : (mt >= 6 ? 4 : 3); }
+constexpr int SR_MAX = 256;  // weight rows per stage (tap group x BN)
+constexpr int LDS_WG = 80 * 1024;
+
+struct FastK {
+    const void* x;
+    const float *scale, *shift, *slope;
+    const void* w;
+    const float* bias;
+    void* y;
+    float* stats;
+    int B, Hin, Win, Hx, Wx, ldx, cin_off, Cin, nchunks;
+    int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad, om, oy0, ox0;
+    int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS, magic;
+    int tiles_x, tiles_y, nblocks_n, ntiles;
+    int sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, stats_rows, accumulate, b_static, stg_off, red_off, dbg, stagger;
+    unsigned bytesA, bytesW;
+    long long* prof;  // debugging: per-workgroup phase timestamps (null in production)
+    int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
+};
+
+static long long* g_prof = nullptr;
+
+__device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+__global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
+    constexpr int CKB = CK * (int)sizeof(CT);
+    constexpr int PS = CKB + 16;
+    constexpr int LHB = CKB / 2;
+    constexpr int NR = LHB / 16;
+    constexpr int SEGS = CKB / 16;
+    constexpr int NT = BN / 32;
+    constexpr int WN = (NT >= 2) ? 2 : 1;
+    constexpr int WM = 4 / WN;
+    constexpr int TM = MT / WM;
+    constexpr int TN = NT / WN;
+    static_assert(TM >= 1 && TM * WM == MT && TN >= 1 && TN * WN == NT, "tile/wave layout");
+    constexpr int NB = (SR_MAX * SEGS + FT - 1) / FT;  // weight segments per thread per stage (a stage = <= SR_MAX weight rows)
+    typedef typename Frag<CT>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + a.sB_off;
+    int* sTap = (int*)(smem + a.tap_off);
+    float* sCoef = (float*)(smem + a.coef_off);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    long long* prof = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
+    if (prof && tid == 0) { prof[0] = wall_clock64(); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); prof[6] = ((long long)xcc << 32) | hw; }
+
+    if (tid < a.ntaps) sTap[tid] = a.ty[tid] * a.RS + a.tx[tid] * PS;
+    const bool has_coef = a.scale != nullptr;
+    if (has_coef) {
+        for (int i = tid; i < a.Cin; i += FT) {
+            sCoef[i] = a.scale[a.cin_off + i];
+            sCoef[a.cstride + i] = a.shift[a.cin_off + i];
+            sCoef[2 * a.cstride + i] = a.slope[a.cin_off + i];
+        }
+    }
+    const float* lcoef = has_coef ? sCoef : nullptr;
+
+    int aBase[TM], bBase[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int prow = 2 * (wm * TM + i) + (r >> 4), pcol = r & 15;
+        aBase[i] = prow * STRIDE * a.RS + pcol * STRIDE * PS + h * LHB;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bBase[j] = ((wn * TN + j) * 32 + r) * PS + h * LHB;
+
+    const __amdgpu_buffer_rsrc_t rsA = abc_make_rsrc(a.x, a.bytesA), rsW = abc_make_rsrc(a.w, a.bytesW);
+    const HaloGeom gA = {a.HH, a.HW, a.magic, a.Hin, a.Win, a.Hx, a.Wx, a.ldx};
+    const int nstages = a.nchunks * a.ngroups;
+
+    // weight segments of a stage: thread-invariant source offset (within the stage's first tap slice), LDS offset and
+    // tap-in-stage index, computed once.  The kernel is bound by instruction issue: the per-stage staging code must
+    // be loads / stores and nothing else.
+    unsigned bvoff[NB];
+    int bdst[NB];  // LDS offset | tap-in-stage << 20
+    const unsigned tap_stride = (unsigned)(a.nchunks * a.Cout_pad * CK) * (unsigned)sizeof(CT);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int sg = tid + i * FT;
+        const int tl = sg / (BN * SEGS), rem = sg - tl * (BN * SEGS);
+        bvoff[i] = (unsigned)tl * tap_stride + (unsigned)rem * 16u;
+        bdst[i] = ((tl * BN + rem / SEGS) * PS + (rem % SEGS) * 16) | (tl << 20);
+    }
+    u32x4 breg[2][NB];
+    HaloTile<InT, CT, CK, fa_max(MT), FT> apre;
+
+    unsigned w_n0 = 0;  // byte offset of the n-block's first weight row
+    auto b_issue = [&](u32x4* set, int c, int g) {
+        const unsigned soff = (unsigned)((g * a.tg * a.nchunks + c) * a.Cout_pad * CK) * (unsigned)sizeof(CT) + w_n0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) set[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bvoff[i], soff, 0);
+    };
+    auto b_commit = [&](const u32x4* set, int g, char* dst) {
+        const int tcnt = min(a.tg, a.ntaps - g * a.tg);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if ((bdst[i] >> 20) < tcnt) *(u32x4*)(dst + (bdst[i] & 0xFFFFF)) = set[i];
+    };
+
+    if (a.stagger > 0) {
+        // the CU's two workgroups run identical code: started together they stay in phase and collide in the MFMA
+        // block while the matrix pipe idles during their staging.  Delay the one in the odd wave slot.
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (hw & 1) for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();  // tap offsets + coefficient table visible
+
+    bool first_tile = true;
+    for (int tile = abc_xcd_remap(blockIdx.x, gridDim.x); tile < a.ntiles; tile += gridDim.x) {
+        int id = tile;
+        const int nb = id % a.nblocks_n; id /= a.nblocks_n;
+        const int mblock = id;
+        const int tx_i = id % a.tiles_x; id /= a.tiles_x;
+        const int ty_i = id % a.tiles_y; id /= a.tiles_y;
+        const int b = id;
+        const int gy0 = ty_i * (2 * MT), gx0 = tx_i * 16;
+        const int n0 = nb * BN;
+        w_n0 = (unsigned)(n0 * CK) * (unsigned)sizeof(CT);
+        const int iy0 = gy0 * STRIDE + a.dy_min, ix0 = gx0 * STRIDE + a.dx_min;
+
+        // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile)
+        apre.setup(gA, a.RS, PS, b, iy0, ix0, a.cin_off, tid);
+        apre.issue(rsA, 0u);
+        int ci = 0, gi = 0;  // (chunk, tap group) of the next stage to issue
+        auto issue_next = [&](u32x4* set) {
+            b_issue(set, ci, gi);
+            if (++gi == a.ngroups) { gi = 0; ++ci; }
+        };
+        if (a.b_static) {
+            // resident weights: one chunk, every tap group loaded once per workgroup, straight to its place
+            if (first_tile) {
+                for (int g = 0; g < a.ngroups; ++g) {
+                    b_issue(breg[0], 0, g);
+                    b_commit(breg[0], g, sB + g * a.sB_bytes);
+                }
+            }
+        } else {
+            issue_next(breg[0]);
+            if (nstages > 1) issue_next(breg[1]);
+        }
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+        if (!first_tile) __syncthreads();  // previous tile's epilogue staging (aliases the halo buffer) is drained
+        apre.commit(sA, lcoef, a.cstride, tid);
+        if (!a.b_static) b_commit(breg[0], 0, sB);
+        first_tile = false;
+        __syncthreads();
+        if (prof && tid == 0) prof[1] = wall_clock64();
+
+        // ---- main loop, unrolled by 2 so that the two register sets have fixed names.  Stage s: its weights sit in
+        // sB[s & 1]; set s & 1 is free (committed at the end of stage s-1) and takes the loads of stage s + 2; the next
+        // chunk's halo is issued when a chunk opens and committed when it closes.
+        int c = 0, g = 0;
+        long long pt_issue = 0, pt_mfma = 0, pt_commit = 0, pt_bar = 0;
+        for (int s0 = 0; s0 < nstages; s0 += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int s = s0 + d;
+                if (s < nstages) {
+                    int gn = g + 1, cn = c;
+                    if (gn == a.ngroups) { gn = 0; cn = c + 1; }
+                    const bool has_next = (s + 1 < nstages);
+                    const bool closes = has_next && (gn == 0);  // last stage of a chunk that has a successor
+                    long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
+                    if (prof) pt0 = clock64();
+                    if (!a.b_static && s + 2 < nstages && !(a.dbg & 1)) issue_next(breg[d]);
+                    if (g == 0 && c + 1 < a.nchunks && !(a.dbg & 2)) apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
+
+                    if (prof) pt1 = clock64();
+                    {
+                        const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
+                        const char* sBc = a.b_static ? sB + g * a.sB_bytes : sB + d * a.sB_bytes;
+                        const int t0 = g * a.tg;
+                        const int tcnt = min(a.tg, a.ntaps - t0);
+                        for (int tl = 0; tl < ((a.dbg & 4) ? 0 : tcnt); ++tl) {
+                            const int aoff = sTap[t0 + tl];
+                            const int boff = tl * BN * PS;
+#pragma unroll
+                            for (int q = 0; q < NR; ++q) {
+                                frag_t fa[TM], fb[TN];
+#pragma unroll
+                                for (int i = 0; i < TM; ++i) fa[i] = *(const frag_t*)(sAc + aBase[i] + aoff + q * 16);
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) fb[j] = *(const frag_t*)(sBc + bBase[j] + boff + q * 16);
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                    for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa[i], fb[j]);
+                            }
+                        }
+                    }
+
+                    if (prof) pt2 = clock64();
+                    if (!a.b_static && has_next && !(a.dbg & 8)) b_commit(breg[1 - d], gn, sB + (1 - d) * a.sB_bytes);
+                    if (closes && !(a.dbg & 16)) {
+                        if (a.a_bufs == 2) {
+                            apre.commit(sA + (cn & 1) * a.sA_bytes, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
+                        } else {
+                            __syncthreads();  // every wave is done reading this chunk's halo
+                            apre.commit(sA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
+                        }
+                    }
+                    if (prof) pt3 = clock64();
+                    __syncthreads();
+                    if (prof) { const long long pt4 = clock64(); pt_issue += pt1 - pt0; pt_mfma += pt2 - pt1; pt_commit += pt3 - pt2; pt_bar += pt4 - pt3; }
+                    c = cn; g = gn;
+                }
+            }
+        }
+
+        if (prof && tid == 0) { prof[2] = wall_clock64(); prof[5] = (pt_issue << 32) | (pt_mfma & 0xffffffff); prof[7] = (pt_commit << 32) | (pt_bar & 0xffffffff); }
+        // ---- epilogue: bias, statistics of the f32 values, store through a wave-private LDS transpose
+        // (a lane of the accumulator layout holds ONE channel of 16 pixels; the transpose turns that into 16-byte
+        // stores of consecutive channels of one pixel).  The staging region aliases the halo / weight buffers: every
+        // wave passed the barrier that ended the last stage, so they are dead (resident weights are kept clear of it).
+        OutT* yo = (OutT*)a.y;
+        float s1[TN], s2[TN], smx[TN], smn[TN], bv[TN];
+        bool nval[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] = 0.f; s2[j] = 0.f; smx[j] = -3.0e38f; smn[j] = 3.0e38f;
+            const int n = n0 + (wn * TN + j) * 32 + r;
+            nval[j] = n < a.Cout;
+            bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
+        }
+        constexpr int TW = TN * 32;
+        constexpr int ROWB = TW * (int)sizeof(OutT) + 16;
+        constexpr int EV = 16 / (int)sizeof(OutT);
+        constexpr int SEG_PER_ROW = TW / EV;
+        char* stg = smem + a.stg_off + wave * (32 * ROWB);
+        const int cbase = n0 + wn * TW;
+        const bool vec_ok = ((a.ldy | a.cout_off) % EV) == 0;
+        if (!(a.dbg & 64)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
+                    const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
+                    const float v = acc[i][j][k] + bv[j];
+                    if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
+                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)v;
+                }
+            }
+            lds_wave_sync();
+#pragma unroll
+            for (int e = lane; e < 32 * SEG_PER_ROW; e += 64) {
+                const int rit = e / SEG_PER_ROW, sg = e - rit * SEG_PER_ROW;
+                const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
+                const int cch = cbase + sg * EV;
+                if (gy < a.Hg && gx < a.Wg && cch < a.Cout) {
+                    const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cch;
+                    const char* src = stg + rit * ROWB + sg * 16;
+                    if (a.accumulate) {
+                        for (int q = 0; q < EV && cch + q < a.Cout; ++q)
+                            yo[o + q] = (OutT)((float)yo[o + q] + (float)*(const OutT*)(src + q * (int)sizeof(OutT)));
+                    } else if (cch + EV <= a.Cout && vec_ok) {
+                        *(f32x4*)(yo + o) = *(const f32x4*)src;
+                    } else {
+                        for (int q = 0; q < EV && cch + q < a.Cout; ++q) yo[o + q] = *(const OutT*)(src + q * (int)sizeof(OutT));
+                    }
+                }
+            }
+            lds_wave_sync();
+        }
+        }
+        if (prof && tid == 0) prof[3] = wall_clock64();
+        if (a.stats != nullptr) {
+            float* red = (float*)(smem + a.red_off);  // [WM][4][BN], clear of the transpose regions
+            const int rows = a.stats_rows == 4 ? 4 : 2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float v1 = s1[j] + __shfl_xor(s1[j], 32);
+                const float v2 = s2[j] + __shfl_xor(s2[j], 32);
+                const float v3 = fmaxf(smx[j], __shfl_xor(smx[j], 32));
+                const float v4 = fminf(smn[j], __shfl_xor(smn[j], 32));
+                if (h == 0) {
+                    const int nl = (wn * TN + j) * 32 + r;
+                    red[(wm * 4 + 0) * BN + nl] = v1;
+                    red[(wm * 4 + 1) * BN + nl] = v2;
+                    red[(wm * 4 + 2) * BN + nl] = v3;
+                    red[(wm * 4 + 3) * BN + nl] = v4;
+                }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < a.Cout) {
+                float v1 = 0.f, v2 = 0.f, v3 = -3.0e38f, v4 = 3.0e38f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    v1 += red[(w * 4 + 0) * BN + tid]; v2 += red[(w * 4 + 1) * BN + tid];
+                    v3 = fmaxf(v3, red[(w * 4 + 2) * BN + tid]); v4 = fminf(v4, red[(w * 4 + 3) * BN + tid]);
+                }
+                a.stats[((size_t)mblock * rows + 0) * a.Cout + n0 + tid] = v1;
+                a.stats[((size_t)mblock * rows + 1) * a.Cout + n0 + tid] = v2;
+                if (rows == 4) {
+                    a.stats[((size_t)mblock * rows + 2) * a.Cout + n0 + tid] = v3;
+                    a.stats[((size_t)mblock * rows + 3) * a.Cout + n0 + tid] = v4;
+                }
+            }
+        }
+        if (prof && tid == 0) prof[4] = wall_clock64();
+    }
+}
+
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
+    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WG);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(g.nwg), dim3(FT), g.lds, st, k);
+    return abc_check_launch("conv_fast");
+}
+
+template <typename InT, typename CT, typename OutT, int CK, int BN>
+int launch_mt(const FastK& k, const abc_fast_geom& g, int stride, hipStream_t st) {
+    if constexpr (BN == 128) {
+        if (stride == 1 && g.MT == 6) return launch_inst<InT, CT, OutT, CK, BN, 1, 6>(k, g, st);
+    }
+    if (stride == 2) return launch_inst<InT, CT, OutT, CK, BN, 2, 4>(k, g, st);
+    return g.MT == 8 ? launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st) : launch_inst<InT, CT, OutT, CK, BN, 1, 4>(k, g, st);
+}
+
+template <typename InT, typename CT, typename OutT, int CK>
+int launch_bn(const FastK& k, const abc_fast_geom& g, int stride, hipStream_t st) {
+    switch (g.BN) {
+        case 128: return launch_mt<InT, CT, OutT, CK, 128>(k, g, stride, st);
+        case 64: return launch_mt<InT, CT, OutT, CK, 64>(k, g, stride, st);
+        default: return launch_mt<InT, CT, OutT, CK, 32>(k, g, stride, st);
+    }
+}
+
+}  // namespace
+
+// debugging hook (not part of the public ABI): device buffer of 8 x int64 per workgroup for phase timestamps
+extern "C" void abc_debug_conv_prof(void* p) { g_prof = (long long*)p; }
+
+// Geometry of the lean kernel for this descriptor, or eligible = 0 (-> the general kernel of conv_igemm.hip).
+int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
+    g->eligible = 0;
+    if (getenv("ABC_CONV_NOFAST")) return ABC_OK;
+    if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->planar_out) return ABC_OK;
+    const int csz = d->dtype_c == ABC_BF16 ? 2 : 4;
+    g->CK = abc_conv_chunk(d->dtype_c, d->Cin);
+    if (g->CK <= 0 || d->Cin % g->CK) return ABC_OK;
+    const int64_t bytes_a = (int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4);
+    if (bytes_a >= (int64_t(1) << 31)) return ABC_OK;
+    g->BN = (d->Cout_pad % 128 == 0) ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
+    g->nbn = d->Cout_pad / g->BN;
+    int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
+    for (int t = 0; t < d->ntaps; ++t) {
+        dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
+        dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
+    }
+    g->dy_min = dymin; g->dx_min = dxmin;
+    const int CKB = g->CK * csz;
+    g->PS = CKB + 16;
+    const int segs = CKB / 16;
+    g->cstride = abc_roundup(d->Cin, 4);
+    const int coef_bytes = abc_roundup(3 * g->cstride * 4, 256);
+    const int osz = d->dtype_out == ABC_BF16 ? 2 : 4;
+    const int tn = g->BN >= 64 ? g->BN / 64 : 1;
+    const int stg = 4 * 32 * (tn * 32 * osz + 16);
+    const int red = 4 * 4 * g->BN * 4;
+
+    // candidate patch heights; score = estimated time of the launch in units of "one 32-pixel m-tile of work"
+    // with 512 workgroup slots (2 per CU): full rounds cost MT each, a last round that fills at most half the slots
+    // runs with a CU to itself (cheaper), see DESIGN.md
+    const int cand_all[3] = {8, 6, 4};
+    int best = -1;
+    double best_cost = 0;
+    const char* force = getenv("ABC_CONV_MT");
+    for (int ci = 0; ci < 3; ++ci) {
+        const int mt = cand_all[ci];
+        if (force && atoi(force) != mt) continue;
+        if (mt == 6 && (g->BN != 128 || d->stride != 1)) continue;
+        if (d->stride == 2 && mt != 4) continue;
+        const int prow = 2 * mt;
+        const int hh = (prow - 1) * d->stride + (dymax - dymin) + 1, hw = 15 * d->stride + (dxmax - dxmin) + 1;
+        if (abc_cdiv(hh * hw * segs, FT) > fa_max(mt) || hh * hw * hw >= 65536) continue;
+        const int rs = abc_roundup(hw * g->PS, 256);
+        const int sa = abc_roundup(hh * rs, 256);
+        if (sa + 2 * 128 * g->PS + coef_bytes + 256 > LDS_WG) continue;
+        const long tiles = (long)g->nbn * abc_cdiv(d->Wg, 16) * abc_cdiv(d->Hg, prow) * d->B;
+        const double rounds = (double)tiles / 512.0;
+        const long full = (long)rounds;
+        const double frac = rounds - full;
+        const double waste = (double)(abc_cdiv(d->Hg, prow) * prow) / d->Hg;  // rows computed beyond the image
+        double cost = (full + (frac == 0 ? 0.0 : (frac <= 0.5 ? 0.65 : 1.0))) * mt * (1.0 + 0.15 * (8 - mt) / 4.0);
+        (void)waste;
+        if (best < 0 || cost < best_cost) { best = mt; best_cost = cost; }
+    }
+    if (best < 0) return ABC_OK;
+    g->MT = best;
+    const int prow = 2 * g->MT;
+    g->HH = (prow - 1) * d->stride + (dymax - dymin) + 1;
+    g->HW = 15 * d->stride + (dxmax - dxmin) + 1;
+    g->RS = abc_roundup(g->HW * g->PS, 256);
+    g->sA_bytes = abc_roundup(g->HH * g->RS, 256);
+    const int budget = LDS_WG - coef_bytes - 256;
+    const int nchunks = d->Cin / g->CK;
+    // a stage = one tap group of <= SR_MAX weight rows; 2 LDS buffers, 2 stages in flight in registers.  Bigger
+    // stages amortise the per-stage control code; a second halo buffer hides the chunk turn-over.  Prefer the big
+    // stage, then the second halo buffer, as the 80 KB allow.
+    int sr = SR_MAX;
+    { const char* e = getenv("ABC_CONV_SR"); if (e) sr = atoi(e); }
+    int tg = 1, abufs = 1;
+    for (;;) {
+        tg = sr / g->BN; if (tg < 1) tg = 1;
+        if (tg > d->ntaps) tg = d->ntaps;
+        g->ngroups = abc_cdiv(d->ntaps, tg);
+        g->tg = abc_cdiv(d->ntaps, g->ngroups);
+        g->sB_bytes = abc_roundup(g->tg * g->BN * g->PS, 256);
+        if (g->sA_bytes + 2 * g->sB_bytes <= budget || sr <= 128) break;
+        sr /= 2;
+    }
+    (void)abufs;
+    // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
+    g->b_static = (nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget) ? 1 : 0;
+    if (g->b_static) {
+        g->a_bufs = 1;
+    } else {
+        g->a_bufs = (nchunks > 1 && 2 * g->sA_bytes + 2 * g->sB_bytes <= budget) ? 2 : 1;
+        if (g->a_bufs * g->sA_bytes + 2 * g->sB_bytes > budget) return ABC_OK;
+    }
+    const int nbuf_b = g->b_static ? g->ngroups : 2;
+    g->tap_off = g->a_bufs * g->sA_bytes + nbuf_b * g->sB_bytes;
+    g->coef_off = g->tap_off + 256;
+    g->lds = g->coef_off + coef_bytes;
+    g->stg_off = g->b_static ? abc_roundup(g->lds, 256) : 0;
+    g->red_off = g->stg_off + stg;
+    if (g->lds < g->red_off + red) g->lds = g->red_off + red;
+    if (g->lds > LDS_WG) return ABC_OK;
+    g->tiles_x = abc_cdiv(d->Wg, 16);
+    g->tiles_y = abc_cdiv(d->Hg, prow);
+    g->ntiles = g->nbn * g->tiles_x * g->tiles_y * d->B;
+    g->nwg = g->b_static ? (g->ntiles < 512 ? g->ntiles : 512) : g->ntiles;
+    g->eligible = 1;
+    return ABC_OK;
+}
+
+int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_stream_t stream) {
+    FastK k;
+    k.x = d->src.x; k.scale = d->src.scale; k.shift = d->src.shift; k.slope = d->src.slope;
+    k.w = d->w; k.bias = d->bias; k.y = d->y; k.stats = d->stats;
+    k.B = d->B; k.Hin = d->Hin; k.Win = d->Win; k.Hx = d->src.Hx; k.Wx = d->src.Wx; k.ldx = d->src.ldx;
+    k.cin_off = d->cin_off; k.Cin = d->Cin; k.nchunks = d->Cin / g.CK;
+    k.Hg = d->Hg; k.Wg = d->Wg; k.Hout = d->Hout; k.Wout = d->Wout; k.ldy = d->ldy; k.cout_off = d->cout_off;
+    k.Cout = d->Cout; k.Cout_pad = d->Cout_pad; k.om = d->om; k.oy0 = d->oy0; k.ox0 = d->ox0;
+    k.ntaps = d->ntaps; k.tg = g.tg; k.ngroups = g.ngroups; k.dy_min = g.dy_min; k.dx_min = g.dx_min;
+    k.HH = g.HH; k.HW = g.HW; k.RS = g.RS; k.magic = 65536 / g.HW + 1;
+    k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y; k.nblocks_n = g.nbn; k.ntiles = g.ntiles;
+    k.sA_bytes = g.sA_bytes; k.a_bufs = g.a_bufs; k.sB_off = g.a_bufs * g.sA_bytes; k.sB_bytes = g.sB_bytes;
+    k.tap_off = g.tap_off; k.coef_off = g.coef_off; k.cstride = g.cstride; k.stats_rows = d->stats_rows;
+    k.accumulate = d->accumulate; k.b_static = g.b_static; k.stg_off = g.stg_off; k.red_off = g.red_off;
+    { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
+    k.prof = g_prof;
+    { const char* e = getenv("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }
+    k.bytesA = (unsigned)((int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4));
+    k.bytesW = (unsigned)((int64_t)d->ntaps * k.nchunks * d->Cout_pad * g.CK * (d->dtype_c == ABC_BF16 ? 2 : 4));
+    for (int t = 0; t < d->ntaps; ++t) {
+        k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);
+        k.tx[t] = (int8_t)(d->tap_dx[t] - g.dx_min);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int di = d->dtype_in, dc = d->dtype_c, dout = d->dtype_out;
+    if (dc == ABC_F32) {
+        if (di != ABC_F32 || dout != ABC_F32) return abc_fail(ABC_EUNSUPPORTED, "conv: f32 compute needs f32 in/out");
+        return launch_bn<float, float, float, 16>(k, g, d->stride, st);
+    }
+    if (di == ABC_BF16 && dout == ABC_BF16)
+        return g.CK == 32 ? launch_bn<bf16, bf16, bf16, 32>(k, g, d->stride, st) : launch_bn<bf16, bf16, bf16, 16>(k, g, d->stride, st);
+    if (di == ABC_BF16 && dout == ABC_F32)
+        return g.CK == 32 ? launch_bn<bf16, bf16, float, 32>(k, g, d->stride, st) : launch_bn<bf16, bf16, float, 16>(k, g, d->stride, st);
+    if (di == ABC_F32 && dout == ABC_BF16)
+        return g.CK == 32 ? launch_bn<float, bf16, bf16, 32>(k, g, d->stride, st) : launch_bn<float, bf16, bf16, 16>(k, g, d->stride, st);
+    return abc_fail(ABC_EUNSUPPORTED, "conv: dtype combination");
+}

@@ -1,0 +1,12 @@
+// Internal interface between conv_igemm.hip (C-ABI entry points) and conv_fast.hip (lean kernel for plain NHWC inputs).
+#pragma once
+#include "../../include/abcnet_hip.h"
+
+struct abc_fast_geom {
+    int eligible;
+    int CK, BN, MT, dy_min, dx_min, HH, HW, PS, RS, tg, ngroups, sA_bytes, a_bufs, sB_bytes, tap_off, coef_off, cstride, lds,
+        tiles_x, tiles_y, nbn, ntiles, nwg, b_static, stg_off, red_off;
+};
+
+int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g);
+int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_stream_t stream);

@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "../../include/abcnet_hip.h"
 #include "capi_util.hpp"
+#include "conv_fast.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -502,6 +503,8 @@ extern "C" int abc_conv_chunk(int dtype_c, int Cin) {
 }
 
 extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, int32_t* ck) {
+    abc_fast_geom f;
+    if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) { *bn = f.BN; *mt = f.MT; *ck = f.CK; return ABC_OK; }
     Geom g;
     int rc = conv_geom(d, &g);
     if (rc) return rc;
@@ -510,6 +513,8 @@ extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, i
 }
 
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
+    abc_fast_geom f;
+    if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return f.tiles_x * f.tiles_y * d->B;
     Geom g;
     if (conv_geom(d, &g)) return -1;
     return g.tiles_x * g.tiles_y * d->B;
@@ -517,7 +522,7 @@ extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
 
 extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     Geom g;
-    int rc = conv_geom(d, &g);
+    int rc = conv_geom(d, &g);  // (also validates the descriptor)
     if (rc) return rc;
     if (d->src.pool && (d->src.Hx / 2 != d->Hin || d->src.Wx / 2 != d->Win))
         return abc_fail(ABC_EINVAL, "conv: pooled dims mismatch");
@@ -555,6 +560,10 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     // the kernel's grid must address only in-range output pixels
     if ((d->Hg - 1) * d->om + d->oy0 >= d->Hout || (d->Wg - 1) * d->om + d->ox0 >= d->Wout)
         return abc_fail(ABC_EINVAL, "conv: output grid exceeds output tensor");
+    {
+        abc_fast_geom f;
+        if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return abc_conv_fast_launch(d, f, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     const int di = d->dtype_in, dc = d->dtype_c, dout = d->dtype_out;
     if (dc == ABC_F32) {
