@@ -52,7 +52,7 @@ static long long* g_prof = nullptr;
 
 __device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC>
 __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
@@ -105,19 +105,16 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     const HaloGeom gA = {a.HH, a.HW, a.magic, a.Hin, a.Win, a.Hx, a.Wx, a.ldx};
     const int nstages = a.nchunks * a.ngroups;
 
-    // weight segments of a stage: thread-invariant source offset (within the stage's first tap slice), LDS offset and
-    // tap-in-stage index, computed once.  The kernel is bound by instruction issue: the per-stage staging code must
-    // be loads / stores and nothing else.
-    unsigned bvoff[NB];
-    int bdst[NB];  // LDS offset | tap-in-stage << 20
+    // weight segments of a stage: segment i of a thread is segment 0 plus CONSTANT steps (source: scalar offset,
+    // LDS: immediate offset), so one VGPR each for source and destination.  The kernel is bound by instruction issue:
+    // the per-stage staging code must be loads / stores and nothing else.
+    constexpr int SEGS_TAP = BN * SEGS;                              // 16-byte segments per tap slice
+    constexpr int PER = SEGS_TAP >= FT ? SEGS_TAP / FT : 1;          // thread-segments per tap slice
+    constexpr int TSTEP = SEGS_TAP >= FT ? 1 : FT / SEGS_TAP;        // tap slices covered by one round of the threads
     const unsigned tap_stride = (unsigned)(a.nchunks * a.Cout_pad * CK) * (unsigned)sizeof(CT);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int sg = tid + i * FT;
-        const int tl = sg / (BN * SEGS), rem = sg - tl * (BN * SEGS);
-        bvoff[i] = (unsigned)tl * tap_stride + (unsigned)rem * 16u;
-        bdst[i] = ((tl * BN + rem / SEGS) * PS + (rem % SEGS) * 16) | (tl << 20);
-    }
+    const int tl0 = tid / SEGS_TAP, rem0 = tid % SEGS_TAP;           // (tl0 = 0 when a slice has >= FT segments)
+    const unsigned bvoff0 = (unsigned)tl0 * tap_stride + (unsigned)rem0 * 16u;
+    const int bdst0 = (tl0 * BN + rem0 / SEGS) * PS + (rem0 % SEGS) * 16;
     u32x4 breg[2][NB];
     HaloTile<InT, CT, CK, fa_max(MT), FT> apre;
 
@@ -125,22 +122,22 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     auto b_issue = [&](u32x4* set, int c, int g) {
         const unsigned soff = (unsigned)((g * a.tg * a.nchunks + c) * a.Cout_pad * CK) * (unsigned)sizeof(CT) + w_n0;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) set[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bvoff[i], soff, 0);
+        for (int i = 0; i < NB; ++i) {
+            const unsigned step = (unsigned)((i / PER) * TSTEP) * tap_stride + (unsigned)((i % PER) * FT * 16);
+            set[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bvoff0, soff + step, 0);
+        }
     };
     auto b_commit = [&](const u32x4* set, int g, char* dst) {
         const int tcnt = min(a.tg, a.ntaps - g * a.tg);
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            if ((bdst[i] >> 20) < tcnt) *(u32x4*)(dst + (bdst[i] & 0xFFFFF)) = set[i];
+        for (int i = 0; i < NB; ++i) {
+            constexpr int dummy = 0; (void)dummy;
+            const int tl = tl0 + (i / PER) * TSTEP;
+            const int doff = ((i / PER) * TSTEP * BN + (i % PER) * (FT / SEGS)) * PS;
+            if (tl < tcnt) *(u32x4*)(dst + bdst0 + doff) = set[i];
+        }
     };
 
-    if (a.stagger > 0) {
-        // the CU's two workgroups run identical code: started together they stay in phase and collide in the MFMA
-        // block while the matrix pipe idles during their staging.  Delay the one in the odd wave slot.
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if (hw & 1) for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     __syncthreads();  // tap offsets + coefficient table visible
 
     bool first_tile = true;
@@ -164,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
             b_issue(set, ci, gi);
             if (++gi == a.ngroups) { gi = 0; ++ci; }
         };
-        if (a.b_static) {
+        if constexpr (STATIC) {
             // resident weights: one chunk, every tap group loaded once per workgroup, straight to its place
             if (first_tile) {
                 for (int g = 0; g < a.ngroups; ++g) {
@@ -174,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
             }
         } else {
             issue_next(breg[0]);
-            if (nstages > 1) issue_next(breg[1]);
+            issue_next(breg[1]);
         }
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -185,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                 for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
         if (!first_tile) __syncthreads();  // previous tile's epilogue staging (aliases the halo buffer) is drained
         apre.commit(sA, lcoef, a.cstride, tid);
-        if (!a.b_static) b_commit(breg[0], 0, sB);
+        if constexpr (!STATIC) b_commit(breg[0], 0, sB);
         first_tile = false;
         __syncthreads();
         if (prof && tid == 0) prof[1] = wall_clock64();
@@ -194,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         // sB[s & 1]; set s & 1 is free (committed at the end of stage s-1) and takes the loads of stage s + 2; the next
         // chunk's halo is issued when a chunk opens and committed when it closes.
         int c = 0, g = 0;
-        long long pt_issue = 0, pt_mfma = 0, pt_commit = 0, pt_bar = 0;
         for (int s0 = 0; s0 < nstages; s0 += 2) {
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
@@ -204,27 +200,62 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                     if (gn == a.ngroups) { gn = 0; cn = c + 1; }
                     const bool has_next = (s + 1 < nstages);
                     const bool closes = has_next && (gn == 0);  // last stage of a chunk that has a successor
-                    long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
-                    if (prof) pt0 = clock64();
-                    if (!a.b_static && s + 2 < nstages && !(a.dbg & 1)) issue_next(breg[d]);
+                    // (unconditional: past the last stage the offsets run off the buffer and the loads return zeros;
+                    //  a conditional issue would make the compiler drain ALL loads before every commit)
+                    if constexpr (!STATIC) issue_next(breg[d]);
                     if (g == 0 && c + 1 < a.nchunks && !(a.dbg & 2)) apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
 
-                    if (prof) pt1 = clock64();
                     {
                         const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
-                        const char* sBc = a.b_static ? sB + g * a.sB_bytes : sB + d * a.sB_bytes;
+                        const char* sBc = STATIC ? sB + g * a.sB_bytes : sB + d * a.sB_bytes;
                         const int t0 = g * a.tg;
                         const int tcnt = min(a.tg, a.ntaps - t0);
-                        for (int tl = 0; tl < ((a.dbg & 4) ? 0 : tcnt); ++tl) {
-                            const int aoff = sTap[t0 + tl];
-                            const int boff = tl * BN * PS;
+                        // fragment reads software-pipelined one K-step ahead of the MFMAs (two named register sets;
+                        // every read unconditional -- the step after the last re-reads the last tap -- so that the
+                        // compiler can count lgkmcnt exactly instead of draining the LDS queue before each MFMA group)
+                        const int ntl = (a.dbg & 4) ? 0 : tcnt;
+                        if constexpr (NR == 2) {
+                            frag_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+                            int aoff = sTap[t0];
 #pragma unroll
-                            for (int q = 0; q < NR; ++q) {
+                            for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff);
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) fb0[j] = *(const frag_t*)(sBc + bBase[j]);
+                            for (int tl = 0; tl < ntl; ++tl) {
+                                const int tn = min(tl + 1, tcnt - 1);
+                                const int boff = tl * BN * PS;
+                                const int aoff_n = sTap[t0 + tn];
+#pragma unroll
+                                for (int i = 0; i < TM; ++i) fa1[i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16);
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) fb1[j] = *(const frag_t*)(sBc + bBase[j] + boff + 16);
+                                __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of the MFMA group (the scheduler sinks them otherwise)
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                    for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa0[i], fb0[j]);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff_n);
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) fb0[j] = *(const frag_t*)(sBc + bBase[j] + tn * BN * PS);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                    for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa1[i], fb1[j]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                aoff = aoff_n;
+                            }
+                        } else {
+                            for (int tl = 0; tl < ntl; ++tl) {
+                                const int aoff = sTap[t0 + tl];
+                                const int boff = tl * BN * PS;
                                 frag_t fa[TM], fb[TN];
 #pragma unroll
-                                for (int i = 0; i < TM; ++i) fa[i] = *(const frag_t*)(sAc + aBase[i] + aoff + q * 16);
+                                for (int i = 0; i < TM; ++i) fa[i] = *(const frag_t*)(sAc + aBase[i] + aoff);
 #pragma unroll
-                                for (int j = 0; j < TN; ++j) fb[j] = *(const frag_t*)(sBc + bBase[j] + boff + q * 16);
+                                for (int j = 0; j < TN; ++j) fb[j] = *(const frag_t*)(sBc + bBase[j] + boff);
 #pragma unroll
                                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -233,8 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                         }
                     }
 
-                    if (prof) pt2 = clock64();
-                    if (!a.b_static && has_next && !(a.dbg & 8)) b_commit(breg[1 - d], gn, sB + (1 - d) * a.sB_bytes);
+                    if constexpr (!STATIC) {
+                        if (has_next && !(a.dbg & 8)) b_commit(breg[1 - d], gn, sB + (1 - d) * a.sB_bytes);
+                    }
                     if (closes && !(a.dbg & 16)) {
                         if (a.a_bufs == 2) {
                             apre.commit(sA + (cn & 1) * a.sA_bytes, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
@@ -243,15 +275,13 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                             apre.commit(sA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
                         }
                     }
-                    if (prof) pt3 = clock64();
                     __syncthreads();
-                    if (prof) { const long long pt4 = clock64(); pt_issue += pt1 - pt0; pt_mfma += pt2 - pt1; pt_commit += pt3 - pt2; pt_bar += pt4 - pt3; }
                     c = cn; g = gn;
                 }
             }
         }
 
-        if (prof && tid == 0) { prof[2] = wall_clock64(); prof[5] = (pt_issue << 32) | (pt_mfma & 0xffffffff); prof[7] = (pt_commit << 32) | (pt_bar & 0xffffffff); }
+        if (prof && tid == 0) prof[2] = wall_clock64();
         // ---- epilogue: bias, statistics of the f32 values, store through a wave-private LDS transpose
         // (a lane of the accumulator layout holds ONE channel of 16 pixels; the transpose turns that into 16-byte
         // stores of consecutive channels of one pixel).  The staging region aliases the halo / weight buffers: every
@@ -347,9 +377,9 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     }
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
-int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
-    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT>;
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC>
+int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
+    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WG);
@@ -357,6 +387,14 @@ int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     }
     hipLaunchKernelGGL(fn, dim3(g.nwg), dim3(FT), g.lds, st, k);
     return abc_check_launch("conv_fast");
+}
+
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
+    if constexpr (BN == 32) {  // resident weights exist for the narrow layers only
+        if (g.b_static) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, true>(k, g, st);
+    }
+    return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false>(k, g, st);
 }
 
 template <typename InT, typename CT, typename OutT, int CK, int BN>
@@ -421,6 +459,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         const int mt = cand_all[ci];
         if (force && atoi(force) != mt) continue;
         if (mt == 6 && (g->BN != 128 || d->stride != 1)) continue;
+        if (mt == 8 && g->BN == 128) continue;  // 4 x 2 tiles per wave + staging registers exceed 256 VGPRs
         if (d->stride == 2 && mt != 4) continue;
         const int prow = 2 * mt;
         const int hh = (prow - 1) * d->stride + (dymax - dymin) + 1, hw = 15 * d->stride + (dxmax - dxmin) + 1;
@@ -463,7 +502,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     }
     (void)abufs;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
-    g->b_static = (nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget) ? 1 : 0;
+    g->b_static = (g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget) ? 1 : 0;
     if (g->b_static) {
         g->a_bufs = 1;
     } else {
