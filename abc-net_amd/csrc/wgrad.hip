@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "../../include/abcnet_hip.h"
 #include "capi_util.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -266,6 +267,181 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const abc_wgrad_reduc
     *o = d.accumulate ? (*o + s) : s;
 }
 
+
+// ---------------------------------------------------------------------------
+// Weight gradient of a head's 1x1 convolution: dW[a][b] = sum_p dL[a][p] * act(H[p][b]) with dL the channel-planar
+// f32 gradient map (the reference's NCHW logits layout, unet.py:119) and H the NHWC feature map (BN + LeakyReLU +
+// dropout applied on load).  HBM-bound on dL (hc x pixels x 4 B, 212 MB for the 360-channel head): dL is already
+// pixel-contiguous per row, i.e. exactly the A-operand layout of the MFMA, so it goes global -> registers with each
+// lane reading 256 contiguous bytes per 128-pixel chunk (a whole chunk prefetched ahead); only H is staged and
+// transposed through LDS.  Workgroup = 8 waves = 4 m-tiles x 2 halves of the 128 b-channels; grid = m-groups x
+// K-splits, slabs reduced by abc_wgrad_reduce like every other weight gradient.
+struct HeadK {
+    const float* dl;
+    const float *psc, *psh, *psl;  // per-row transform of dL (scale = d(loss weight), shift 0, slope 1) or null
+    const void* q;
+    const float *qsc, *qsh, *qsl;
+    float* partial;
+    int HW, hc, ldq, cq_off, nchunks, nsplit, mtiles, Ca_pad;
+    float drop_p;
+    uint32_t drop_seed;
+    unsigned bytesP, bytesQ;
+};
+
+constexpr int HQ_PSW = 320;  // pixel stride of the [pixel][128 channel] bf16 LDS image (wgrad Q layout)
+
+__global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int mi = wave & 3, nh = wave >> 2;
+    const int split = blockIdx.x, mg = blockIdx.y;
+    const int mt = mg * 4 + mi;
+    const bool active = mt < a.mtiles;
+    const int co = mt * 32 + r;
+    const bool co_ok = active && co < a.hc;
+    const float psc = (co_ok && a.psc) ? a.psc[co] : 1.f, psh = (co_ok && a.psh) ? a.psh[co] : 0.f,
+                psl = (co_ok && a.psl) ? a.psl[co] : 1.f;
+    const bool ptrans = a.psc != nullptr;
+    const int c0 = (int)((long long)split * a.nchunks / a.nsplit), c1 = (int)((long long)(split + 1) * a.nchunks / a.nsplit);
+
+    const __amdgpu_buffer_rsrc_t rsP = abc_make_rsrc(a.dl, a.bytesP), rsQ = abc_make_rsrc(a.q, a.bytesQ);
+    // Q staging: 128 pixels x 16 segments of 8 channels over 512 threads -> 4 per thread, same channel segment always
+    const int part = tid & 15, pix0 = tid >> 4;  // segment i: pixel pix0 + 32 i
+    const bool qtrans = a.qsc != nullptr;
+    float* sCoef = (float*)(smem + 2 * 128 * HQ_PSW);  // [3][128]: re-read at every commit (registers go to the dL prefetch)
+    if (qtrans && tid < 128) {
+        sCoef[tid] = a.qsc[a.cq_off + tid]; sCoef[128 + tid] = a.qsh[a.cq_off + tid]; sCoef[256 + tid] = a.qsl[a.cq_off + tid];
+    }
+    __syncthreads();
+    const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    u32x4 qreg[4];
+    const int CPI = a.HW / 128;  // chunks per image
+    u32x4 areg0[16], areg1[16];  // two sets (current / next chunk) x [K-step x 2]: lane (r, h) holds dL[co][64 h + 8 kk + j]
+    auto issue = [&](int c, u32x4 (&as)[16]) {
+        const int b = c / CPI, pp0 = (c - b * CPI) * 128;
+        const unsigned qoff = (unsigned)(((unsigned)(c * 128 + pix0) * (unsigned)a.ldq + (unsigned)(a.cq_off + part * 8)) * 2u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + (unsigned)(i * 32 * a.ldq * 2), 0, 0);
+        const unsigned poff = co_ok ? (unsigned)((((unsigned)(b * a.hc + co)) * (unsigned)a.HW + (unsigned)(pp0 + 64 * h)) * 4u) : 0x80000000u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) as[k] = __builtin_amdgcn_raw_buffer_load_b128(rsP, poff + (unsigned)(k * 16), 0, 0);
+    };
+    auto commit = [&](int c, char* sQ) {
+        float qsc[8], qsh[8], qsl[8];
+        if (qtrans) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qsc[j] = sCoef[part * 8 + j]; qsh[j] = sCoef[128 + part * 8 + j]; qsl[j] = sCoef[256 + part * 8 + j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pix = pix0 + 32 * i;
+            const uint32_t eoff = (uint32_t)(c * 128 + pix) * (uint32_t)a.ldq + (uint32_t)(a.cq_off + part * 8);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(qreg[i][j] << 16); v[2 * j + 1] = __uint_as_float(qreg[i][j] & 0xFFFF0000u); }
+            if (qtrans) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = abc_act(v[j], qsc[j], qsh[j], qsl[j]);
+            }
+            if (a.drop_p > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(eoff + j, a.drop_seed, a.drop_p) ? v[j] * dscale : 0.f;
+            }
+            *(bf16x8*)(sQ + pix * HQ_PSW + part * 16) = pack_frag<bf16>(v);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
+
+    const int sub = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int qlane = (64 * h + ((lane & 15) >> 2)) * HQ_PSW + sub * 2;  // + 8 kk pixels + b-tile * 64 bytes
+    constexpr int QBUF = 128 * HQ_PSW;
+
+    auto compute = [&](const u32x4 (&cur)[16], const char* sQ) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(cur[2 * kk][j]); f[4 + j] = __uint_as_float(cur[2 * kk + 1][j]); }
+            if (ptrans) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = abc_act(f[j], psc, psh, psl);
+            }
+            const bf16x8 fa = pack_frag<bf16>(f);
+            const char* qb = sQ + qlane + kk * 8 * HQ_PSW + nh * 128;
+            const bf16x8 fb0 = tr_read8(qb, qb + 4 * HQ_PSW);
+            const bf16x8 fb1 = tr_read8(qb + 64, qb + 64 + 4 * HQ_PSW);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, acc[1], 0, 0, 0);
+        }
+    };
+
+    if (c0 < c1) {
+        issue(c0, areg0);
+        commit(c0, smem);
+    }
+    __syncthreads();
+    // two chunks per trip so that the register sets have fixed names: even chunks (relative) live in areg0 / LDS
+    // buffer 0, odd ones in areg1 / buffer 1
+    for (int c = c0; c < c1; c += 2) {
+        const bool n1 = c + 1 < c1, n2 = c + 2 < c1;
+        if (n1) issue(c + 1, areg1);
+        if (active) compute(areg0, smem);
+        if (n1) commit(c + 1, smem + QBUF);
+        __syncthreads();
+        if (n1) {
+            if (n2) issue(c + 2, areg0);
+            if (active) compute(areg1, smem + QBUF);
+            if (n2) commit(c + 2, smem);
+            __syncthreads();
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* out = a.partial + ((size_t)split * a.Ca_pad + mt * 32) * 128 + (nh * 2 + j) * 32 + r;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int arow = (k & 3) + 8 * (k >> 2) + 4 * h;
+                out[(size_t)arow * 128] = acc[j][k];
+            }
+        }
+    }
+}
+
+// dL planar f32 (x) activated NHWC bf16 features, 1x1, 128 b-channels, whole 128-pixel chunks per image
+static bool head_ok(const abc_wgrad_desc* d) {
+    if (getenv("ABC_WGRAD_NOHEAD")) return false;
+    if (!d->p.planar || d->dtype_p != ABC_F32 || d->dtype_q != ABC_BF16 || d->dtype_c != ABC_BF16) return false;
+    if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->Cb != 128 || d->cp_off != 0) return false;
+    if (d->q.pool || d->q.planar || d->p.pool || d->p.drop_p > 0.f || (d->Hg * d->Wg) % 128) return false;
+    if (d->p.ctot != d->Ca) return false;
+    const int64_t bp = (int64_t)d->B * d->Ca * d->Hg * d->Wg * 4, bq = (int64_t)d->B * d->Hg * d->Wg * d->q.ldx * 2;
+    return bp < (int64_t(1) << 31) && bq < (int64_t(1) << 31) && (d->q.ldx % 8) == 0 && (d->cq_off % 8) == 0;
+}
+
+static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
+    HeadK k;
+    k.dl = (const float*)d->p.x; k.psc = d->p.scale; k.psh = d->p.shift; k.psl = d->p.slope;
+    k.q = d->q.x; k.qsc = d->q.scale; k.qsh = d->q.shift; k.qsl = d->q.slope;
+    k.partial = d->partial; k.HW = d->Hg * d->Wg; k.hc = d->Ca; k.ldq = d->q.ldx; k.cq_off = d->cq_off;
+    k.nchunks = d->B * k.HW / 128; k.nsplit = d->nsplit; k.mtiles = abc_cdiv(d->Ca, 32); k.Ca_pad = k.mtiles * 32;
+    k.drop_p = d->q.drop_p; k.drop_seed = d->q.drop_seed;
+    k.bytesP = (unsigned)((int64_t)d->B * d->Ca * k.HW * 4); k.bytesQ = (unsigned)((int64_t)d->B * k.HW * d->q.ldx * 2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)head_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(d->nsplit, abc_cdiv(k.mtiles, 4)), dim3(512), 2 * 128 * HQ_PSW + 3 * 128 * 4, st, k);
+    return abc_check_launch("head_wgrad");
+}
+
 struct WGeom {
     int AT, BT, dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, lds, tgw, ngroups, nta, ntb, npatch,
         tiles_x, tiles_y, fast_p, fast_q, nbuf, PM;
@@ -374,6 +550,7 @@ static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipSt
 }  // namespace
 
 extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad) {
+    if (head_ok(d)) { *ca_pad = abc_cdiv(d->Ca, 32) * 32; *cb_pad = 128; return ABC_OK; }
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -383,6 +560,7 @@ extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t*
 }
 
 extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt) {
+    if (head_ok(d)) { *at = 0; *bt = 0; return ABC_OK; }  // (0, 0) = the head kernel
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -391,16 +569,21 @@ extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt)
 }
 
 extern "C" int abc_wgrad_blocks(const abc_wgrad_desc* d) {
+    if (head_ok(d)) return abc_cdiv(abc_cdiv(d->Ca, 32), 4);
     WGeom g;
     if (wgeom(d, &g)) return -1;
     return g.nta * g.ntb * g.ngroups;
 }
 
 extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
+    if (d->nsplit < 1) return abc_fail(ABC_EINVAL, "wgrad: nsplit");
+    if (d->ntaps >= 1 && d->ntaps <= ABC_MAX_TAPS && head_ok(d)) {
+        if (d->p.Hx != d->Hg || d->p.Wx != d->Wg || d->q.Hx != d->Hg || d->q.Wx != d->Wg) return abc_fail(ABC_EINVAL, "wgrad: dims mismatch");
+        return head_launch(d, (hipStream_t)stream);
+    }
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
-    if (d->nsplit < 1) return abc_fail(ABC_EINVAL, "wgrad: nsplit");
     WgK k;
     auto cp = [](ActSrc& o, const abc_act_src& i) {
         o.x = i.x; o.scale = i.scale; o.shift = i.shift; o.slope = i.slope; o.Hx = i.Hx; o.Wx = i.Wx; o.ldx = i.ldx;

@@ -157,6 +157,51 @@ def test_head_conv1x1_backward_from_nchw(lib, dt, Cn):
     np.testing.assert_allclose(db.cpu(), (dl * scale).sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("Cn,nsplit", [(14, 3), (360, 5), (60, 1), (1, 7)])
+def test_head_wgrad_fused_activation(lib, Cn, nsplit):
+    """weight gradient of a head's 1x1 conv in bf16 mode (dedicated kernel): NCHW f32 dlogits with a per-channel scale
+    against BN + LeakyReLU + dropout applied on load to a channel slice of the NHWC feature map (unet.py:67-70)"""
+    from abcnet_amd.dropout import keep_mask
+    dt = L.BF16
+    g = torch.Generator().manual_seed(35)
+    B, H, W, ld, coff, Cin = 2, 16, 32, 256, 128, 128
+    x = q(torch.randn((B, ld, H, W), generator=g), dt)
+    sc, sh = torch.rand(ld, generator=g) * 2 - 0.6, torch.randn(ld, generator=g) * 0.3
+    sl = torch.full((ld,), 0.01)
+    p_drop, seed = 0.2, 4242
+    idx = (torch.arange(B * H * W).view(B, H, W, 1) * ld + torch.arange(ld).view(1, 1, 1, ld))
+    keep = keep_mask(idx, seed, p_drop).permute(0, 3, 1, 2).float()
+    a = q((act(x, sc, sh, sl) * keep / (1 - p_drop))[:, coff:coff + Cin], dt)
+    dl = torch.randn((B, Cn, H, W), generator=g)
+    scale = torch.rand(Cn, generator=g) + 0.2
+    ref = torch.einsum("bohw,bihw->oi", q(dl * scale.view(1, -1, 1, 1), dt).double(), a.double())
+    dld = dl.to(U.DEV).contiguous()
+    cs = tuple(t.to(U.DEV) for t in (scale, torch.zeros(Cn), torch.ones(Cn)))
+    d = L.WgradDesc()
+    U.fill_src(d.p, dld, H, W, 0, cs)
+    d.p.planar, d.p.ctot = 1, Cn
+    xd = U.nhwc(x, dt)
+    qcoef = tuple(t.to(U.DEV) for t in (sc, sh, sl))  # (kept alive: the descriptor holds raw pointers)
+    U.fill_src(d.q, xd, H, W, ld, qcoef, False, p_drop, seed)
+    d.dtype_p, d.dtype_q, d.dtype_c = L.F32, dt, dt
+    d.B, d.Hg, d.Wg, d.Hq, d.Wq, d.Ca, d.Cb, d.stride, d.nsplit, d.cq_off = B, H, W, H, W, Cn, Cin, 1, nsplit, coff
+    L.set_taps(d, [(0, 0)])
+    ca, cb = L.i32(), L.i32()
+    L.check(lib.abc_wgrad_pads(C.byref(d), C.byref(ca), C.byref(cb)), "pads")
+    at, bt = L.i32(), L.i32()
+    L.check(lib.abc_wgrad_tile(C.byref(d), C.byref(at), C.byref(bt)), "tile")
+    assert (at.value, bt.value) == (0, 0)  # the head kernel took it
+    part = torch.full((nsplit * ca.value * cb.value,), float("nan"), dtype=torch.float32, device=U.DEV)
+    d.partial = part.data_ptr()
+    L.check(lib.abc_wgrad(C.byref(d), U.stream()), "wgrad")
+    dw = torch.zeros((Cn, Cin, 1), dtype=torch.float32, device=U.DEV)
+    r = L.WgradReduceDesc()
+    r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), nsplit, 1, Cn, Cin, ca.value, cb.value, dw.data_ptr(), 0
+    L.check(lib.abc_wgrad_reduce(C.byref(r), U.stream()), "reduce")
+    torch.cuda.synchronize()
+    assert U.relerr(dw.cpu().view(Cn, Cin), ref) < U.tol(dt)
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv_transpose_into_concat(lib, dt):
     """4 parity phases == ConvTranspose2d(k3,s2) + crop of first row/col, written at a channel offset"""
