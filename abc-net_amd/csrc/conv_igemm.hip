@@ -513,6 +513,7 @@ extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, i
 }
 
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
+    { int nb = 0; if (abc_conv_stem_ok(d, &nb)) return nb; }
     abc_fast_geom f;
     if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return f.tiles_x * f.tiles_y * d->B;
     Geom g;
@@ -560,6 +561,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     // the kernel's grid must address only in-range output pixels
     if ((d->Hg - 1) * d->om + d->oy0 >= d->Hout || (d->Wg - 1) * d->om + d->ox0 >= d->Wout)
         return abc_fail(ABC_EINVAL, "conv: output grid exceeds output tensor");
+    if (abc_conv_stem_ok(d, nullptr)) return abc_conv_stem_launch(d, stream);
     {
         abc_fast_geom f;
         if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return abc_conv_fast_launch(d, f, stream);

@@ -1,0 +1,140 @@
+// First convolution of the network (unet.py:12 with in_channels = 1): a ONE-channel f32 image into <= 64 output
+// channels.  K = 9 is no matrix shape: plain FMAs with the tap weights in registers, bound by writing the output once
+// (the implicit-GEMM kernels pad K to 16 and spend an MFMA stage on it).  A thread owns 8 output channels of one
+// pixel-column slot; the image rows a row of output needs sit in LDS.  BatchNorm statistics (sum, sum of squares of
+// the f32 values) are reduced per workgroup like in the GEMM kernels' epilogue.
+#include "common.hpp"
+#include "../../include/abcnet_hip.h"
+#include "capi_util.hpp"
+#include "conv_fast.hpp"
+#include <stdlib.h>
+
+namespace {
+
+struct StemK {
+    const float* x;
+    const void* w;       // packed [tap][Cout_pad][16] in the compute type (column 0 = the only input channel)
+    const float* bias;
+    void* y;
+    float* stats;
+    int B, H, W, Cout, Cout_pad, ldy, cout_off, ntaps, dy_min, dy_max, rows_per_wg;
+    int8_t ty[9], tx[9];
+};
+
+template <typename CT, typename OutT>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
+    __shared__ float sx[4][512 + 8];
+    __shared__ float red[4][2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncg = a.Cout / 8;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const int nslot = 256 / ncg;
+    const int nrows = a.B * a.H;
+    const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(r0 + a.rows_per_wg, nrows);
+    const int nxr = a.dy_max - a.dy_min + 1;
+    float wv[9][8], bv[8], s1[8], s2[8];
+    const CT* wp = (const CT*)a.w;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[t][j] = (t < a.ntaps) ? (float)wp[((size_t)t * a.Cout_pad + cg * 8 + j) * 16] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bv[j] = a.bias ? a.bias[cg * 8 + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    OutT* yo = (OutT*)a.y;
+    for (int row = r0; row < r1; ++row) {
+        const int b = row / a.H, y = row - b * a.H;
+        __syncthreads();
+        for (int i = tid; i < nxr * (a.W + 8); i += 256) {
+            const int rr = i / (a.W + 8), xx = i - rr * (a.W + 8) - 4;
+            const int yy = y + a.dy_min + rr;
+            sx[rr][xx + 4] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? a.x[((size_t)b * a.H + yy) * a.W + xx] : 0.f;
+        }
+        __syncthreads();
+        for (int x0 = slot; x0 < a.W; x0 += nslot) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = bv[j];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t < a.ntaps) {
+                    const float xv = sx[a.ty[t]][x0 + 4 + a.tx[t]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaf(wv[t][j], xv, v[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            OutT* dst = yo + ((size_t)row * a.W + x0) * a.ldy + a.cout_off + cg * 8;
+            if constexpr (sizeof(OutT) == 2) {
+                *(bf16x8*)dst = pack_frag<bf16>(v);
+            } else {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo[j] = v[j]; hi[j] = v[4 + j]; }
+                *(f32x4*)dst = lo; *(f32x4*)(dst + 4) = hi;
+            }
+        }
+    }
+    if (a.stats != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float u = s1[j], q = s2[j];
+            for (int m = ncg; m < 64; m <<= 1) { u += __shfl_xor(u, m); q += __shfl_xor(q, m); }
+            s1[j] = u; s2[j] = q;
+        }
+        __syncthreads();
+        if (lane < ncg) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[wave][lane * 8 + j] = s1[j]; red[wave][64 + lane * 8 + j] = s2[j]; }
+        }
+        __syncthreads();
+        if (tid < a.Cout) {
+            a.stats[((size_t)blockIdx.x * 2 + 0) * a.Cout + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            a.stats[((size_t)blockIdx.x * 2 + 1) * a.Cout + tid] = red[0][64 + tid] + red[1][64 + tid] + red[2][64 + tid] + red[3][64 + tid];
+        }
+    }
+}
+
+constexpr int STEM_ROWS = 4;
+
+}  // namespace
+
+// 1 when the one-channel kernel takes this descriptor; *stat_blocks = statistics partials it writes
+int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks) {
+    if (getenv("ABC_CONV_NOSTEM")) return 0;
+    if (d->Cin != 1 || d->cin_off != 0 || d->src.ldx != 1 || d->dtype_in != ABC_F32 || d->src.scale || d->src.pool || d->src.planar ||
+        d->src.drop_p > 0.f)
+        return 0;
+    if (d->planar_out || d->accumulate || d->stats_rows == 4 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0 || d->ntaps > 9) return 0;
+    if (d->Cout % 8 || d->Cout > 64 || (d->Cout & (d->Cout - 1)) || d->Wg > 512 || d->Hg != d->Hin || d->Wg != d->Win ||
+        d->Hout != d->Hg || d->Wout != d->Wg)
+        return 0;
+    const int esz = d->dtype_out == ABC_BF16 ? 2 : 4;
+    if ((d->ldy * esz) % 16 || (d->cout_off * esz) % 16) return 0;
+    if (d->dtype_c == ABC_F32 && d->dtype_out != ABC_F32) return 0;
+    int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
+    for (int t = 0; t < d->ntaps; ++t) {
+        dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
+        dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
+    }
+    if (dymax - dymin > 3 || dxmin < -4 || dxmax > 4) return 0;
+    if (stat_blocks) *stat_blocks = abc_cdiv(d->B * d->Hg, STEM_ROWS);
+    return 1;
+}
+
+int abc_conv_stem_launch(const abc_conv_desc* d, abc_stream_t stream) {
+    StemK k;
+    k.x = (const float*)d->src.x; k.w = d->w; k.bias = d->bias; k.y = d->y; k.stats = d->stats;
+    k.B = d->B; k.H = d->Hg; k.W = d->Wg; k.Cout = d->Cout; k.Cout_pad = d->Cout_pad; k.ldy = d->ldy; k.cout_off = d->cout_off;
+    k.ntaps = d->ntaps; k.rows_per_wg = STEM_ROWS;
+    int dymin = 127, dymax = -127;
+    for (int t = 0; t < d->ntaps; ++t) { dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax; }
+    k.dy_min = dymin; k.dy_max = dymax;
+    for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - dymin); k.tx[t] = (int8_t)d->tap_dx[t]; }
+    const int nwg = abc_cdiv(d->B * d->Hg, STEM_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype_c == ABC_F32) hipLaunchKernelGGL((stem_conv_kernel<float, float>), dim3(nwg), dim3(256), 0, st, k);
+    else if (d->dtype_out == ABC_BF16) hipLaunchKernelGGL((stem_conv_kernel<bf16, bf16>), dim3(nwg), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((stem_conv_kernel<bf16, float>), dim3(nwg), dim3(256), 0, st, k);
+    return abc_check_launch("stem_conv");
+}

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
     constexpr int ROWS = PROWS / RSPLIT;    // patch rows per wave
     constexpr int CWP = AT * 32, CWQ = BT * 32;
     constexpr int NPF_P = (PROWS * 16 * (CWP / Frag<CT>::NV) + WTHR - 1) / WTHR;
-    constexpr int NPF_Q = (PM > 1) ? 5 : ((sizeof(CT) == 2) ? 4 : 6);
+    constexpr int NPF_Q = (PM > 1 || STRIDE == 2) ? 5 : ((sizeof(CT) == 2) ? 4 : 6);  // (stride 2: 17 x 33 halo pixels)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int buf_bytes = a.sP_bytes + a.sQ_bytes;
     float* sCoefP = (float*)(smem + a.coef_off);
@@ -442,6 +442,123 @@ static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
     return abc_check_launch("head_wgrad");
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient against a ONE-channel operand (the network's first convolution, unet.py:12 with in_channels = 1):
+// dW[t][a] = sum_p dY[p][a] * x[p + d_t].  No matrix shape to speak of (N = 1): plain FMAs, bound by reading dY once.
+// A thread owns 8 a-channels of one pixel column slot; the three image rows a row of dY needs sit in LDS.
+struct C1K {
+    const void* p;       // dY, NHWC [B][H][W][ldp]
+    const float* x;      // image, [B][H][W] (one channel, f32)
+    float* partial;      // [nsplit][ntaps][Ca]
+    int B, H, W, ldp, cp_off, Ca, ntaps, nsplit, dy_min, dy_max, dx_min, dx_max;
+    int8_t ty[9], tx[9];
+};
+
+template <typename PT>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
+    __shared__ float sx[4][512 + 8];     // up to 4 image rows (3x3: 3), W <= 512 columns, 4-column halo either side
+    __shared__ float red[4][9 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncg = a.Ca / 8;                 // channel groups of 8 (1, 2, 4 or 8)
+    const int cg = tid % ncg, slot = tid / ncg;
+    const int nslot = 256 / ncg;              // pixels per step
+    const int nrows = a.B * a.H;
+    const int r0 = (int)((long long)blockIdx.x * nrows / a.nsplit), r1 = (int)((long long)(blockIdx.x + 1) * nrows / a.nsplit);
+    const int nxr = a.dy_max - a.dy_min + 1;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (int row = r0; row < r1; ++row) {
+        const int b = row / a.H, y = row - b * a.H;
+        __syncthreads();
+        for (int i = tid; i < nxr * (a.W + 8); i += 256) {
+            const int rr = i / (a.W + 8), xx = i - rr * (a.W + 8) - 4;
+            const int yy = y + a.dy_min + rr;
+            sx[rr][xx + 4] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? a.x[((size_t)b * a.H + yy) * a.W + xx] : 0.f;
+        }
+        __syncthreads();
+        for (int x0 = slot; x0 < a.W; x0 += nslot) {
+            float g[8];
+            const PT* src = (const PT*)a.p + ((size_t)row * a.W + x0) * a.ldp + a.cp_off + cg * 8;
+            LoadVec<PT, 8>::ld(src, g);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t < a.ntaps) {
+                    const float xv = sx[a.ty[t]][x0 + 4 + a.tx[t]];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(g[j], xv, acc[t][j]);
+                }
+            }
+        }
+    }
+    // fold the pixel slots: lanes with equal cg inside the wave (ncg divides 64), then the 4 waves through LDS
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[t][j];
+            for (int m = ncg; m < 64; m <<= 1) v += __shfl_xor(v, m);
+            acc[t][j] = v;
+        }
+    __syncthreads();
+    if (lane < ncg) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int i = tid; i < a.ntaps * a.Ca; i += 256) {
+        const int t = i / a.Ca, c = i - t * a.Ca;
+        a.partial[((size_t)blockIdx.x * a.ntaps + t) * a.Ca + c] = red[0][t * 64 + c] + red[1][t * 64 + c] + red[2][t * 64 + c] + red[3][t * 64 + c];
+    }
+}
+
+static bool c1_ok(const abc_wgrad_desc* d) {
+    if (getenv("ABC_WGRAD_NOC1")) return false;
+    if (d->Cb != 1 || d->cq_off != 0 || d->q.ldx != 1 || d->dtype_q != ABC_F32 || d->q.scale || d->q.pool || d->q.planar || d->q.drop_p > 0.f) return false;
+    if (d->p.scale || d->p.pool || d->p.planar || d->p.drop_p > 0.f || d->stride != 1 || d->ntaps > 9) return false;
+    if (d->Ca % 8 || d->Ca > 64 || (d->Ca & (d->Ca - 1)) || d->Wg > 512 || (d->p.ldx % 8) || (d->cp_off % 8)) return false;
+    int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
+    for (int t = 0; t < d->ntaps; ++t) {
+        dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
+        dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
+    }
+    return dymax - dymin <= 3 && dxmin >= -4 && dxmax <= 4 && d->Hq == d->Hg && d->Wq == d->Wg;
+}
+
+static int c1_launch(const abc_wgrad_desc* d, hipStream_t st) {
+    C1K k;
+    k.p = d->p.x; k.x = (const float*)d->q.x; k.partial = d->partial;
+    k.B = d->B; k.H = d->Hg; k.W = d->Wg; k.ldp = d->p.ldx; k.cp_off = d->cp_off; k.Ca = d->Ca; k.ntaps = d->ntaps; k.nsplit = d->nsplit;
+    int dymin = 127, dymax = -127;
+    for (int t = 0; t < d->ntaps; ++t) { dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax; }
+    k.dy_min = dymin; k.dy_max = dymax; k.dx_min = 0; k.dx_max = 0;
+    for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - dymin); k.tx[t] = (int8_t)d->tap_dx[t]; }
+    if (d->dtype_p == ABC_BF16) hipLaunchKernelGGL(wgrad_c1_kernel<bf16>, dim3(d->nsplit), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(wgrad_c1_kernel<float>, dim3(d->nsplit), dim3(256), 0, st, k);
+    return abc_check_launch("wgrad_c1");
+}
+
+// Few outputs, many slabs (the one-channel layer: 288 sums over 1024 slabs): one wave per output element, lanes stride
+// the slabs, fixed shuffle tree -> still bitwise reproducible.
+__global__ __launch_bounds__(64) void wgrad_reduce_wave_kernel(const abc_wgrad_reduce_desc d) {
+    const int idx = blockIdx.x;
+    const int bi = idx % d.Cb, ai = (idx / d.Cb) % d.Ca, t = idx / (d.Cb * d.Ca);
+    const size_t slab = (size_t)d.Ca_pad * d.Cb_pad;
+    const float* p = d.partial + (size_t)t * slab + (size_t)ai * d.Cb_pad + bi;
+    const size_t step = (size_t)d.ntaps * slab;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < d.nsplit; k += 64) s += p[(size_t)k * step];
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (threadIdx.x == 0) {
+        float* o = d.dw + ((size_t)ai * d.Cb + bi) * d.ntaps + t;
+        *o = d.accumulate ? (*o + s) : s;
+    }
+}
+
 struct WGeom {
     int AT, BT, dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, lds, tgw, ngroups, nta, ntb, npatch,
         tiles_x, tiles_y, fast_p, fast_q, nbuf, PM;
@@ -489,7 +606,7 @@ static int wgeom_pm(const abc_wgrad_desc* d, WGeom* g, int pm) {
     const int64_t bytesP = (int64_t)d->B * d->p.Hx * d->p.Wx * d->p.ldx * (d->dtype_p == ABC_BF16 ? 2 : 4);
     const int64_t bytesQ = (int64_t)d->B * d->q.Hx * d->q.Wx * d->q.ldx * (d->dtype_q == ABC_BF16 ? 2 : 4);
     g->fast_p = (fast_ok(d->p, csz, lastP, bytesP) && g->HH * g->HW * g->HW < 65536) ? 1 : 0;
-    g->fast_q = (fast_ok(d->q, csz, lastQ, bytesQ) && abc_cdiv(g->HH * g->HW * segq, WTHR) <= (pm > 1 ? 5 : (csz == 2 ? 4 : 6))) ? 1 : 0;
+    g->fast_q = (fast_ok(d->q, csz, lastQ, bytesQ) && abc_cdiv(g->HH * g->HW * segq, WTHR) <= ((pm > 1 || (d->stride == 2 && csz == 2)) ? 5 : (csz == 2 ? 4 : 6))) ? 1 : 0;
     g->ngroups = abc_cdiv(d->ntaps, (g->fast_p && g->fast_q) ? MAXT_FAST : MAXT_SLOW);
     g->tgw = abc_cdiv(d->ntaps, g->ngroups);
     return ABC_OK;
@@ -551,6 +668,7 @@ static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipSt
 
 extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad) {
     if (head_ok(d)) { *ca_pad = abc_cdiv(d->Ca, 32) * 32; *cb_pad = 128; return ABC_OK; }
+    if (c1_ok(d)) { *ca_pad = d->Ca; *cb_pad = 1; return ABC_OK; }
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -561,6 +679,7 @@ extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t*
 
 extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt) {
     if (head_ok(d)) { *at = 0; *bt = 0; return ABC_OK; }  // (0, 0) = the head kernel
+    if (c1_ok(d)) { *at = 0; *bt = 1; return ABC_OK; }    // (0, 1) = the one-channel kernel
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -570,6 +689,7 @@ extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt)
 
 extern "C" int abc_wgrad_blocks(const abc_wgrad_desc* d) {
     if (head_ok(d)) return abc_cdiv(abc_cdiv(d->Ca, 32), 4);
+    if (c1_ok(d)) return 1;
     WGeom g;
     if (wgeom(d, &g)) return -1;
     return g.nta * g.ntb * g.ngroups;
@@ -580,6 +700,10 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     if (d->ntaps >= 1 && d->ntaps <= ABC_MAX_TAPS && head_ok(d)) {
         if (d->p.Hx != d->Hg || d->p.Wx != d->Wg || d->q.Hx != d->Hg || d->q.Wx != d->Wg) return abc_fail(ABC_EINVAL, "wgrad: dims mismatch");
         return head_launch(d, (hipStream_t)stream);
+    }
+    if (d->ntaps >= 1 && c1_ok(d)) {
+        if (d->p.Hx != d->Hg || d->p.Wx != d->Wg || d->q.Hx != d->Hg || d->q.Wx != d->Wg) return abc_fail(ABC_EINVAL, "wgrad: dims mismatch");
+        return c1_launch(d, (hipStream_t)stream);
     }
     WGeom g;
     int rc = wgeom(d, &g);
@@ -618,6 +742,10 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
 
 extern "C" int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream) {
     const int64_t n = (int64_t)d->ntaps * d->Ca * d->Cb;
+    if (n <= 4096 && d->nsplit >= 128) {
+        hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((int)n), dim3(64), 0, (hipStream_t)stream, *d);
+        return abc_check_launch("wgrad_reduce");
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
     return abc_check_launch("wgrad_reduce");
 }

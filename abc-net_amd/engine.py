@@ -220,14 +220,16 @@ class Engine:
         npatch = self.B * (-(-gh // 8)) * (-(-gw // 16))
         # one 8-wave workgroup per CU is resident: a single round of ~256 workgroups keeps the split-K slabs small
         nsplit = max(1, min(max(1, npatch // 2), 256 // per_split))
+        at_, bt_ = L.i32(), L.i32()
+        L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
+        if (at_.value, bt_.value) == (0, 1):   # one-channel kernel: 256-thread workgroups streaming dY, several per CU
+            nsplit = min(self.B * gh, 1024)
         d.nsplit = nsplit
         need = nsplit * len(taps) * ca_pad * cb_pad
         self._ws_need = max(self._ws_need, need)
         r = L.WgradReduceDesc()
         r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = nsplit, len(taps), Ca, Cb, ca_pad, cb_pad, dw_ptr, 0
         self._ws_users += [d, r]
-        at_, bt_ = L.i32(), L.i32()
-        L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
         meta = {"kernel": "wgrad<%s,%s,%s,%dx%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), at_.value, bt_.value, stride),
                 "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
                 "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt))}

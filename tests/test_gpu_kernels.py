@@ -264,7 +264,7 @@ def test_conv_transpose_dgrad_wgrad(lib, dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", [dict(Cin=64, Cout=128, k=3), dict(Cin=16, Cout=16, k=3), dict(Cin=32, Cout=64, k=3, pool=True),
-                                  dict(Cin=1, Cout=16, k=3, img=True), dict(Cin=128, Cout=14, k=1, f32dy=True),
+                                  dict(Cin=1, Cout=16, k=3, img=True), dict(Cin=1, Cout=32, k=3, img=True, H=40, W=56), dict(Cin=128, Cout=14, k=1, f32dy=True),
                                   dict(Cin=32, Cout=32, k=5)])
 def test_conv_wgrad(lib, dt, case):
     g = torch.Generator().manual_seed(11)
