@@ -166,6 +166,7 @@ SYMBOLS = {
     "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),
+    "abc_pool_act": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_sizeof": (C.c_int, [C.c_int]),
     "abc_last_error": (C.c_char_p, []),
     "abc_version": (C.c_int, []),

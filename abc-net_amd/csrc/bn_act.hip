@@ -384,6 +384,66 @@ extern "C" int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld
     return abc_check_launch("colsum");
 }
 
+// 2x2 max-pool of the activated tensor, 8 channels (16 / 32 bytes) per thread
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(256) void pool_act_kernel(const InT* x, const float* sc, const float* sh, const float* sl, int Hx, int Wx,
+                                                        int ldx, int c_off, int C, int64_t nseg, OutT* out, int ld_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nseg) return;
+    const int segs = C / 8;
+    const int sg = (int)(i % segs);
+    int64_t pix = i / segs;
+    const int Wo = Wx / 2, Ho = Hx / 2;
+    const int xo = (int)(pix % Wo); pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    const int c = c_off + sg * 8;
+    float a[8], s_[8], t_[8];
+    const bool tr = sc != nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[j] = tr ? sc[c + j] : 1.f; s_[j] = tr ? sh[c + j] : 0.f; t_[j] = tr ? sl[c + j] : 1.f; }
+    float m[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v[8];
+        LoadVec<InT, 8>::ld(x + ((size_t)(b * Hx + 2 * yo + (q >> 1)) * Wx + 2 * xo + (q & 1)) * ldx + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = tr ? abc_act(v[j], a[j], s_[j], t_[j]) : v[j];
+            m[j] = (q == 0) ? y : fmaxf(m[j], y);
+        }
+    }
+    OutT* dst = out + ((size_t)(b * Ho + yo) * Wo + xo) * ld_out + sg * 8;
+    if constexpr (sizeof(OutT) == 2) {
+        *(bf16x8*)dst = pack_frag<bf16>(m);
+    } else {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lo[j] = m[j]; hi[j] = m[4 + j]; }
+        *(f32x4*)dst = lo; *(f32x4*)(dst + 4) = hi;
+    }
+}
+
+extern "C" int abc_pool_act(const abc_act_src* src, int32_t dtype_in, int32_t c_off, int32_t C, int32_t B, void* out, int32_t dtype_out,
+                            int32_t ld_out, abc_stream_t stream) {
+    if (C % 8 || c_off % 8 || src->ldx % 8 || ld_out % 8 || (src->Hx & 1) || (src->Wx & 1)) return abc_fail(ABC_EINVAL, "pool_act: alignment");
+    if (src->planar || src->drop_p > 0.f) return abc_fail(ABC_EUNSUPPORTED, "pool_act: planar / dropout source");
+    const int64_t nseg = (int64_t)B * (src->Hx / 2) * (src->Wx / 2) * (C / 8);
+    const dim3 grid((unsigned)((nseg + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype_in == ABC_BF16 && dtype_out == ABC_BF16)
+        hipLaunchKernelGGL((pool_act_kernel<bf16, bf16>), grid, dim3(256), 0, st, (const bf16*)src->x, src->scale, src->shift, src->slope, src->Hx,
+                           src->Wx, src->ldx, c_off, C, nseg, (bf16*)out, ld_out);
+    else if (dtype_in == ABC_F32 && dtype_out == ABC_F32)
+        hipLaunchKernelGGL((pool_act_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src->x, src->scale, src->shift, src->slope,
+                           src->Hx, src->Wx, src->ldx, c_off, C, nseg, (float*)out, ld_out);
+    else if (dtype_in == ABC_F32 && dtype_out == ABC_BF16)
+        hipLaunchKernelGGL((pool_act_kernel<float, bf16>), grid, dim3(256), 0, st, (const float*)src->x, src->scale, src->shift, src->slope,
+                           src->Hx, src->Wx, src->ldx, c_off, C, nseg, (bf16*)out, ld_out);
+    else return abc_fail(ABC_EUNSUPPORTED, "pool_act: dtype combination");
+    return abc_check_launch("pool_act");
+}
+
 extern "C" int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream) {
     if (n <= 0) return ABC_OK;
     hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, v, n);

@@ -298,7 +298,22 @@ class Engine:
         return b
 
     def pooled(self, s: Src):
-        return Src(s.t, s.dt, s.H, s.W, s.ld, s.coff, s.C, coef=s.coef, pool=True, producer=s.producer)
+        """nn.MaxPool2d(2) (unet.py:30).  unet: materialised once by abc_pool_act, so that the level's first conv and
+        its weight gradient read a plain tensor on their prefetch paths; the gradient still routes to the producer
+        as a pooled one (via_pool).  unet2 keeps pooling on load (its residual path reads the same source)."""
+        if self.variant != "unet":
+            return Src(s.t, s.dt, s.H, s.W, s.ld, s.coff, s.C, coef=s.coef, pool=True, producer=s.producer)
+        Ho, Wo = s.H // 2, s.W // 2
+        out = self.new((self.B, Ho, Wo, s.C))
+        a = L.ActSrc()
+        s.fill(a)
+        lib = self.lib
+        args = (a, s.dt, s.coff, s.C, self.B, out.data_ptr(), self.dt, s.C)
+        self.fwd_ops.append((lambda _r, st, g=args: lib.abc_pool_act(C.byref(g[0]), *g[1:], st), None, "pool", (),
+                             {"kernel": "pool_act", "flops": 0, "bytes": float(self.B * s.H * s.W * s.C * self._esz(s.dt) * 1.25)}))
+        r = Src(out, self.dt, Ho, Wo, s.C, 0, s.C, coef=None, pool=False, producer=s.producer)
+        r.via_pool = True
+        return r
 
     def up(self, name, low: Src, cat, cat_coef, Hs, Ws, Ctot, cout, skip_producer=None):
         """ConvTranspose2d(Ctot -> Ctot/2, k3, s2) of `low` into cat[..., Ctot/2:], then DoubleConv(Ctot -> cout)"""
@@ -469,7 +484,7 @@ class Engine:
             # the skip half belongs to the conv that wrote channels [0:half) of the cat buffer
             skip = [r for r in self.recs if r.kind == "conv" and r.y is src.t and r.coff == 0][0]
             skip.grad_same = (dsrc, rec.cin, 0)
-        elif src.pool:
+        elif src.pool or getattr(src, "via_pool", False):
             prod.grad_pool = (dsrc, rec.cin, 0)
         else:
             prod.grad_same = (dsrc, rec.cin, 0)

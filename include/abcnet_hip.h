@@ -302,6 +302,13 @@ int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream);
 int abc_add_into(void* dst, int32_t ld_dst, int32_t cdst_off, const void* src, int32_t ld_src, int32_t csrc_off, int32_t C,
                  int64_t npix, int32_t dtype, abc_stream_t stream);
 
+/* nn.MaxPool2d(2) of an activated tensor (unet.py:30), materialised once: out[b][y][x][c] = max over the 2x2 window
+ * of act(src[b][2y+dy][2x+dx][c_off + c]) (src->pool is ignored: src is read at full resolution).  The encoder's
+ * first convolution of every level and its weight gradient then read a plain NHWC tensor on their prefetch paths
+ * instead of pooling on load twice. */
+int abc_pool_act(const abc_act_src* src, int32_t dtype_in, int32_t c_off, int32_t C, int32_t B, void* out, int32_t dtype_out,
+                 int32_t ld_out, abc_stream_t stream);
+
 /* layout conversion helpers (multi-channel NCHW input images -> NHWC) */
 int abc_nhwc_to_nchw_f32(const float* src, int32_t ld, int32_t c_off, int32_t C, int32_t B, int32_t H, int32_t W,
                          float* dst, abc_stream_t stream);

@@ -203,6 +203,25 @@ def test_head_wgrad_fused_activation(lib, Cn, nsplit):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_pool_act_materialised(lib, dt):
+    """abc_pool_act == max_pool2d(act(x), 2) on a channel slice (unet.py:30)"""
+    g = torch.Generator().manual_seed(41)
+    B, H, W, ld, coff, Cn = 2, 12, 20, 48, 16, 24
+    x = q(torch.randn((B, ld, H, W), generator=g), dt)
+    sc, sh = torch.rand(ld, generator=g) * 2 - 0.6, torch.randn(ld, generator=g) * 0.3
+    sl = torch.tensor([0.0, 0.01, 1.0])[torch.randint(0, 3, (ld,), generator=g)]
+    ref = F.max_pool2d(act(x, sc, sh, sl)[:, coff:coff + Cn], 2)
+    xd = U.nhwc(x, dt)
+    coef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
+    a = L.ActSrc()
+    U.fill_src(a, xd, H, W, ld, coef)
+    out = torch.zeros((B, H // 2, W // 2, Cn), dtype=U.tdt(dt), device=U.DEV)
+    L.check(lib.abc_pool_act(C.byref(a), dt, coff, Cn, B, out.data_ptr(), dt, Cn, U.stream()), "pool_act")
+    torch.cuda.synchronize()
+    assert U.relerr(U.to_nchw(out), q(ref, dt)) < (1e-6 if dt == L.F32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_conv_transpose_into_concat(lib, dt):
     """4 parity phases == ConvTranspose2d(k3,s2) + crop of first row/col, written at a channel offset"""
     g = torch.Generator().manual_seed(5)
