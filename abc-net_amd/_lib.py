@@ -123,6 +123,7 @@ _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnAppl
 P = C.POINTER
 SYMBOLS = {
     "abc_conv_stat_blocks": (C.c_int, [P(ConvDesc)]),
+    "abc_conv_variant": (C.c_int, [vp]),
     "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),
     "abc_conv_chunk": (C.c_int, [C.c_int, C.c_int]),
     "abc_conv_tile": (C.c_int, [P(ConvDesc), P(i32), P(i32), P(i32)]),

@@ -512,6 +512,13 @@ extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, i
     return ABC_OK;
 }
 
+extern "C" int abc_conv_variant(const abc_conv_desc* d) {
+    if (abc_conv_stem_ok(d, nullptr)) return 2;
+    abc_fast_geom f;
+    if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return 1;
+    return 0;
+}
+
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
     { int nb = 0; if (abc_conv_stem_ok(d, &nb)) return nb; }
     abc_fast_geom f;

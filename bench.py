@@ -57,6 +57,19 @@ def cpu_baseline(size, seconds_budget=25.0, variant="unet"):
             "sample": "oracle fwd+loss+bwd (no optimiser), fp32, batch %d at %dx%d, median of %d warm iterations" % (B, size, size, len(times))}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/README.md says
+    how they were collected and corrected); None when no pass exists for this kernel label."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    rec = table.get(kernel)
+    return None if rec is None else rec["bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +154,7 @@ def main():
         r = prof[dom]
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK[a.dtype], "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": None,
+                           "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": pmc_traffic(dom),
                            "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
                            "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
         out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]}
