@@ -124,13 +124,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const abc_act_bwd_desc d) 
     T* g = (T*)d.g;
     const float dscale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
 
-    for (int64_t it = (int64_t)blockIdx.x * 256 + tid; it < nitems; it += stride) {
-        int64_t pix = it / ncv;
-        const int wx = (int)(pix % Ww); pix /= Ww;
-        const int wy = (int)(pix % Hw);
-        const int b = (int)(pix / Hw);
+    // 32-bit index arithmetic (checked on the host: fewer than 2^31 items); the vector count per pixel is a power of
+    // two for every layer of the network -> shift instead of a division
+    const bool pow2 = (ncv & (ncv - 1)) == 0;
+    const int lg = 31 - __builtin_clz((unsigned)ncv);
+    const unsigned n32 = (unsigned)nitems, st32 = (unsigned)stride;
+    for (unsigned it = blockIdx.x * 256u + tid; it < n32; it += st32) {
+        unsigned pix = pow2 ? (it >> lg) : (it / (unsigned)ncv);
         if (!pooled) {
-            const size_t p = ((size_t)b * d.H + wy) * d.W + wx;
+            const size_t p = pix;  // dense pixel index: (b, y, x) are not needed
             float x[N], da[N], out[N];
             ldv<T, N>(yr + p * d.ld_y + d.cy_off + c, x);
             ldv<T, N>(ds + p * d.ld_same + d.csame_off + c, da);
@@ -146,6 +148,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const abc_act_bwd_desc d) 
             }
             stv<N>(g + p * d.ld_g + c, out);
         } else {
+            const int wx = (int)(pix % (unsigned)Ww); pix /= (unsigned)Ww;
+            const int wy = (int)(pix % (unsigned)Hw);
+            const int b = (int)(pix / (unsigned)Hw);
             float x[4][N], dpool[N];
             size_t pq[4];
 #pragma unroll
@@ -336,6 +341,7 @@ static int act_bwd_check(const abc_act_bwd_desc* d) {
     if (d->dA_pool && ((d->H & 1) || (d->W & 1))) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: pooled dims must be even");
     if (!d->dA_pool && !d->dA_same) return abc_fail(ABC_EINVAL, "act_bwd: no gradient source");
     if ((d->ld_y | d->ld_g | d->cy_off) % N) return abc_fail(ABC_EINVAL, "act_bwd: alignment");
+    if ((int64_t)d->B * d->H * d->W * ncv >= (int64_t(1) << 31)) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: tensor too large for 32-bit indexing");
     return ABC_OK;
 }
 

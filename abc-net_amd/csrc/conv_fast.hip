@@ -22,12 +22,13 @@
 #include "capi_util.hpp"
 #include "conv_fast.hpp"
 #include <stdlib.h>
+#include <math.h>
 
 namespace {
 
 constexpr int FT = 256;      // threads per workgroup
 // halo segments a thread may hold (3x3 taps, 64-byte chunks: (2*MT+2) x 18 pixels x 4 segments over 256 threads)
-__host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 6 : (mt >= 6 ? 4 : 3); }
+__host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 6 : (mt >= 6 ? 4 : (mt >= 4 ? 3 : 2)); }
 constexpr int SR_MAX = 256;  // weight rows per stage (tap group x BN)
 constexpr int LDS_WG = 80 * 1024;
 
@@ -403,7 +404,13 @@ int launch_mt(const FastK& k, const abc_fast_geom& g, int stride, hipStream_t st
         if (stride == 1 && g.MT == 6) return launch_inst<InT, CT, OutT, CK, BN, 1, 6>(k, g, st);
     }
     if (stride == 2) return launch_inst<InT, CT, OutT, CK, BN, 2, 4>(k, g, st);
-    return g.MT == 8 ? launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st) : launch_inst<InT, CT, OutT, CK, BN, 1, 4>(k, g, st);
+    if constexpr (BN >= 64) {
+        if (g.MT == 2) return launch_inst<InT, CT, OutT, CK, BN, 1, 2>(k, g, st);
+    }
+    if constexpr (BN != 128) {
+        if (g.MT == 8) return launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st);
+    }
+    return launch_inst<InT, CT, OutT, CK, BN, 1, 4>(k, g, st);
 }
 
 template <typename InT, typename CT, typename OutT, int CK>
@@ -430,8 +437,6 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     if (g->CK <= 0 || d->Cin % g->CK) return ABC_OK;
     const int64_t bytes_a = (int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4);
     if (bytes_a >= (int64_t(1) << 31)) return ABC_OK;
-    g->BN = (d->Cout_pad % 128 == 0) ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
-    g->nbn = d->Cout_pad / g->BN;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
     for (int t = 0; t < d->ntaps; ++t) {
         dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
@@ -444,40 +449,55 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->cstride = abc_roundup(d->Cin, 4);
     const int coef_bytes = abc_roundup(3 * g->cstride * 4, 256);
     const int osz = d->dtype_out == ABC_BF16 ? 2 : 4;
-    const int tn = g->BN >= 64 ? g->BN / 64 : 1;
-    const int stg = 4 * 32 * (tn * 32 * osz + 16);
-    const int red = 4 * 4 * g->BN * 4;
 
-    // candidate patch heights; score = estimated time of the launch in units of "one 32-pixel m-tile of work"
-    // with 512 workgroup slots (2 per CU): full rounds cost MT each, a last round that fills at most half the slots
-    // runs with a CU to itself (cheaper), see DESIGN.md
-    const int cand_all[3] = {8, 6, 4};
-    int best = -1;
-    double best_cost = 0;
+    // tile shape (BN output channels x MT*32 pixels) by a small time model calibrated on the round-1 profiles
+    // (DESIGN.md section 3): a workgroup walks nchunks x ngroups stages; a stage costs max(0.47 us of staging /
+    // barrier latency, its MFMAs at 32 cycles each, twice that when the CU is shared); a round costs ~12 us of
+    // prologue + epilogue; rounds = ceil(tiles / 512 slots).  Deep layers (12x12 .. 24x24 pixels, K loops of 80 .. 160
+    // stages) thus get narrow tiles with few tap groups, wide layers the biggest tile that fits the registers.
+    const int bn_nat = (d->Cout_pad % 128 == 0) ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
     const char* force = getenv("ABC_CONV_MT");
-    for (int ci = 0; ci < 3; ++ci) {
-        const int mt = cand_all[ci];
-        if (force && atoi(force) != mt) continue;
-        if (mt == 6 && (g->BN != 128 || d->stride != 1)) continue;
-        if (mt == 8 && g->BN == 128) continue;  // 4 x 2 tiles per wave + staging registers exceed 256 VGPRs
-        if (d->stride == 2 && mt != 4) continue;
-        const int prow = 2 * mt;
-        const int hh = (prow - 1) * d->stride + (dymax - dymin) + 1, hw = 15 * d->stride + (dxmax - dxmin) + 1;
-        if (abc_cdiv(hh * hw * segs, FT) > fa_max(mt) || hh * hw * hw >= 65536) continue;
-        const int rs = abc_roundup(hw * g->PS, 256);
-        const int sa = abc_roundup(hh * rs, 256);
-        if (sa + 2 * 128 * g->PS + coef_bytes + 256 > LDS_WG) continue;
-        const long tiles = (long)g->nbn * abc_cdiv(d->Wg, 16) * abc_cdiv(d->Hg, prow) * d->B;
-        const double rounds = (double)tiles / 512.0;
-        const long full = (long)rounds;
-        const double frac = rounds - full;
-        const double waste = (double)(abc_cdiv(d->Hg, prow) * prow) / d->Hg;  // rows computed beyond the image
-        double cost = (full + (frac == 0 ? 0.0 : (frac <= 0.5 ? 0.65 : 1.0))) * mt * (1.0 + 0.15 * (8 - mt) / 4.0);
-        (void)waste;
-        if (best < 0 || cost < best_cost) { best = mt; best_cost = cost; }
+    const char* force_bn = getenv("ABC_CONV_BN");
+    int best = -1, best_bn = 0;
+    double best_cost = 0;
+    for (int bn = bn_nat; bn >= 32; bn >>= 1) {
+        if (bn < 64 && bn != bn_nat) break;          // only 128 -> 64 is offered as a narrower tile
+        if (force_bn && atoi(force_bn) != bn) continue;
+        const int cand_all[4] = {8, 6, 4, 2};
+        for (int ci = 0; ci < 4; ++ci) {
+            const int mt = cand_all[ci];
+            if (force && atoi(force) != mt) continue;
+            if (mt == 6 && (bn != 128 || d->stride != 1)) continue;
+            if (mt == 8 && bn == 128) continue;  // 4 x 2 tiles per wave + staging registers exceed 256 VGPRs
+            if (mt == 2 && bn == 32) continue;   // 4 x 1 wave layout needs 4 m-tiles
+            if (d->stride == 2 && mt != 4) continue;
+            const int prow = 2 * mt;
+            const int hh = (prow - 1) * d->stride + (dymax - dymin) + 1, hw = 15 * d->stride + (dxmax - dxmin) + 1;
+            if (abc_cdiv(hh * hw * segs, FT) > fa_max(mt) || hh * hw * hw >= 65536) continue;
+            const int rs = abc_roundup(hw * g->PS, 256);
+            const int sa = abc_roundup(hh * rs, 256);
+            if (sa + 2 * 128 * g->PS + coef_bytes + 256 > LDS_WG) continue;
+            const long tiles = (long)(d->Cout_pad / bn) * abc_cdiv(d->Wg, 16) * abc_cdiv(d->Hg, prow) * d->B;
+            int tg = SR_MAX / bn; if (tg > d->ntaps) tg = d->ntaps;
+            const int ngroups = abc_cdiv(d->ntaps, tg);
+            const int nstages = (d->Cin / g->CK) * ngroups;
+            const int wn = bn >= 64 ? 2 : 1, tm = mt / (4 / wn), tnn = (bn / 32) / wn;
+            const double mfma_stage = (double)d->ntaps / ngroups * (CKB / 32) * tm * tnn * (csz == 2 ? 1 : 8);
+            const double share = tiles > 256 ? 2.0 : 1.0;
+            const double t_stage = fmax(0.47, 0.0168 * share * mfma_stage);
+            const double rounds = ceil((double)tiles / 512.0);
+            // (ties: the shape with more workgroups covers more CUs and wastes fewer rows)
+            const double cost = rounds * (nstages * t_stage + 12.0) - 1e-3 * (double)(tiles < 512 ? tiles : 512);
+            if (best < 0 || cost < best_cost) { best = mt; best_bn = bn; best_cost = cost; }
+        }
     }
     if (best < 0) return ABC_OK;
     g->MT = best;
+    g->BN = best_bn;
+    g->nbn = d->Cout_pad / g->BN;
+    const int tn = g->BN >= 64 ? g->BN / 64 : 1;
+    const int stg = 4 * 32 * (tn * 32 * osz + 16);
+    const int red = 4 * 4 * g->BN * 4;
     const int prow = 2 * g->MT;
     g->HH = (prow - 1) * d->stride + (dymax - dymin) + 1;
     g->HW = 15 * d->stride + (dxmax - dxmin) + 1;
