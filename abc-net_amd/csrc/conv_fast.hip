@@ -153,10 +153,21 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         const int n0 = nb * BN;
         w_n0 = (unsigned)(n0 * CK) * (unsigned)sizeof(CT);
         const int iy0 = gy0 * STRIDE + a.dy_min, ix0 = gx0 * STRIDE + a.dx_min;
+        float bv[TN];   // bias of this lane's output channels: loaded here, used in the epilogue (latency under the main loop)
+        bool nval[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + r;
+            nval[j] = n < a.Cout;
+            bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
+        }
 
-        // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile)
-        apre.setup(gA, a.RS, PS, b, iy0, ix0, a.cin_off, tid);
-        apre.issue(rsA, 0u);
+        // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile).
+        // Persistent (resident-weight) workgroups prefetched this tile's halo during the previous tile.
+        if (!STATIC || first_tile) {
+            apre.setup(gA, a.RS, PS, b, iy0, ix0, a.cin_off, tid);
+            apre.issue(rsA, 0u);
+        }
         int ci = 0, gi = 0;  // (chunk, tap group) of the next stage to issue
         auto issue_next = [&](u32x4* set) {
             b_issue(set, ci, gi);
@@ -186,6 +197,18 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         if constexpr (!STATIC) b_commit(breg[0], 0, sB);
         first_tile = false;
         __syncthreads();
+        if constexpr (STATIC) {
+            // narrow layers are bound by the latency of one tile (10 KB in, 8 KB out, 18 MFMAs per wave): start the
+            // next tile's halo now, it lands under this tile's MFMAs and stores
+            const int nt = tile + (int)gridDim.x;
+            if (nt < a.ntiles) {
+                int id2 = nt / a.nblocks_n;
+                const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
+                const int ty2 = id2 % a.tiles_y; id2 /= a.tiles_y;
+                apre.setup(gA, a.RS, PS, id2, ty2 * (2 * MT) * STRIDE + a.dy_min, tx2 * 16 * STRIDE + a.dx_min, a.cin_off, tid);
+                apre.issue(rsA, 0u);
+            }
+        }
         if (prof && tid == 0) prof[1] = wall_clock64();
 
         // ---- main loop, unrolled by 2 so that the two register sets have fixed names.  Stage s: its weights sit in
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                             apre.commit(sA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
                         }
                     }
-                    __syncthreads();
+                    if constexpr (!STATIC) __syncthreads();  // (resident weights + single halo chunk: nothing changes hands)
                     c = cn; g = gn;
                 }
             }
@@ -288,15 +311,9 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         // stores of consecutive channels of one pixel).  The staging region aliases the halo / weight buffers: every
         // wave passed the barrier that ended the last stage, so they are dead (resident weights are kept clear of it).
         OutT* yo = (OutT*)a.y;
-        float s1[TN], s2[TN], smx[TN], smn[TN], bv[TN];
-        bool nval[TN];
+        float s1[TN], s2[TN], smx[TN], smn[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            s1[j] = 0.f; s2[j] = 0.f; smx[j] = -3.0e38f; smn[j] = 3.0e38f;
-            const int n = n0 + (wn * TN + j) * 32 + r;
-            nval[j] = n < a.Cout;
-            bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
-        }
+        for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; smx[j] = -3.0e38f; smn[j] = 3.0e38f; }
         constexpr int TW = TN * 32;
         constexpr int ROWB = TW * (int)sizeof(OutT) + 16;
         constexpr int EV = 16 / (int)sizeof(OutT);
@@ -304,7 +321,53 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         char* stg = smem + a.stg_off + wave * (32 * ROWB);
         const int cbase = n0 + wn * TW;
         const bool vec_ok = ((a.ldy | a.cout_off) % EV) == 0;
-        if (!(a.dbg & 64)) {
+        // The epilogue is VALU work per output value (narrow layers are bound by it: 16 instructions per value cost
+        // 39 us on the 16-channel 384x384 layers).  Fast path for whole tiles with plain 16-byte stores: add bias,
+        // sum, sum of squares, convert, one ds_write per value with an immediate offset; max / min in a second sweep
+        // only when unet2's CBAM asks for them; the general path keeps every check.
+        const bool whole = (gy0 + 2 * MT <= a.Hg) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok;
+        if (a.dbg & 64) {
+        } else if (whole) {
+            char* wbase = stg + 4 * h * ROWB + r * (int)sizeof(OutT);
+            const int lrow = lane / SEG_PER_ROW, lsg = lane % SEG_PER_ROW;   // this lane's (pixel row, segment) in the store sweep
+            constexpr int RSTEP = 64 / SEG_PER_ROW;                            // pixel rows covered per sweep step
+            const bool seg_ok = cbase + lsg * EV < a.Cout;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float v = acc[i][j][k] + bv[j];
+                        s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
+                        *(OutT*)(wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT)) = (OutT)v;
+                    }
+                }
+                lds_wave_sync();
+                // pixel rit = lrow + RSTEP * step of the wave's 32: patch row 2 (wm TM + i) + (rit >> 4), column rit & 15
+                const int gyb = gy0 + 2 * (wm * TM + i);
+#pragma unroll
+                for (int st = 0; st < 32 / RSTEP; ++st) {
+                    const int rit = lrow + RSTEP * st;
+                    const int gy = gyb + (rit >> 4), gx = gx0 + (rit & 15);
+                    const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cbase + lsg * EV;
+                    if (seg_ok) *(f32x4*)(yo + o) = *(const f32x4*)(stg + rit * ROWB + lsg * 16);
+                }
+                lds_wave_sync();
+            }
+            if (a.stats_rows == 4) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) { const float v = acc[i][j][k] + bv[j]; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
+            }
+            // channels past Cout (padding lanes of the last n-block) carry bias-free zeros: keep them out of the sums
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (!nval[j]) { s1[j] = 0.f; s2[j] = 0.f; }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
