@@ -91,6 +91,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # (testing hooks: ABC_BENCH_DEVICE pins every rank to one device and ABC_BENCH_BACKEND=gloo replaces RCCL, so that
+    #  the N > 1 code path -- bucketed all-reduce between graph segments -- can be exercised on a 1-GPU box)
+    if "ABC_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["ABC_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -104,7 +108,7 @@ def main():
         from abcnet_amd.unet import UNet
 
     if world > 1:
-        D.init_process_group(rank=rank, world_size=world)
+        D.init_process_group(backend=os.environ.get("ABC_BENCH_BACKEND"), rank=rank, world_size=world)
 
     model = UNet(1, HEADS, dtype=a.dtype)
     model.reset_parameters(seed=1234)  # identical random init on every rank (and re-broadcast below)
@@ -137,6 +141,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
     loss = tr.loss_value()["total"]
+    if world > 1 and os.environ.get("ABC_BENCH_CHECK"):
+        # replicas must hold identical parameters after the averaged updates
+        chk = model._flat.data.double().sum().reshape(1)
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        if rank == 0:
+            print("replica checksums", [b.item() for b in both], file=sys.stderr)
+            assert all(abs(b.item() - both[0].item()) == 0.0 for b in both), "replicas diverged"
 
     out = {
         "metric": "training images/sec (384x384, b16/GPU)", "value": round(world * a.batch * a.steps / el, 2), "unit": "images/sec",
