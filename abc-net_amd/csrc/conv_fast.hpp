@@ -14,3 +14,7 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
 // one-channel first convolution (stem.hip)
 int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks);
 int abc_conv_stem_launch(const abc_conv_desc* d, abc_stream_t stream);
+
+// heads' 1x1 convolution forward into NCHW f32 (heads.hip)
+int abc_head_fwd_ok(const abc_conv_desc* d);
+int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream);

@@ -1,0 +1,125 @@
+// Forward of the heads' 1x1 convolutions (unet.py:70, out_modules[i].conv2): logits[co][p] = b[co] + sum_ci W[co][ci] a[p][ci]
+// with a = dropout(LeakyReLU(BN(h))) applied on load and the output in the reference's NCHW f32 layout.
+//
+// GEMM view: M = output channels (<= 360), N = pixels, K = 128.  Both operands already have the MFMA fragment layout in
+// memory: a pixel's 128 channels are contiguous (NHWC) = the B operand's 8 consecutive k per lane, the packed weights
+// give the A operand, and the accumulator layout (lane = pixel column, registers = output channels) stores straight into
+// channel-planar rows, 128 contiguous bytes per row.  So: no LDS, no barriers; every wave owns 64 pixels (two 32-pixel
+// tiles whose activated fragments stay in registers) and walks the m-tiles.  HBM-bound on the logits it writes.
+#include "common.hpp"
+#include "../../include/abcnet_hip.h"
+#include "capi_util.hpp"
+#include "conv_fast.hpp"
+#include <stdlib.h>
+
+namespace {
+
+struct HeadFwdK {
+    const void* x;
+    const float *sc, *sh, *sl;
+    const void* w;        // packed [1 tap][4 chunks][Cout_pad][32] bf16
+    const float* bias;
+    float* y;             // [B][ctot][HW]
+    int HW, ldx, cin_off, Cout, Cout_pad, ctot, cout_off, npairs;
+    float drop_p;
+    uint32_t drop_seed;
+    unsigned bytesX, bytesW;
+};
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdK a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.x * 4 + wave;   // 64 consecutive pixels (never straddling an image: HW % 64 == 0)
+    if (pair >= a.npairs) return;
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX), rsW = abc_make_rsrc(a.w, a.bytesW);
+    const bool tr = a.sc != nullptr;
+    const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+
+    // ---- B fragments of both pixel tiles: lane (pixel r, half h) takes channels 16 kk + 8 h .. + 8 of its pixel
+    bf16x8 fb[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t pix = (uint32_t)pair * 64u + t * 32 + r;
+        const uint32_t e0 = pix * (uint32_t)a.ldx + (uint32_t)a.cin_off + 8 * h;
+        u32x4 raw[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (e0 + 16 * kk) * 2u, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(raw[kk][j] << 16); v[2 * j + 1] = __uint_as_float(raw[kk][j] & 0xFFFF0000u); }
+            const int c = a.cin_off + 16 * kk + 8 * h;
+            if (tr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = abc_act(v[j], a.sc[c + j], a.sh[c + j], a.sl[c + j]);
+            }
+            if (a.drop_p > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(e0 + 16 * kk + j, a.drop_seed, a.drop_p) ? v[j] * dscale : 0.f;
+            }
+            fb[t][kk] = pack_frag<bf16>(v);
+        }
+    }
+    const int b = (pair * 64) / a.HW, pp = pair * 64 - b * a.HW;
+    const int mtiles = a.Cout_pad / 32;
+    for (int mt = 0; mt < mtiles; ++mt) {
+        // A fragments of this m-tile: row co = 32 mt + r, channels 16 kk + 8 h .. + 8 (chunk kk / 2 of the packed layout)
+        bf16x8 fa[8];
+        const int co = mt * 32 + r;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const unsigned off = (unsigned)((((kk >> 1) * a.Cout_pad + co) * 32 + 16 * (kk & 1) + 8 * h) * 2);
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
+            fa[kk] = *(const bf16x8*)&t;
+        }
+        float bvv[16];  // bias of this lane's 16 output rows of the m-tile (loaded once, both pixel tiles use it)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+            bvv[k] = (a.bias && oc < a.Cout) ? a.bias[oc] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[t][kk], acc, 0, 0, 0);
+            // accumulator: column = pixel r of tile t, register k = output channel 32 mt + (k & 3) + 8 (k >> 2) + 4 h
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                if (oc < a.Cout) {
+                    const float v = acc[k] + bvv[k];
+                    a.y[((size_t)(b * a.ctot + a.cout_off + oc)) * a.HW + pp + t * 32 + r] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int abc_head_fwd_ok(const abc_conv_desc* d) {
+    if (getenv("ABC_CONV_NOHEAD")) return 0;
+    if (!d->planar_out || d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
+    if (d->Cin != 128 || d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_F32) return 0;
+    if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr) return 0;
+    if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
+    if ((d->src.ldx % 8) || (d->cin_off % 8) || d->Cout_pad % 32) return 0;
+    const int64_t bx = (int64_t)d->B * d->Hg * d->Wg * d->src.ldx * 2;
+    return bx < (int64_t(1) << 31);
+}
+
+int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream) {
+    HeadFwdK k;
+    k.x = d->src.x; k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.w = d->w; k.bias = d->bias; k.y = (float*)d->y;
+    k.HW = d->Hg * d->Wg; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;
+    k.ctot = d->ctot_out; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
+    k.drop_p = d->src.drop_p; k.drop_seed = d->src.drop_seed;
+    k.bytesX = (unsigned)((int64_t)d->B * k.HW * d->src.ldx * 2);
+    k.bytesW = (unsigned)((int64_t)4 * d->Cout_pad * 32 * 2);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+    return abc_check_launch("head_fwd");
+}
