@@ -37,7 +37,7 @@ struct WgK {
     int B, Hg, Wg, Hq, Wq;
     int cp_off, Ca, cq_off, Cb, Ca_pad, Cb_pad;
     int ntaps, tgw, nsplit, npatch, tiles_x, tiles_y;
-    int dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, nta, ntb, fast_p, fast_q, nbuf, dbg, magicQ;
+    int dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, nta, ntb, fast_p, fast_q, nbuf, dbg, magicQ, k3;
     unsigned bytesP, bytesQ;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
@@ -58,7 +58,7 @@ __device__ inline void stage_slow(char* dst, int RS, int PS, int HH, int HW, int
     stage_halo<T, CT, CW>(dst, RS, PS, HH, HW, b, iy0, ix0, Hin, Win, *s, c0, tid, WTHR, cvalid);
 }
 
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM>
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
     constexpr int MAXT = FAST ? MAXT_FAST : MAXT_SLOW;
     constexpr int RSPLIT = 8 / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
@@ -173,7 +173,31 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
 #pragma unroll 1
             for (int rr = 0; rr < ROWS; ++rr) {
                 const int row = row_lo + rr;
-                if constexpr (sizeof(CT) == 2) {
+                if constexpr (sizeof(CT) == 2 && FAST && K3) {
+                    {
+                        // the usual case, a full 3x3 tap square: tap offsets are immediates, all 10 fragments of the
+                        // K-step are read first (one wait), then 9 MFMAs back to back; the generic loop below pays a
+                        // branch, two address adds and an exposed LDS round trip per tap
+                        constexpr int HW3 = 15 * STRIDE + 3;
+                        constexpr int PQ = CWQ == 32 ? 64 : (CWQ == 64 ? 192 : 320);
+                        constexpr int PP = CWP == 32 ? 64 : (CWP == 64 ? 192 : 320);
+                        const int kq = 8 * h + ((lane & 15) >> 2);
+                        const char* pa = sP + (row * 16 + kq) * PP + pch;
+                        const char* qb = sQ + ((row * STRIDE) * HW3 + kq * STRIDE) * PQ + qch;
+                        const bf16x8 fa = tr_read8(pa, pa + 4 * PP);
+                        bf16x8 fb[9];
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int off = ((t / 3) * HW3 + (t % 3)) * PQ;
+                            fb[t] = tr_read8(qb + off, qb + off + 4 * STRIDE * PQ);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[t], acc[t], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if constexpr (sizeof(CT) == 2) {
                     // lane supplies the address of pixel k = 8h + 4q + ((lane&15)>>2), 4 channels
                     const int kq = 8 * h + ((lane & 15) >> 2);
                     const char* pa = sP + (row * 16 + kq) * PSWP + pch;
@@ -619,7 +643,8 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     const int ta = abc_cdiv(d->Ca, 32), tb = abc_cdiv(d->Cb, 32);
     // 32x32 tile pairs per workgroup (one pair per wave, the remaining waves split the patch rows).  Ragged channel
     // tails are fine (zero-filled): wide tiles are what keeps the operands from being re-staged per pair.
-    if (d->stride == 1 && csz == 2 && ta >= 3 && tb >= 2) { g->AT = 4; g->BT = 2; }
+    static const bool no42 = getenv("ABC_WGRAD_NO42") != nullptr;  // (experiment switch)
+    if (!no42 && d->stride == 1 && csz == 2 && ta >= 3 && tb >= 2) { g->AT = 4; g->BT = 2; }
     else if (d->stride == 1 && ta >= 2 && tb >= 2) { g->AT = 2; g->BT = 2; }
     else if (d->stride == 1 && csz == 2 && ta == 1 && tb >= 4) { g->AT = 1; g->BT = 4; }
     else { g->AT = 1; g->BT = 1; }
@@ -632,9 +657,9 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     return wgeom_pm(d, g, 1);
 }
 
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM = 1>
-static int wlaunch2(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
-    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM>;
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3>
+static int wlaunch3(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
+    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -642,6 +667,14 @@ static int wlaunch2(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
     }
     hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(WTHR), g.lds, st, k);
     return abc_check_launch("wgrad");
+}
+
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM = 1>
+static int wlaunch2(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
+    if constexpr (FAST && sizeof(CT) == 2) {
+        if (k.k3) return wlaunch3<PT, QT, CT, AT, BT, STRIDE, FAST, PM, true>(k, g, nsplit, st);
+    }
+    return wlaunch3<PT, QT, CT, AT, BT, STRIDE, FAST, PM, false>(k, g, nsplit, st);
 }
 
 template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE>
@@ -725,6 +758,9 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     k.sP_bytes = g.sP_bytes; k.sQ_bytes = g.sQ_bytes; k.coef_off = g.coef_off; k.cstrP = g.cstrP; k.cstrQ = g.cstrQ;
     k.nta = g.nta; k.ntb = g.ntb; k.fast_p = g.fast_p; k.fast_q = g.fast_q; k.nbuf = g.nbuf;
     k.magicQ = 65536 / g.HW + 1;
+    k.k3 = (d->ntaps == 9 && g.ngroups == 1 && g.HW == 15 * d->stride + 3) ? 1 : 0;
+    for (int t = 0; t < d->ntaps && k.k3; ++t)
+        if (d->tap_dy[t] - g.dy_min != t / 3 || d->tap_dx[t] - g.dx_min != t % 3) k.k3 = 0;
     k.bytesP = (unsigned)((int64_t)d->B * d->p.Hx * d->p.Wx * d->p.ldx * (d->dtype_p == ABC_BF16 ? 2 : 4));
     k.bytesQ = (unsigned)((int64_t)d->B * d->q.Hx * d->q.Wx * d->q.ldx * (d->dtype_q == ABC_BF16 ? 2 : 4));
     { const char* e = getenv("ABC_WGRAD_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
