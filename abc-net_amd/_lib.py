@@ -54,7 +54,8 @@ class ActBwdDesc(C.Structure):
 
 class BnBwdDesc(C.Structure):
     _fields_ = [("partial", vp), ("nblk", i32), ("C", i32), ("count", f64), ("gamma", vp), ("invstd", vp),
-                ("dgamma", vp), ("dbeta", vp), ("k1", vp), ("k2", vp), ("gscale", vp)]
+                ("dgamma", vp), ("dbeta", vp), ("k1", vp), ("k2", vp), ("gscale", vp),
+                ("mean", vp), ("ca", vp), ("cb", vp), ("cc", vp)]
 
 
 class BnApplyDesc(C.Structure):
@@ -66,7 +67,8 @@ class WgradDesc(C.Structure):
     _fields_ = [("p", ActSrc), ("q", ActSrc), ("partial", vp), ("dtype_p", i32), ("dtype_q", i32), ("dtype_c", i32),
                 ("B", i32), ("Hg", i32), ("Wg", i32), ("Hq", i32), ("Wq", i32), ("cp_off", i32), ("Ca", i32),
                 ("cq_off", i32), ("Cb", i32), ("stride", i32), ("ntaps", i32), ("nsplit", i32),
-                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS)]
+                ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS),
+                ("p2", vp), ("ld_p2", i32), ("cp2_off", i32), ("p_dual", i32), ("p_out", vp), ("ld_pout", i32)]
 
 
 class WgradReduceDesc(C.Structure):
@@ -137,6 +139,7 @@ SYMBOLS = {
     "abc_act_bwd": (C.c_int, [P(ActBwdDesc), vp]),
     "abc_bn_finalize_bwd": (C.c_int, [P(BnBwdDesc), vp]),
     "abc_bn_apply_bwd": (C.c_int, [P(BnApplyDesc), vp]),
+    "abc_wgrad_fuses_apply": (C.c_int, [vp]),
     "abc_wgrad_pads": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),
     "abc_wgrad_blocks": (C.c_int, [P(WgradDesc)]),
     "abc_wgrad_tile": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),

@@ -77,7 +77,14 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const abc_bn_bwd_d
         if (d.dgamma != nullptr) d.dgamma[c] = (float)s2;
         d.k1[c] = (float)(s1 / d.count);
         d.k2[c] = (float)(s2 / d.count);
-        d.gscale[c] = d.gamma[c] * d.invstd[c];
+        const float gs = d.gamma[c] * d.invstd[c];
+        d.gscale[c] = gs;
+        if (d.ca != nullptr) {
+            const float k1 = (float)(s1 / d.count), k2 = (float)(s2 / d.count), is = d.invstd[c];
+            d.ca[c] = gs;
+            d.cb[c] = -gs * k2 * is;
+            d.cc[c] = gs * (d.mean[c] * is * k2 - k1);
+        }
     }
 }
 

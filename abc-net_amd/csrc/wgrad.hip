@@ -38,7 +38,8 @@ struct WgK {
     int cp_off, Ca, cq_off, Cb, Ca_pad, Cb_pad;
     int ntaps, tgw, nsplit, npatch, tiles_x, tiles_y;
     int dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, nta, ntb, fast_p, fast_q, nbuf, dbg, magicQ, k3;
-    unsigned bytesP, bytesQ;
+    unsigned bytesP, bytesQ, bytesP2;
+    const void* p2; void* p_out; int ld_p2, cp2_off, ld_pout;  // BN-backward correction fused into the load of P (DUAL)
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
 
@@ -58,7 +59,7 @@ __device__ inline void stage_slow(char* dst, int RS, int PS, int HH, int HW, int
     stage_halo<T, CT, CW>(dst, RS, PS, HH, HW, b, iy0, ix0, Hin, Win, *s, c0, tid, WTHR, cvalid);
 }
 
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3>
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
     constexpr int MAXT = FAST ? MAXT_FAST : MAXT_SLOW;
     constexpr int RSPLIT = 8 / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
@@ -128,6 +129,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
     HaloFetch<PT, CT, CWP, FAST ? NPF_P : 1, WTHR> pp;
     HaloFetch<QT, CT, CWQ, FAST ? NPF_Q : 1, WTHR> pq;
     const __amdgpu_buffer_rsrc_t rsP = abc_make_rsrc(a.p.x, a.bytesP), rsQ = abc_make_rsrc(a.q.x, a.bytesQ);
+    // DUAL: P = ca * g + cb * y_raw + cc (the BatchNorm-backward correction, abc_bn_bwd_desc.ca/cb/cc), g and y_raw
+    // fetched side by side; the corrected values go to LDS for the MFMAs and (from the b-tile-0 workgroups) to p_out
+    // for the data-gradient conv: one pass over g and y instead of abc_bn_apply_bwd's read-modify-write plus a re-read
+    HaloFetch<PT, CT, CWP, (FAST && DUAL) ? NPF_P : 1, WTHR> pp2;
+    const __amdgpu_buffer_rsrc_t rsP2 = abc_make_rsrc(DUAL ? a.p2 : a.p.x, DUAL ? a.bytesP2 : a.bytesP);
+    const HaloGeom gP2 = {PROWS, 16, 4097, a.Hg, a.Wg, a.Hg, a.Wg, a.ld_p2};
     const HaloGeom gP = {PROWS, 16, 4097, a.Hg, a.Wg, a.p.Hx, a.p.Wx, a.p.ldx};
     const HaloGeom gQ = {a.HH, a.HW, a.magicQ, a.Hq, a.Wq, a.q.Hx, a.q.Wx, a.q.ldx};
 
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
         patch_origin(patch, b, gy0, gx0);
         if constexpr (FAST) {
             pp.issue(rsP, gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
+            if constexpr (DUAL) pp2.issue(rsP2, gP2, b, gy0, gx0, a.cp2_off + ca0, tid, cvalP);
             pq.issue(rsQ, gQ, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.cq_off + cb0, tid, cvalQ);
         }
     };
@@ -151,7 +159,34 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
         char* sP = buf;
         char* sQ = buf + a.sP_bytes;
         if constexpr (FAST) {
-            pp.commit(sP, 16 * PSWP, PSWP, gP, coefP ? sCoefP : nullptr, a.cstrP, tid, cvalP);
+            if constexpr (DUAL) {
+                constexpr int NV = Frag<CT>::NV, SEGS = CWP / NV;
+                const int lt = abc_launder(tid);
+                const int part = lt % SEGS, cch = part * NV;
+                const bool chan = cch < cvalP;
+                float ka[NV], kb[NV], kc[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) { ka[j] = sCoefP[cch + j]; kc[j] = sCoefP[a.cstrP + cch + j]; kb[j] = sCoefP[2 * a.cstrP + cch + j]; }
+                const bool store = (bt == 0) && (blockIdx.y == 0) && a.p_out != nullptr;
+#pragma unroll
+                for (int i = 0; i < NPF_P; ++i) {
+                    const int sidx = lt + i * WTHR;
+                    if (sidx < PROWS * 16 * SEGS) {
+                        const int pix = sidx / SEGS, hy = pix >> 4, hx = pix & 15;
+                        float v1[NV], v2[NV];
+                        pp.raw[i].get(v1); pp2.raw[i].get(v2);
+                        const bool in = chan && ((pp.inb >> i) & 1u);
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) v1[j] = in ? fmaf(ka[j], v1[j], fmaf(kb[j], v2[j], kc[j])) : 0.f;
+                        const typename Frag<CT>::type f = pack_frag<CT>(v1);
+                        *(typename Frag<CT>::type*)(sP + (hy * 16 + hx) * PSWP + part * 16) = f;
+                        if (store && in)
+                            *(typename Frag<CT>::type*)((CT*)a.p_out + ((size_t)(b * a.Hg + gy0 + hy) * a.Wg + gx0 + hx) * a.ld_pout + ca0 + cch) = f;
+                    }
+                }
+            } else {
+                pp.commit(sP, 16 * PSWP, PSWP, gP, coefP ? sCoefP : nullptr, a.cstrP, tid, cvalP);
+            }
             pq.commit(sQ, a.HW * PSWQ, PSWQ, gQ, coefQ ? sCoefQ : nullptr, a.cstrQ, tid, cvalQ);
         } else {
             stage_slow<PT, CT, CWP>(sP, 16 * PSWP, PSWP, PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, &a.p, a.cp_off + ca0, tid, cvalP);
@@ -636,7 +671,18 @@ static int wgeom_pm(const abc_wgrad_desc* d, WGeom* g, int pm) {
     return ABC_OK;
 }
 
+// BN-backward correction on load of P: prefetch path for both operands, bf16 everywhere, full 3x3 square, stride 1
+static bool dual_ok(const abc_wgrad_desc* d, const WGeom& g) {
+    if (!(g.fast_p && g.fast_q) || d->stride != 1 || d->ntaps != 9 || g.ngroups != 1 || g.HW != 18) return false;
+    if (d->dtype_p != ABC_BF16 || d->dtype_q != ABC_BF16 || d->dtype_c != ABC_BF16) return false;
+    if (d->p.scale == nullptr || d->p2 == nullptr || (d->ld_p2 % 8) || (d->cp2_off % 8) || (d->p_out && (d->ld_pout % 8))) return false;
+    for (int t = 0; t < 9; ++t)
+        if (d->tap_dy[t] - g.dy_min != t / 3 || d->tap_dx[t] - g.dx_min != t % 3) return false;
+    return (int64_t)d->B * d->Hg * d->Wg * d->ld_p2 * 2 < (int64_t(1) << 31);
+}
+
 static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
+
     if (d->ntaps < 1 || d->ntaps > ABC_MAX_TAPS) return abc_fail(ABC_EINVAL, "wgrad: ntaps");
     if (d->stride != 1 && d->stride != 2) return abc_fail(ABC_EUNSUPPORTED, "wgrad: stride");
     const int csz = d->dtype_c == ABC_BF16 ? 2 : 4;
@@ -657,9 +703,9 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     return wgeom_pm(d, g, 1);
 }
 
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3>
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false>
 static int wlaunch3(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
-    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3>;
+    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3, DUAL>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -672,8 +718,12 @@ static int wlaunch3(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
 template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM = 1>
 static int wlaunch2(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
     if constexpr (FAST && sizeof(CT) == 2) {
+        if constexpr (sizeof(PT) == 2 && sizeof(QT) == 2 && STRIDE == 1) {
+            if (k.k3 && k.p2 != nullptr) return wlaunch3<PT, QT, CT, AT, BT, STRIDE, FAST, PM, true, true>(k, g, nsplit, st);
+        }
         if (k.k3) return wlaunch3<PT, QT, CT, AT, BT, STRIDE, FAST, PM, true>(k, g, nsplit, st);
     }
+    if (k.p2 != nullptr) return abc_fail(ABC_EUNSUPPORTED, "wgrad: p_dual needs the prefetch path with 3x3 taps in bf16");
     return wlaunch3<PT, QT, CT, AT, BT, STRIDE, FAST, PM, false>(k, g, nsplit, st);
 }
 
@@ -698,6 +748,13 @@ static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipSt
 }
 
 }  // namespace
+
+extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {
+    if (head_ok(d) || c1_ok(d)) return 0;
+    WGeom g;
+    if (wgeom(d, &g)) return 0;
+    return dual_ok(d, g) ? 1 : 0;
+}
 
 extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad) {
     if (head_ok(d)) { *ca_pad = abc_cdiv(d->Ca, 32) * 32; *cb_pad = 128; return ABC_OK; }
@@ -758,6 +815,12 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     k.sP_bytes = g.sP_bytes; k.sQ_bytes = g.sQ_bytes; k.coef_off = g.coef_off; k.cstrP = g.cstrP; k.cstrQ = g.cstrQ;
     k.nta = g.nta; k.ntb = g.ntb; k.fast_p = g.fast_p; k.fast_q = g.fast_q; k.nbuf = g.nbuf;
     k.magicQ = 65536 / g.HW + 1;
+    k.p2 = nullptr; k.p_out = nullptr; k.ld_p2 = 0; k.cp2_off = 0; k.ld_pout = 0; k.bytesP2 = 0;
+    if (d->p_dual) {
+        if (!dual_ok(d, g)) return abc_fail(ABC_EUNSUPPORTED, "wgrad: p_dual is not served for this descriptor (abc_wgrad_fuses_apply)");
+        k.p2 = d->p2; k.p_out = d->p_out; k.ld_p2 = d->ld_p2; k.cp2_off = d->cp2_off; k.ld_pout = d->ld_pout;
+        k.bytesP2 = (unsigned)((int64_t)d->B * d->Hg * d->Wg * d->ld_p2 * 2);
+    }
     k.k3 = (d->ntaps == 9 && g.ngroups == 1 && g.HW == 15 * d->stride + 3) ? 1 : 0;
     for (int t = 0; t < d->ntaps && k.k3; ++t)
         if (d->tap_dy[t] - g.dy_min != t / 3 || d->tap_dx[t] - g.dx_min != t % 3) k.k3 = 0;

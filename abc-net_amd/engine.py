@@ -201,7 +201,10 @@ class Engine:
         self._emit(ops, self.lib.abc_conv_fwd, d, what, meta=meta)
         return st, nblk
 
-    def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None):
+    def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None):
+        """dual = (y_raw tensor, ld, channel offset, dY tensor): fuse the BatchNorm-backward correction into the load of P
+        (p = act_bwd output with coef = (ca, cc, cb)); returns False without emitting anything when the library does not
+        serve this descriptor that way"""
         dw_ptr = self.G(wname)
         d = L.WgradDesc()
         p.fill(d.p)
@@ -214,6 +217,11 @@ class Engine:
         d.cq_off = q.coff if cq_off is None else cq_off
         d.Ca, d.Cb, d.stride = Ca, Cb, stride
         L.set_taps(d, taps)
+        if dual is not None:
+            y2, ld2, c2, out = dual
+            d.p2, d.ld_p2, d.cp2_off, d.p_dual, d.p_out, d.ld_pout = y2.data_ptr(), ld2, c2, 1, out.data_ptr(), Ca
+            if not self.lib.abc_wgrad_fuses_apply(C.byref(d)):
+                return False
         ca_pad, cb_pad = L.i32(), L.i32()
         L.check(self.lib.abc_wgrad_pads(C.byref(d), C.byref(ca_pad), C.byref(cb_pad)), "wgrad_pads")
         ca_pad, cb_pad = ca_pad.value, cb_pad.value
@@ -237,6 +245,7 @@ class Engine:
         self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
         self._emit(ops, self.lib.abc_wgrad_reduce, r, what + " reduce", writes=(wname,) if wname else (),
                    meta={"kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)})
+        return True
 
     def emit_colsum(self, ops, t, dt, npix, ld, c_off, Cn, chan_scale, bname, what):
         out_ptr = self.G(bname)
@@ -422,8 +431,11 @@ class Engine:
             self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
 
     # ------------------------------------------------------------------ backward plan
-    def _bn_backward(self, ops, rec, same, pool, drop=None):
-        """act_bwd + bn finalize + apply for rec; returns Src of dY (plain)"""
+    def _bn_backward(self, ops, rec, same, pool, drop=None, defer=False):
+        """act_bwd + bn finalize + apply for rec; returns Src of dY (plain).
+        defer=True: the apply pass is NOT emitted; returns (Src of g with coef = (ca, cc, cb) for a consumer that applies
+        dY = ca*g + cb*y_raw + cc on load, emit_apply) where emit_apply() emits the classic in-place pass and returns
+        the plain Src -- the caller picks one"""
         C_ = rec.cout
         g = self.new((self.B, rec.H, rec.W, C_))
         d = L.ActBwdDesc()
@@ -450,19 +462,42 @@ class Engine:
         f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
         f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
         f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        if defer:
+            ca, cb, cc = (self.new((C_,), torch.float32) for _ in range(3))
+            f.mean, f.ca, f.cb, f.cc = rec.mean.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
         self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
         a = L.BnApplyDesc()
         a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = g.data_ptr(), C_, rec.y.data_ptr(), rec.ld, rec.coff
         a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
         a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
-        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
-                   meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
-        rec.dY = g
-        return Src(g, self.dt, rec.H, rec.W, C_, 0, C_)
 
-    def _conv_backward(self, ops, rec, dY: Src, want_dgrad=True):
-        """wgrad (+ dgrad into a fresh buffer registered with the producer of rec.src)"""
-        self.emit_wgrad(ops, dY, rec.src, rec.cout, rec.cin, rec.taps, 1, rec.cname + ".weight", "wgrad " + rec.cname)
+        def emit_apply():
+            self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
+                       meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
+            rec.dY = g
+            return Src(g, self.dt, rec.H, rec.W, C_, 0, C_)
+
+        if defer:
+            return Src(g, self.dt, rec.H, rec.W, C_, 0, C_, coef=(ca, cc, cb)), emit_apply
+        return emit_apply()
+
+    def _conv_backward(self, ops, rec, dY, want_dgrad=True):
+        """wgrad (+ dgrad into a fresh buffer registered with the producer of rec.src).
+        dY is a plain Src, or the deferred pair of _bn_backward(defer=True): then the weight-gradient kernel applies the
+        BatchNorm-backward correction on load and writes dY for the data-gradient conv (one pass less over g and y);
+        layers whose weight gradient runs on another kernel fall back to the separate apply pass."""
+        if isinstance(dY, tuple):
+            gsrc, emit_apply = dY
+            out = self.new((self.B, rec.H, rec.W, rec.cout))
+            if self.emit_wgrad(ops, gsrc, rec.src, rec.cout, rec.cin, rec.taps, 1, rec.cname + ".weight", "wgrad " + rec.cname,
+                               dual=(rec.y, rec.ld, rec.coff, out)):
+                rec.dY = out
+                dY = Src(out, self.dt, rec.H, rec.W, rec.cout, 0, rec.cout)
+            else:
+                dY = emit_apply()
+                self.emit_wgrad(ops, dY, rec.src, rec.cout, rec.cin, rec.taps, 1, rec.cname + ".weight", "wgrad " + rec.cname)
+        else:
+            self.emit_wgrad(ops, dY, rec.src, rec.cout, rec.cin, rec.taps, 1, rec.cname + ".weight", "wgrad " + rec.cname)
         prod = rec.src.producer
         if not want_dgrad or prod is None:
             return None
@@ -497,7 +532,7 @@ class Engine:
         body = [r for r in self.recs if not getattr(r, "is_head", False)]
         for rec in reversed(body):
             if rec.kind == "conv":
-                dY = self._bn_backward(ops, rec, rec.grad_same, rec.grad_pool)
+                dY = self._bn_backward(ops, rec, rec.grad_same, rec.grad_pool, defer=True)
                 dsrc = self._conv_backward(ops, rec, dY)
                 if dsrc is not None:
                     self._route(rec, dsrc)

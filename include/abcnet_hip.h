@@ -162,6 +162,10 @@ typedef struct abc_bn_bwd_desc {
     const float* partial; int32_t nblk; int32_t C; double count;
     const float* gamma; const float* invstd;
     float* dgamma; float* dbeta; float* k1; float* k2; float* gscale; /* gscale = gamma*invstd */
+    /* optional (all or none): the same correction as ONE per-channel affine of (g, y_raw),
+     *   dY = ca*g + cb*y_raw + cc,  ca = gscale, cb = -gscale*k2*invstd, cc = gscale*(mean*invstd*k2 - k1),
+     * for consumers that apply it on load (abc_wgrad_desc.p_dual) instead of a separate abc_bn_apply_bwd pass */
+    const float* mean; float* ca; float* cb; float* cc;
 } abc_bn_bwd_desc;
 int abc_bn_finalize_bwd(const abc_bn_bwd_desc* d, abc_stream_t stream);
 typedef struct abc_bn_apply_desc {
@@ -188,7 +192,14 @@ typedef struct abc_wgrad_desc {
     int32_t stride, ntaps, nsplit;
     int8_t tap_dy[ABC_MAX_TAPS_C];
     int8_t tap_dx[ABC_MAX_TAPS_C];
+    /* BatchNorm-backward correction fused into the load of P (replaces abc_bn_apply_bwd for this layer):
+     * p_dual = 1: P[p][a] = p.scale[a]*p.x[p][a] + p.slope[a]*p2[p][cp2_off + a] + p.shift[a]  (no activation), where p.x is
+     * the act_bwd output g and p2 the layer's raw conv output; the corrected values are also stored to p_out
+     * (NHWC, pixel stride ld_pout, same dtype as p) for the data-gradient conv that runs afterwards.
+     * Only where abc_wgrad_fuses_apply() says so; otherwise abc_wgrad returns ABC_EUNSUPPORTED for p_dual. */
+    const void* p2; int32_t ld_p2, cp2_off, p_dual; void* p_out; int32_t ld_pout;
 } abc_wgrad_desc;
+int abc_wgrad_fuses_apply(const abc_wgrad_desc* d); /* 1: this descriptor (with p_dual set) is served by the fused path */
 int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad);
 int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt); /* 32x32 tile pairs per workgroup: at x bt */
 int abc_wgrad_blocks(const abc_wgrad_desc* d); /* workgroups per split: choose nsplit so that blocks*nsplit fills the GPU */

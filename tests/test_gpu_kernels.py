@@ -221,6 +221,49 @@ def test_pool_act_materialised(lib, dt):
     assert U.relerr(U.to_nchw(out), q(ref, dt)) < (1e-6 if dt == L.F32 else 1e-2)
 
 
+@pytest.mark.parametrize("Cout,Cin", [(128, 128), (64, 32), (32, 64)])
+def test_wgrad_fused_bn_apply(lib, Cout, Cin):
+    """abc_wgrad with p_dual: P = ca*g + cb*y_raw + cc applied on load (the BatchNorm-backward correction), the corrected
+    tensor written to p_out -- against the explicit formula followed by the plain weight gradient"""
+    dt = L.BF16
+    g_ = torch.Generator().manual_seed(51)
+    B, H, W, k, ldy, coff = 2, 24, 32, 3, Cout + 32, 16
+    gq = q(torch.randn((B, Cout, H, W), generator=g_), dt)
+    yq = q(torch.randn((B, ldy, H, W), generator=g_), dt)
+    ca, cb, cc = (torch.randn(Cout, generator=g_) * s_ for s_ in (1.0, 0.3, 0.05))
+    dy = q(ca.view(1, -1, 1, 1) * gq + cb.view(1, -1, 1, 1) * yq[:, coff:coff + Cout] + cc.view(1, -1, 1, 1), dt)
+    x = q(torch.randn((B, Cin, H, W), generator=g_), dt)
+    sc, sh = torch.rand(Cin, generator=g_) * 2 - 0.6, torch.randn(Cin, generator=g_) * 0.3
+    sl = torch.zeros(Cin)
+    a = q(act(x, sc, sh, sl), dt)
+    w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    F.conv2d(a, w, None, padding=1).backward(dy)
+    gd, yd, xd = U.nhwc(gq, dt), U.nhwc(yq, dt), U.nhwc(x, dt)
+    pcoef = tuple(t.to(U.DEV) for t in (ca, cc, cb))   # (scale, shift, slope) = (ca, cc, cb)
+    qcoef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
+    out = torch.zeros((B, H, W, Cout), dtype=U.tdt(dt), device=U.DEV)
+    d = L.WgradDesc()
+    U.fill_src(d.p, gd, H, W, Cout, pcoef)
+    U.fill_src(d.q, xd, H, W, Cin, qcoef)
+    d.dtype_p, d.dtype_q, d.dtype_c = dt, dt, dt
+    d.B, d.Hg, d.Wg, d.Hq, d.Wq, d.Ca, d.Cb, d.stride, d.nsplit = B, H, W, H, W, Cout, Cin, 1, 3
+    L.set_taps(d, taps_square(k))
+    d.p2, d.ld_p2, d.cp2_off, d.p_dual, d.p_out, d.ld_pout = yd.data_ptr(), ldy, coff, 1, out.data_ptr(), Cout
+    assert lib.abc_wgrad_fuses_apply(C.byref(d)) == 1
+    ca_, cb_ = L.i32(), L.i32()
+    L.check(lib.abc_wgrad_pads(C.byref(d), C.byref(ca_), C.byref(cb_)), "pads")
+    part = torch.zeros(3 * 9 * ca_.value * cb_.value, dtype=torch.float32, device=U.DEV)
+    d.partial = part.data_ptr()
+    L.check(lib.abc_wgrad(C.byref(d), U.stream()), "wgrad")
+    dw = torch.zeros((Cout, Cin, 9), dtype=torch.float32, device=U.DEV)
+    r = L.WgradReduceDesc()
+    r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), 3, 9, Cout, Cin, ca_.value, cb_.value, dw.data_ptr(), 0
+    L.check(lib.abc_wgrad_reduce(C.byref(r), U.stream()), "reduce")
+    torch.cuda.synchronize()
+    assert U.relerr(U.to_nchw(out), dy) < 1e-2           # bf16 rounding of the same f32 formula
+    assert U.relerr(dw.cpu().view(Cout, Cin, k, k), w.grad) < U.tol(dt)
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_conv_transpose_into_concat(lib, dt):
     """4 parity phases == ConvTranspose2d(k3,s2) + crop of first row/col, written at a channel offset"""
