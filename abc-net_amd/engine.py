@@ -14,6 +14,7 @@ PyTorch is used here only to own device memory and the stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -202,7 +203,7 @@ class Engine:
         return st, nblk
 
     def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None):
-        """dual = (y_raw tensor, ld, channel offset, dY tensor): fuse the BatchNorm-backward correction into the load of P
+        """dual = (y_raw tensor, ld, channel offset, dY pointer, dY pixel stride): fuse the BatchNorm-backward correction into the load of P
         (p = act_bwd output with coef = (ca, cc, cb)); returns False without emitting anything when the library does not
         serve this descriptor that way"""
         dw_ptr = self.G(wname)
@@ -218,8 +219,8 @@ class Engine:
         d.Ca, d.Cb, d.stride = Ca, Cb, stride
         L.set_taps(d, taps)
         if dual is not None:
-            y2, ld2, c2, out = dual
-            d.p2, d.ld_p2, d.cp2_off, d.p_dual, d.p_out, d.ld_pout = y2.data_ptr(), ld2, c2, 1, out.data_ptr(), Ca
+            y2, ld2, c2, out_ptr, ld_out = dual
+            d.p2, d.ld_p2, d.cp2_off, d.p_dual, d.p_out, d.ld_pout = y2.data_ptr(), ld2, c2, 1, out_ptr, ld_out
             if not self.lib.abc_wgrad_fuses_apply(C.byref(d)):
                 return False
         ca_pad, cb_pad = L.i32(), L.i32()
@@ -490,7 +491,7 @@ class Engine:
             gsrc, emit_apply = dY
             out = self.new((self.B, rec.H, rec.W, rec.cout))
             if self.emit_wgrad(ops, gsrc, rec.src, rec.cout, rec.cin, rec.taps, 1, rec.cname + ".weight", "wgrad " + rec.cname,
-                               dual=(rec.y, rec.ld, rec.coff, out)):
+                               dual=(rec.y, rec.ld, rec.coff, out.data_ptr(), rec.cout)):
                 rec.dY = out
                 dY = Src(out, self.dt, rec.H, rec.W, rec.cout, 0, rec.cout)
             else:
@@ -568,8 +569,17 @@ class Engine:
         wd_all = self.packed(9, 128 * nh, 128)
         for i, rec in enumerate(self.head_recs):
             drop = (self.drop_p, self.drop_seed) if self.drop_p > 0 else None
-            dY = self._bn_backward_into(ops, rec, (dfeat, 128 * nh, 128 * i), dyh, 128 * nh, 128 * i, drop)
-            self.emit_wgrad(ops, dY, rec.src, 128, 128, taps, 1, rec.cname + ".weight", "wgrad " + rec.cname)
+            if self.dt == L.BF16 and not os.environ.get("ABC_NO_HEAD_FUSE"):
+                # bf16: the weight-gradient kernel applies the BN-backward correction on load and writes dY into this
+                # head's channel slice of dyh (no separate apply pass)
+                gsrc, _apply = self._bn_backward(ops, rec, (dfeat, 128 * nh, 128 * i), None, drop=drop, defer=True)
+                ok = self.emit_wgrad(ops, gsrc, rec.src, 128, 128, taps, 1, rec.cname + ".weight", "wgrad " + rec.cname,
+                                     dual=(rec.y, rec.ld, rec.coff, dyh.data_ptr() + 128 * i * dyh.element_size(), 128 * nh))
+                if not ok:
+                    raise RuntimeError("fused BN-backward apply was refused for " + rec.cname)
+            else:
+                dY = self._bn_backward_into(ops, rec, (dfeat, 128 * nh, 128 * i), dyh, 128 * nh, 128 * i, drop)
+                self.emit_wgrad(ops, dY, rec.src, 128, 128, taps, 1, rec.cname + ".weight", "wgrad " + rec.cname)
             self.emit_pack(rec.cname + ".weight", wd_all, 1, 128, 128, 3, 128, 128, red_total=128 * nh, red_off=128 * i)
         dtrunk = self.new((B, h, w, 128))
         dy_all = Src(dyh, self.dt, h, w, 128 * nh, 0, 128 * nh)
