@@ -18,3 +18,5 @@ int abc_conv_stem_launch(const abc_conv_desc* d, abc_stream_t stream);
 // heads' 1x1 convolution forward into NCHW f32 (heads.hip)
 int abc_head_fwd_ok(const abc_conv_desc* d);
 int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream);
+int abc_head_dgrad_ok(const abc_conv_desc* d);
+int abc_head_dgrad_launch(const abc_conv_desc* d, abc_stream_t stream);

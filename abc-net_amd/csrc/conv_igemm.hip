@@ -515,6 +515,7 @@ extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, i
 extern "C" int abc_conv_variant(const abc_conv_desc* d) {
     if (abc_conv_stem_ok(d, nullptr)) return 2;
     if (abc_head_fwd_ok(d)) return 3;
+    if (abc_head_dgrad_ok(d)) return 4;
     abc_fast_geom f;
     if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return 1;
     return 0;
@@ -571,6 +572,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
         return abc_fail(ABC_EINVAL, "conv: output grid exceeds output tensor");
     if (abc_conv_stem_ok(d, nullptr)) return abc_conv_stem_launch(d, stream);
     if (abc_head_fwd_ok(d)) return abc_head_fwd_launch(d, stream);
+    if (abc_head_dgrad_ok(d)) return abc_head_dgrad_launch(d, stream);
     {
         abc_fast_geom f;
         if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return abc_conv_fast_launch(d, f, stream);

@@ -99,6 +99,113 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdK a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Data gradient of the heads' 1x1 convolutions: dH[p][ci] = sum_co act(dL[co][p]) * W[co][ci] with dL the NCHW f32
+// logit gradients (act = the per-channel loss scale) and dH a 128-channel slice of an NHWC tensor.
+// GEMM view (transposed so that dL's memory layout is usable): D[ci][p] = W^T[ci][co] x dL[co][p]; A = W^T from the
+// packed data-gradient weights, B = dL: rows of pixels per output channel = k-major, which is what
+// ds_read_b64_tr_b16 turns into per-lane k-fragments -> each wave stages 16 co x 64 pixels (f32 -> bf16, 128-byte
+// line reads) in a private LDS tile, no workgroup barriers.  HBM-bound on dL (read once) and the dH slice written.
+struct HeadDgK {
+    const float* dl;
+    const float *sc, *sh, *sl;
+    const void* w;       // packed [1][nchunks][128][CK] bf16 (rows = ci, reduction = co)
+    bf16* y;             // NHWC
+    int HW, hc, CK, ksteps, ldy, cout_off, npairs;
+    unsigned bytesDL, bytesW;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_h;
+__device__ inline bf16x8 tr_read8h(const char* b0, const char* b1) {
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)b0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)b1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadDgK a) {
+    constexpr int ROWB = 64 * 2 + 16;          // LDS row: 64 pixels bf16 + pad
+    __shared__ __attribute__((aligned(16))) char smem[4][2][16 * ROWB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.npairs) return;
+    const __amdgpu_buffer_rsrc_t rsD = abc_make_rsrc(a.dl, a.bytesDL), rsW = abc_make_rsrc(a.w, a.bytesW);
+    const int b = (pair * 64) / a.HW, pp = pair * 64 - b * a.HW;
+    // staging role of this lane: row co = lane >> 2 of the 16-row step, pixels 16 * (lane & 3) .. + 16
+    const int srow = lane >> 2, spx = (lane & 3) * 16;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][m][k] = 0.f;
+
+    u32x4 raw[4];
+    auto issue = [&](int ks) {
+        const int co = ks * 16 + srow;
+        const unsigned off = co < a.hc ? (unsigned)((((unsigned)(b * a.hc + co)) * (unsigned)a.HW + (unsigned)(pp + spx)) * 4u) : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsD, off + 16u * i, 0, 0);
+    };
+    auto commit = [&](int ks, char* buf) {
+        const int co = ks * 16 + srow;
+        const bool ok = co < a.hc;
+        const float sc = (ok && a.sc) ? a.sc[co] : 1.f, sh = (ok && a.sh) ? a.sh[co] : 0.f, sl = (ok && a.sl) ? a.sl[co] : 1.f;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = __uint_as_float(raw[i][j]);
+                v[4 * i + j] = (ok && a.sc) ? abc_act(x, sc, sh, sl) : x;
+            }
+        *(bf16x8*)(buf + srow * ROWB + spx * 2) = pack_frag<bf16>(v);
+        *(bf16x8*)(buf + srow * ROWB + spx * 2 + 16) = pack_frag<bf16>(v + 8);
+    };
+    issue(0);
+    commit(0, smem[wave][0]);
+    // transposing read: lane supplies row 8 h + ((lane & 15) >> 2) (+4), columns 16 ((lane >> 4) & 1) + 4 (lane & 3) (+32 for tile 1)
+    const int trow = 8 * h + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+        const bool has_next = ks + 1 < a.ksteps;
+        if (has_next) issue(ks + 1);
+        const char* buf = smem[wave][ks & 1];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own LDS writes of the tile are complete
+        // A fragments: rows ci = 32 m + r, reduction co = 16 ks + 8 h .. + 8
+        bf16x8 fa[4];
+        const int chunk = (16 * ks) / a.CK, within = (16 * ks) % a.CK + 8 * h;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsW, (unsigned)(((chunk * 128 + 32 * m + r) * a.CK + within) * 2), 0, 0);
+            fa[m] = *(const bf16x8*)&t;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const char* q0 = buf + trow * ROWB + (tcol + 32 * t) * 2;
+            const bf16x8 fb = tr_read8h(q0, q0 + 4 * ROWB);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb, acc[t][m], 0, 0, 0);
+        }
+        if (has_next) commit(ks + 1, smem[wave][(ks + 1) & 1]);
+    }
+    // D[ci][p]: column = pixel r of tile t, registers 4 q .. 4 q + 3 = ci 32 m + 8 q + 4 h .. + 4 -> 8-byte stores
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bf16* dst = a.y + ((size_t)(pair * 64 + 32 * t + r)) * a.ldy + a.cout_off;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][m][4 * q + j];
+                *(bf16x4*)(dst + 32 * m + 8 * q + 4 * h) = o;
+            }
+    }
+}
+
 }  // namespace
 
 int abc_head_fwd_ok(const abc_conv_desc* d) {
@@ -122,4 +229,25 @@ int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream) {
     k.bytesW = (unsigned)((int64_t)4 * d->Cout_pad * 32 * 2);
     hipLaunchKernelGGL(head_fwd_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
     return abc_check_launch("head_fwd");
+}
+
+int abc_head_dgrad_ok(const abc_conv_desc* d) {
+    if (getenv("ABC_CONV_NOHEAD")) return 0;
+    if (!d->src.planar || d->dtype_in != ABC_F32 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16 || d->planar_out) return 0;
+    if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
+    if (d->Cout != 128 || d->Cout_pad != 128 || d->cin_off != 0 || d->src.ctot != d->Cin || d->bias != nullptr || d->stats != nullptr || d->accumulate) return 0;
+    if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
+    if ((d->ldy % 4) || (d->cout_off % 4)) return 0;
+    return (int64_t)d->B * d->Cin * d->Hg * d->Wg * 4 < (int64_t(1) << 31);
+}
+
+int abc_head_dgrad_launch(const abc_conv_desc* d, abc_stream_t stream) {
+    HeadDgK k;
+    k.dl = (const float*)d->src.x; k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.w = d->w; k.y = (bf16*)d->y;
+    k.HW = d->Hg * d->Wg; k.hc = d->Cin; k.CK = abc_conv_chunk(d->dtype_c, d->Cin);
+    k.ksteps = abc_roundup(d->Cin, k.CK) / 16; k.ldy = d->ldy; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
+    k.bytesDL = (unsigned)((int64_t)d->B * d->Cin * k.HW * 4);
+    k.bytesW = (unsigned)((int64_t)abc_roundup(d->Cin, k.CK) * 128 * 2);
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+    return abc_check_launch("head_dgrad");
 }

@@ -90,7 +90,7 @@ typedef struct abc_conv_desc {
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
 int abc_conv_stat_blocks(const abc_conv_desc* d);
 /* which kernel abc_conv_fwd runs for this descriptor: 0 = general implicit GEMM (pool / dropout / planar / ragged
- * inputs), 1 = lean 4-wave kernel for plain NHWC inputs, 2 = one-channel first layer, 3 = heads' 1x1 into NCHW f32.  Labels only. */
+ * inputs), 1 = lean 4-wave kernel for plain NHWC inputs, 2 = one-channel first layer, 3 = heads' 1x1 into NCHW f32, 4 = its data gradient from NCHW f32.  Labels only. */
 int abc_conv_variant(const abc_conv_desc* d);
 int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream);
 /* tile the launcher picks for this descriptor: BN output channels x (2*mt x 16) pixels per workgroup, K-chunk ck */
