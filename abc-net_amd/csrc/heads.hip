@@ -126,6 +126,7 @@ __device__ inline bf16x8 tr_read8h(const char* b0, const char* b1) {
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadDgK a) {
     constexpr int ROWB = 64 * 2 + 16;          // LDS row: 64 pixels bf16 + pad
     __shared__ __attribute__((aligned(16))) char smem[4][2][16 * ROWB];
+    __shared__ __attribute__((aligned(16))) char stile[4][32 * (128 * 2 + 16)];  // per-wave output transpose tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int pair = blockIdx.x * 4 + wave;
@@ -190,10 +191,14 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadDgK a) {
         }
         if (has_next) commit(ks + 1, smem[wave][(ks + 1) & 1]);
     }
-    // D[ci][p]: column = pixel r of tile t, registers 4 q .. 4 q + 3 = ci 32 m + 8 q + 4 h .. + 4 -> 8-byte stores
+    // D[ci][p]: column = pixel r of tile t, registers 4 q .. 4 q + 3 = ci 32 m + 8 q + 4 h .. + 4.  Transposed through
+    // the wave's LDS tile ([32 pixels][128 ci], reusing the staging buffers' space) into 16-byte stores: a pixel's 256
+    // bytes leave as one contiguous run instead of 32 scattered 8-byte pieces.
+    constexpr int OROW = 128 * 2 + 16;
+    char* ot = stile[wave];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        bf16* dst = a.y + ((size_t)(pair * 64 + 32 * t + r)) * a.ldy + a.cout_off;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -201,8 +206,15 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadDgK a) {
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (bf16)acc[t][m][4 * q + j];
-                *(bf16x4*)(dst + 32 * m + 8 * q + 4 * h) = o;
+                *(bf16x4*)(ot + r * OROW + (32 * m + 8 * q + 4 * h) * 2) = o;
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int px = it * 4 + (lane >> 4), sg = lane & 15;
+            const f32x4 v = *(const f32x4*)(ot + px * OROW + sg * 16);
+            *(f32x4*)(a.y + ((size_t)(pair * 64 + 32 * t + px)) * a.ldy + a.cout_off + sg * 8) = v;
+        }
     }
 }
 
@@ -237,7 +249,7 @@ int abc_head_dgrad_ok(const abc_conv_desc* d) {
     if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
     if (d->Cout != 128 || d->Cout_pad != 128 || d->cin_off != 0 || d->src.ctot != d->Cin || d->bias != nullptr || d->stats != nullptr || d->accumulate) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
-    if ((d->ldy % 4) || (d->cout_off % 4)) return 0;
+    if ((d->ldy % 8) || (d->cout_off % 8)) return 0;
     return (int64_t)d->B * d->Cin * d->Hg * d->Wg * 4 < (int64_t(1) << 31);
 }
 
