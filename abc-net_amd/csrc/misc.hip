@@ -59,40 +59,61 @@ __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunk
 
 // batched form: one launch over a device-resident table of descriptors (the plan packs ~100 small weights per step)
 struct PackItem { abc_pack_desc d; int32_t CK, ntaps, nchunks, is_bf16; int64_t first; };
+__device__ inline void pack_one(const PackItem& it, unsigned r) {
+    const abc_pack_desc& d = it.d;
+    const unsigned CK = it.CK, ntaps = it.ntaps, nchunks = it.nchunks, rows = d.rows_pad;
+    const unsigned k = r % CK; r /= CK;
+    const unsigned n = r % rows; r /= rows;
+    const unsigned c = r % nchunks;
+    const unsigned t = r / nchunks;
+    const unsigned rc = c * CK + k;
+    float v = 0.f;
+    if (d.mode == 0) {
+        if (n < (unsigned)d.Cout && rc < (unsigned)d.Cin) v = d.w[((size_t)n * d.Cin + rc) * ntaps + t];
+    } else if (d.mode == 1) {
+        if (n < (unsigned)d.Cin && rc < (unsigned)d.Cout) v = d.w[((size_t)rc * d.Cin + n) * ntaps + t];
+    } else if (d.mode == 2) {
+        const unsigned nx = d.px ? 2 : 1;
+        const unsigned iy = t / nx, ix = t % nx;
+        const unsigned ky = d.py ? (iy == 0 ? 0 : 2) : 1;
+        const unsigned kx = d.px ? (ix == 0 ? 0 : 2) : 1;
+        if (n < (unsigned)d.Cout && rc < (unsigned)d.Cin) v = d.w[(((size_t)rc * d.Cout + n) * 3 + ky) * 3 + kx];
+    } else {
+        if (n < (unsigned)d.Cin && rc < (unsigned)d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
+    }
+    const unsigned nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
+    const size_t o = (((size_t)t * nch_total + ch_off + c) * rows + n) * CK + k;
+    if (it.is_bf16) ((bf16*)d.dst)[o] = (bf16)v; else ((float*)d.dst)[o] = v;
+}
+
+// A block owns 2048 consecutive destination elements of the concatenated items.  The item lookup (binary search over
+// ~100 entries) is done once per block by thread 0; blocks inside one item -- nearly all -- then run with the item
+// in scalar registers and 32-bit index arithmetic; the rare block that straddles items searches per element.
+constexpr int PACK_CHUNK = 2048;
+__device__ inline int pack_find(const PackItem* items, int nitems, int64_t i) {
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackItem* items, int nitems, int64_t total) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        // binary search for the item whose [first, next.first) contains i
-        int lo = 0, hi = nitems - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (items[mid].first <= i) lo = mid; else hi = mid - 1;
-        }
+    __shared__ int s_lo, s_hi;
+    const int64_t i0 = (int64_t)blockIdx.x * PACK_CHUNK;
+    const int64_t i1 = (i0 + PACK_CHUNK < total) ? i0 + PACK_CHUNK : total;
+    if (threadIdx.x == 0) { s_lo = pack_find(items, nitems, i0); s_hi = pack_find(items, nitems, i1 - 1); }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    if (lo == hi) {
         const PackItem& it = items[lo];
-        const abc_pack_desc& d = it.d;
-        const int CK = it.CK, ntaps = it.ntaps, nchunks = it.nchunks;
-        int64_t r = i - it.first;
-        const int k = (int)(r % CK); r /= CK;
-        const int n = (int)(r % d.rows_pad); r /= d.rows_pad;
-        const int c = (int)(r % nchunks);
-        const int t = (int)(r / nchunks);
-        const int rc = c * CK + k;
-        float v = 0.f;
-        if (d.mode == 0) {
-            if (n < d.Cout && rc < d.Cin) v = d.w[((size_t)n * d.Cin + rc) * ntaps + t];
-        } else if (d.mode == 1) {
-            if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)rc * d.Cin + n) * ntaps + t];
-        } else if (d.mode == 2) {
-            const int nx = d.px ? 2 : 1;
-            const int iy = t / nx, ix = t % nx;
-            const int ky = d.py ? (iy == 0 ? 0 : 2) : 1;
-            const int kx = d.px ? (ix == 0 ? 0 : 2) : 1;
-            if (n < d.Cout && rc < d.Cin) v = d.w[(((size_t)rc * d.Cout + n) * 3 + ky) * 3 + kx];
-        } else {
-            if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
+        const unsigned base = (unsigned)(i0 - it.first);
+        for (unsigned e = threadIdx.x; e < (unsigned)(i1 - i0); e += 256) pack_one(it, base + e);
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const int j = pack_find(items, nitems, i);
+            pack_one(items[j], (unsigned)(i - items[j].first));
         }
-        const int nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
-        const size_t o = (((size_t)t * nch_total + ch_off + c) * d.rows_pad + n) * CK + k;
-        if (it.is_bf16) ((bf16*)d.dst)[o] = (bf16)v; else ((float*)d.dst)[o] = v;
     }
 }
 
@@ -242,8 +263,7 @@ extern "C" int64_t abc_pack_item_fill(void* item, const abc_pack_desc* d, int64_
 
 extern "C" int abc_pack_batch(const void* items_dev, int32_t nitems, int64_t total, abc_stream_t stream) {
     if (nitems < 1 || total < 1) return abc_fail(ABC_EINVAL, "pack_batch: empty");
-    int64_t nb = (total + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    const int64_t nb = (total + PACK_CHUNK - 1) / PACK_CHUNK;
     hipLaunchKernelGGL(pack_batch_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const PackItem*)items_dev, nitems, total);
     return abc_check_launch("pack_batch");
 }
