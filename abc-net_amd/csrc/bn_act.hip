@@ -105,6 +105,67 @@ template <int N> __device__ inline void stv(bf16* p, const float* v) {
     *(bf16x8*)p = t;
 }
 
+// The common case -- one full-resolution gradient source, no dropout: two items per thread in flight, the x-hat
+// product folded into one FMA per element (sum of g*(x - mean), scaled by invstd once per block).
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_plain_kernel(const abc_act_bwd_desc d) {
+    constexpr int N = VecOf<T>::N;
+    __shared__ float red[256][2 * N + 1];
+    const int ncv = d.C / N;
+    const unsigned nitems = (unsigned)((int64_t)d.B * d.H * d.W * ncv);
+    const unsigned stride = gridDim.x * 256u;
+    const int tid = threadIdx.x;
+    const int cv = (int)((blockIdx.x * 256 + tid) % ncv);
+    const int c = cv * N;
+    const int lg = 31 - __builtin_clz((unsigned)ncv);
+    float sc[N], sh[N], sl[N], mu[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { sc[j] = d.scale[c + j]; sh[j] = d.shift[c + j]; sl[j] = d.slope[c + j]; mu[j] = d.mean[c + j]; }
+    float a1[N], a2[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+    const T* yr = (const T*)d.y_raw + d.cy_off + c;
+    const T* ds = (const T*)d.dA_same + d.csame_off + c;
+    T* g = (T*)d.g + c;
+    auto one = [&](const float* x, const float* da, size_t p) {
+        float out[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float y = fmaf(x[j], sc[j], sh[j]);
+            const float gg = y > 0.f ? da[j] : sl[j] * da[j];
+            out[j] = gg;
+            a1[j] += gg;
+            a2[j] = fmaf(gg, x[j] - mu[j], a2[j]);
+        }
+        stv<N>(g + p * d.ld_g, out);
+    };
+    unsigned it = blockIdx.x * 256u + tid;
+    for (; it + stride < nitems; it += 2 * stride) {
+        const size_t p0 = it >> lg, p1 = (it + stride) >> lg;
+        float x0[N], d0[N], x1[N], d1[N];
+        ldv<T, N>(yr + p0 * d.ld_y, x0); ldv<T, N>(ds + p0 * d.ld_same, d0);
+        ldv<T, N>(yr + p1 * d.ld_y, x1); ldv<T, N>(ds + p1 * d.ld_same, d1);
+        one(x0, d0, p0);
+        one(x1, d1, p1);
+    }
+    if (it < nitems) {
+        const size_t p0 = it >> lg;
+        float x0[N], d0[N];
+        ldv<T, N>(yr + p0 * d.ld_y, x0); ldv<T, N>(ds + p0 * d.ld_same, d0);
+        one(x0, d0, p0);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { red[tid][j] = a1[j]; red[tid][N + j] = a2[j]; }
+    __syncthreads();
+    for (int cc = tid; cc < d.C; cc += 256) {
+        const int v = cc / N, j = cc % N;
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = v; t < 256; t += ncv) { s1 += red[t][j]; s2 += red[t][N + j]; }
+        d.partial[((size_t)blockIdx.x * 2 + 0) * d.C + cc] = s1;
+        d.partial[((size_t)blockIdx.x * 2 + 1) * d.C + cc] = s2 * d.invstd[cc];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const abc_act_bwd_desc d) {
     constexpr int N = VecOf<T>::N;
@@ -363,6 +424,11 @@ extern "C" int abc_act_bwd(const abc_act_bwd_desc* d, abc_stream_t stream) {
     int rc = act_bwd_check(d);
     if (rc) return rc;
     const int nb = abc_act_bwd_blocks(d);
+    if (d->dA_pool == nullptr && d->drop_p <= 0.f) {
+        if (d->dtype == ABC_BF16) hipLaunchKernelGGL(act_bwd_plain_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
+        else hipLaunchKernelGGL(act_bwd_plain_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
+        return abc_check_launch("act_bwd");
+    }
     if (d->dtype == ABC_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
     else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
     return abc_check_launch("act_bwd");
