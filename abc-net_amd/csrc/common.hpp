@@ -358,20 +358,28 @@ struct HaloFetch {
     static constexpr int SEGS = CK / NV;
     RawBuf<InT, NV> raw[NMAX];
     unsigned inb;  // bit i: segment i lies inside the image
+    // (cvalid = channels that exist from the tile's first one; 1 << 30 = all)
+    __device__ static inline int live_segs(int cvalid) {
+        const int n = (cvalid + NV - 1) / NV;
+        return (n >= SEGS || (n & (n - 1))) ? SEGS : n;
+    }
 
     __device__ inline void issue(__amdgpu_buffer_rsrc_t rs, const HaloGeom& g, int b, int iy0, int ix0, int c0, int tid_, int cvalid) {
         const int tid = abc_launder(tid_);
-        const int part = tid % SEGS;
-        const int total = (part * NV < cvalid) ? g.HH * g.HW * SEGS : 0;
+        // live segments per pixel: with fewer valid channels than the tile is wide (and a power-of-two count) the threads
+        // are spread over the live segments only -- the padding is zeroed once by the caller and never touched
+        const int live = live_segs(cvalid);
+        const int part = tid % live;
+        const int total = g.HH * g.HW * live;
         const int base = ((b * g.Hx + iy0) * g.Wx + ix0) * g.ldx + c0 + part * NV;
         inb = 0;
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) {
             const int sidx = tid + i * NTHR;
-            const int pix = sidx / SEGS;
+            const int pix = sidx / live;
             const int hy = (pix * g.magic) >> 16, hx = pix - hy * g.HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            const bool ok = sidx < total && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+            const bool ok = sidx < total && part * NV < cvalid && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
             const unsigned off = ok ? (unsigned)(base + (hy * g.Wx + hx) * g.ldx) * (unsigned)sizeof(InT) : 0x80000000u;
             raw[i].ld(rs, off);
             inb |= ok ? (1u << i) : 0u;
@@ -380,11 +388,12 @@ struct HaloFetch {
     // lcoef = LDS table [3][cstride] of (scale, shift, slope), index = channel relative to the workgroup's first one
     __device__ inline void commit(char* sA, int RS, int PS, const HaloGeom& g, const float* lcoef, int cstride, int tid_, int cvalid) {
         const int tid = abc_launder(tid_);
-        const int part = tid % SEGS;
+        const int live = live_segs(cvalid);
+        const int part = tid % live;
         const int cch = part * NV;
-        const int total = g.HH * g.HW * SEGS;
+        const int total = g.HH * g.HW * live;
         float sc[NV], sh[NV], sl[NV];
-        const bool has_t = lcoef != nullptr && (cch < cvalid);
+        const bool has_t = lcoef != nullptr;
         if (has_t) {
 #pragma unroll
             for (int j = 0; j < NV; ++j) { sc[j] = lcoef[cch + j]; sh[j] = lcoef[cstride + cch + j]; sl[j] = lcoef[2 * cstride + cch + j]; }
@@ -393,7 +402,7 @@ struct HaloFetch {
         for (int i = 0; i < NMAX; ++i) {
             const int sidx = tid + i * NTHR;
             if (sidx < total) {
-                const int pix = sidx / SEGS;
+                const int pix = sidx / live;
                 const int hy = (pix * g.magic) >> 16, hx = pix - hy * g.HW;
                 char* dst = sA + hy * RS + hx * PS + part * 16;
                 if constexpr (sizeof(InT) == sizeof(CT)) {

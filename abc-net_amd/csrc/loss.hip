@@ -182,18 +182,24 @@ __global__ __launch_bounds__(256) void loss_kernel(const abc_loss_desc d) {
         d.partial[(size_t)blockIdx.x * 16 + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void loss_finalize_kernel(const abc_loss_fin_desc d) {
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const abc_loss_fin_desc d) {
     __shared__ double tot[16];
+    __shared__ double red[64][16];
     __shared__ float cscale[8];
     const int t = threadIdx.x;
     {
-        // 4 lanes per sum, fixed order -> reproducible
+        // 64 lanes per sum (a single 64-thread block walking 576 partial blocks cost 39 us of dependent loads), fixed
+        // order -> reproducible
         const int which = t & 15, part = t >> 4;
         double s = 0.0;
-        for (int k = part; k < d.nblk; k += 4) s += d.partial[(size_t)k * 16 + which];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (t < 16) tot[t] = s;
+        for (int k = part; k < d.nblk; k += 64) s += d.partial[(size_t)k * 16 + which];
+        red[part][which] = s;
+        __syncthreads();
+        if (t < 16) {
+            double a = 0.0;
+            for (int p = 0; p < 64; ++p) a += red[p][t];
+            tot[t] = a;
+        }
     }
     __syncthreads();
     if (t == 0) {
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const abc_loss_fin_de
         d.out[0] = total;
     }
     __syncthreads();
-    for (int c = t; c < d.nchan; c += 64) {
+    for (int c = t; c < d.nchan; c += 1024) {
         float v = 0.f;
         for (int i = 0; i < 8; ++i)
             if (c >= d.chan_off[i] && c < d.chan_off[i] + d.head_c[i]) v = cscale[i];
@@ -235,6 +241,6 @@ extern "C" int abc_loss_fwd_bwd(const abc_loss_desc* d, abc_stream_t stream) {
 }
 
 extern "C" int abc_loss_finalize(const abc_loss_fin_desc* d, abc_stream_t stream) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *d);
     return abc_check_launch("loss_finalize");
 }

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
         char* sQ = buf + a.sP_bytes;
         if constexpr (FAST) {
             if constexpr (DUAL) {
-                constexpr int NV = Frag<CT>::NV, SEGS = CWP / NV;
+                constexpr int NV = Frag<CT>::NV;
+                const int SEGS = pp.live_segs(cvalP);   // same thread -> segment mapping as HaloFetch::issue
                 const int lt = abc_launder(tid);
                 const int part = lt % SEGS, cch = part * NV;
                 const bool chan = cch < cvalP;
@@ -195,6 +196,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
         }
     };
 
+    if constexpr (FAST) {
+        // zero both patch buffers once: channel padding (Ca / Cb below the 32-wide tile) is never written again
+        if (cvalP < CWP || cvalQ < CWQ) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (int i = tid * 16; i < a.nbuf * buf_bytes; i += WTHR * 16) *(f32x4*)(smem + i) = z;
+        }
+    }
     __syncthreads();  // coefficient tables visible
     // it = -1 is the prologue (stage the first patch, no compute): one call site for issue / commit
     int patch = split - a.nsplit;
