@@ -68,7 +68,8 @@ class WgradDesc(C.Structure):
                 ("B", i32), ("Hg", i32), ("Wg", i32), ("Hq", i32), ("Wq", i32), ("cp_off", i32), ("Ca", i32),
                 ("cq_off", i32), ("Cb", i32), ("stride", i32), ("ntaps", i32), ("nsplit", i32),
                 ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS),
-                ("p2", vp), ("ld_p2", i32), ("cp2_off", i32), ("p_dual", i32), ("p_out", vp), ("ld_pout", i32)]
+                ("p2", vp), ("ld_p2", i32), ("cp2_off", i32), ("p_dual", i32), ("p_out", vp), ("ld_pout", i32),
+                ("rowsum_partial", vp)]
 
 
 class WgradReduceDesc(C.Structure):
@@ -140,6 +141,7 @@ SYMBOLS = {
     "abc_bn_finalize_bwd": (C.c_int, [P(BnBwdDesc), vp]),
     "abc_bn_apply_bwd": (C.c_int, [P(BnApplyDesc), vp]),
     "abc_wgrad_fuses_apply": (C.c_int, [vp]),
+    "abc_wgrad_rowsum_ok": (C.c_int, [vp]),
     "abc_wgrad_pads": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),
     "abc_wgrad_blocks": (C.c_int, [P(WgradDesc)]),
     "abc_wgrad_tile": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),

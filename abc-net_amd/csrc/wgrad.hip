@@ -349,6 +349,7 @@ struct HeadK {
     const void* q;
     const float *qsc, *qsh, *qsl;
     float* partial;
+    float* rowsum;   // [nsplit][Ca_pad] or null
     int HW, hc, ldq, cq_off, nchunks, nsplit, mtiles, Ca_pad;
     float drop_p;
     uint32_t drop_seed;
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
     const int qlane = (64 * h + ((lane & 15) >> 2)) * HQ_PSW + sub * 2;  // + 8 kk pixels + b-tile * 64 bytes
     constexpr int QBUF = 128 * HQ_PSW;
 
+    float rsum = 0.f;  // this lane's share of sum_p P[co][p] (the conv's bias gradient), nh == 0 waves only
     auto compute = [&](const u32x4 (&cur)[16], const char* sQ) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = abc_act(f[j], psc, psh, psl);
             }
+            if (nh == 0) rsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
             const bf16x8 fa = pack_frag<bf16>(f);
             const char* qb = sQ + qlane + kk * 8 * HQ_PSW + nh * 128;
             const bf16x8 fb0 = tr_read8(qb, qb + 4 * HQ_PSW);
@@ -468,6 +471,10 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
             __syncthreads();
         }
     }
+    if (active && nh == 0 && a.rowsum != nullptr) {
+        rsum += __shfl_xor(rsum, 32);   // the two pixel halves of the row
+        if (h == 0) a.rowsum[(size_t)split * a.Ca_pad + mt * 32 + r] = co_ok ? rsum : 0.f;
+    }
     if (active) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -496,7 +503,7 @@ static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
     HeadK k;
     k.dl = (const float*)d->p.x; k.psc = d->p.scale; k.psh = d->p.shift; k.psl = d->p.slope;
     k.q = d->q.x; k.qsc = d->q.scale; k.qsh = d->q.shift; k.qsl = d->q.slope;
-    k.partial = d->partial; k.HW = d->Hg * d->Wg; k.hc = d->Ca; k.ldq = d->q.ldx; k.cq_off = d->cq_off;
+    k.partial = d->partial; k.rowsum = d->rowsum_partial; k.HW = d->Hg * d->Wg; k.hc = d->Ca; k.ldq = d->q.ldx; k.cq_off = d->cq_off;
     k.nchunks = d->B * k.HW / 128; k.nsplit = d->nsplit; k.mtiles = abc_cdiv(d->Ca, 32); k.Ca_pad = k.mtiles * 32;
     k.drop_p = d->q.drop_p; k.drop_seed = d->q.drop_seed;
     k.bytesP = (unsigned)((int64_t)d->B * d->Ca * k.HW * 4); k.bytesQ = (unsigned)((int64_t)d->B * k.HW * d->q.ldx * 2);
@@ -756,6 +763,8 @@ static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipSt
 }
 
 }  // namespace
+
+extern "C" int abc_wgrad_rowsum_ok(const abc_wgrad_desc* d) { return head_ok(d) ? 1 : 0; }
 
 extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {
     if (head_ok(d) || c1_ok(d)) return 0;

@@ -202,7 +202,7 @@ class Engine:
         self._emit(ops, self.lib.abc_conv_fwd, d, what, meta=meta)
         return st, nblk
 
-    def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None):
+    def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None, rowsum_to=None):
         """dual = (y_raw tensor, ld, channel offset, dY pointer, dY pixel stride): fuse the BatchNorm-backward correction into the load of P
         (p = act_bwd output with coef = (ca, cc, cb)); returns False without emitting anything when the library does not
         serve this descriptor that way"""
@@ -244,8 +244,20 @@ class Engine:
                 "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
                 "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt))}
         self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
+        fused_rowsum = False
+        if rowsum_to is not None and self.lib.abc_wgrad_rowsum_ok(C.byref(d)):
+            # the heads' kernel also leaves per-split row sums of P = the conv's bias gradient (no separate pass over dL)
+            rs = self.new((nsplit, ca_pad), torch.float32)
+            d.rowsum_partial = rs.data_ptr()
+            r2 = L.WgradReduceDesc()
+            r2.partial, r2.nsplit, r2.ntaps, r2.Ca, r2.Cb, r2.Ca_pad, r2.Cb_pad, r2.dw, r2.accumulate = rs.data_ptr(), nsplit, 1, Ca, 1, ca_pad, 1, self.G(rowsum_to), 0
+            fused_rowsum = True
         self._emit(ops, self.lib.abc_wgrad_reduce, r, what + " reduce", writes=(wname,) if wname else (),
                    meta={"kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)})
+        if fused_rowsum:
+            self._emit(ops, self.lib.abc_wgrad_reduce, r2, "dbias " + what[6:] + " reduce", writes=(rowsum_to,),
+                       meta={"kernel": "wgrad_reduce", "flops": 0, "bytes": float(nsplit * ca_pad * 4)})
+            return "rowsum"
         return True
 
     def emit_colsum(self, ops, t, dt, npix, ld, c_off, Cn, chan_scale, bname, what):
@@ -554,12 +566,14 @@ class Engine:
             i, hc = r2.idx, r2.cout
             cs = self.chan_scale[self.head_off[i]:self.head_off[i] + hc]
             dl = Src(self.dlogits[i], L.F32, h, w, 0, 0, hc, coef=(cs, zero, one), planar=True)
-            self.emit_wgrad(ops, dl, r2.src, hc, 128, [(0, 0)], 1, r2.cname + ".weight", "wgrad " + r2.cname)
-            lib = self.lib
-            psw = self.new((lib.abc_plane_sum_work(hc),), torch.float32)
-            a = (self.dlogits[i].data_ptr(), B, hc, h * w, cs.data_ptr(), psw.data_ptr(), self.G(r2.cname + ".bias"))
-            ops.append((lambda _r, st, a=a: lib.abc_plane_sum(*a, st), None, "dbias " + r2.cname, (r2.cname + ".bias",),
-                        {"kernel": "plane_sum", "flops": 0, "bytes": float(B * hc * h * w * 4)}))
+            got = self.emit_wgrad(ops, dl, r2.src, hc, 128, [(0, 0)], 1, r2.cname + ".weight", "wgrad " + r2.cname,
+                                  rowsum_to=r2.cname + ".bias")
+            if got != "rowsum":
+                lib = self.lib
+                psw = self.new((lib.abc_plane_sum_work(hc),), torch.float32)
+                a = (self.dlogits[i].data_ptr(), B, hc, h * w, cs.data_ptr(), psw.data_ptr(), self.G(r2.cname + ".bias"))
+                ops.append((lambda _r, st, a=a: lib.abc_plane_sum(*a, st), None, "dbias " + r2.cname, (r2.cname + ".bias",),
+                            {"kernel": "plane_sum", "flops": 0, "bytes": float(B * hc * h * w * 4)}))
             wd = self.packed(1, hc, 128)
             self.emit_pack(r2.cname + ".weight", wd, 1, hc, 128, 1, 128, hc)
             self.emit_conv(ops, dl, wd, None, dfeat, self.dt, h, w, 128 * nh, 128 * i, 128, [(0, 0)], what="dgrad " + r2.cname)

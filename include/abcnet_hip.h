@@ -198,7 +198,12 @@ typedef struct abc_wgrad_desc {
      * (NHWC, pixel stride ld_pout, same dtype as p) for the data-gradient conv that runs afterwards.
      * Only where abc_wgrad_fuses_apply() says so; otherwise abc_wgrad returns ABC_EUNSUPPORTED for p_dual. */
     const void* p2; int32_t ld_p2, cp2_off, p_dual; void* p_out; int32_t ld_pout;
+    /* optional, heads' 1x1 kernel only (planar f32 P): per-split row sums of the transformed P, [nsplit][Ca_pad] --
+     * the bias gradient of the conv (sum over pixels of dY) falls out of the operand the kernel holds anyway;
+     * reduce with abc_wgrad_reduce(ntaps = 1, Cb = Cb_pad = 1).  abc_wgrad_rowsum_ok() says whether it is written. */
+    float* rowsum_partial;
 } abc_wgrad_desc;
+int abc_wgrad_rowsum_ok(const abc_wgrad_desc* d);
 int abc_wgrad_fuses_apply(const abc_wgrad_desc* d); /* 1: this descriptor (with p_dual set) is served by the fused path */
 int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad);
 int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt); /* 32x32 tile pairs per workgroup: at x bt */
