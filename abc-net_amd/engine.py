@@ -237,10 +237,13 @@ class Engine:
         d.nsplit = nsplit
         need = nsplit * len(taps) * ca_pad * cb_pad
         self._ws_need = max(self._ws_need, need)
+        # split-K slabs alternate between two workspaces so that the reduction of one layer can run on the side stream
+        # under the next layer's kernels (see _run)
+        wsk = self._ws_k = 1 - getattr(self, "_ws_k", 1)
         r = L.WgradReduceDesc()
         r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = nsplit, len(taps), Ca, Cb, ca_pad, cb_pad, dw_ptr, 0
-        self._ws_users += [d, r]
-        meta = {"kernel": "wgrad<%s,%s,%s,%dx%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), at_.value, bt_.value, stride),
+        self._ws_users += [(d, wsk), (r, wsk)]
+        meta = {"ws": wsk, "kernel": "wgrad<%s,%s,%s,%dx%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), at_.value, bt_.value, stride),
                 "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
                 "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt))}
         self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
@@ -253,7 +256,7 @@ class Engine:
             r2.partial, r2.nsplit, r2.ntaps, r2.Ca, r2.Cb, r2.Ca_pad, r2.Cb_pad, r2.dw, r2.accumulate = rs.data_ptr(), nsplit, 1, Ca, 1, ca_pad, 1, self.G(rowsum_to), 0
             fused_rowsum = True
         self._emit(ops, self.lib.abc_wgrad_reduce, r, what + " reduce", writes=(wname,) if wname else (),
-                   meta={"kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)})
+                   meta={"ws": wsk, "side": True, "kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)})
         if fused_rowsum:
             self._emit(ops, self.lib.abc_wgrad_reduce, r2, "dbias " + what[6:] + " reduce", writes=(rowsum_to,),
                        meta={"kernel": "wgrad_reduce", "flops": 0, "bytes": float(nsplit * ca_pad * 4)})
@@ -415,9 +418,9 @@ class Engine:
         self.pack_ops.append((lambda _r, st, a=a: lib.abc_pack_batch(a[0], a[1], a[2], st), None, "pack weights", (),
                               {"kernel": "pack_batch", "flops": 0, "bytes": float(first * (2 if self.dt == L.BF16 else 4) + first * 4)}))
         # shared workspaces
-        self.ws = self.new((max(self._ws_need, 4),), torch.float32)
-        for d in self._ws_users:
-            d.partial = self.ws.data_ptr()
+        self.ws = [self.new((max(self._ws_need, 4),), torch.float32) for _ in range(2)]
+        for d, k in self._ws_users:
+            d.partial = self.ws[k].data_ptr()
         self.cs_ws = self.new((max(self._colsum_need, 4),), torch.float32)
         for a in self._colsum_users:
             a[7] = self.cs_ws.data_ptr()
@@ -870,15 +873,40 @@ class Engine:
         return Src(gbuf, self.dt, rec.H, rec.W, C_, 0, C_)
 
     # ------------------------------------------------------------------ execution
-    @staticmethod
-    def _run(ops, stream):
+    def _run(self, ops, stream):
+        """launch ops in order on `stream` (the current stream's handle).  Ops marked side (the split-K reductions: they
+        only produce final parameter gradients, nothing before the optimiser reads them) go to a second stream and
+        overlap with the following layers' kernels; the two slab workspaces are fenced with events, and everything
+        is joined before returning (so graph capture sees a closed fork/join and all-reduce buckets are complete)."""
         skip = os.environ.get("ABC_EXP_SKIP")   # (timing experiments only: drop ops whose label contains this text)
-        for fn, ref, what, _w, _m in ops:
+        # measured on MI355X: the fork/join dependencies cost more than the overlap gains (1733 vs 1823 img/s inside the
+        # hipGraph), so the second stream is opt-in (ABC_SIDE_STREAM=1) and the default is one stream
+        use_side = bool(os.environ.get("ABC_SIDE_STREAM")) and any(m.get("side") for _f, _r, _w, _x, m in ops)
+        if use_side:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            side = self._side
+        pending = {}
+        for fn, ref, what, _w, m in ops:
             if skip and skip in what:
                 continue
-            rc = fn(ref, stream)
+            if use_side and m.get("side"):
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                rc = fn(ref, side.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(side)
+                pending[m["ws"]] = done
+            else:
+                if use_side and m.get("ws") in pending:
+                    main.wait_event(pending.pop(m["ws"]))   # the slabs of two layers ago have been consumed
+                rc = fn(ref, stream)
             if rc != 0:
                 L.check(rc, what)
+        for done in pending.values():
+            main.wait_event(done)
 
     def run_pack(self, stream):
         self._run(self.pack_ops, stream)
