@@ -199,12 +199,21 @@ __global__ __launch_bounds__(256) void cbam_conv7_bwd_kernel(const abc_cbam_conv
     }
 }
 
-__global__ void cbam_conv7_reduce_kernel(const float* partial, int nblk, float* dw7, float* db7) {
-    const int t = threadIdx.x;
-    if (t >= 99) return;
+// one workgroup per output (98 weights + bias): 256 lanes stride the per-workgroup partials, fixed tree -> reproducible
+// (one THREAD per output walking 9216 partials serially cost 6 ms per step)
+__global__ __launch_bounds__(256) void cbam_conv7_reduce_kernel(const float* partial, int nblk, float* dw7, float* db7) {
+    __shared__ double red[4];
+    const int t = blockIdx.x;
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += (double)partial[(size_t)k * 99 + t];
-    if (t < 98) dw7[t] = (float)s; else db7[0] = (float)s;
+    for (int k = threadIdx.x; k < nblk; k += 256) s += (double)partial[(size_t)k * 99 + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        if (t < 98) dw7[t] = (float)tot; else db7[0] = (float)tot;
+    }
 }
 
 // ------------------------------------------------------------------ apply (forward): out = relu(sa*ca*z + r)
@@ -359,52 +368,63 @@ __global__ __launch_bounds__(256) void cbam_bwd2_kernel(const abc_cbam_pix_desc 
     }
 }
 
-// ------------------------------------------------------------------ channel attention backward (one workgroup)
+// ------------------------------------------------------------------ channel attention backward
+// Every workgroup first rebuilds the small per-image intermediates in LDS (dt[B][C], d_hidden[B][mid]: a few hundred
+// thousand MACs), then the outputs -- weight / bias gradients summed over the images in REGISTERS in image order, and the
+// per-image pool gradients -- are partitioned over the grid.  (The first version was one workgroup walking the images
+// serially with global read-modify-write accumulation: 400 us per call.)
 __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_channel_desc d) {
     extern __shared__ float sm[];
-    float* dt = sm;               // [C]
-    float* dha = sm + d.C;        // [mid]
-    float* dhm = dha + d.mid;     // [mid]
+    float* dt = sm;                      // [B][C]
+    float* dha = sm + d.B * d.C;         // [B][mid]
+    float* dhm = dha + d.B * d.mid;      // [B][mid]
     const int tid = threadIdx.x;
-    // zero the parameter gradients (accumulated over the images below)
-    for (int i = tid; i < d.mid * d.C; i += 256) { d.dw1[i] = 0.f; d.dw2[i] = 0.f; }
-    for (int i = tid; i < d.mid; i += 256) d.db1[i] = 0.f;
-    for (int i = tid; i < d.C; i += 256) d.db2[i] = 0.f;
+    const int C_ = d.C, mid = d.mid, B = d.B, T = d.tiles_per_img;
+    for (int idx = tid; idx < B * C_; idx += 256) {
+        const int n = idx / C_, c = idx - n * C_;
+        double s = 0.0;
+        for (int k = 0; k < T; ++k) s += (double)d.partial[((size_t)n * T + k) * C_ + c];
+        const float ca = d.ca[idx];
+        dt[idx] = (float)s * ca * (1.f - ca);
+    }
     __syncthreads();
-    for (int n = 0; n < d.B; ++n) {
-        for (int c = tid; c < d.C; c += 256) {
-            double s = 0.0;
-            for (int k = 0; k < d.tiles_per_img; ++k) s += (double)d.partial[((size_t)n * d.tiles_per_img + k) * d.C + c];
-            const float ca = d.ca[(size_t)n * d.C + c];
-            const float t = (float)s * ca * (1.f - ca);
-            dt[c] = t;
-            d.db2[c] += 2.f * t;
-        }
-        __syncthreads();
-        for (int j = tid; j < d.mid; j += 256) {
-            float s = 0.f;
-            for (int c = 0; c < d.C; ++c) s += d.w2[(size_t)c * d.mid + j] * dt[c];
-            const float a = d.hid_avg[(size_t)n * d.mid + j] > 0.f ? s : 0.f;
-            const float m = d.hid_max[(size_t)n * d.mid + j] > 0.f ? s : 0.f;
-            dha[j] = a; dhm[j] = m;
-            d.db1[j] += a + m;
-        }
-        __syncthreads();
-        for (int i = tid; i < d.C * d.mid; i += 256) {
-            const int c = i / d.mid, j = i % d.mid;
-            d.dw2[i] += dt[c] * (d.hid_avg[(size_t)n * d.mid + j] + d.hid_max[(size_t)n * d.mid + j]);
-        }
-        for (int i = tid; i < d.mid * d.C; i += 256) {
-            const int j = i / d.C, c = i % d.C;
-            d.dw1[i] += dha[j] * d.avgz[(size_t)n * d.C + c] + dhm[j] * d.maxz[(size_t)n * d.C + c];
-        }
-        for (int c = tid; c < d.C; c += 256) {
-            float a = 0.f, m = 0.f;
-            for (int j = 0; j < d.mid; ++j) { const float w = d.w1[(size_t)j * d.C + c]; a += w * dha[j]; m += w * dhm[j]; }
-            d.d_avgz[(size_t)n * d.C + c] = a;
-            d.d_maxz[(size_t)n * d.C + c] = m;
-        }
-        __syncthreads();
+    for (int idx = tid; idx < B * mid; idx += 256) {
+        const int n = idx / mid, j = idx - n * mid;
+        float s = 0.f;
+        for (int c = 0; c < C_; ++c) s += d.w2[(size_t)c * mid + j] * dt[n * C_ + c];
+        dha[idx] = d.hid_avg[idx] > 0.f ? s : 0.f;
+        dhm[idx] = d.hid_max[idx] > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    const int gsz = gridDim.x * 256, gt = blockIdx.x * 256 + tid;
+    for (int i = gt; i < C_ * mid; i += gsz) {
+        const int c = i / mid, j = i - c * mid;
+        float s = 0.f;
+        for (int n = 0; n < B; ++n) s += dt[n * C_ + c] * (d.hid_avg[n * mid + j] + d.hid_max[n * mid + j]);
+        d.dw2[i] = s;
+    }
+    for (int i = gt; i < mid * C_; i += gsz) {
+        const int j = i / C_, c = i - j * C_;
+        float s = 0.f;
+        for (int n = 0; n < B; ++n) s += dha[n * mid + j] * d.avgz[(size_t)n * C_ + c] + dhm[n * mid + j] * d.maxz[(size_t)n * C_ + c];
+        d.dw1[i] = s;
+    }
+    for (int c = gt; c < C_; c += gsz) {
+        float s = 0.f;
+        for (int n = 0; n < B; ++n) s += 2.f * dt[n * C_ + c];
+        d.db2[c] = s;
+    }
+    for (int j = gt; j < mid; j += gsz) {
+        float s = 0.f;
+        for (int n = 0; n < B; ++n) s += dha[n * mid + j] + dhm[n * mid + j];
+        d.db1[j] = s;
+    }
+    for (int idx = gt; idx < B * C_; idx += gsz) {
+        const int n = idx / C_, c = idx - n * C_;
+        float a = 0.f, m = 0.f;
+        for (int j = 0; j < mid; ++j) { const float w = d.w1[(size_t)j * C_ + c]; a += w * dha[n * mid + j]; m += w * dhm[n * mid + j]; }
+        d.d_avgz[idx] = a;
+        d.d_maxz[idx] = m;
     }
 }
 
@@ -496,8 +516,15 @@ extern "C" int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t
 }
 
 extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream) {
-    const size_t sh = (size_t)(d->C + 2 * d->mid) * sizeof(float);
-    hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(1), dim3(256), sh, (hipStream_t)stream, *d);
+    const size_t sh = (size_t)d->B * (d->C + 2 * d->mid) * sizeof(float);
+    if (sh > 150 * 1024) return abc_fail(ABC_EUNSUPPORTED, "cbam_channel_bwd: B * (C + 2 mid) floats exceed the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)cbam_channel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int nb = abc_cdiv(d->C * d->mid, 256 * 8) < 1 ? 1 : (abc_cdiv(d->C * d->mid, 256 * 8) > 32 ? 32 : abc_cdiv(d->C * d->mid, 256 * 8));
+    hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(nb), dim3(256), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_bwd");
 }
 
@@ -558,7 +585,7 @@ extern "C" int abc_cbam_conv7_blocks(const abc_cbam_conv7_desc* d) { return abc_
 
 extern "C" int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream) {
     hipLaunchKernelGGL(cbam_conv7_bwd_kernel, dim3(abc_cdiv(d->W, 16), abc_cdiv(d->H, 16), d->B), dim3(256), 0, (hipStream_t)stream, *d);
-    hipLaunchKernelGGL(cbam_conv7_reduce_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, (const float*)d->dw_partial,
+    hipLaunchKernelGGL(cbam_conv7_reduce_kernel, dim3(99), dim3(256), 0, (hipStream_t)stream, (const float*)d->dw_partial,
                        abc_cbam_conv7_blocks(d), d->dw7, d->db7);
     return abc_check_launch("cbam_conv7_bwd");
 }
