@@ -1,0 +1,105 @@
+"""Inference harness: the heat-map half of /root/reference/src/img2smiles2.py:42-79 on the HIP kernels.
+
+    model.eval(); preds = model(imgs)                       (img2smiles2.py:56-59)
+    3x3 / circular 3-tap local-max masks, |rho|             (img2smiles2.py:61-79)
+
+One step = eval-mode forward (running-statistics BatchNorm folded into the consumers' loads, no dropout) + the
+peak-NMS kernel, on a batch already resident in HBM, replayed from one hipGraph.  The weights do not change between
+steps, so re-packing them (and the BatchNorm coefficients) happens in `refresh()`, not in the step; call it again
+after `load_state_dict`.  The SMILES assembly that follows in the reference (img2smiles2.py:104-344, RDKit) is out of
+scope: the step ends with the four mask / |rho| maps the decoder reads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class InferenceRunner:
+    def __init__(self, model, batch, height, width, use_graph=True, device=None):
+        if not torch.cuda.is_available():
+            raise L.AbcNetHipError("InferenceRunner needs an MI355X; abcnet_amd has no CPU fallback")
+        self.model = model
+        dev = device or next(model.parameters()).device
+        self.dev = dev
+        model.eval()
+        x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
+        self.eng = eng = model._engine_for(x0, False)
+        lg = eng.logits
+        self.atom_mask, self.bond_mask = torch.empty_like(lg[0]), torch.empty_like(lg[4])
+        self.rho_abs, self.omega_mask = torch.empty_like(lg[6]), torch.empty_like(lg[7])
+        d = L.NmsDesc()
+        d.atom, d.bond, d.rho, d.omega = lg[0].data_ptr(), lg[4].data_ptr(), lg[6].data_ptr(), lg[7].data_ptr()
+        d.B, d.h, d.w, d.n_omega = eng.B, eng.h, eng.w, lg[7].shape[1]
+        d.atom_mask, d.bond_mask = self.atom_mask.data_ptr(), self.bond_mask.data_ptr()
+        d.rho_abs, d.omega_mask = self.rho_abs.data_ptr(), self.omega_mask.data_ptr()
+        self._nms = d
+        self.use_graph = use_graph
+        self._graph = None
+        self.steps = 0
+        self.refresh()
+
+    def refresh(self):
+        """re-pack the (changed) weights; the next step re-derives the BatchNorm coefficients itself"""
+        self.eng.run_pack(torch.cuda.current_stream().cuda_stream)
+
+    def load_batch(self, imgs):
+        self.eng.img.copy_(imgs.reshape(self.eng.img.shape), non_blocking=True)
+
+    def _run(self, st):
+        self.eng.run_forward(st)
+        L.check(self.eng.lib.abc_nms_peaks(C.byref(self._nms), st), "nms_peaks")
+
+    def step(self):
+        """forward + NMS on the batch in the static image buffer; results in .logits / .atom_mask / ..."""
+        if self.use_graph and self._graph is None and self.steps >= 1:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run(torch.cuda.current_stream().cuda_stream)
+            self._graph = g
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._run(torch.cuda.current_stream().cuda_stream)
+        self.steps += 1
+
+    @property
+    def logits(self):
+        return self.eng.logits
+
+    def profile(self, iters=3):
+        """eager steps with a HIP event pair around every launch on the launch stream (as Trainer.profile)"""
+        eng = self.eng
+        stream = torch.cuda.current_stream()
+        st = stream.cuda_stream
+        acc = {}
+        for _ in range(iters):
+            marks = []
+            for fn, ref, what, _w, meta in eng.fwd_ops:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                rc = fn(ref, st)
+                e1.record(stream)
+                if rc != 0:
+                    L.check(rc, what)
+                marks.append((meta["kernel"], meta["flops"], meta["bytes"], e0, e1))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            L.check(eng.lib.abc_nms_peaks(C.byref(self._nms), st), "nms_peaks")
+            e1.record(stream)
+            marks.append(("nms", 0.0, float(eng.B * eng.h * eng.w * 122 * 4 * 2), e0, e1))
+            torch.cuda.synchronize()
+            for k, fl, by, a, b in marks:
+                r = acc.setdefault(k, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                r["calls"] += 1
+                r["ms"] += a.elapsed_time(b)
+                r["flops"] += fl
+                r["bytes"] += by
+        for r in acc.values():
+            for f in ("calls", "ms", "flops", "bytes"):
+                r[f] /= iters
+        return acc

@@ -57,6 +57,32 @@ def cpu_baseline(size, seconds_budget=25.0, variant="unet"):
             "sample": "oracle fwd+loss+bwd (no optimiser), fp32, batch %d at %dx%d, median of %d warm iterations" % (B, size, size, len(times))}
 
 
+def cpu_baseline_infer(size, seconds_budget=25.0, variant="unet"):
+    """oracle eval forward + oracle NMS (img2smiles2.py:56-79 restated) on the host, batch 4 at the benchmark resolution"""
+    from abcnet_amd.synthetic import synthetic_images
+    from oracle import nms_oracle
+    from oracle import unet_oracle as uo
+    B = 4
+    x = synthetic_images(B, size, seed=7)
+    sd = uo.filled_state(variant, 1, HEADS, seed=0)
+    times = []
+    t_start = time.time()
+    with torch.no_grad():
+        for it in range(4):
+            t0 = time.time()
+            p = uo.forward(variant, sd, x, train=False)
+            nms_oracle.nms(p[0], p[4], p[6], p[7])
+            dt = time.time() - t0
+            if it > 0:
+                times.append(dt)
+            if time.time() - t_start > seconds_budget and times:
+                break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle eval forward + NMS, fp32, batch %d at %dx%d, median of %d warm iterations" % (B, size, size, len(times))}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/README.md says
     how they were collected and corrected); None when no pass exists for this kernel label."""
@@ -75,14 +101,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=384)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = the headline metric (configs 2-4); infer = config 5, img2smiles2.py heat-map path (eval forward + NMS)")
+    ap.add_argument("--size", type=int, default=None, help="default 384 (train) / 512 (infer)")
+    ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (train) / 64 (infer)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--variant", default="unet", choices=["unet", "unet2"], help="unet.py (headline) or unet2.py (config 3)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
+    if a.size is None:
+        a.size = 384 if a.mode == "train" else 512
+    if a.batch is None:
+        a.batch = 16 if a.mode == "train" else 64
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -115,11 +147,16 @@ def main():
     model = model.to(dev)
     if world > 1:
         D.broadcast_parameters(model._flat.data, model._flat_buf)
-    tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph)
-    # each rank owns its shard of the synthetic stream (weak scaling: batch 16 per GPU)
+    # each rank owns its shard of the synthetic stream (weak scaling: fixed batch per GPU)
     imgs = synthetic_images(a.batch, a.size, seed=7 + rank)
-    tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
-    tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
+    if a.mode == "infer":
+        from abcnet_amd.infer import InferenceRunner
+        tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph)
+        tr.load_batch(imgs.to(dev))
+    else:
+        tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph)
+        tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
+        tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
     torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -140,8 +177,8 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
-    loss = tr.loss_value()["total"]
-    if world > 1 and os.environ.get("ABC_BENCH_CHECK"):
+    loss = tr.loss_value()["total"] if a.mode == "train" else float(tr.atom_mask.sum().item())
+    if a.mode == "train" and world > 1 and os.environ.get("ABC_BENCH_CHECK"):
         # replicas must hold identical parameters after the averaged updates
         chk = model._flat.data.double().sum().reshape(1)
         both = [torch.zeros_like(chk) for _ in range(world)]
@@ -150,13 +187,19 @@ def main():
             print("replica checksums", [b.item() for b in both], file=sys.stderr)
             assert all(abs(b.item() - both[0].item()) == 0.0 for b in both), "replicas diverged"
 
+    if a.mode == "train":
+        metric = "training images/sec (%dx%d, b%d/GPU)" % (a.size, a.size, a.batch)
+        workload = a.variant + ".py train step (pack+fwd+fused loss+bwd+allreduce+Adam), %dx%d, batch %d/GPU, dropout 0.2" % (a.size, a.size, a.batch)
+    else:
+        metric = "inference images/sec, heat-map only (%dx%d, b%d/GPU)" % (a.size, a.size, a.batch)
+        workload = "img2smiles2.py heat-map path on %s.py (eval forward + peak NMS), %dx%d, batch %d/GPU" % (a.variant, a.size, a.size, a.batch)
     out = {
-        "metric": "training images/sec (384x384, b16/GPU)", "value": round(world * a.batch * a.steps / el, 2), "unit": "images/sec",
+        "metric": metric, "value": round(world * a.batch * a.steps / el, 2), "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": a.variant + ".py train step (pack+fwd+fused loss+bwd+allreduce+Adam), %dx%d, batch %d/GPU, dropout 0.2" % (a.size, a.size, a.batch),
+        "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph},
-        "final_loss": round(loss, 4),
+        ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 
     if rank == 0 and not a.no_profile:
@@ -169,7 +212,9 @@ def main():
                            "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": pmc_traffic(dom),
                            "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
                            "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
-        out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("ABC_BENCH_TOP", 12))]}
+        if os.environ.get("ABC_BENCH_TOP"):
+            out["kernel_calls"] = {k: v["calls"] for k, v in prof.items()}
         out["eager_step_ms_sum_of_kernels"] = round(tot, 3)
         flops_step = sum(v["flops"] for v in prof.values())
         bytes_step = sum(v["bytes"] for v in prof.values())
@@ -177,7 +222,7 @@ def main():
                              "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK[a.dtype], 4),
                              "hbm_frac": round(bytes_step / (el / a.steps) / 1e9 / HBM_PEAK, 4)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.size, variant=a.variant)
+        out["cpu_baseline"] = (cpu_baseline if a.mode == "train" else cpu_baseline_infer)(a.size, variant=a.variant)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
