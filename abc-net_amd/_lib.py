@@ -102,7 +102,7 @@ class CbamChannelDesc(C.Structure):
     _fields_ = [("partial", vp), ("tiles_per_img", i32), ("B", i32), ("C", i32), ("mid", i32), ("HW", f64), ("scale", vp),
                 ("shift", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("ca", vp), ("avgz", vp), ("maxz", vp),
                 ("hid_avg", vp), ("hid_max", vp), ("dw1", vp), ("db1", vp), ("dw2", vp), ("db2", vp), ("d_avgz", vp),
-                ("d_maxz", vp)]
+                ("d_maxz", vp), ("work", vp)]
 
 
 class CbamPixDesc(C.Structure):

@@ -33,7 +33,37 @@ __device__ inline void st8(bf16* p, const float* v) {
 __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------ channel attention (forward)
-// one workgroup per image
+// pass 1: global avg / max pool of z per (image, channel) from the conv epilogue's per-tile partials.  One workgroup per
+// (image, 64 channels): 4 tile groups x 64 channels, so the partial rows are read as 256-byte lines by 4 waves at once
+// (one workgroup per image with a thread per channel walked 576 tiles serially: 51 us per call).
+__global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const abc_cbam_channel_desc d) {
+    __shared__ double ssum[4][64];
+    __shared__ float smax[4][64], smin[4][64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    float vmax = -3.0e38f, vmin = 3.0e38f;
+    if (c < d.C) {
+        for (int k = grp; k < d.tiles_per_img; k += 4) {
+            const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k) * 4) * d.C + c;
+            s += (double)p[0];
+            vmax = fmaxf(vmax, p[2 * d.C]);
+            vmin = fminf(vmin, p[3 * d.C]);
+        }
+    }
+    ssum[grp][cl] = s; smax[grp][cl] = vmax; smin[grp][cl] = vmin;
+    __syncthreads();
+    if (grp == 0 && c < d.C) {
+        s = (ssum[0][cl] + ssum[1][cl]) + (ssum[2][cl] + ssum[3][cl]);
+        vmax = fmaxf(fmaxf(smax[0][cl], smax[1][cl]), fmaxf(smax[2][cl], smax[3][cl]));
+        vmin = fminf(fminf(smin[0][cl], smin[1][cl]), fminf(smin[2][cl], smin[3][cl]));
+        const float sc = d.scale[c], sh = d.shift[c];
+        d.avgz[(size_t)n * d.C + c] = sc * (float)(s / d.HW) + sh;
+        d.maxz[(size_t)n * d.C + c] = (sc >= 0.f ? sc * vmax : sc * vmin) + sh;
+    }
+}
+
+// pass 2: the shared MLP on both pooled vectors + sigmoid, one workgroup per image
 __global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_channel_desc d) {
     extern __shared__ float sm[];
     float* av = sm;              // [C] avg(z)
@@ -42,29 +72,23 @@ __global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_ch
     float* hm = ha + d.mid;      // [mid]
     const int n = blockIdx.x;
     for (int c = threadIdx.x; c < d.C; c += 256) {
-        double s = 0.0;
-        float vmax = -3.0e38f, vmin = 3.0e38f;
-        for (int k = 0; k < d.tiles_per_img; ++k) {
-            const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k) * 4) * d.C + c;
-            s += (double)p[0];
-            vmax = fmaxf(vmax, p[2 * d.C]);
-            vmin = fminf(vmin, p[3 * d.C]);
-        }
-        const float sc = d.scale[c], sh = d.shift[c];
-        const float a = sc * (float)(s / d.HW) + sh;
-        const float m = (sc >= 0.f ? sc * vmax : sc * vmin) + sh;
-        av[c] = a; mx[c] = m;
-        d.avgz[(size_t)n * d.C + c] = a;
-        d.maxz[(size_t)n * d.C + c] = m;
+        av[c] = d.avgz[(size_t)n * d.C + c];
+        mx[c] = d.maxz[(size_t)n * d.C + c];
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < d.mid; j += 256) {
-        float sa = d.b1[j], sb = d.b1[j];
-        for (int c = 0; c < d.C; ++c) { const float w = d.w1[(size_t)j * d.C + c]; sa += w * av[c]; sb += w * mx[c]; }
-        sa = fmaxf(sa, 0.f); sb = fmaxf(sb, 0.f);
-        ha[j] = sa; hm[j] = sb;
-        d.hid_avg[(size_t)n * d.mid + j] = sa;
-        d.hid_max[(size_t)n * d.mid + j] = sb;
+    // hidden unit j: 256 / mid lanes share the dot products (mid <= 32 is a power of two)
+    {
+        const int per = 256 / d.mid;                  // lanes per hidden unit (>= 8)
+        const int j = threadIdx.x / per, sub = threadIdx.x % per;
+        float sa = 0.f, sb = 0.f;
+        for (int c = sub; c < d.C; c += per) { const float w = d.w1[(size_t)j * d.C + c]; sa += w * av[c]; sb += w * mx[c]; }
+        for (int o = 1; o < per && o < 64; o <<= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+        if (sub == 0) {
+            sa = fmaxf(sa + d.b1[j], 0.f); sb = fmaxf(sb + d.b1[j], 0.f);
+            ha[j] = sa; hm[j] = sb;
+            d.hid_avg[(size_t)n * d.mid + j] = sa;
+            d.hid_max[(size_t)n * d.mid + j] = sb;
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < d.C; c += 256) {
@@ -75,29 +99,46 @@ __global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_ch
 }
 
 // ------------------------------------------------------------------ spatial statistics (forward)
-// thread group of C/N lanes per pixel; mean and max over channels of o1 = ca*(scale*y+shift), + argmax channel
-template <typename T>
+// The per-pixel passes below share one decomposition: grid = (workgroups per image, B), so the image index is uniform
+// per workgroup, and a thread keeps ONE fixed group of N channels (C / N is a power of two that divides 256), so every
+// per-channel and per-(image, channel) coefficient is loaded once into registers and the loop body is the tensor
+// traffic alone.  (The first versions re-read ca[n][c], scale[c], ... per element: 8-10 scalar loads per 16-byte vector
+// load, 4-5x off the HBM time.)
+//
+// thread group of C/N lanes per pixel (NVL vectors per lane when C/N > 64); mean and max over channels of
+// o1 = ca*(scale*y+shift), + argmax channel
+template <typename T, int NVL>
 __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const abc_cbam_pix_desc d) {
     constexpr int N = V8<T>::N;
     const int ncv = d.C / N;
-    const int cpp = ncv < 64 ? ncv : 64;  // lanes per pixel (power of two <= 64); a lane walks vectors sub, sub+cpp, ...
-    const int64_t npix = (int64_t)d.B * d.H * d.W;
-    const int ppb = 256 / cpp;  // pixels per workgroup pass
+    const int cpp = ncv / NVL;            // lanes per pixel (power of two <= 64)
+    const int hw = d.H * d.W;
+    const int n = blockIdx.y;
+    const int ppb = 256 / cpp;            // pixels per workgroup pass
     const int sub = threadIdx.x % cpp, pl = threadIdx.x / cpp;
     const T* y = (const T*)d.y;
-    for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < npix; p += (int64_t)gridDim.x * ppb) {
-        const int n = (int)(p / ((int64_t)d.H * d.W));
+    float sc[NVL][N], sh[NVL][N], ca[NVL][N];
+#pragma unroll
+    for (int u = 0; u < NVL; ++u)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int c = (sub + u * cpp) * N + j;
+            sc[u][j] = d.scale[c]; sh[u][j] = d.shift[c]; ca[u][j] = d.ca[(size_t)n * d.C + c];
+        }
+    for (int q = blockIdx.x * ppb + pl; q < hw; q += gridDim.x * ppb) {
+        const int64_t p = (int64_t)n * hw + q;
         float s = 0.f, m = -3.0e38f;
         int am = 0;
-        for (int vi = sub; vi < ncv; vi += cpp) {
+#pragma unroll
+        for (int u = 0; u < NVL; ++u) {
+            const int vi = sub + u * cpp;
             float v[N];
             ld8<T, N>(y + p * d.ld_y + d.cy_off + vi * N, v);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                const int c = vi * N + j;
-                const float o1 = d.ca[(size_t)n * d.C + c] * fmaf(v[j], d.scale[c], d.shift[c]);
+                const float o1 = ca[u][j] * fmaf(v[j], sc[u][j], sh[u][j]);
                 s += o1;
-                if (o1 > m) { m = o1; am = c; }
+                if (o1 > m) { m = o1; am = vi * N + j; }
             }
         }
         for (int o = 1; o < cpp; o <<= 1) {
@@ -144,59 +185,74 @@ __global__ __launch_bounds__(256) void cbam_conv7_fwd_kernel(const abc_cbam_conv
     }
 }
 
-// d_st[pix][ch] = sum_taps du[pix - off] * w[ch][tap]; weight/bias gradient partials per workgroup
+// d_st[pix][ch] = sum_taps du[pix - off] * w[ch][tap]; weight/bias gradient partials per workgroup.
+// Persistent workgroups: a thread keeps its 99 weight-gradient sums in registers over ALL the 16x16 tiles its
+// workgroup walks and the cross-lane reduction (99 x 6 shuffles) runs once per workgroup, not once per tile
+// (per tile it cost more than the 98 MACs per pixel it reduces: 89 us per call on average).
 __global__ __launch_bounds__(256) void cbam_conv7_bwd_kernel(const abc_cbam_conv7_desc d) {
     __shared__ float tdu[22][22];
     __shared__ float tst[22][22][2];
     __shared__ float w[98];
     __shared__ float red[4][99];
-    const int b = blockIdx.z, y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
+    const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + 15) / 16;
+    const int ntiles = tiles_x * tiles_y * d.B;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     if (threadIdx.x < 98) w[threadIdx.x] = d.w7[threadIdx.x];
-    for (int i = threadIdx.x; i < 22 * 22; i += 256) {
-        const int hy = i / 22, hx = i % 22;
-        const int yy = y0 + hy - 3, xx = x0 + hx - 3;
-        const bool in = yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
-        const size_t o = ((size_t)b * d.H + yy) * d.W + xx;
-        tdu[hy][hx] = in ? d.du[o] : 0.f;
-        tst[hy][hx][0] = in ? d.st[o * 2] : 0.f;
-        tst[hy][hx][1] = in ? d.st[o * 2 + 1] : 0.f;
-    }
-    __syncthreads();
-    const int yy = y0 + ty, xx = x0 + tx;
-    const bool valid = yy < d.H && xx < d.W;
-    // data gradient: correlation with the flipped kernel
-    if (valid) {
-        float g0 = 0.f, g1 = 0.f;
+    float acc[99];
+#pragma unroll
+    for (int t = 0; t < 99; ++t) acc[t] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int y0 = by * 16, x0 = bx * 16;
+        __syncthreads();   // previous tile's readers are done (and w[] is visible on the first pass)
+        for (int i = threadIdx.x; i < 22 * 22; i += 256) {
+            const int hy = i / 22, hx = i % 22;
+            const int yy = y0 + hy - 3, xx = x0 + hx - 3;
+            const bool in = yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
+            const size_t o = ((size_t)b * d.H + yy) * d.W + xx;
+            tdu[hy][hx] = in ? d.du[o] : 0.f;
+            tst[hy][hx][0] = in ? d.st[o * 2] : 0.f;
+            tst[hy][hx][1] = in ? d.st[o * 2 + 1] : 0.f;
+        }
+        __syncthreads();
+        const int yy = y0 + ty, xx = x0 + tx;
+        const bool valid = yy < d.H && xx < d.W;
+        // data gradient: correlation with the flipped kernel
+        if (valid) {
+            float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const float u = tdu[ty + 6 - ky][tx + 6 - kx];  // du at (y + 3 - ky, x + 3 - kx)
+                    g0 += u * w[ky * 7 + kx];
+                    g1 += u * w[49 + ky * 7 + kx];
+                }
+            d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 0] = g0;
+            d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 1] = g1;
+        }
+        // weight gradient: dW[ch][ky][kx] = sum_pix st[pix + (ky-3, kx-3)][ch] * du[pix]
+        const float u = valid ? tdu[ty + 3][tx + 3] : 0.f;
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
-                const float u = tdu[ty + 6 - ky][tx + 6 - kx];  // du at (y + 3 - ky, x + 3 - kx)
-                g0 += u * w[ky * 7 + kx];
-                g1 += u * w[49 + ky * 7 + kx];
+                acc[ky * 7 + kx] = fmaf(u, tst[ty + ky][tx + kx][0], acc[ky * 7 + kx]);
+                acc[49 + ky * 7 + kx] = fmaf(u, tst[ty + ky][tx + kx][1], acc[49 + ky * 7 + kx]);
             }
-        d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 0] = g0;
-        d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 1] = g1;
+        acc[98] += u;
     }
-    // weight gradient: dW[ch][ky][kx] = sum_pix st[pix + (ky-3, kx-3)][ch] * du[pix]
-    const float u = valid ? tdu[ty + 3][tx + 3] : 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
     for (int t = 0; t < 99; ++t) {
-        float v;
-        if (t < 98) {
-            const int ch = t / 49, ky = (t % 49) / 7, kx = t % 7;
-            v = u * tst[ty + ky][tx + kx][ch];
-        } else v = u;
+        float v = acc[t];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if (lane == 0) red[wave][t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 99) {
-        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        d.dw_partial[(size_t)blk * 99 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    }
+    if (threadIdx.x < 99)
+        d.dw_partial[(size_t)blockIdx.x * 99 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // one workgroup per output (98 weights + bias): 256 lanes stride the per-workgroup partials, fixed tree -> reproducible
@@ -221,35 +277,39 @@ template <typename T>
 __global__ __launch_bounds__(256) void cbam_apply_kernel(const abc_cbam_pix_desc d) {
     constexpr int N = V8<T>::N;
     const int ncv = d.C / N;
-    const int64_t nitems = (int64_t)d.B * d.H * d.W * ncv;
+    const int hw = d.H * d.W;
+    const int n = blockIdx.y;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int c = (gt % ncv) * N;
+    const int ppass = gridDim.x * (256 / ncv);
     const T* y = (const T*)d.y;
     const T* rs = (const T*)d.res;
     T* out = (T*)d.out;
-    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < nitems; it += (int64_t)gridDim.x * 256) {
-        const int64_t p = it / ncv;
-        const int c = (int)(it % ncv) * N;
-        const int x = (int)(p % d.W);
-        const int yy = (int)((p / d.W) % d.H);
-        const int n = (int)(p / ((int64_t)d.H * d.W));
+    float sc[N], sh[N], ca[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { sc[j] = d.scale[c + j]; sh[j] = d.shift[c + j]; ca[j] = d.ca[(size_t)n * d.C + c + j]; }
+    for (int q = gt / ncv; q < hw; q += ppass) {
+        const int64_t p = (int64_t)n * hw + q;
         float v[N], r[N], o[N];
         ld8<T, N>(y + p * d.ld_y + d.cy_off + c, v);
         if (!d.res_pool) {
             ld8<T, N>(rs + p * d.ld_res + d.cres_off + c, r);
         } else {  // residual = 2x2 max-pool of a tensor at twice the resolution (unet2.Down: MaxPool2d then DoubleConv)
+            const int yy = q / d.W, x = q - yy * d.W;
             float t[N];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const size_t pp = ((size_t)n * 2 * d.H + 2 * yy + (q >> 1)) * (2 * d.W) + 2 * x + (q & 1);
+            for (int k = 0; k < 4; ++k) {
+                const size_t pp = ((size_t)n * 2 * d.H + 2 * yy + (k >> 1)) * (2 * d.W) + 2 * x + (k & 1);
                 ld8<T, N>(rs + pp * d.ld_res + d.cres_off + c, t);
 #pragma unroll
-                for (int j = 0; j < N; ++j) r[j] = (q == 0) ? t[j] : fmaxf(r[j], t[j]);
+                for (int j = 0; j < N; ++j) r[j] = (k == 0) ? t[j] : fmaxf(r[j], t[j]);
             }
         }
         const float sa = d.sa[p];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const float z = fmaf(v[j], d.scale[c + j], d.shift[c + j]);
-            o[j] = fmaxf(sa * d.ca[(size_t)n * d.C + c + j] * z + r[j], 0.f);
+            const float z = fmaf(v[j], sc[j], sh[j]);
+            o[j] = fmaxf(sa * ca[j] * z + r[j], 0.f);
         }
         st8(out + p * d.ld_out + d.cout_off + c, o);
     }
@@ -257,12 +317,13 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const abc_cbam_pix_desc
 
 // ------------------------------------------------------------------ backward pass 1
 // g = (dOut_same + unpool(dOut_pool)) * [out > 0];   du = (sum_c g*o1) * sa*(1-sa)
-template <typename T>
+template <typename T, int NVL>
 __global__ __launch_bounds__(256) void cbam_bwd1_kernel(const abc_cbam_pix_desc d) {
     constexpr int N = V8<T>::N;
     const int ncv = d.C / N;
-    const int cpp = ncv < 64 ? ncv : 64;
-    const int64_t npix = (int64_t)d.B * d.H * d.W;
+    const int cpp = ncv / NVL;
+    const int hw = d.H * d.W;
+    const int n = blockIdx.y;
     const int ppb = 256 / cpp;
     const int sub = threadIdx.x % cpp, pl = threadIdx.x / cpp;
     const T* y = (const T*)d.y;
@@ -270,13 +331,21 @@ __global__ __launch_bounds__(256) void cbam_bwd1_kernel(const abc_cbam_pix_desc 
     const T* ds = (const T*)d.d_same;
     const T* dp = (const T*)d.d_pool;
     T* g = (T*)d.g;
-    for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < npix; p += (int64_t)gridDim.x * ppb) {
-        const int x = (int)(p % d.W);
-        const int yy = (int)((p / d.W) % d.H);
-        const int n = (int)(p / ((int64_t)d.H * d.W));
+    float sc[NVL][N], sh[NVL][N], ca[NVL][N];
+#pragma unroll
+    for (int u = 0; u < NVL; ++u)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int c = (sub + u * cpp) * N + j;
+            sc[u][j] = d.scale[c]; sh[u][j] = d.shift[c]; ca[u][j] = d.ca[(size_t)n * d.C + c];
+        }
+    for (int q = blockIdx.x * ppb + pl; q < hw; q += gridDim.x * ppb) {
+        const int64_t p = (int64_t)n * hw + q;
+        const int yy = q / d.W, x = q - yy * d.W;
         float dsa = 0.f;
-        for (int vi = sub; vi < ncv; vi += cpp) {
-            const int c = vi * N;
+#pragma unroll
+        for (int u = 0; u < NVL; ++u) {
+            const int c = (sub + u * cpp) * N;
             float ov[N], gv[N], v[N];
             ld8<T, N>(out + p * d.ld_out + d.cout_off + c, ov);
 #pragma unroll
@@ -295,12 +364,12 @@ __global__ __launch_bounds__(256) void cbam_bwd1_kernel(const abc_cbam_pix_desc 
                 int arg[N];
                 float best[N];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const size_t pp = ((size_t)n * d.H + 2 * wy + (q >> 1)) * d.W + 2 * wx + (q & 1);
+                for (int k = 0; k < 4; ++k) {
+                    const size_t pp = ((size_t)n * d.H + 2 * wy + (k >> 1)) * d.W + 2 * wx + (k & 1);
                     ld8<T, N>(out + pp * d.ld_out + d.cout_off + c, w);
 #pragma unroll
                     for (int j = 0; j < N; ++j)
-                        if (q == 0 || w[j] > best[j]) { best[j] = w[j]; arg[j] = q; }
+                        if (k == 0 || w[j] > best[j]) { best[j] = w[j]; arg[j] = k; }
                 }
 #pragma unroll
                 for (int j = 0; j < N; ++j) gv[j] += (arg[j] == me) ? t[j] : 0.f;
@@ -309,7 +378,7 @@ __global__ __launch_bounds__(256) void cbam_bwd1_kernel(const abc_cbam_pix_desc 
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 gv[j] = (ov[j] > 0.f) ? gv[j] : 0.f;
-                const float o1 = d.ca[(size_t)n * d.C + c + j] * fmaf(v[j], d.scale[c + j], d.shift[c + j]);
+                const float o1 = ca[u][j] * fmaf(v[j], sc[u][j], sh[u][j]);
                 dsa += gv[j] * o1;
             }
             st8(g + p * d.ld_g + c, gv);
@@ -331,26 +400,27 @@ __global__ __launch_bounds__(256) void cbam_bwd2_kernel(const abc_cbam_pix_desc 
     const int ncv = d.C / N;
     const int hw = d.H * d.W;
     const int n = blockIdx.y;  // image
-    const int64_t nitems = (int64_t)hw * ncv;
     const int tid = threadIdx.x;
-    const int cv = (int)((blockIdx.x * 256 + tid) % ncv);
-    const int c = cv * N;
+    const int gt = blockIdx.x * 256 + tid;
+    const int c = (gt % ncv) * N;
+    const int ppass = gridDim.x * (256 / ncv);
     const T* y = (const T*)d.y;
     const T* g = (const T*)d.g;
     T* dz = (T*)d.dz;
-    float acc[N];
+    float acc[N], sc[N], sh[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) acc[j] = 0.f;
-    for (int64_t it = (int64_t)blockIdx.x * 256 + tid; it < nitems; it += (int64_t)gridDim.x * 256) {
-        const int64_t p = (int64_t)n * hw + it / ncv;
+    for (int j = 0; j < N; ++j) { acc[j] = 0.f; sc[j] = d.scale[c + j]; sh[j] = d.shift[c + j]; }
+    const float invC = 1.f / d.C;
+    for (int q = gt / ncv; q < hw; q += ppass) {
+        const int64_t p = (int64_t)n * hw + q;
         float gv[N], v[N], o[N];
         ld8<T, N>(g + p * d.ld_g + c, gv);
         ld8<T, N>(y + p * d.ld_y + d.cy_off + c, v);
-        const float sa = d.sa[p], dm = d.dst[p * 2] / d.C, dx = d.dst[p * 2 + 1];
+        const float sa = d.sa[p], dm = d.dst[p * 2] * invC, dx = d.dst[p * 2 + 1];
         const int am = d.amax[p];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const float z = fmaf(v[j], d.scale[c + j], d.shift[c + j]);
+            const float z = fmaf(v[j], sc[j], sh[j]);
             const float t = gv[j] * sa + dm + ((c + j) == am ? dx : 0.f);
             o[j] = t;
             acc[j] += t * z;
@@ -369,32 +439,46 @@ __global__ __launch_bounds__(256) void cbam_bwd2_kernel(const abc_cbam_pix_desc 
 }
 
 // ------------------------------------------------------------------ channel attention backward
-// Every workgroup first rebuilds the small per-image intermediates in LDS (dt[B][C], d_hidden[B][mid]: a few hundred
-// thousand MACs), then the outputs -- weight / bias gradients summed over the images in REGISTERS in image order, and the
-// per-image pool gradients -- are partitioned over the grid.  (The first version was one workgroup walking the images
-// serially with global read-modify-write accumulation: 400 us per call.)
+// Three small launches (the first version was one workgroup walking the images serially: 400 us per call; the second
+// had EVERY workgroup rebuild the per-image intermediates from the pass-2 partials: 158 us):
+//   pre1: dt[n][c] = (sum of the pass-2 partials) * ca (1 - ca), one thread per (image, channel)      -> work[0 .. B C)
+//   pre2: d_hidden[n][j] for both pooled branches, one workgroup per image                              -> work[B C ..)
+//   main: weight / bias gradients summed over the images in REGISTERS in image order, and the per-image pool
+//         gradients, partitioned over the grid; the intermediates come from `work` into LDS.
+__global__ __launch_bounds__(256) void cbam_channel_bwd_pre1_kernel(const abc_cbam_channel_desc d) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= d.B * d.C) return;
+    const int n = idx / d.C, c = idx - n * d.C;
+    const int T = d.tiles_per_img;
+    double s = 0.0;
+    for (int k = 0; k < T; ++k) s += (double)d.partial[((size_t)n * T + k) * d.C + c];
+    const float ca = d.ca[idx];
+    d.work[idx] = (float)s * ca * (1.f - ca);
+}
+
+__global__ __launch_bounds__(256) void cbam_channel_bwd_pre2_kernel(const abc_cbam_channel_desc d) {
+    const int n = blockIdx.x;
+    const int per = 256 / d.mid;
+    const int j = threadIdx.x / per, sub = threadIdx.x % per;
+    const float* dt = d.work + (size_t)n * d.C;
+    float s = 0.f;
+    for (int c = sub; c < d.C; c += per) s += d.w2[(size_t)c * d.mid + j] * dt[c];
+    for (int o = 1; o < per && o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (sub == 0) {
+        const int idx = n * d.mid + j;
+        d.work[(size_t)d.B * d.C + idx] = d.hid_avg[idx] > 0.f ? s : 0.f;
+        d.work[(size_t)d.B * d.C + d.B * d.mid + idx] = d.hid_max[idx] > 0.f ? s : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_channel_desc d) {
     extern __shared__ float sm[];
     float* dt = sm;                      // [B][C]
     float* dha = sm + d.B * d.C;         // [B][mid]
     float* dhm = dha + d.B * d.mid;      // [B][mid]
     const int tid = threadIdx.x;
-    const int C_ = d.C, mid = d.mid, B = d.B, T = d.tiles_per_img;
-    for (int idx = tid; idx < B * C_; idx += 256) {
-        const int n = idx / C_, c = idx - n * C_;
-        double s = 0.0;
-        for (int k = 0; k < T; ++k) s += (double)d.partial[((size_t)n * T + k) * C_ + c];
-        const float ca = d.ca[idx];
-        dt[idx] = (float)s * ca * (1.f - ca);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < B * mid; idx += 256) {
-        const int n = idx / mid, j = idx - n * mid;
-        float s = 0.f;
-        for (int c = 0; c < C_; ++c) s += d.w2[(size_t)c * mid + j] * dt[n * C_ + c];
-        dha[idx] = d.hid_avg[idx] > 0.f ? s : 0.f;
-        dhm[idx] = d.hid_max[idx] > 0.f ? s : 0.f;
-    }
+    const int C_ = d.C, mid = d.mid, B = d.B;
+    for (int idx = tid; idx < B * (C_ + 2 * mid); idx += 256) sm[idx] = d.work[idx];
     __syncthreads();
     const int gsz = gridDim.x * 256, gt = blockIdx.x * 256 + tid;
     for (int i = gt; i < C_ * mid; i += gsz) {
@@ -435,43 +519,48 @@ __global__ __launch_bounds__(256) void cbam_bwd3_kernel(const abc_cbam_pix_desc 
     constexpr int N = V8<T>::N;
     __shared__ float red[256][2 * N + 1];
     const int ncv = d.C / N;
-    const int64_t hw = (int64_t)d.H * d.W;
-    const int64_t nitems = (int64_t)d.B * hw * ncv;
+    const int hw = d.H * d.W;
+    const int n = blockIdx.y;
     const int tid = threadIdx.x;
-    const int cv = (int)((blockIdx.x * 256 + tid) % ncv);
-    const int c = cv * N;
+    const int gt = blockIdx.x * 256 + tid;
+    const int c = (gt % ncv) * N;
+    const int ppass = gridDim.x * (256 / ncv);
     const T* y = (const T*)d.y;
     T* dz = (T*)d.dz;
-    float a1[N], a2[N];
+    float a1[N], a2[N], sc[N], sh[N], mu[N], is[N], ca[N], dav[N], mz[N], dmz[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
-    for (int64_t it = (int64_t)blockIdx.x * 256 + tid; it < nitems; it += (int64_t)gridDim.x * 256) {
-        const int64_t p = it / ncv;
-        const int n = (int)(p / hw);
+    for (int j = 0; j < N; ++j) {
+        const size_t nc = (size_t)n * d.C + c + j;
+        a1[j] = 0.f; a2[j] = 0.f;
+        sc[j] = d.scale[c + j]; sh[j] = d.shift[c + j]; mu[j] = d.mean[c + j]; is[j] = d.invstd[c + j];
+        ca[j] = d.ca[nc]; dav[j] = d.d_avgz[nc] / (float)hw; mz[j] = d.maxz[nc]; dmz[j] = d.d_maxz[nc];
+    }
+    for (int q = gt / ncv; q < hw; q += ppass) {
+        const int64_t p = (int64_t)n * hw + q;
         float t[N], v[N], o[N];
         ld8<T, N>(dz + p * d.ld_dz + c, t);
         ld8<T, N>(y + p * d.ld_y + d.cy_off + c, v);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const size_t nc = (size_t)n * d.C + c + j;
-            const float z = fmaf(v[j], d.scale[c + j], d.shift[c + j]);
-            float gz = t[j] * d.ca[nc] + d.d_avgz[nc] / (float)hw;
-            if (z == d.maxz[nc]) gz += d.d_maxz[nc];
+            const float z = fmaf(v[j], sc[j], sh[j]);
+            float gz = t[j] * ca[j] + dav[j];
+            if (z == mz[j]) gz += dmz[j];
             o[j] = gz;
             a1[j] += gz;
-            a2[j] += gz * ((v[j] - d.mean[c + j]) * d.invstd[c + j]);
+            a2[j] += gz * ((v[j] - mu[j]) * is[j]);
         }
         st8(dz + p * d.ld_dz + c, o);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) { red[tid][j] = a1[j]; red[tid][N + j] = a2[j]; }
     __syncthreads();
+    const size_t blk = (size_t)n * gridDim.x + blockIdx.x;
     for (int cc = tid; cc < d.C; cc += 256) {
         const int v = cc / N, j = cc % N;
         float s1 = 0.f, s2 = 0.f;
         for (int t = v; t < 256; t += ncv) { s1 += red[t][j]; s2 += red[t][N + j]; }
-        d.partial[((size_t)blockIdx.x * 2 + 0) * d.C + cc] = s1;
-        d.partial[((size_t)blockIdx.x * 2 + 1) * d.C + cc] = s2;
+        d.partial[(blk * 2 + 0) * d.C + cc] = s1;
+        d.partial[(blk * 2 + 1) * d.C + cc] = s2;
     }
 }
 
@@ -509,13 +598,24 @@ static int check_pix(const abc_cbam_pix_desc* d) {
 
 }  // namespace
 
+static int check_channel(const abc_cbam_channel_desc* d) {
+    if (d->mid < 1 || d->mid > 32 || (d->mid & (d->mid - 1))) return abc_fail(ABC_EUNSUPPORTED, "cbam_channel: mid must be a power of two <= 32");
+    return ABC_OK;
+}
+
 extern "C" int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t stream) {
+    int rc = check_channel(d);
+    if (rc) return rc;
     const size_t sh = (size_t)(2 * d->C + 2 * d->mid) * sizeof(float);
+    hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(abc_cdiv(d->C, 64), d->B), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_fwd_kernel, dim3(d->B), dim3(256), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_fwd");
 }
 
 extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream) {
+    int rc = check_channel(d);
+    if (rc) return rc;
+    if (d->work == nullptr) return abc_fail(ABC_EINVAL, "cbam_channel_bwd: work buffer of B * (C + 2 mid) floats required");
     const size_t sh = (size_t)d->B * (d->C + 2 * d->mid) * sizeof(float);
     if (sh > 150 * 1024) return abc_fail(ABC_EUNSUPPORTED, "cbam_channel_bwd: B * (C + 2 mid) floats exceed the LDS");
     static bool attr_done = false;
@@ -524,18 +624,28 @@ extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t
         attr_done = true;
     }
     const int nb = abc_cdiv(d->C * d->mid, 256 * 8) < 1 ? 1 : (abc_cdiv(d->C * d->mid, 256 * 8) > 32 ? 32 : abc_cdiv(d->C * d->mid, 256 * 8));
+    hipLaunchKernelGGL(cbam_channel_bwd_pre1_kernel, dim3(abc_cdiv(d->B * d->C, 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(cbam_channel_bwd_pre2_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(nb), dim3(256), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_bwd");
 }
 
+// workgroups per image of the per-pixel passes: enough to fill the chip a few times over, few enough that the
+// per-thread coefficient loads amortise (every thread walks >= ~8 items on the big levels)
+static int per_image_blocks(const abc_cbam_pix_desc* d, int items_per_thread_min, int cap_total) {
+    const int N = d->dtype == ABC_BF16 ? 8 : 4;
+    const int64_t items = (int64_t)d->H * d->W * (d->C / N);
+    int64_t b = (items + 256 * (int64_t)items_per_thread_min - 1) / (256 * (int64_t)items_per_thread_min);
+    const int cap = cap_total / d->B > 1 ? cap_total / d->B : 1;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
 extern "C" int abc_cbam_bwd2_blocks(const abc_cbam_pix_desc* d) {
-    const int N = d->dtype == ABC_BF16 ? 8 : 4;
-    return pix_blocks((int64_t)d->H * d->W * (d->C / N)) > 64 ? 64 : pix_blocks((int64_t)d->H * d->W * (d->C / N));
+    const int b = per_image_blocks(d, 4, 4096);
+    return b > 128 ? 128 : b;
 }
-extern "C" int abc_cbam_bwd3_blocks(const abc_cbam_pix_desc* d) {
-    const int N = d->dtype == ABC_BF16 ? 8 : 4;
-    return pix_blocks((int64_t)d->B * d->H * d->W * (d->C / N));
-}
+extern "C" int abc_cbam_bwd3_blocks(const abc_cbam_pix_desc* d) { return per_image_blocks(d, 4, 4096) * d->B; }
 
 #define ABC_PIX_LAUNCH(KERNEL, GRID)                                                                                 \
     do {                                                                                                             \
@@ -545,24 +655,46 @@ extern "C" int abc_cbam_bwd3_blocks(const abc_cbam_pix_desc* d) {
         else hipLaunchKernelGGL(KERNEL<float>, GRID, dim3(256), 0, (hipStream_t)stream, *d);                         \
     } while (0)
 
-extern "C" int abc_cbam_spatial_stats(const abc_cbam_pix_desc* d, abc_stream_t stream) {
+// lanes-per-pixel kernels: NVL = vectors per lane (2 only when C / N = 128, i.e. f32 with 512 channels)
+#define ABC_PIXGROUP_LAUNCH(KERNEL, GRID)                                                                            \
+    do {                                                                                                             \
+        int rc = check_pix(d);                                                                                       \
+        if (rc) return rc;                                                                                           \
+        const int ncv_ = d->C / (d->dtype == ABC_BF16 ? 8 : 4);                                                      \
+        if (ncv_ > 128) return abc_fail(ABC_EUNSUPPORTED, "cbam: more than 128 channel vectors per pixel");          \
+        if (d->dtype == ABC_BF16) {                                                                                  \
+            if (ncv_ > 64) hipLaunchKernelGGL((KERNEL<bf16, 2>), GRID, dim3(256), 0, (hipStream_t)stream, *d);       \
+            else hipLaunchKernelGGL((KERNEL<bf16, 1>), GRID, dim3(256), 0, (hipStream_t)stream, *d);                 \
+        } else {                                                                                                     \
+            if (ncv_ > 64) hipLaunchKernelGGL((KERNEL<float, 2>), GRID, dim3(256), 0, (hipStream_t)stream, *d);      \
+            else hipLaunchKernelGGL((KERNEL<float, 1>), GRID, dim3(256), 0, (hipStream_t)stream, *d);                \
+        }                                                                                                            \
+    } while (0)
+
+static int group_blocks(const abc_cbam_pix_desc* d) {
     const int N = d->dtype == ABC_BF16 ? 8 : 4;
-    const int ppb = 256 / ((d->C / N) < 64 ? (d->C / N) : 64);
-    ABC_PIX_LAUNCH(cbam_spatial_stats_kernel, dim3(pix_blocks(((int64_t)d->B * d->H * d->W + ppb - 1) / ppb * 256)));
+    const int ncv = d->C / N;
+    const int cpp = ncv > 64 ? ncv / 2 : ncv;
+    const int ppb = 256 / cpp;
+    int64_t b = ((int64_t)d->H * d->W + 4 * ppb - 1) / (4 * ppb);   // ~4 pixels per lane group
+    const int cap = 4096 / d->B > 1 ? 4096 / d->B : 1;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" int abc_cbam_spatial_stats(const abc_cbam_pix_desc* d, abc_stream_t stream) {
+    ABC_PIXGROUP_LAUNCH(cbam_spatial_stats_kernel, dim3(group_blocks(d), d->B));
     return abc_check_launch("cbam_spatial_stats");
 }
 
 extern "C" int abc_cbam_apply_fwd(const abc_cbam_pix_desc* d, abc_stream_t stream) {
-    const int N = d->dtype == ABC_BF16 ? 8 : 4;
-    ABC_PIX_LAUNCH(cbam_apply_kernel, dim3(pix_blocks((int64_t)d->B * d->H * d->W * (d->C / N))));
+    ABC_PIX_LAUNCH(cbam_apply_kernel, dim3(per_image_blocks(d, 4, 4096), d->B));
     return abc_check_launch("cbam_apply_fwd");
 }
 
 extern "C" int abc_cbam_bwd1(const abc_cbam_pix_desc* d, abc_stream_t stream) {
-    const int N = d->dtype == ABC_BF16 ? 8 : 4;
     if (d->d_pool && ((d->H | d->W) & 1)) return abc_fail(ABC_EUNSUPPORTED, "cbam: pooled dims must be even");
-    const int ppb = 256 / ((d->C / N) < 64 ? (d->C / N) : 64);
-    ABC_PIX_LAUNCH(cbam_bwd1_kernel, dim3(pix_blocks(((int64_t)d->B * d->H * d->W + ppb - 1) / ppb * 256)));
+    ABC_PIXGROUP_LAUNCH(cbam_bwd1_kernel, dim3(group_blocks(d), d->B));
     return abc_check_launch("cbam_bwd1");
 }
 
@@ -572,7 +704,7 @@ extern "C" int abc_cbam_bwd2(const abc_cbam_pix_desc* d, abc_stream_t stream) {
 }
 
 extern "C" int abc_cbam_bwd3(const abc_cbam_pix_desc* d, abc_stream_t stream) {
-    ABC_PIX_LAUNCH(cbam_bwd3_kernel, dim3(abc_cbam_bwd3_blocks(d)));
+    ABC_PIX_LAUNCH(cbam_bwd3_kernel, dim3(abc_cbam_bwd3_blocks(d) / d->B, d->B));
     return abc_check_launch("cbam_bwd3");
 }
 
@@ -581,10 +713,13 @@ extern "C" int abc_cbam_conv7_fwd(const abc_cbam_conv7_desc* d, abc_stream_t str
     return abc_check_launch("cbam_conv7_fwd");
 }
 
-extern "C" int abc_cbam_conv7_blocks(const abc_cbam_conv7_desc* d) { return abc_cdiv(d->W, 16) * abc_cdiv(d->H, 16) * d->B; }
+extern "C" int abc_cbam_conv7_blocks(const abc_cbam_conv7_desc* d) {
+    const int ntiles = abc_cdiv(d->W, 16) * abc_cdiv(d->H, 16) * d->B;
+    return ntiles < 1024 ? ntiles : 1024;   // persistent: 4 workgroups per CU
+}
 
 extern "C" int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream) {
-    hipLaunchKernelGGL(cbam_conv7_bwd_kernel, dim3(abc_cdiv(d->W, 16), abc_cdiv(d->H, 16), d->B), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(cbam_conv7_bwd_kernel, dim3(abc_cbam_conv7_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_conv7_reduce_kernel, dim3(99), dim3(256), 0, (hipStream_t)stream, (const float*)d->dw_partial,
                        abc_cbam_conv7_blocks(d), d->dw7, d->db7);
     return abc_check_launch("cbam_conv7_bwd");

@@ -27,8 +27,9 @@
 namespace {
 
 constexpr int FT = 256;      // threads per workgroup
-// halo segments a thread may hold (3x3 taps, 64-byte chunks: (2*MT+2) x 18 pixels x 4 segments over 256 threads)
-__host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 6 : (mt >= 6 ? 4 : (mt >= 4 ? 3 : 2)); }
+// halo segments a thread may hold (3x3 taps, 64-byte chunks: (2*MT+2) x 18 pixels x 4 segments over 256 threads;
+// MT = 8 also takes unet2's 5x5 taps: 20 x 20 pixels x 4 segments = 6.25 per thread)
+__host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 7 : (mt >= 6 ? 4 : (mt >= 4 ? 3 : 2)); }
 constexpr int SR_MAX = 256;  // weight rows per stage (tap group x BN)
 constexpr int LDS_WG = 80 * 1024;
 

@@ -227,8 +227,9 @@ int abc_head_fwd_ok(const abc_conv_desc* d) {
     if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
     if ((d->src.ldx % 8) || (d->cin_off % 8) || d->Cout_pad % 32) return 0;
+    // (all offsets in the kernel are unsigned 32-bit bytes: a batch-64 512x512 feature buffer of 8 x 128 channels is 2^31)
     const int64_t bx = (int64_t)d->B * d->Hg * d->Wg * d->src.ldx * 2;
-    return bx < (int64_t(1) << 31);
+    return bx < (int64_t(1) << 32) - 4096;
 }
 
 int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream) {

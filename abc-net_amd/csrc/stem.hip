@@ -18,28 +18,31 @@ struct StemK {
     void* y;
     float* stats;
     int B, H, W, Cout, Cout_pad, ldy, cout_off, ntaps, dy_min, dy_max, rows_per_wg;
-    int8_t ty[9], tx[9];
+    int8_t ty[25], tx[25];
 };
 
-template <typename CT, typename OutT>
+// NT = tap capacity (9: the 3x3 stem of unet.py; 25: the 5x5 stem of unet2.py:135), CPT = output channels per thread
+// (the tap weights live in registers: NT * CPT of them)
+template <typename CT, typename OutT, int NT, int CPT>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
-    __shared__ float sx[4][512 + 8];
+    constexpr int NR = NT > 9 ? 5 : 4;
+    __shared__ float sx[NR][512 + 8];
     __shared__ float red[4][2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ncg = a.Cout / 8;
+    const int ncg = a.Cout / CPT;
     const int cg = tid % ncg, slot = tid / ncg;
     const int nslot = 256 / ncg;
     const int nrows = a.B * a.H;
     const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(r0 + a.rows_per_wg, nrows);
     const int nxr = a.dy_max - a.dy_min + 1;
-    float wv[9][8], bv[8], s1[8], s2[8];
+    float wv[NT][CPT], bv[CPT], s1[CPT], s2[CPT];
     const CT* wp = (const CT*)a.w;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wv[t][j] = (t < a.ntaps) ? (float)wp[((size_t)t * a.Cout_pad + cg * 8 + j) * 16] : 0.f;
+        for (int j = 0; j < CPT; ++j) wv[t][j] = (t < a.ntaps) ? (float)wp[((size_t)t * a.Cout_pad + cg * CPT + j) * 16] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { bv[j] = a.bias ? a.bias[cg * 8 + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    for (int j = 0; j < CPT; ++j) { bv[j] = a.bias ? a.bias[cg * CPT + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
     OutT* yo = (OutT*)a.y;
     for (int row = r0; row < r1; ++row) {
         const int b = row / a.H, y = row - b * a.H;
@@ -51,21 +54,33 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
         }
         __syncthreads();
         for (int x0 = slot; x0 < a.W; x0 += nslot) {
-            float v[8];
+            float v[CPT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = bv[j];
+            for (int j = 0; j < CPT; ++j) v[j] = bv[j];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 if (t < a.ntaps) {
                     const float xv = sx[a.ty[t]][x0 + 4 + a.tx[t]];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = fmaf(wv[t][j], xv, v[j]);
+                    for (int j = 0; j < CPT; ++j) v[j] = fmaf(wv[t][j], xv, v[j]);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-            OutT* dst = yo + ((size_t)row * a.W + x0) * a.ldy + a.cout_off + cg * 8;
-            if constexpr (sizeof(OutT) == 2) {
+            for (int j = 0; j < CPT; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            OutT* dst = yo + ((size_t)row * a.W + x0) * a.ldy + a.cout_off + cg * CPT;
+            if constexpr (CPT == 4) {
+                if constexpr (sizeof(OutT) == 2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+                    *(bf16x4*)dst = o;
+                } else {
+                    f32x4 lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lo[j] = v[j];
+                    *(f32x4*)dst = lo;
+                }
+            } else if constexpr (sizeof(OutT) == 2) {
                 *(bf16x8*)dst = pack_frag<bf16>(v);
             } else {
                 f32x4 lo, hi;
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
     }
     if (a.stats != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CPT; ++j) {
             float u = s1[j], q = s2[j];
             for (int m = ncg; m < 64; m <<= 1) { u += __shfl_xor(u, m); q += __shfl_xor(q, m); }
             s1[j] = u; s2[j] = q;
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
         __syncthreads();
         if (lane < ncg) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { red[wave][lane * 8 + j] = s1[j]; red[wave][64 + lane * 8 + j] = s2[j]; }
+            for (int j = 0; j < CPT; ++j) { red[wave][lane * CPT + j] = s1[j]; red[wave][64 + lane * CPT + j] = s2[j]; }
         }
         __syncthreads();
         if (tid < a.Cout) {
@@ -105,7 +120,7 @@ int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks) {
     if (d->Cin != 1 || d->cin_off != 0 || d->src.ldx != 1 || d->dtype_in != ABC_F32 || d->src.scale || d->src.pool || d->src.planar ||
         d->src.drop_p > 0.f)
         return 0;
-    if (d->planar_out || d->accumulate || d->stats_rows == 4 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0 || d->ntaps > 9) return 0;
+    if (d->planar_out || d->accumulate || d->stats_rows == 4 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0 || d->ntaps > 25) return 0;
     if (d->Cout % 8 || d->Cout > 64 || (d->Cout & (d->Cout - 1)) || d->Wg > 512 || d->Hg != d->Hin || d->Wg != d->Win ||
         d->Hout != d->Hg || d->Wout != d->Wg)
         return 0;
@@ -117,7 +132,7 @@ int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks) {
         dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
         dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
     }
-    if (dymax - dymin > 3 || dxmin < -4 || dxmax > 4) return 0;
+    if (dymax - dymin > (d->ntaps > 9 ? 4 : 3) || dxmin < -4 || dxmax > 4) return 0;
     if (stat_blocks) *stat_blocks = abc_cdiv(d->B * d->Hg, STEM_ROWS);
     return 1;
 }
@@ -133,8 +148,12 @@ int abc_conv_stem_launch(const abc_conv_desc* d, abc_stream_t stream) {
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - dymin); k.tx[t] = (int8_t)d->tap_dx[t]; }
     const int nwg = abc_cdiv(d->B * d->Hg, STEM_ROWS);
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype_c == ABC_F32) hipLaunchKernelGGL((stem_conv_kernel<float, float>), dim3(nwg), dim3(256), 0, st, k);
-    else if (d->dtype_out == ABC_BF16) hipLaunchKernelGGL((stem_conv_kernel<bf16, bf16>), dim3(nwg), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((stem_conv_kernel<bf16, float>), dim3(nwg), dim3(256), 0, st, k);
+    if (d->ntaps > 9) {
+        if (d->dtype_c == ABC_F32) hipLaunchKernelGGL((stem_conv_kernel<float, float, 25, 4>), dim3(nwg), dim3(256), 0, st, k);
+        else if (d->dtype_out == ABC_BF16) hipLaunchKernelGGL((stem_conv_kernel<bf16, bf16, 25, 4>), dim3(nwg), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((stem_conv_kernel<bf16, float, 25, 4>), dim3(nwg), dim3(256), 0, st, k);
+    } else if (d->dtype_c == ABC_F32) hipLaunchKernelGGL((stem_conv_kernel<float, float, 9, 8>), dim3(nwg), dim3(256), 0, st, k);
+    else if (d->dtype_out == ABC_BF16) hipLaunchKernelGGL((stem_conv_kernel<bf16, bf16, 9, 8>), dim3(nwg), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((stem_conv_kernel<bf16, float, 9, 8>), dim3(nwg), dim3(256), 0, st, k);
     return abc_check_launch("stem_conv");
 }

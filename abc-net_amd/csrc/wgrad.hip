@@ -525,25 +525,28 @@ struct C1K {
     const float* x;      // image, [B][H][W] (one channel, f32)
     float* partial;      // [nsplit][ntaps][Ca]
     int B, H, W, ldp, cp_off, Ca, ntaps, nsplit, dy_min, dy_max, dx_min, dx_max;
-    int8_t ty[9], tx[9];
+    int8_t ty[25], tx[25];
 };
 
-template <typename PT>
+// NT = tap capacity (9: 3x3 stem of unet.py; 25: 5x5 stem of unet2.py:135), CPT = dY channels per thread (NT * CPT
+// accumulators live in registers)
+template <typename PT, int NT, int CPT>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
-    __shared__ float sx[4][512 + 8];     // up to 4 image rows (3x3: 3), W <= 512 columns, 4-column halo either side
-    __shared__ float red[4][9 * 64];
+    constexpr int NR = NT > 9 ? 5 : 4;
+    __shared__ float sx[NR][512 + 8];    // the image rows a row of dY needs, W <= 512 columns, 4-column halo either side
+    __shared__ float red[4][NT * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ncg = a.Ca / 8;                 // channel groups of 8 (1, 2, 4 or 8)
+    const int ncg = a.Ca / CPT;               // channel groups (a power of two <= 16)
     const int cg = tid % ncg, slot = tid / ncg;
     const int nslot = 256 / ncg;              // pixels per step
     const int nrows = a.B * a.H;
     const int r0 = (int)((long long)blockIdx.x * nrows / a.nsplit), r1 = (int)((long long)(blockIdx.x + 1) * nrows / a.nsplit);
     const int nxr = a.dy_max - a.dy_min + 1;
-    float acc[9][8];
+    float acc[NT][CPT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+        for (int j = 0; j < CPT; ++j) acc[t][j] = 0.f;
     for (int row = r0; row < r1; ++row) {
         const int b = row / a.H, y = row - b * a.H;
         __syncthreads();
@@ -554,24 +557,24 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
         }
         __syncthreads();
         for (int x0 = slot; x0 < a.W; x0 += nslot) {
-            float g[8];
-            const PT* src = (const PT*)a.p + ((size_t)row * a.W + x0) * a.ldp + a.cp_off + cg * 8;
-            LoadVec<PT, 8>::ld(src, g);
+            float g[CPT];
+            const PT* src = (const PT*)a.p + ((size_t)row * a.W + x0) * a.ldp + a.cp_off + cg * CPT;
+            LoadVec<PT, CPT>::ld(src, g);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 if (t < a.ntaps) {
                     const float xv = sx[a.ty[t]][x0 + 4 + a.tx[t]];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[t][j] = fmaf(g[j], xv, acc[t][j]);
+                    for (int j = 0; j < CPT; ++j) acc[t][j] = fmaf(g[j], xv, acc[t][j]);
                 }
             }
         }
     }
     // fold the pixel slots: lanes with equal cg inside the wave (ncg divides 64), then the 4 waves through LDS
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CPT; ++j) {
             float v = acc[t][j];
             for (int m = ncg; m < 64; m <<= 1) v += __shfl_xor(v, m);
             acc[t][j] = v;
@@ -579,9 +582,9 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
     __syncthreads();
     if (lane < ncg) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[wave][t * 64 + lane * 8 + j] = acc[t][j];
+            for (int j = 0; j < CPT; ++j) red[wave][t * 64 + lane * CPT + j] = acc[t][j];
     }
     __syncthreads();
     for (int i = tid; i < a.ntaps * a.Ca; i += 256) {
@@ -593,14 +596,14 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
 static bool c1_ok(const abc_wgrad_desc* d) {
     if (getenv("ABC_WGRAD_NOC1")) return false;
     if (d->Cb != 1 || d->cq_off != 0 || d->q.ldx != 1 || d->dtype_q != ABC_F32 || d->q.scale || d->q.pool || d->q.planar || d->q.drop_p > 0.f) return false;
-    if (d->p.scale || d->p.pool || d->p.planar || d->p.drop_p > 0.f || d->stride != 1 || d->ntaps > 9) return false;
+    if (d->p.scale || d->p.pool || d->p.planar || d->p.drop_p > 0.f || d->stride != 1 || d->ntaps > 25) return false;
     if (d->Ca % 8 || d->Ca > 64 || (d->Ca & (d->Ca - 1)) || d->Wg > 512 || (d->p.ldx % 8) || (d->cp_off % 8)) return false;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
     for (int t = 0; t < d->ntaps; ++t) {
         dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
         dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
     }
-    return dymax - dymin <= 3 && dxmin >= -4 && dxmax <= 4 && d->Hq == d->Hg && d->Wq == d->Wg;
+    return dymax - dymin <= (d->ntaps > 9 ? 4 : 3) && dxmin >= -4 && dxmax <= 4 && d->Hq == d->Hg && d->Wq == d->Wg;
 }
 
 static int c1_launch(const abc_wgrad_desc* d, hipStream_t st) {
@@ -611,8 +614,11 @@ static int c1_launch(const abc_wgrad_desc* d, hipStream_t st) {
     for (int t = 0; t < d->ntaps; ++t) { dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax; }
     k.dy_min = dymin; k.dy_max = dymax; k.dx_min = 0; k.dx_max = 0;
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - dymin); k.tx[t] = (int8_t)d->tap_dx[t]; }
-    if (d->dtype_p == ABC_BF16) hipLaunchKernelGGL(wgrad_c1_kernel<bf16>, dim3(d->nsplit), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL(wgrad_c1_kernel<float>, dim3(d->nsplit), dim3(256), 0, st, k);
+    if (d->ntaps > 9) {
+        if (d->dtype_p == ABC_BF16) hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 25, 4>), dim3(d->nsplit), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((wgrad_c1_kernel<float, 25, 4>), dim3(d->nsplit), dim3(256), 0, st, k);
+    } else if (d->dtype_p == ABC_BF16) hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 9, 8>), dim3(d->nsplit), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((wgrad_c1_kernel<float, 9, 8>), dim3(d->nsplit), dim3(256), 0, st, k);
     return abc_check_launch("wgrad_c1");
 }
 

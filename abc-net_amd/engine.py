@@ -807,6 +807,7 @@ class Engine:
             ch.hid_avg, ch.hid_max = blk.hid_a.data_ptr(), blk.hid_m.data_ptr()
             ch.dw1, ch.db1, ch.dw2, ch.db2 = self.G(m + ".0.weight"), self.G(m + ".0.bias"), self.G(m + ".2.weight"), self.G(m + ".2.bias")
             ch.d_avgz, ch.d_maxz = d_avgz.data_ptr(), d_maxz.data_ptr()
+            ch.work = self.f32buf(B * (Cc + 2 * blk.mid)).data_ptr()
             self._emit(ops, lib.abc_cbam_channel_bwd, ch, "cbam_channel_bwd " + blk.prefix,
                        writes=(m + ".0.weight", m + ".0.bias", m + ".2.weight", m + ".2.bias"))
             d3 = pix()

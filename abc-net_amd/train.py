@@ -9,6 +9,8 @@ all-reduce launch points (a single graph when world size is 1).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -152,6 +154,7 @@ class Trainer:
         st = stream.cuda_stream
         groups = [eng.pack_ops, eng.fwd_ops, None, eng.bwd_ops]
         acc = {}
+        by_op = os.environ.get("ABC_PROFILE_OPS")  # (diagnostics: one row per launch label instead of per kernel)
         for _ in range(iters):
             marks = []
             for ops in groups:
@@ -169,7 +172,7 @@ class Trainer:
                     e1.record(stream)
                     if rc != 0:
                         L.check(rc, what)
-                    marks.append((meta["kernel"], meta["flops"], meta["bytes"], e0, e1))
+                    marks.append((meta["kernel"] + " | " + what if by_op else meta["kernel"], meta["flops"], meta["bytes"], e0, e1))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             self.opt.step(st)

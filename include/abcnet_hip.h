@@ -282,6 +282,7 @@ typedef struct abc_cbam_channel_desc { /* ChannelAttentionModule (unet2.py:6-22)
     const float* w1; const float* b1; const float* w2; const float* b2; /* shared_MLP.0 / .2 */
     float* ca; float* avgz; float* maxz; float* hid_avg; float* hid_max; /* [B][C], [B][C], [B][C], [B][mid] x2 */
     float* dw1; float* db1; float* dw2; float* db2; float* d_avgz; float* d_maxz; /* backward outputs */
+    float* work;           /* backward scratch, B * (C + 2 mid) floats */
 } abc_cbam_channel_desc;
 int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
 int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
