@@ -16,6 +16,8 @@ What is produced (all float32 unless noted):
   loss_128.npz             the 8 weighted loss terms, total and dL/dlogit samples
                            for seeded logits/targets at [2,.,128,128]
   nms_128.npz              NMS masks (bit-packed) from exec of img2smiles2.py:61-79
+  metrics_128.npz          sum / count of the 17 training meters after one update (exec of
+                           train.py:95-105 + 145-215 with the reference's meter.AverageMeter)
   adam.npz                 one torch.optim.Adam step (train.py:55 settings)
   meta.json                state_dict key/shape lists, parameter counts
 """
@@ -160,6 +162,36 @@ def loss_goldens():
     print("wrote loss", loss.item(), loss.dtype)
 
 
+def metrics_goldens():
+    """train.py:95-105 (activations) + train.py:145-215 (the 17 meters) executed on the seeded inputs with the
+    reference's own meter.AverageMeter; stored: sum and count of every meter after ONE update"""
+    import re
+    from meter import AverageMeter
+    from abcnet_amd.synthetic import correlated_logits
+    tg = synthetic_targets(2, 128, seed=3)
+    preds = correlated_logits(tg, seed=19)
+    ns = {"torch": torch}
+    for n, v in zip(PRED_NAMES, preds):
+        ns[n] = v
+    for n, v in zip(TGT_NAMES, tg):
+        ns[n] = v
+    text = slice_text(os.path.join(REF, "train.py"), 145, 215)
+    names = []
+    for m in re.finditer(r"(train_\w+)\.update", text):
+        if m.group(1) not in names:
+            names.append(m.group(1))
+    for n in names:
+        ns[n] = AverageMeter()
+    exec(slice_text(os.path.join(REF, "train.py"), 95, 105), ns)
+    exec(text, ns)
+    res = {"names": np.array(names), "sum": np.array([float(ns[n].sum) for n in names]),
+           "count": np.array([float(ns[n].count) for n in names])}
+    np.savez(os.path.join(HERE, "metrics_128.npz"), **res)
+    print("wrote metrics")
+    for n in names:
+        print("  %-36s sum %12.4f count %12.4f" % (n, ns[n].sum, ns[n].count))
+
+
 def nms_goldens():
     g = torch.Generator().manual_seed(13)
     ns = {"torch": torch}
@@ -214,7 +246,11 @@ def meta():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":   # (added after the other fixtures: regenerate this one alone)
+        metrics_goldens()
+        sys.exit(0)
     meta()
+    metrics_goldens()
     adam_goldens()
     nms_goldens()
     loss_goldens()
