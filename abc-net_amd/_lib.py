@@ -119,8 +119,14 @@ class CbamConv7Desc(C.Structure):
                 ("db7", vp), ("B", i32), ("H", i32), ("W", i32)]
 
 
+class MetricsDesc(C.Structure):
+    _fields_ = [("logits", vp * 8), ("t_atom", vp), ("t_types", vp), ("t_charges", vp), ("t_hs", vp), ("t_bond", vp),
+                ("t_btypes", vp), ("t_rho", vp), ("t_omega", vp), ("B", i32), ("h", i32), ("w", i32), ("peaks", vp),
+                ("partial", vp), ("totals", vp), ("last", vp)]
+
+
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
-            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc]
+            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc]
 
 # every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
@@ -154,6 +160,8 @@ SYMBOLS = {
     "abc_loss_finalize": (C.c_int, [P(LossFinDesc), vp]),
     "abc_adam_step": (C.c_int, [P(AdamDesc), vp]),
     "abc_nms_peaks": (C.c_int, [P(NmsDesc), vp]),
+    "abc_metrics_blocks": (C.c_int, [P(MetricsDesc)]),
+    "abc_metrics_update": (C.c_int, [P(MetricsDesc), vp]),
     "abc_plane_sum": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "abc_plane_sum_work": (C.c_int, [i32]),
     "abc_cbam_channel_fwd": (C.c_int, [P(CbamChannelDesc), vp]),

@@ -58,6 +58,66 @@ class FusedLoss:
         return r
 
 
+METER_NAMES = [
+    "atom_targets_precision", "atom_targets_precision3", "atom_targets_recall", "atom_targets_recall3",
+    "atom_types_acc", "atom_charges_acc", "atom_hs_acc",
+    "bond_targets_precision", "bond_targets_precision3", "bond_targets_recall", "bond_targets_recall3",
+    "bond_types_acc", "bond_rhos_mae",
+    "bond_omega_precision", "bond_omega_recall3", "bond_omega_recall", "bond_omega_precision3",
+]
+
+
+class FusedMetrics:
+    """The 17 AverageMeters of train.py:145-215 as one device-resident table: `run` adds the current batch
+    (logits + targets already in HBM), `result` reads it (the only host sync), `reset` is the new-epoch
+    re-creation of the meters (train.py:58-81)."""
+
+    def __init__(self, logits, targets):
+        lib = L.load()
+        self.lib = lib
+        B, _, h, w = logits[0].shape
+        exp = [(B, 1), (B, 14), (B, 3), (B, 2), (B, 1), (B, 6, 60), (B, 60), (B, 60)]
+        dts = [torch.float32] * 6 + [torch.float64] * 2
+        for t, e, dt in zip(targets, exp, dts):
+            if tuple(t.shape) != tuple(e) + (h, w) or t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+                raise L.AbcNetHipError("metrics: target %s %s does not match the contract %s %s (device tensors; no CPU "
+                                       "fallback)" % (tuple(t.shape), t.dtype, e, dt))
+        for t, c in zip(logits, [1, 14, 3, 2, 1, 360, 60, 60]):
+            if tuple(t.shape) != (B, c, h, w) or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                raise L.AbcNetHipError("metrics: logits must be the 8 contiguous NCHW f32 device maps of heads [1,14,3,2,1,360,60,60]")
+        self.keep = (list(logits), list(targets))
+        dev = logits[0].device
+        d = L.MetricsDesc()
+        for i in range(8):
+            d.logits[i] = logits[i].data_ptr()
+        (d.t_atom, d.t_types, d.t_charges, d.t_hs, d.t_bond, d.t_btypes, d.t_rho, d.t_omega) = (t.data_ptr() for t in targets)
+        d.B, d.h, d.w = B, h, w
+        self.peaks = torch.zeros((2, B, h, w), dtype=torch.uint8, device=dev)
+        self.partial = torch.zeros((lib.abc_metrics_blocks(C.byref(d)), 24), dtype=torch.float64, device=dev)
+        self.totals = torch.zeros((17, 2), dtype=torch.float64, device=dev)
+        self.last = torch.zeros((17, 2), dtype=torch.float64, device=dev)
+        d.peaks, d.partial, d.totals, d.last = self.peaks.data_ptr(), self.partial.data_ptr(), self.totals.data_ptr(), self.last.data_ptr()
+        self.d = d
+
+    def run(self, stream=None):
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        L.check(self.lib.abc_metrics_update(C.byref(self.d), stream), "metrics_update")
+
+    def reset(self):
+        self.totals.zero_()
+
+    def result(self):
+        """{name: {"sum", "count", "avg", "val"}} -- the AverageMeter fields (device sync)"""
+        tot, last = self.totals.cpu(), self.last.cpu()
+        out = {}
+        for i, n in enumerate(METER_NAMES):
+            s, c = tot[i, 0].item(), tot[i, 1].item()
+            ln, ld = last[i, 0].item(), last[i, 1].item()
+            out[n] = {"sum": s, "count": c, "avg": s / c if c else float("nan"), "val": ln / ld if ld else float("nan")}
+        return out
+
+
 def nms_peaks(atom, bond, rho, omega):
     """img2smiles2.py:61-79 on the NCHW f32 head maps: (atom_mask[B,1,h,w], bond_mask[B,1,h,w],
     |rho|[B,60,h,w], omega_mask[B,60,h,w])"""

@@ -15,12 +15,12 @@ import torch
 
 from . import _lib as L
 from . import distributed as D
-from .ops import FusedAdam, FusedLoss
+from .ops import FusedAdam, FusedLoss, FusedMetrics
 
 
 class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
-                 process_group=None, device=None):
+                 process_group=None, device=None, metrics=False):
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("Trainer needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
@@ -40,6 +40,8 @@ class Trainer:
         off_s, _ = model._lay_p["s"]
         self.loss = FusedLoss(eng, self.targets, model._flat.data.data_ptr() + 4 * off_s, model._flat_grad.data_ptr() + 4 * off_s,
                               grad_scale=1.0 / self.world)
+        # train.py:145-215: the 17 meters, updated every step on the device (no host round trips); off by default
+        self.metrics = FusedMetrics(eng.logits, self.targets) if metrics else None
         self.lr, self.wd = lr, weight_decay
         self.opt = FusedAdam(model._flat.data, model._flat_grad, lr=lr, weight_decay=weight_decay)
         # ---- gradient buckets: which backward op finalises which parameter
@@ -75,6 +77,8 @@ class Trainer:
         self._seg_buckets[k] are complete and their all-reduce is launched"""
         eng = self.eng
         pre = [eng.run_pack, eng.run_forward, self.loss.run]
+        if self.metrics is not None:
+            pre.append(self.metrics.run)
         cut = sorted(set(b[2] for b in self.buckets)) if self.world > 1 else []
         segs, seg_b = [], []
         cur = list(pre)

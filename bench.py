@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (train) / 64 (infer)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--variant", default="unet", choices=["unet", "unet2"], help="unet.py (headline) or unet2.py (config 3)")
+    ap.add_argument("--metrics", action="store_true", help="also update the 17 training meters of train.py:145-215 on the device every step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -154,7 +155,7 @@ def main():
         tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph)
         tr.load_batch(imgs.to(dev))
     else:
-        tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph)
+        tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics)
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
         tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
     torch.cuda.synchronize()
@@ -198,7 +199,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
-                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph},
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics)},
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 

@@ -274,6 +274,24 @@ typedef struct abc_nms_desc {
 } abc_nms_desc;
 int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream);
 
+/* The 17 training meters of train.py:145-215 (each an AverageMeter.update(num/den, den), meter.py:12-16), from the
+ * NCHW f32 head maps and the targets of the loss; replaces 34 host round trips per step by one device-side table.
+ * Meter order: atom_targets {precision, precision3, recall, recall3}, atom_types_acc, atom_charges_acc, atom_hs_acc,
+ * bond_targets {precision, precision3, recall, recall3}, bond_types_acc, bond_rhos_mae, bond_omega {precision,
+ * recall3, recall, precision3}.  last[2i], last[2i+1] = (num, den) of this batch; totals += the same. */
+typedef struct abc_metrics_desc {
+    const float* logits[8];
+    const float* t_atom; const float* t_types; const float* t_charges; const float* t_hs; const float* t_bond;
+    const float* t_btypes; const double* t_rho; const double* t_omega;
+    int32_t B, h, w;
+    uint8_t* peaks;    /* scratch [2][B][h][w] */
+    double* partial;   /* scratch [abc_metrics_blocks][24] */
+    double* totals;    /* [17][2] running (sum, count), accumulated in place */
+    double* last;      /* [17][2] */
+} abc_metrics_desc;
+int abc_metrics_blocks(const abc_metrics_desc* d);
+int abc_metrics_update(const abc_metrics_desc* d, abc_stream_t stream);
+
 /* ---- unet2: CBAM attention + residual (unet2.py:6-74).  See csrc/cbam.hip for the pass structure. ---- */
 typedef struct abc_cbam_channel_desc { /* ChannelAttentionModule (unet2.py:6-22), one MLP evaluation per image */
     const float* partial;  /* fwd: conv stats [B*tiles_per_img][4][C] (sum,sumsq,max,min of y2); bwd: [B*tiles_per_img][C] */
@@ -336,7 +354,7 @@ int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int3
                          int32_t c_off, abc_stream_t stream);
 int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream);
 
-/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15):
+/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16):
  * lets a foreign-language binding check its mirror structs at load time */
 int abc_sizeof(int which);
 const char* abc_last_error(void);

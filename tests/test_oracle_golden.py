@@ -138,3 +138,20 @@ def test_gradients_match_reference(variant, golden_dir):
         assert abs(got.double().norm().item() - gn) <= tol, name
         np.testing.assert_allclose(got.reshape(-1)[:64].double().numpy(), gold["head/" + name],
                                    rtol=1e-3, atol=1e-4 * gn + 1e-7, err_msg=name)
+
+
+def test_metrics_oracle_matches_reference(golden_dir):
+    """train.py:145-215 (17 meters): the oracle's (num, den) pairs against sum / count of the reference's own
+    AverageMeters after one update on the same seeded inputs (exec of the reference text, make_golden.py)."""
+    from abcnet_amd.synthetic import correlated_logits
+    from oracle import metrics_oracle as mo
+    gold = np.load(os.path.join(golden_dir, "metrics_128.npz"))
+    tg = synthetic_targets(2, 128, seed=3)
+    m = mo.metrics(loss_oracle.activations(correlated_logits(tg, seed=19)), tg)
+    assert [n[len("train_"):] for n in gold["names"]] == mo.METER_NAMES
+    for n, s, c in zip(mo.METER_NAMES, gold["sum"], gold["count"]):
+        num, den = m[n]
+        assert abs(num.item() - s) <= 1e-5 * max(1.0, abs(s)), n   # the reference accumulates float32 numpy scalars
+        assert abs(den.item() - c) <= 1e-5 * max(1.0, abs(c)), n
+    # the fixture is informative: neither empty nor saturated
+    assert 0 < gold["sum"][0] < gold["count"][0] and 0 < gold["sum"][13] < gold["count"][13]
