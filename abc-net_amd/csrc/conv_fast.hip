@@ -54,7 +54,8 @@ static long long* g_prof = nullptr;
 
 __device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC>
+// WD ("weights direct"): the 3x3 main loop below that streams the B operand from global memory (see there).
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, bool WD = false>
 __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
@@ -182,9 +183,32 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                     b_commit(breg[0], g, sB + g * a.sB_bytes);
                 }
             }
-        } else {
+        } else if constexpr (!WD) {
             issue_next(breg[0]);
             issue_next(breg[1]);
+        }
+        // ---- WD: the packed weights [tap][chunk][Cout_pad][CK] ARE the MFMA B fragments (row n, bytes 32 h + 16 kk of a
+        // 64-byte chunk row), so each lane loads its own fragments straight from global memory (L1 / L2: the CU's waves
+        // all stream the same 295 KB) into a ring of 3 taps, 3 taps ahead of their use.  LDS then carries the
+        // activation halo only: 3 instead of 5 ds_read_b128 per 6 MFMAs (the LDS pipe was as busy as the matrix
+        // pipe), no weight staging writes, and one workgroup barrier per 64-byte chunk instead of one per tap pair.
+        u32x4 bq[WD ? 3 : 1][TN][2];
+        const unsigned chunk_stride = (unsigned)(a.Cout_pad * CK) * (unsigned)sizeof(CT);
+        // (the wave's n-offset sits in the VGPR part: everything in the scalar offset must be provably wave-uniform, or
+        //  the compiler wraps every load in a readfirstlane loop)
+        const unsigned bq_voff = (unsigned)((wn * TN * 32 + r) * CKB + h * LHB);
+        auto bq_load = [&](int slot, int c, int t) {
+            const unsigned soff = w_n0 + (unsigned)t * tap_stride + (unsigned)c * chunk_stride;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 16), soff, 0);
+        };
+        if constexpr (WD) {
+            bq_load(0, 0, 0);
+            bq_load(1, 0, 1);
+            bq_load(2, 0, 2);
         }
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -195,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                 for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
         if (!first_tile) __syncthreads();  // previous tile's epilogue staging (aliases the halo buffer) is drained
         apre.commit(sA, lcoef, a.cstride, tid);
-        if constexpr (!STATIC) b_commit(breg[0], 0, sB);
+        if constexpr (!STATIC && !WD) b_commit(breg[0], 0, sB);
         first_tile = false;
         __syncthreads();
         if constexpr (STATIC) {
@@ -215,6 +239,57 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         // ---- main loop, unrolled by 2 so that the two register sets have fixed names.  Stage s: its weights sit in
         // sB[s & 1]; set s & 1 is free (committed at the end of stage s-1) and takes the loads of stage s + 2; the next
         // chunk's halo is issued when a chunk opens and committed when it closes.
+        if constexpr (WD) {
+            static_assert(NR == 2 && !STATIC, "WD: 64-byte chunks, streamed weights");
+            for (int c = 0; c < a.nchunks; ++c) {
+                const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
+                const bool more = c + 1 < a.nchunks;
+                if (more) apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
+                frag_t fa0[TM], fa1[TM];
+                // (tap offsets from the kernel arguments: scalar registers, no LDS round trip in front of the fragment reads)
+                {
+                    const int aoff = a.ty[0] * a.RS + a.tx[0] * PS;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff);
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int slot = t % 3;
+                    const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
+                    const int aoff_n = a.ty[t < 8 ? t + 1 : 8] * a.RS + a.tx[t < 8 ? t + 1 : 8] * PS;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa1[i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa0[i], *(const frag_t*)&bq[slot][j][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t < 8) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff_n);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa1[i], *(const frag_t*)&bq[slot][j][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the slot is free: tap t + 3 (of this chunk or the next; past the last chunk the offsets run off
+                    // the buffer and the loads return zeros -- unconditional, so that vmcnt stays exact)
+                    bq_load(slot, t + 3 < 9 ? c : c + 1, t + 3 < 9 ? t + 3 : t + 3 - 9);
+                }
+                if (more) {
+                    if (a.a_bufs == 2) {
+                        apre.commit(sA + ((c + 1) & 1) * a.sA_bytes, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
+                    } else {
+                        __syncthreads();
+                        apre.commit(sA, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
+                    }
+                }
+                __syncthreads();   // next chunk's halo visible; after the last chunk: the halo is dead (the epilogue aliases it)
+            }
+        } else {
         int c = 0, g = 0;
         for (int s0 = 0; s0 < nstages; s0 += 2) {
 #pragma unroll
@@ -304,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                     c = cn; g = gn;
                 }
             }
+        }
         }
 
         if (prof && tid == 0) prof[2] = wall_clock64();
@@ -442,9 +518,9 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     }
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, bool WD = false>
 int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
-    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC>;
+    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WG);
@@ -458,6 +534,10 @@ template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, 
 int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     if constexpr (BN == 32) {  // resident weights exist for the narrow layers only
         if (g.b_static) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, true>(k, g, st);
+    }
+    if constexpr (BN == 128 && MT == 6 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
+        // 3x3 (any 9-tap list) over 64-byte chunks: weights straight from global memory into the MFMA operands
+        if (g.wd) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, true>(k, g, st);
     }
     return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false>(k, g, st);
 }
@@ -585,6 +665,9 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         sr /= 2;
     }
     (void)abufs;
+    // weights-direct main loop (3x3 over 64-byte bf16 chunks on the 192 x 128 tile): no weights in LDS at all
+    g->wd = (csz == 2 && g->CK == 32 && g->BN == 128 && g->MT == 6 && d->stride == 1 && d->ntaps == 9 && !getenv("ABC_CONV_NOWD")) ? 1 : 0;
+    if (g->wd) g->sB_bytes = 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
     g->b_static = (g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget) ? 1 : 0;
     if (g->b_static) {
@@ -593,7 +676,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         g->a_bufs = (nchunks > 1 && 2 * g->sA_bytes + 2 * g->sB_bytes <= budget) ? 2 : 1;
         if (g->a_bufs * g->sA_bytes + 2 * g->sB_bytes > budget) return ABC_OK;
     }
-    const int nbuf_b = g->b_static ? g->ngroups : 2;
+    const int nbuf_b = g->b_static ? g->ngroups : (g->wd ? 0 : 2);
     g->tap_off = g->a_bufs * g->sA_bytes + nbuf_b * g->sB_bytes;
     g->coef_off = g->tap_off + 256;
     g->lds = g->coef_off + coef_bytes;

@@ -67,7 +67,7 @@ def synthetic_targets(batch: int, h: int, seed: int = 1, n_atoms: int = 30, n_bo
     return [at, aty, ach, ahs, bt, bty, rho, om]
 
 
-def correlated_logits(targets, seed: int = 19):
+def correlated_logits(targets, seed: int = 19, centre_noise: float = 1.2):
     """Head logits [B,{1,14,3,2,1,360,60,60},h,h] f32 that CORRELATE with the given target maps (so that the
     training meters of train.py:145-215 are non-trivial): target-shaped signal plus seeded Gaussian noise; the
     omega logits are quantised to quarter steps so that exact ties between neighbouring bins occur."""
@@ -76,11 +76,11 @@ def correlated_logits(targets, seed: int = 19):
     B, _, h, w = t_at.shape
     rn = lambda c: torch.randn((B, c, h, w), generator=g)
     return [
-        5.0 * t_at - 2.5 + 1.2 * rn(1),
+        5.0 * t_at - 2.5 + centre_noise * rn(1),
         4.0 * t_ty + rn(14),
         4.0 * t_ch + rn(3),
         4.0 * t_hs + rn(2),
-        5.0 * t_bt - 2.5 + 1.2 * rn(1),
+        5.0 * t_bt - 2.5 + centre_noise * rn(1),
         4.0 * t_bty.reshape(B, 360, h, w) + rn(360),
         (t_rho + 0.5 * rn(60).double()).float(),
         torch.round((5.0 * t_om.float() - 2.5 + rn(60)) * 4) / 4,

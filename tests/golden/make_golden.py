@@ -18,6 +18,7 @@ What is produced (all float32 unless noted):
   nms_128.npz              NMS masks (bit-packed) from exec of img2smiles2.py:61-79
   metrics_128.npz          sum / count of the 17 training meters after one update (exec of
                            train.py:95-105 + 145-215 with the reference's meter.AverageMeter)
+  decode_128.npz           atom / bond candidate lists of img2smiles2.py:113-183 for seeded head maps
   adam.npz                 one torch.optim.Adam step (train.py:55 settings)
   meta.json                state_dict key/shape lists, parameter counts
 """
@@ -192,6 +193,41 @@ def metrics_goldens():
         print("  %-36s sum %12.4f count %12.4f" % (n, ns[n].sum, ns[n].count))
 
 
+def decode_goldens():
+    """img2smiles2.py:61-79 (NMS) + 113-183 (candidate extraction) executed on seeded head maps; stored per image: the
+    accepted atoms (x, y, type, charge, hs) and the bond candidates (x, y, delta_x, delta_y, type) exactly as the
+    reference lists hold them.  The slice sits inside `for j in range(B)` and uses `continue`, so it is executed
+    wrapped in that loop; the vocab look-ups (atom_type_devocab / atom_charge_devocab) are identity maps here."""
+    from abcnet_amd.synthetic import correlated_logits
+    tg = synthetic_targets(2, 128, seed=3)
+    lg = correlated_logits(tg, seed=29, centre_noise=0.5)
+    ns = {"torch": torch, "np": np}
+    for n, v in zip(PRED_NAMES, lg):
+        ns[n] = v
+    ns["imgs"] = torch.zeros(2, 1, 512, 512)
+    exec(slice_text(os.path.join(REF, "img2smiles2.py"), 61, 79), ns)
+
+    class _Ident(dict):
+        def __missing__(self, k):
+            return k
+    ns["atom_type_devocab"], ns["atom_charge_devocab"] = _Ident(), _Ident()
+    ns["results"] = []
+    ns["collected"] = []
+    body = slice_text(os.path.join(REF, "img2smiles2.py"), 113, 183)
+    src = "for j in range(2):\n" + "".join("    " + l if l.strip() else l for l in body.splitlines(True))
+    src += "\n    collected.append((atoms_position_list, atoms_type_list, atoms_charge_list, atoms_hs_list, bonds_position_list, bonds_property_list, bonds_delta_list))\n"
+    exec(src, ns)
+    res = {}
+    for j, (ap, aty, ach, ahs, bp, bpr, bd) in enumerate(ns["collected"]):
+        res["atoms%d" % j] = np.concatenate([np.array(ap, dtype=np.int64).reshape(-1, 2), np.array(aty, dtype=np.int64).reshape(-1, 1),
+                                             np.array(ach, dtype=np.int64).reshape(-1, 1), np.array(ahs, dtype=np.int64).reshape(-1, 1)], axis=1)
+        res["bond_pos%d" % j] = np.array(bp, dtype=np.int64).reshape(-1, 2)
+        res["bond_type%d" % j] = np.array(bpr, dtype=np.int64)
+        res["bond_delta%d" % j] = np.array(bd, dtype=np.float64).reshape(-1, 2)
+    np.savez_compressed(os.path.join(HERE, "decode_128.npz"), **res)
+    print("wrote decode", [(res["atoms%d" % j].shape, res["bond_pos%d" % j].shape) for j in range(2)])
+
+
 def nms_goldens():
     g = torch.Generator().manual_seed(13)
     ns = {"torch": torch}
@@ -246,11 +282,12 @@ def meta():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "metrics":   # (added after the other fixtures: regenerate this one alone)
-        metrics_goldens()
+    if len(sys.argv) > 1 and sys.argv[1] in ("metrics", "decode"):   # (added after the other fixtures: regenerate one alone)
+        {"metrics": metrics_goldens, "decode": decode_goldens}[sys.argv[1]]()
         sys.exit(0)
     meta()
     metrics_goldens()
+    decode_goldens()
     adam_goldens()
     nms_goldens()
     loss_goldens()
