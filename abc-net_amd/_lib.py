@@ -125,8 +125,14 @@ class MetricsDesc(C.Structure):
                 ("partial", vp), ("totals", vp), ("last", vp)]
 
 
+class ExtractDesc(C.Structure):
+    _fields_ = [("atom_mask", vp), ("bond_mask", vp), ("types", vp), ("charges", vp), ("hs", vp), ("btypes", vp), ("rho", vp),
+                ("omega", vp), ("B", i32), ("h", i32), ("w", i32), ("cap_atoms", i32), ("cap_bonds", i32), ("counts", vp),
+                ("atoms", vp), ("bonds", vp), ("bond_rho", vp), ("work", vp), ("work_masks", vp)]
+
+
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
-            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc]
+            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc, ExtractDesc]
 
 # every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
@@ -160,6 +166,9 @@ SYMBOLS = {
     "abc_loss_finalize": (C.c_int, [P(LossFinDesc), vp]),
     "abc_adam_step": (C.c_int, [P(AdamDesc), vp]),
     "abc_nms_peaks": (C.c_int, [P(NmsDesc), vp]),
+    "abc_extract_work_ints": (i64, [P(ExtractDesc)]),
+    "abc_extract_work_masks": (i64, [P(ExtractDesc)]),
+    "abc_extract_peaks": (C.c_int, [P(ExtractDesc), vp]),
     "abc_metrics_blocks": (C.c_int, [P(MetricsDesc)]),
     "abc_metrics_update": (C.c_int, [P(MetricsDesc), vp]),
     "abc_plane_sum": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp]),

@@ -535,7 +535,7 @@ int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     if constexpr (BN == 32) {  // resident weights exist for the narrow layers only
         if (g.b_static) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, true>(k, g, st);
     }
-    if constexpr (BN == 128 && MT == 6 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
+    if constexpr (BN >= 64 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
         // 3x3 (any 9-tap list) over 64-byte chunks: weights straight from global memory into the MFMA operands
         if (g.wd) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, true>(k, g, st);
     }
@@ -665,8 +665,12 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         sr /= 2;
     }
     (void)abufs;
-    // weights-direct main loop (3x3 over 64-byte bf16 chunks on the 192 x 128 tile): no weights in LDS at all
-    g->wd = (csz == 2 && g->CK == 32 && g->BN == 128 && g->MT == 6 && d->stride == 1 && d->ntaps == 9 && !getenv("ABC_CONV_NOWD")) ? 1 : 0;
+    // weights-direct main loop (3x3 over 64-byte bf16 chunks, tiles of >= 64 channels): no weights in LDS at all
+    {
+        const char* e = getenv("ABC_CONV_NOWD");   // "1": never; "2": only the 192 x 128 tile (experiments)
+        const int lim = e ? atoi(e) : 0;
+        g->wd = (csz == 2 && g->CK == 32 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 1 : 0;
+    }
     if (g->wd) g->sB_bytes = 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
     g->b_static = (g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget) ? 1 : 0;

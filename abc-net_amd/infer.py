@@ -19,7 +19,7 @@ from . import _lib as L
 
 
 class InferenceRunner:
-    def __init__(self, model, batch, height, width, use_graph=True, device=None):
+    def __init__(self, model, batch, height, width, use_graph=True, device=None, extract=False, cap_atoms=512, cap_bonds=16384):
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("InferenceRunner needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
@@ -37,6 +37,11 @@ class InferenceRunner:
         d.atom_mask, d.bond_mask = self.atom_mask.data_ptr(), self.bond_mask.data_ptr()
         d.rho_abs, d.omega_mask = self.rho_abs.data_ptr(), self.omega_mask.data_ptr()
         self._nms = d
+        # img2smiles2.py:113-191: compact candidate lists for the CPU graph-assembly stage, inside the same graph
+        self.extractor = None
+        if extract:
+            from .ops import PeakExtractor
+            self.extractor = PeakExtractor(lg, self.atom_mask, self.bond_mask, cap_atoms=cap_atoms, cap_bonds=cap_bonds)
         self.use_graph = use_graph
         self._graph = None
         self.steps = 0
@@ -52,6 +57,14 @@ class InferenceRunner:
     def _run(self, st):
         self.eng.run_forward(st)
         L.check(self.eng.lib.abc_nms_peaks(C.byref(self._nms), st), "nms_peaks")
+        if self.extractor is not None:
+            self.extractor.run(st)
+
+    def candidates(self):
+        """the per-image atom / bond candidate lists of the last step (host sync; needs extract=True)"""
+        if self.extractor is None:
+            raise L.AbcNetHipError("InferenceRunner was built without extract=True")
+        return self.extractor.lists()
 
     def step(self):
         """forward + NMS on the batch in the static image buffer; results in .logits / .atom_mask / ..."""

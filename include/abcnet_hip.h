@@ -274,6 +274,30 @@ typedef struct abc_nms_desc {
 } abc_nms_desc;
 int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream);
 
+/* Candidate extraction for the SMILES decoder (img2smiles2.py:113-191; replaces its per-pixel .cpu().item() loops):
+ * from the NMS masks of abc_nms_peaks and the raw head maps (all NCHW f32) to compact ordered lists per image.
+ *   atoms[b][i] = (x, y, type, charge, hs)      raster order, greedy suppression within squared distance < 4
+ *   bonds[b][i] = (x, y, omega bin, type), bond_rho[b][i] = |rho|   raster order of bond peaks, bins ascending,
+ *                                                 a bin kept unless its opposite direction wins (lines 141-157)
+ *   counts[b]   = (atom peaks, atoms accepted, bond peaks, bond candidates) -- true totals; the lists hold at most
+ *                 cap_atoms / cap_bonds entries (and at most 4096 bond peaks per image are expanded).
+ * x = row, y = column as in the reference. */
+typedef struct abc_extract_desc {
+    const float* atom_mask; const float* bond_mask;               /* [B][1][h][w] */
+    const float* types; const float* charges; const float* hs;    /* [B][14|3|2][h][w] logits */
+    const float* btypes; const float* rho; const float* omega;    /* [B][360|60|60][h][w] raw maps */
+    int32_t B, h, w, cap_atoms, cap_bonds;                        /* cap_atoms <= 2048 */
+    int32_t* counts;      /* [B][4] */
+    int32_t* atoms;       /* [B][cap_atoms][5] */
+    int32_t* bonds;       /* [B][cap_bonds][4] */
+    float* bond_rho;      /* [B][cap_bonds] */
+    int32_t* work;        /* scratch, abc_extract_work_ints() int32 */
+    uint64_t* work_masks; /* scratch, abc_extract_work_masks() uint64 */
+} abc_extract_desc;
+int64_t abc_extract_work_ints(const abc_extract_desc* d);
+int64_t abc_extract_work_masks(const abc_extract_desc* d);
+int abc_extract_peaks(const abc_extract_desc* d, abc_stream_t stream);
+
 /* The 17 training meters of train.py:145-215 (each an AverageMeter.update(num/den, den), meter.py:12-16), from the
  * NCHW f32 head maps and the targets of the loss; replaces 34 host round trips per step by one device-side table.
  * Meter order: atom_targets {precision, precision3, recall, recall3}, atom_types_acc, atom_charges_acc, atom_hs_acc,
@@ -354,7 +378,7 @@ int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int3
                          int32_t c_off, abc_stream_t stream);
 int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream);
 
-/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16):
+/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17):
  * lets a foreign-language binding check its mirror structs at load time */
 int abc_sizeof(int which);
 const char* abc_last_error(void);

@@ -1,10 +1,10 @@
 """Oracle (test infrastructure, not product): the candidate extraction of the reference inference driver,
-/root/reference/src/img2smiles2.py:113-183, restated as a function of one image's head maps.
+/root/reference/src/img2smiles2.py:113-191, restated as a function of one image's head maps.
 
 What the reference does between the NMS (img2smiles2.py:61-79) and the graph assembly / RDKit stage
-(img2smiles2.py:185-344, out of scope):
+(img2smiles2.py:193-344, out of scope):
 
-  bonds (128-161): for every bond-centre peak (x, y) in raster order, for every omega bin k whose RAW
+  bonds (128-169): for every bond-centre peak (x, y) in raster order, for every omega bin k whose RAW
       logit is non-zero (`bond_omega_img[:, x, y].nonzero()` -- the NMS'd omega map computed at 75-79 is
       not consulted), keep the bin unless the opposite direction wins:
           k <= 28 : drop if v[k] <  max(v[k+29], v[k+30])
@@ -12,7 +12,7 @@ What the reference does between the NMS (img2smiles2.py:61-79) and the graph ass
           k == 30 : drop if v[30] <= v[0] or v[30] <= v[59]
           k >= 31 : drop if v[k] <= max(v[k-31], v[k-30])
       and emit (x, y, k, argmax over the 6 bond types at bin k, |rho|[k, x, y]);
-  atoms (163-183): for every atom-centre peak in raster order, skip it if an ALREADY ACCEPTED atom lies
+  atoms (171-191): for every atom-centre peak in raster order, skip it if an ALREADY ACCEPTED atom lies
       within squared distance < 4, else emit (x, y, argmax type, argmax charge, argmax hs).
 
 x is the row index and y the column index, as in the reference (`x, y = position`).

@@ -18,7 +18,7 @@ What is produced (all float32 unless noted):
   nms_128.npz              NMS masks (bit-packed) from exec of img2smiles2.py:61-79
   metrics_128.npz          sum / count of the 17 training meters after one update (exec of
                            train.py:95-105 + 145-215 with the reference's meter.AverageMeter)
-  decode_128.npz           atom / bond candidate lists of img2smiles2.py:113-183 for seeded head maps
+  decode_128.npz           atom / bond candidate lists of img2smiles2.py:113-191 for seeded head maps
   adam.npz                 one torch.optim.Adam step (train.py:55 settings)
   meta.json                state_dict key/shape lists, parameter counts
 """
@@ -194,7 +194,7 @@ def metrics_goldens():
 
 
 def decode_goldens():
-    """img2smiles2.py:61-79 (NMS) + 113-183 (candidate extraction) executed on seeded head maps; stored per image: the
+    """img2smiles2.py:61-79 (NMS) + 113-191 (candidate extraction) executed on seeded head maps; stored per image: the
     accepted atoms (x, y, type, charge, hs) and the bond candidates (x, y, delta_x, delta_y, type) exactly as the
     reference lists hold them.  The slice sits inside `for j in range(B)` and uses `continue`, so it is executed
     wrapped in that loop; the vocab look-ups (atom_type_devocab / atom_charge_devocab) are identity maps here."""
@@ -213,7 +213,7 @@ def decode_goldens():
     ns["atom_type_devocab"], ns["atom_charge_devocab"] = _Ident(), _Ident()
     ns["results"] = []
     ns["collected"] = []
-    body = slice_text(os.path.join(REF, "img2smiles2.py"), 113, 183)
+    body = slice_text(os.path.join(REF, "img2smiles2.py"), 113, 191)
     src = "for j in range(2):\n" + "".join("    " + l if l.strip() else l for l in body.splitlines(True))
     src += "\n    collected.append((atoms_position_list, atoms_type_list, atoms_charge_list, atoms_hs_list, bonds_position_list, bonds_property_list, bonds_delta_list))\n"
     exec(src, ns)

@@ -155,3 +155,23 @@ def test_metrics_oracle_matches_reference(golden_dir):
         assert abs(den.item() - c) <= 1e-5 * max(1.0, abs(c)), n
     # the fixture is informative: neither empty nor saturated
     assert 0 < gold["sum"][0] < gold["count"][0] and 0 < gold["sum"][13] < gold["count"][13]
+
+
+def test_decode_oracle_matches_reference(golden_dir):
+    """img2smiles2.py:113-191 (candidate extraction): the oracle's lists against the lists the reference text itself
+    produced (exec by make_golden.py), bit for bit, including the reference's float64 bond deltas."""
+    from abcnet_amd.synthetic import correlated_logits
+    from oracle import decode_oracle as do
+    gold = np.load(os.path.join(golden_dir, "decode_128.npz"))
+    tg = synthetic_targets(2, 128, seed=3)
+    lg = correlated_logits(tg, seed=29, centre_noise=0.5)
+    am, bm, rho, _ = nms_oracle.nms(lg[0], lg[4], lg[6], lg[7])
+    for j in range(2):
+        atoms, bonds, rhos = do.extract(am[j, 0], bm[j, 0], lg[1][j], lg[2][j], lg[3][j], lg[5][j], rho[j], lg[7][j])
+        assert len(atoms) > 10 and len(bonds) > 100
+        assert np.array_equal(atoms.numpy(), gold["atoms%d" % j])
+        assert np.array_equal(bonds[:, :2].numpy(), gold["bond_pos%d" % j])
+        assert np.array_equal(bonds[:, 3].numpy(), gold["bond_type%d" % j])
+        omega = bonds[:, 2].numpy().astype(np.float64) * (np.pi / 30) + np.pi / 60 - np.pi / 2   # img2smiles2.py:160
+        r = rhos.numpy().astype(np.float64)
+        assert np.array_equal(np.stack([r * np.cos(omega), r * np.sin(omega)], 1), gold["bond_delta%d" % j])
