@@ -30,6 +30,8 @@ constexpr int FT = 256;      // threads per workgroup
 // halo segments a thread may hold (3x3 taps, 64-byte chunks: (2*MT+2) x 18 pixels x 4 segments over 256 threads;
 // MT = 8 also takes unet2's 5x5 taps: 20 x 20 pixels x 4 segments = 6.25 per thread)
 __host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 7 : (mt >= 6 ? 4 : (mt >= 4 ? 3 : 2)); }
+// resident-weight (persistent, narrow-layer) workgroups only ever see 3x3 / 1x1 taps: 6 segments, and three of them per CU
+__host__ __device__ constexpr int fa_static(int mt) { return mt >= 8 ? 6 : fa_max(mt); }
 constexpr int SR_MAX = 256;  // weight rows per stage (tap group x BN)
 constexpr int LDS_WG = 80 * 1024;
 
@@ -54,9 +56,10 @@ static long long* g_prof = nullptr;
 
 __device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// WD ("weights direct"): the 3x3 main loop below that streams the B operand from global memory (see there).
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, bool WD = false>
-__global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
+// WD ("weights direct", 0 = off, else the tap count 9 or 25): the main loop below that streams the B operand from global
+// memory (see there).
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0>
+__global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const FastK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
     constexpr int LHB = CKB / 2;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     const unsigned bvoff0 = (unsigned)tl0 * tap_stride + (unsigned)rem0 * 16u;
     const int bdst0 = (tl0 * BN + rem0 / SEGS) * PS + (rem0 % SEGS) * 16;
     u32x4 breg[2][NB];
-    HaloTile<InT, CT, CK, fa_max(MT), FT> apre;
+    HaloTile<InT, CT, CK, STATIC ? fa_static(MT) : fa_max(MT), FT> apre;
 
     unsigned w_n0 = 0;  // byte offset of the n-block's first weight row
     auto b_issue = [&](u32x4* set, int c, int g) {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                     b_commit(breg[0], g, sB + g * a.sB_bytes);
                 }
             }
-        } else if constexpr (!WD) {
+        } else if constexpr (WD == 0) {
             issue_next(breg[0]);
             issue_next(breg[1]);
         }
@@ -192,7 +195,10 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         // all stream the same 295 KB) into a ring of 3 taps, 3 taps ahead of their use.  LDS then carries the
         // activation halo only: 3 instead of 5 ds_read_b128 per 6 MFMAs (the LDS pipe was as busy as the matrix
         // pipe), no weight staging writes, and one workgroup barrier per 64-byte chunk instead of one per tap pair.
-        u32x4 bq[WD ? 3 : 1][TN][2];
+        constexpr int WNT = WD ? WD : 1;              // taps (static: the loop is fully unrolled)
+        constexpr int RING = WD == 25 ? 5 : 3;        // taps in flight; divides the tap count
+        static_assert(WNT % RING == 0 || !WD, "ring must divide the tap count");
+        u32x4 bq[WD ? RING : 1][TN][2];
         const unsigned chunk_stride = (unsigned)(a.Cout_pad * CK) * (unsigned)sizeof(CT);
         // (the wave's n-offset sits in the VGPR part: everything in the scalar offset must be provably wave-uniform, or
         //  the compiler wraps every load in a readfirstlane loop)
@@ -205,10 +211,9 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                 for (int kk = 0; kk < 2; ++kk)
                     bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 16), soff, 0);
         };
-        if constexpr (WD) {
-            bq_load(0, 0, 0);
-            bq_load(1, 0, 1);
-            bq_load(2, 0, 2);
+        if constexpr (WD != 0) {
+#pragma unroll
+            for (int q = 0; q < RING; ++q) bq_load(q, 0, q);
         }
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                 for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
         if (!first_tile) __syncthreads();  // previous tile's epilogue staging (aliases the halo buffer) is drained
         apre.commit(sA, lcoef, a.cstride, tid);
-        if constexpr (!STATIC && !WD) b_commit(breg[0], 0, sB);
+        if constexpr (!STATIC && WD == 0) b_commit(breg[0], 0, sB);
         first_tile = false;
         __syncthreads();
         if constexpr (STATIC) {
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
         // ---- main loop, unrolled by 2 so that the two register sets have fixed names.  Stage s: its weights sit in
         // sB[s & 1]; set s & 1 is free (committed at the end of stage s-1) and takes the loads of stage s + 2; the next
         // chunk's halo is issued when a chunk opens and committed when it closes.
-        if constexpr (WD) {
+        if constexpr (WD != 0) {
             static_assert(NR == 2 && !STATIC, "WD: 64-byte chunks, streamed weights");
             for (int c = 0; c < a.nchunks; ++c) {
                 const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
@@ -253,10 +258,10 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
                     for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff);
                 }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int slot = t % 3;
+                for (int t = 0; t < WNT; ++t) {
+                    const int slot = t % RING;
                     const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
-                    const int aoff_n = a.ty[t < 8 ? t + 1 : 8] * a.RS + a.tx[t < 8 ? t + 1 : 8] * PS;
+                    const int aoff_n = a.ty[t < WNT - 1 ? t + 1 : WNT - 1] * a.RS + a.tx[t < WNT - 1 ? t + 1 : WNT - 1] * PS;
 #pragma unroll
                     for (int i = 0; i < TM; ++i) fa1[i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16);
                     __builtin_amdgcn_sched_barrier(0);
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa0[i], *(const frag_t*)&bq[slot][j][0]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t < 8) {
+                    if (t < WNT - 1) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff_n);
                     }
@@ -275,9 +280,9 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa1[i], *(const frag_t*)&bq[slot][j][1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    // the slot is free: tap t + 3 (of this chunk or the next; past the last chunk the offsets run off
+                    // the slot is free: tap t + RING (of this chunk or the next; past the last chunk the offsets run off
                     // the buffer and the loads return zeros -- unconditional, so that vmcnt stays exact)
-                    bq_load(slot, t + 3 < 9 ? c : c + 1, t + 3 < 9 ? t + 3 : t + 3 - 9);
+                    bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
                 }
                 if (more) {
                     if (a.a_bufs == 2) {
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void conv_fast_kernel(const FastK a) {
     }
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, bool WD = false>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0>
 int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD>;
     static bool attr_done = false;
@@ -537,7 +542,11 @@ int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     }
     if constexpr (BN >= 64 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
         // 3x3 (any 9-tap list) over 64-byte chunks: weights straight from global memory into the MFMA operands
-        if (g.wd) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, true>(k, g, st);
+        if (g.wd == 9) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9>(k, g, st);
+    }
+    if constexpr (BN == 32 && MT == 8 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
+        // unet2's 5x5 32 -> 32 convolutions: 25 taps, a ring of 5
+        if (g.wd == 25) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 25>(k, g, st);
     }
     return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false>(k, g, st);
 }
@@ -669,11 +678,19 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     {
         const char* e = getenv("ABC_CONV_NOWD");   // "1": never; "2": only the 192 x 128 tile (experiments)
         const int lim = e ? atoi(e) : 0;
-        g->wd = (csz == 2 && g->CK == 32 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 1 : 0;
+        g->wd = (csz == 2 && g->CK == 32 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 9 : 0;
+        if (csz == 2 && g->CK == 32 && g->BN == 32 && g->MT == 8 && d->stride == 1 && d->ntaps == 25 && lim == 0) g->wd = 25;
     }
     if (g->wd) g->sB_bytes = 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
-    g->b_static = (g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget) ? 1 : 0;
+    g->b_static = (!g->wd && g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget &&
+                   abc_cdiv(g->HH * g->HW * segs, FT) <= fa_static(g->MT)) ? 1 : 0;
+    if (g->b_static && d->ntaps % 3 == 0 && d->ntaps > 3) {
+        // resident weights are loaded once: tap groups of 3 leave no padding rows (9 taps in two groups of 8 cost 24.5 KB of
+        // LDS instead of 13.8 KB), which is what lets a third workgroup share the CU
+        g->tg = 3; g->ngroups = d->ntaps / 3;
+        g->sB_bytes = abc_roundup(g->tg * g->BN * g->PS, 256);
+    }
     if (g->b_static) {
         g->a_bufs = 1;
     } else {
@@ -691,7 +708,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->tiles_x = abc_cdiv(d->Wg, 16);
     g->tiles_y = abc_cdiv(d->Hg, prow);
     g->ntiles = g->nbn * g->tiles_x * g->tiles_y * d->B;
-    g->nwg = g->b_static ? (g->ntiles < 512 ? g->ntiles : 512) : g->ntiles;
+    g->nwg = g->b_static ? (g->ntiles < 768 ? g->ntiles : 768) : g->ntiles;   // persistent: three workgroups per CU
     g->eligible = 1;
     return ABC_OK;
 }

@@ -83,16 +83,17 @@ def cpu_baseline_infer(size, seconds_budget=25.0, variant="unet"):
             "sample": "oracle eval forward + NMS, fp32, batch %d at %dx%d, median of %d warm iterations" % (B, size, size, len(times))}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, mode="train", variant="unet"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/README.md says
-    how they were collected and corrected); None when no pass exists for this kernel label."""
+    how they were collected and corrected; keyed by mode:variant:label because one instantiation serves different
+    shapes in different workloads); None when no pass exists for this kernel label."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             table = json.load(f)
     except (OSError, ValueError):
         return None
-    rec = table.get(kernel)
+    rec = table.get("%s:%s:%s" % (mode, variant, kernel))
     return None if rec is None else rec["bytes_per_launch"]
 
 
@@ -210,7 +211,8 @@ def main():
         r = prof[dom]
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK[a.dtype], "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": pmc_traffic(dom),
+                           "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": pmc_traffic(dom, a.mode, a.variant),
+                           "algorithmic_mb_per_launch": round(r["bytes"] / r["calls"] / 1e6, 2),
                            "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
                            "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
         out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("ABC_BENCH_TOP", 12))]}
