@@ -679,7 +679,9 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         const char* e = getenv("ABC_CONV_NOWD");   // "1": never; "2": only the 192 x 128 tile (experiments)
         const int lim = e ? atoi(e) : 0;
         g->wd = (csz == 2 && g->CK == 32 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 9 : 0;
-        if (csz == 2 && g->CK == 32 && g->BN == 32 && g->MT == 8 && d->stride == 1 && d->ntaps == 25 && lim == 0) g->wd = 25;
+        // (25-tap form for unet2's 5x5 32 -> 32 layers: measured SLOWER than the LDS-staged weights, 136 vs 121 us -- a
+        //  32-channel tile has only 4 MFMAs per tap to cover the global-load latency of the ring; opt-in for experiments)
+        if (csz == 2 && g->CK == 32 && g->BN == 32 && g->MT == 8 && d->stride == 1 && d->ntaps == 25 && getenv("ABC_CONV_WD25")) g->wd = 25;
     }
     if (g->wd) g->sB_bytes = 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups

@@ -77,28 +77,53 @@ __device__ inline double wave_sum(double v) {
 
 __constant__ float c_type_w[14] = {1.f, 0.1f, 0.1f, 0.1f, 1.f, 1.f, 1.f, 1.f, 1.f, 10.f, 10.f, 10.f, 10.f, 10.f};  // train.py:16
 
+// Four threads per pixel: wave `sub` of the workgroup takes omega bins [15 sub, 15 sub + 15) of the workgroup's 64 pixels
+// (lane = pixel, so every plane access stays a coalesced 256-byte row) and a share of the small heads.  One thread per
+// pixel walking all 60 bins left 9 waves per CU with a 60-deep dependent loop: 247 us for 660 MB.
+constexpr int LPX = 64;   // pixels per workgroup
+
 __global__ __launch_bounds__(256) void loss_kernel(const abc_loss_desc d) {
     __shared__ double sm[4][16];
+    __shared__ double wsum[4][LPX];
     const int hw = d.h * d.w;
     const int64_t npix = (int64_t)d.B * hw;
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * LPX + lane;
+    const bool live = p < npix;
+    const int b = live ? (int)(p / hw) : 0, yx = live ? (int)(p % hw) : 0;
     double num[8], den[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { num[i] = 0.0; den[i] = 0.0; }
-    if (p < npix) {
-        const int b = (int)(p / hw), yx = (int)(p % hw);
-        // plane (b, c) of a head with C channels: base + (b*C + c)*hw + yx
+    // plane (b, c) of a head with C channels: base + (b*C + c)*hw + yx
 #define PL(ptr, C, c) (ptr)[((size_t)b * (C) + (c)) * hw + yx]
-        // ---- head 0: atom centre
-        {
-            const float t = PL(d.t_atom, 1, 0);
-            float dz;
-            num[0] = center_focal(PL(d.logits[0], 1, 0), t, 1.f, &dz);
-            den[0] = (t == 1.f) ? 1.0 : 0.0;
-            PL(d.dlogits[0], 1, 0) = dz;
-        }
-        // ---- head 1: atom types (14-way softmax, class weights)
-        {
+    const int o_lo = 15 * sub, o_hi = o_lo + 15;
+    // ---- omega per-pixel weight = sum over the 60 bins of the omega target (train.py:124): partial per wave, then all
+    double wpart = 0.0;
+    if (live)
+        for (int o = o_lo; o < o_hi; ++o) wpart += PL(d.t_omega, 60, o);
+    wsum[sub][lane] = wpart;
+    __syncthreads();
+    const double wpix = (wsum[0][lane] + wsum[1][lane]) + (wsum[2][lane] + wsum[3][lane]);
+    if (live) {
+        if (sub == 0) {
+            // ---- head 0: atom centre, head 4: bond centre
+            {
+                const float t = PL(d.t_atom, 1, 0);
+                float dz;
+                num[0] = center_focal(PL(d.logits[0], 1, 0), t, 1.f, &dz);
+                den[0] = (t == 1.f) ? 1.0 : 0.0;
+                PL(d.dlogits[0], 1, 0) = dz;
+            }
+            {
+                const float t = PL(d.t_bond, 1, 0);
+                float dz;
+                num[4] = center_focal(PL(d.logits[4], 1, 0), t, 1.f, &dz);
+                den[4] = (t == 1.f) ? 1.0 : 0.0;
+                PL(d.dlogits[4], 1, 0) = dz;
+            }
+            den[7] = wpix;
+        } else if (sub == 1) {
+            // ---- head 1: atom types (14-way softmax, class weights)
             float z[14], t[14], dz[14], dn = 0.f;
 #pragma unroll
             for (int k = 0; k < 14; ++k) { z[k] = PL(d.logits[1], 14, k); t[k] = PL(d.t_types, 14, k); }
@@ -106,42 +131,30 @@ __global__ __launch_bounds__(256) void loss_kernel(const abc_loss_desc d) {
             den[1] = dn;
 #pragma unroll
             for (int k = 0; k < 14; ++k) PL(d.dlogits[1], 14, k) = dz[k];
-        }
-        // ---- head 2: charges (3-way)
-        {
-            float z[3], t[3], dz[3], dn = 0.f;
+        } else if (sub == 2) {
+            // ---- head 2: charges (3-way), head 3: hydrogens (2-way)
+            {
+                float z[3], t[3], dz[3], dn = 0.f;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { z[k] = PL(d.logits[2], 3, k); t[k] = PL(d.t_charges, 3, k); }
-            num[2] = class_focal<3>(z, t, nullptr, dz, &dn);
-            den[2] = dn;
+                for (int k = 0; k < 3; ++k) { z[k] = PL(d.logits[2], 3, k); t[k] = PL(d.t_charges, 3, k); }
+                num[2] = class_focal<3>(z, t, nullptr, dz, &dn);
+                den[2] = dn;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) PL(d.dlogits[2], 3, k) = dz[k];
-        }
-        // ---- head 3: hydrogens (2-way)
-        {
-            float z[2], t[2], dz[2], dn = 0.f;
+                for (int k = 0; k < 3; ++k) PL(d.dlogits[2], 3, k) = dz[k];
+            }
+            {
+                float z[2], t[2], dz[2], dn = 0.f;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { z[k] = PL(d.logits[3], 2, k); t[k] = PL(d.t_hs, 2, k); }
-            num[3] = class_focal<2>(z, t, nullptr, dz, &dn);
-            den[3] = dn;
+                for (int k = 0; k < 2; ++k) { z[k] = PL(d.logits[3], 2, k); t[k] = PL(d.t_hs, 2, k); }
+                num[3] = class_focal<2>(z, t, nullptr, dz, &dn);
+                den[3] = dn;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) PL(d.dlogits[3], 2, k) = dz[k];
+                for (int k = 0; k < 2; ++k) PL(d.dlogits[3], 2, k) = dz[k];
+            }
         }
-        // ---- head 4: bond centre
-        {
-            const float t = PL(d.t_bond, 1, 0);
-            float dz;
-            num[4] = center_focal(PL(d.logits[4], 1, 0), t, 1.f, &dz);
-            den[4] = (t == 1.f) ? 1.0 : 0.0;
-            PL(d.dlogits[4], 1, 0) = dz;
-        }
-        // ---- omega per-pixel weight = sum over the 60 bins of the omega target (train.py:124)
-        double wpix = 0.0;
-        for (int o = 0; o < 60; ++o) wpix += PL(d.t_omega, 60, o);
-        den[7] = wpix;
-        // ---- heads 5,6,7 per omega bin; bond-type channel = type*60 + omega (train.py:101 view)
+        // ---- heads 5,6,7 for this wave's omega bins; bond-type channel = type*60 + omega (train.py:101 view)
         double n5 = 0.0, n6 = 0.0, n7 = 0.0, d5 = 0.0;
-        for (int o = 0; o < 60; ++o) {
+        for (int o = o_lo; o < o_hi; ++o) {
             float z[6], t[6], dz[6], dn = 0.f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { z[k] = PL(d.logits[5], 360, k * 60 + o); t[k] = PL(d.t_btypes, 360, k * 60 + o); }
@@ -167,15 +180,14 @@ __global__ __launch_bounds__(256) void loss_kernel(const abc_loss_desc d) {
                 PL(d.dlogits[7], 60, o) = dz7;
             }
         }
-#undef PL
         num[5] = n5; den[5] = d5; num[6] = n6; den[6] = d5; num[7] = n7;
     }
+#undef PL
     // ---- block reduction of the 16 sums
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const double a = wave_sum(num[i]), bsum = wave_sum(den[i]);
-        if (lane == 0) { sm[wave][i] = a; sm[wave][8 + i] = bsum; }
+        if (lane == 0) { sm[sub][i] = a; sm[sub][8 + i] = bsum; }
     }
     __syncthreads();
     if (threadIdx.x < 16)
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const abc_loss_fin_
 
 }  // namespace
 
-extern "C" int abc_loss_blocks(const abc_loss_desc* d) { return abc_cdiv(d->B * d->h * d->w, 256); }
+extern "C" int abc_loss_blocks(const abc_loss_desc* d) { return abc_cdiv(d->B * d->h * d->w, LPX); }
 
 extern "C" int abc_loss_fwd_bwd(const abc_loss_desc* d, abc_stream_t stream) {
     if (d->B < 1 || d->h < 1 || d->w < 1) return abc_fail(ABC_EINVAL, "loss: empty");

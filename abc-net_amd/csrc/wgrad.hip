@@ -59,10 +59,15 @@ __device__ inline void stage_slow(char* dst, int RS, int PS, int HH, int HW, int
     stage_halo<T, CT, CW>(dst, RS, PS, HH, HW, b, iy0, ix0, Hin, Win, *s, c0, tid, WTHR, cvalid);
 }
 
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false>
+// TS ("tap split", one 32x32 tile pair, more than 9 taps -- unet2's 5x5 convolutions): the 8 waves split the TAPS instead
+// of the patch rows (wave w owns taps w, w + 8, w + 16, w + 24: <= 4 accumulators), every wave walks the whole patch, and
+// ONE workgroup pass covers all taps.  With the row split 25 taps ran as 3 tap groups (grid.y) that each re-staged both
+// operands: 596 MB fetched per launch against 302 MB algorithmic (profiles/r01_f_unet2_pmc_summary.json).
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
-    constexpr int MAXT = FAST ? MAXT_FAST : MAXT_SLOW;
-    constexpr int RSPLIT = 8 / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
+    static_assert(!TS || (AT == 1 && BT == 1 && FAST && !K3 && !DUAL && sizeof(CT) == 2), "tap split: one bf16 tile pair on the prefetch path");
+    constexpr int MAXT = TS ? 4 : (FAST ? MAXT_FAST : MAXT_SLOW);
+    constexpr int RSPLIT = TS ? 1 : 8 / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
     constexpr int PROWS = 8 * PM;           // patch rows (x 16 columns)
     constexpr int ROWS = PROWS / RSPLIT;    // patch rows per wave
     constexpr int CWP = AT * 32, CWQ = BT * 32;
@@ -82,7 +87,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
     const int t0 = blockIdx.y * a.tgw;
     const int tcnt = min(a.tgw, a.ntaps - t0);
 
-    const int pair = wave / RSPLIT, rs = wave % RSPLIT;
+    const int pair = TS ? 0 : wave / RSPLIT, rs = TS ? 0 : wave % RSPLIT;
+    // tap owned by accumulator slot j (TS: wave-uniform, kept scalar)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto tap_of = [&](int j) { return TS ? wave_u + 8 * j : t0 + j; };
+    auto tap_ok = [&](int j) { return TS ? (wave_u + 8 * j < a.ntaps) : (j < tcnt); };
     const int ai = pair / BT, bi = pair % BT;
     const int row_lo = rs * ROWS;
     const int PSWP = a.PSWP, PSWQ = a.PSWQ;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
 
     int tapoff[MAXT];  // LDS byte offset of each tap inside the Q halo
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) tapoff[t] = (t < tcnt) ? (a.ty[t0 + t] * a.HW + a.tx[t0 + t]) * PSWQ : 0;
+    for (int t = 0; t < MAXT; ++t) tapoff[t] = tap_ok(t) ? (a.ty[tap_of(t)] * a.HW + a.tx[tap_of(t)]) * PSWQ : 0;
 
     // per-lane channel byte offsets inside a pixel
     int pch, qch;
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
                     const char* qb = sQ + ((row * STRIDE) * a.HW + kq * STRIDE) * PSWQ + qch;
 #pragma unroll
                     for (int t = 0; t < MAXT; ++t) {
-                        if (t < tcnt) {
+                        if (tap_ok(t)) {
                             const bf16x8 fb = tr_read8(qb + tapoff[t], qb + tapoff[t] + 4 * STRIDE * PSWQ);
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
                         }
@@ -299,8 +308,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
 
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        if (t < tcnt) {
-            float* out = a.partial + ((size_t)(split * a.ntaps + t0 + t) * a.Ca_pad + ca0 + ai * 32) * a.Cb_pad + cb0 + bi * 32 + r;
+        if (tap_ok(t)) {
+            float* out = a.partial + ((size_t)(split * a.ntaps + tap_of(t)) * a.Ca_pad + ca0 + ai * 32) * a.Cb_pad + cb0 + bi * 32 + r;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int arow = (k & 3) + 8 * (k >> 2) + 4 * h;
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(64) void wgrad_reduce_wave_kernel(const abc_wgrad_r
 
 struct WGeom {
     int AT, BT, dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, lds, tgw, ngroups, nta, ntb, npatch,
-        tiles_x, tiles_y, fast_p, fast_q, nbuf, PM;
+        tiles_x, tiles_y, fast_p, fast_q, nbuf, PM, ts;
 };
 
 static int psw_for(int cw, int csz) {
@@ -717,16 +726,26 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     else { g->AT = 1; g->BT = 1; }
     // narrow layers (one tile pair, 8-way row split) take 32-row patches when both operands can be prefetched:
     // 4 K-steps per wave between barriers instead of 1
+    g->ts = 0;
     if (g->AT == 1 && g->BT == 1 && d->stride == 1 && csz == 2 && d->Hg % 32 == 0) {
         int rc = wgeom_pm(d, g, 4);
         if (rc == ABC_OK && g->fast_p && g->fast_q) return ABC_OK;
     }
+    // more than 9 taps on one tile pair (5x5): split the taps over the waves, one pass over the operands
+    static const bool nots = getenv("ABC_WGRAD_NOTS") != nullptr;  // (experiment switch)
+    if (!nots && g->AT == 1 && g->BT == 1 && d->stride == 1 && csz == 2 && d->ntaps > MAXT_FAST && d->ntaps <= 32 &&
+        d->dtype_p == ABC_BF16 && d->dtype_q == ABC_BF16 && d->p2 == nullptr) {
+        for (int pm = (d->Hg % 16 == 0) ? 2 : 1; pm >= 1; --pm) {
+            int rc = wgeom_pm(d, g, pm);
+            if (rc == ABC_OK && g->fast_p && g->fast_q) { g->ts = 1; g->ngroups = 1; g->tgw = d->ntaps; return ABC_OK; }
+        }
+    }
     return wgeom_pm(d, g, 1);
 }
 
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false>
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false>
 static int wlaunch3(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
-    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3, DUAL>;
+    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3, DUAL, TS>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -762,6 +781,10 @@ static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipSt
     if (g.AT == 2) return wlaunch<PT, QT, CT, 2, 2, 1>(k, g, nsplit, st);
     if constexpr (sizeof(CT) == 2) {
         if (g.BT == 4) return wlaunch<PT, QT, CT, 1, 4, 1>(k, g, nsplit, st);
+        if constexpr (sizeof(PT) == 2 && sizeof(QT) == 2) {
+            if (g.ts && g.PM == 2) return wlaunch3<PT, QT, CT, 1, 1, 1, true, 2, false, false, true>(k, g, nsplit, st);
+            if (g.ts) return wlaunch3<PT, QT, CT, 1, 1, 1, true, 1, false, false, true>(k, g, nsplit, st);
+        }
         if (g.PM == 4) return wlaunch2<PT, QT, CT, 1, 1, 1, true, 4>(k, g, nsplit, st);
     }
     if (stride == 1) return wlaunch<PT, QT, CT, 1, 1, 1>(k, g, nsplit, st);

@@ -51,6 +51,9 @@ def act(x, sc, sh, sl):
     dict(Cin=16, Cout=32, k=3, H=256, W=384, pool=True),
     dict(Cin=16, Cout=16, k=3, H=192, W=256, coef=True),
     dict(Cin=128, Cout=128, k=3, H=96, W=192, coef=True),
+    # unet2's 5x5 stem: 25-tap one-channel kernel; 5x5 32 -> 32 on the lean kernel over many tiles
+    dict(Cin=1, Cout=32, k=5, H=40, W=24, img=True),
+    dict(Cin=32, Cout=32, k=5, H=128, W=192, coef=True),
 ])
 def test_conv_forward(lib, dt, case):
     g = torch.Generator().manual_seed(3)
@@ -327,10 +330,12 @@ def test_conv_transpose_dgrad_wgrad(lib, dt):
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", [dict(Cin=64, Cout=128, k=3), dict(Cin=16, Cout=16, k=3), dict(Cin=32, Cout=64, k=3, pool=True),
                                   dict(Cin=1, Cout=16, k=3, img=True), dict(Cin=1, Cout=32, k=3, img=True, H=40, W=56), dict(Cin=128, Cout=14, k=1, f32dy=True),
-                                  dict(Cin=32, Cout=32, k=5)])
+                                  dict(Cin=32, Cout=32, k=5),
+                                  # 25 taps: tap-split weight gradient with 16-row patches; 25-tap one-channel kernel
+                                  dict(Cin=32, Cout=32, k=5, H=32, W=48), dict(Cin=1, Cout=32, k=5, img=True)])
 def test_conv_wgrad(lib, dt, case):
     g = torch.Generator().manual_seed(11)
-    B, H, W, Cin, Cout, k = 2, 24, 40, case["Cin"], case["Cout"], case["k"]
+    B, H, W, Cin, Cout, k = 2, case.get("H", 24), case.get("W", 40), case["Cin"], case["Cout"], case["k"]
     pool, img = case.get("pool", False), case.get("img", False)
     Hx, Wx = (2 * H, 2 * W) if pool else (H, W)
     dt_q = L.F32 if img else dt
