@@ -818,10 +818,13 @@ class Engine:
                        meta={"kernel": "cbam_bwd3", "flops": 0, "bytes": float(npx * Cc * esz * 3)})
             # BN2 backward on d_z, then the second conv
             rec2, rec1 = blk.rec2, blk.rec1
-            dY2 = self._bn_finish(ops, rec2, part3, nb3, dz)
+            # (fusing the BN-backward apply into the weight gradient's load, as unet does, measured neutral here: bn_apply
+            #  -0.27 ms, dual weight gradients +0.33 ms per step -- ABC_UNET2_DEFER=1 to try again)
+            defer2 = bool(os.environ.get("ABC_UNET2_DEFER"))
+            dY2 = self._bn_finish(ops, rec2, part3, nb3, dz, defer=defer2)
             dA1 = self._conv_backward(ops, rec2, dY2)
             rec1.grad_same = (dA1, rec1.cout, 0)
-            dY1 = self._bn_backward(ops, rec1, rec1.grad_same, None)
+            dY1 = self._bn_backward(ops, rec1, rec1.grad_same, None, defer=defer2)
             xin = blk.xin
             has_prod = xin.producer is not None
             d_x = self._conv_backward(ops, rec1, dY1, want_dgrad=has_prod)
@@ -855,8 +858,9 @@ class Engine:
         else:
             src.producer.grad_same = (d_x, blk.cin, 0)
 
-    def _bn_finish(self, ops, rec, part, nblk, gbuf):
-        """bn_finalize_bwd + bn_apply for a BN whose G and partials were produced elsewhere (CBAM bwd3)"""
+    def _bn_finish(self, ops, rec, part, nblk, gbuf, defer=False):
+        """bn_finalize_bwd + bn_apply for a BN whose G and partials were produced elsewhere (CBAM bwd3).
+        defer=True: as _bn_backward(defer=True) -- the apply pass is left to the weight-gradient kernel's load where it can"""
         C_ = rec.cout
         k1, k2, gs = (self.new((C_,), torch.float32) for _ in range(3))
         f = L.BnBwdDesc()
@@ -864,14 +868,24 @@ class Engine:
         f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
         f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
         f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+        if defer:
+            ca, cb, cc = (self.new((C_,), torch.float32) for _ in range(3))
+            f.mean, f.ca, f.cb, f.cc = rec.mean.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
         self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
         a = L.BnApplyDesc()
         a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = gbuf.data_ptr(), C_, rec.y.data_ptr(), rec.ld, rec.coff
         a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
         a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
-        self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
-                   meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
-        return Src(gbuf, self.dt, rec.H, rec.W, C_, 0, C_)
+
+        def emit_apply():
+            self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
+                       meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
+            rec.dY = gbuf
+            return Src(gbuf, self.dt, rec.H, rec.W, C_, 0, C_)
+
+        if defer:
+            return Src(gbuf, self.dt, rec.H, rec.W, C_, 0, C_, coef=(ca, cc, cb)), emit_apply
+        return emit_apply()
 
     # ------------------------------------------------------------------ execution
     def _run(self, ops, stream):
