@@ -131,8 +131,14 @@ class ExtractDesc(C.Structure):
                 ("atoms", vp), ("bonds", vp), ("bond_rho", vp), ("work", vp), ("work_masks", vp)]
 
 
+class RasterDesc(C.Structure):
+    _fields_ = [("t_atom", vp), ("t_types", vp), ("t_charges", vp), ("t_hs", vp), ("t_bond", vp), ("t_btypes", vp), ("t_rho", vp),
+                ("t_omega", vp), ("B", i32), ("h", i32), ("w", i32), ("max_atoms", i32), ("max_bonds", i32), ("atoms", vp),
+                ("n_atoms", vp), ("bonds", vp), ("n_bonds", vp), ("rho", vp)]
+
+
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
-            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc, ExtractDesc]
+            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc, ExtractDesc, RasterDesc]
 
 # every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
@@ -169,6 +175,7 @@ SYMBOLS = {
     "abc_extract_work_ints": (i64, [P(ExtractDesc)]),
     "abc_extract_work_masks": (i64, [P(ExtractDesc)]),
     "abc_extract_peaks": (C.c_int, [P(ExtractDesc), vp]),
+    "abc_rasterize_targets": (C.c_int, [P(RasterDesc), vp]),
     "abc_metrics_blocks": (C.c_int, [P(MetricsDesc)]),
     "abc_metrics_update": (C.c_int, [P(MetricsDesc), vp]),
     "abc_plane_sum": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp]),

@@ -318,6 +318,7 @@ extern "C" int abc_sizeof(int which) {
         case 15: return (int)sizeof(abc_cbam_conv7_desc);
         case 16: return (int)sizeof(abc_metrics_desc);
         case 17: return (int)sizeof(abc_extract_desc);
+        case 18: return (int)sizeof(abc_raster_desc);
         default: return -1;
     }
 }

@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--variant", default="unet", choices=["unet", "unet2"], help="unet.py (headline) or unet2.py (config 3)")
     ap.add_argument("--metrics", action="store_true", help="also update the 17 training meters of train.py:145-215 on the device every step")
+    ap.add_argument("--raster", action="store_true", help="rasterise the targets on the device every step from compact records "
+                    "(utils.py:83-228 on the GPU) instead of keeping pre-rasterised maps resident")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -159,6 +161,18 @@ def main():
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics)
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
         tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
+        if a.raster:
+            # the data path a real loader would use: a few KB of records per batch, maps built where the loss reads them
+            from abcnet_amd.raster import TargetRasterizer, parse_record
+            from oracle.raster_oracle import random_annotations   # (test-data generator only: seeded annotation strings)
+            rz = TargetRasterizer(a.batch, a.size // 4, max_atoms=64, max_bonds=64, targets=tr.targets)
+            rz.load([parse_record(*random_annotations(30, 32, 900 + 16 * rank + i, size=a.size), h=a.size // 4) for i in range(a.batch)])
+            _step = tr.step
+
+            def step_with_raster():
+                rz.run()
+                _step()
+            tr.step = step_with_raster
     torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -200,7 +214,8 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
-                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics)},
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),
+                   "device_rasteriser": bool(a.raster)},
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 

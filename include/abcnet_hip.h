@@ -274,6 +274,21 @@ typedef struct abc_nms_desc {
 } abc_nms_desc;
 int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream);
 
+/* Target rasteriser (utils.py:83-228, MolecularImageDataset.__getitem__) from compact per-molecule records: zeroes the 8
+ * target maps of the loss (same layouts / dtypes as abc_loss_desc) and rasterises atoms, then bonds, in record order
+ * (the reference's slice assignments are order dependent).  atoms[b][i] = (x, y, type, charge, hs in {0,1} or -1);
+ * bonds[b][i] = (x, y, type, omega bin, single: 1 = one direction (stereo types 4, 5), 0 = bins k and k + 30);
+ * rho[b][i] float64.  x = row, y = column, inside the map.  The string parsing, vocabulary look-ups and atan of
+ * utils.py:94-163 stay on the host (abcnet_amd/raster.py). */
+typedef struct abc_raster_desc {
+    float* t_atom; float* t_types; float* t_charges; float* t_hs; float* t_bond; float* t_btypes; double* t_rho; double* t_omega;
+    int32_t B, h, w, max_atoms, max_bonds;
+    const int32_t* atoms; const int32_t* n_atoms;   /* [B][max_atoms][5], [B] */
+    const int32_t* bonds; const int32_t* n_bonds;   /* [B][max_bonds][5], [B] */
+    const double* rho;                              /* [B][max_bonds] */
+} abc_raster_desc;
+int abc_rasterize_targets(const abc_raster_desc* d, abc_stream_t stream);
+
 /* Candidate extraction for the SMILES decoder (img2smiles2.py:113-191; replaces its per-pixel .cpu().item() loops):
  * from the NMS masks of abc_nms_peaks and the raw head maps (all NCHW f32) to compact ordered lists per image.
  *   atoms[b][i] = (x, y, type, charge, hs)      raster order, greedy suppression within squared distance < 4
@@ -378,7 +393,7 @@ int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int3
                          int32_t c_off, abc_stream_t stream);
 int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream);
 
-/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17):
+/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17, abc_raster_desc = 18):
  * lets a foreign-language binding check its mirror structs at load time */
 int abc_sizeof(int which);
 const char* abc_last_error(void);

@@ -18,6 +18,7 @@ What is produced (all float32 unless noted):
   nms_128.npz              NMS masks (bit-packed) from exec of img2smiles2.py:61-79
   metrics_128.npz          sum / count of the 17 training meters after one update (exec of
                            train.py:95-105 + 145-215 with the reference's meter.AverageMeter)
+  raster_128.npz           the 8 target maps of utils.py:83-228 for seeded annotation strings (sparse)
   decode_128.npz           atom / bond candidate lists of img2smiles2.py:113-191 for seeded head maps
   adam.npz                 one torch.optim.Adam step (train.py:55 settings)
   meta.json                state_dict key/shape lists, parameter counts
@@ -228,6 +229,35 @@ def decode_goldens():
     print("wrote decode", [(res["atoms%d" % j].shape, res["bond_pos%d" % j].shape) for j in range(2)])
 
 
+def raster_goldens():
+    """utils.py:83-228 (target rasteriser inside MolecularImageDataset.__getitem__) executed on seeded annotation strings
+    with the vocabularies of utils.py:12-15; stored: the 8 target maps as sparse (index, value) lists.
+    The slice uses `np.math.atan`, which numpy >= 2 no longer has: the namespace's `np` is numpy plus a `math`
+    attribute (the standard library module, which is what np.math was)."""
+    import math
+    import types
+    from oracle.raster_oracle import random_annotations
+    npx = types.SimpleNamespace(**{k: getattr(np, k) for k in dir(np) if not k.startswith("__")})
+    npx.math = math
+    res = {}
+    cases = [(40, 45, 101, 1, 1, 0, 0), (25, 30, 102, 0.8317, 1, 43, 0), (60, 70, 103, 1, 0.9071, 0, 23)]
+    for ci, (na, nb, seed, sx, sy, ddx, ddy) in enumerate(cases):
+        atoms_string, bonds_string = random_annotations(na, nb, seed, size=int(512 * min(sx, sy)) - 1)
+        ns = {"np": npx, "atoms_string": atoms_string, "bonds_string": bonds_string, "scale_x": sx, "scale_y": sy, "ddx": ddx, "ddy": ddy}
+        exec(slice_text(os.path.join(REF, "utils.py"), 12, 15), ns)
+        exec(slice_text(os.path.join(REF, "utils.py"), 83, 228), ns)
+        maps = [ns[n] for n in ("atom_target", "atom_type", "atom_charge", "atom_hs", "bond_target", "bond_type", "bond_rho", "bond_omega_type")]
+        for mi, m in enumerate(maps):
+            flat = m.reshape(-1)
+            nz = np.flatnonzero(flat)
+            res["c%d_m%d_idx" % (ci, mi)] = nz.astype(np.int64)
+            res["c%d_m%d_val" % (ci, mi)] = flat[nz]
+            res["c%d_m%d_dtype" % (ci, mi)] = np.array(str(m.dtype))
+        res["c%d_args" % ci] = np.array([na, nb, seed, sx, sy, ddx, ddy], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "raster_128.npz"), **res)
+    print("wrote raster", [len(res["c%d_m5_idx" % c]) for c in range(3)])
+
+
 def nms_goldens():
     g = torch.Generator().manual_seed(13)
     ns = {"torch": torch}
@@ -282,12 +312,13 @@ def meta():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("metrics", "decode"):   # (added after the other fixtures: regenerate one alone)
-        {"metrics": metrics_goldens, "decode": decode_goldens}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("metrics", "decode", "raster"):   # (added after the other fixtures: regenerate one alone)
+        {"metrics": metrics_goldens, "decode": decode_goldens, "raster": raster_goldens}[sys.argv[1]]()
         sys.exit(0)
     meta()
     metrics_goldens()
     decode_goldens()
+    raster_goldens()
     adam_goldens()
     nms_goldens()
     loss_goldens()

@@ -175,3 +175,35 @@ def test_decode_oracle_matches_reference(golden_dir):
         omega = bonds[:, 2].numpy().astype(np.float64) * (np.pi / 30) + np.pi / 60 - np.pi / 2   # img2smiles2.py:160
         r = rhos.numpy().astype(np.float64)
         assert np.array_equal(np.stack([r * np.cos(omega), r * np.sin(omega)], 1), gold["bond_delta%d" % j])
+
+
+def _raster_case(gold, ci):
+    from oracle import raster_oracle as ro
+    na, nb, seed, sx, sy, ddx, ddy = gold["c%d_args" % ci]
+    a, b = ro.random_annotations(int(na), int(nb), int(seed), size=int(512 * min(sx, sy)) - 1)
+    sx = int(sx) if sx == 1 else float(sx)   # the reference's un-augmented scale is the int 1
+    sy = int(sy) if sy == 1 else float(sy)
+    return a, b, sx, sy, int(ddx), int(ddy)
+
+
+def test_raster_oracle_matches_reference(golden_dir):
+    """utils.py:83-228 (target rasteriser): the oracle's 8 maps against the maps the reference text itself produced
+    (exec by make_golden.py), bit for bit, dtypes included; and the product's host-side record parser against the
+    same strings (same coordinates / bins, no GPU needed)."""
+    from abcnet_amd.raster import parse_record
+    from oracle import raster_oracle as ro
+    gold = np.load(os.path.join(golden_dir, "raster_128.npz"))
+    for ci in range(3):
+        a, b, sx, sy, ddx, ddy = _raster_case(gold, ci)
+        maps = ro.rasterize(a, b, sx, sy, ddx, ddy)
+        for mi, m in enumerate(maps):
+            flat = m.reshape(-1)
+            nz = np.flatnonzero(flat)
+            assert str(m.dtype) == str(gold["c%d_m%d_dtype" % (ci, mi)])
+            assert np.array_equal(nz, gold["c%d_m%d_idx" % (ci, mi)]), (ci, mi)
+            assert np.array_equal(flat[nz], gold["c%d_m%d_val" % (ci, mi)]), (ci, mi)
+        atoms, bonds, rho = parse_record(a, b, sx, sy, ddx, ddy)
+        assert len(atoms) == len(a.split(";")) - 1 and len(bonds) == len(b.split(";")) - 1 == len(rho)
+        # every bond centre the parser reports is a 1 in the reference's bond-centre map unless a later ring overwrote it
+        bt = maps[4][0]
+        assert all(bt[x, y] in (1.0, np.float32(0.8)) for x, y in bonds[:, :2])
