@@ -623,7 +623,10 @@ extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t
         (void)hipFuncSetAttribute((const void*)cbam_channel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    const int nb = abc_cdiv(d->C * d->mid, 256 * 8) < 1 ? 1 : (abc_cdiv(d->C * d->mid, 256 * 8) > 32 ? 32 : abc_cdiv(d->C * d->mid, 256 * 8));
+    // one (c, j) weight-gradient element per thread where possible: the per-element loops over the images are chains of
+    // dependent global loads, so width beats depth (8 elements per thread cost 50 us per call)
+    const int want = abc_cdiv(d->C * d->mid, 256);
+    const int nb = want < 1 ? 1 : (want > 64 ? 64 : want);
     hipLaunchKernelGGL(cbam_channel_bwd_pre1_kernel, dim3(abc_cdiv(d->B * d->C, 256)), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_bwd_pre2_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(nb), dim3(256), sh, (hipStream_t)stream, *d);
