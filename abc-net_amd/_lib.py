@@ -147,6 +147,7 @@ SYMBOLS = {
     "abc_conv_variant": (C.c_int, [vp]),
     "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),
     "abc_conv_chunk": (C.c_int, [C.c_int, C.c_int]),
+    "abc_heads_batch": (C.c_int, [vp, i32, i32, vp]),
     "abc_conv_tile": (C.c_int, [P(ConvDesc), P(i32), P(i32), P(i32)]),
     "abc_pack_conv_weights": (C.c_int, [P(PackDesc), vp]),
     "abc_pack_item_bytes": (C.c_int, []),

@@ -26,7 +26,7 @@ struct HeadFwdK {
     unsigned bytesX, bytesW;
 };
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdK a) {
+__device__ inline void head_fwd_body(const HeadFwdK& a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int pair = blockIdx.x * 4 + wave;   // 64 consecutive pixels (never straddling an image: HW % 64 == 0)
@@ -100,6 +100,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdK a) {
 }
 
 
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdK a) { head_fwd_body(a); }
+
+// All heads of the network in ONE launch (blockIdx.y = head): eight back-to-back launches each drained the chip before the
+// next began, and the five small heads (1 .. 14 channels) are far too short to fill it on their own.
+constexpr int MAX_HEADS = 8;
+struct HeadFwdBatch { HeadFwdK k[MAX_HEADS]; };
+__global__ __launch_bounds__(256) void head_fwd_batch_kernel(const HeadFwdBatch bt) { head_fwd_body(bt.k[blockIdx.y]); }
+
 // ---------------------------------------------------------------------------
 // Data gradient of the heads' 1x1 convolutions: dH[p][ci] = sum_co act(dL[co][p]) * W[co][ci] with dL the NCHW f32
 // logit gradients (act = the per-channel loss scale) and dH a 128-channel slice of an NHWC tensor.
@@ -123,7 +131,7 @@ __device__ inline bf16x8 tr_read8h(const char* b0, const char* b1) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadDgK a) {
+__device__ inline void head_dgrad_body(const HeadDgK& a) {
     constexpr int ROWB = 64 * 2 + 16;          // LDS row: 64 pixels bf16 + pad
     __shared__ __attribute__((aligned(16))) char smem[4][2][16 * ROWB];
     __shared__ __attribute__((aligned(16))) char stile[4][32 * (128 * 2 + 16)];  // per-wave output transpose tile
@@ -218,6 +226,27 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadDgK a) {
     }
 }
 
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadDgK a) { head_dgrad_body(a); }
+struct HeadDgBatch { HeadDgK k[MAX_HEADS]; };
+__global__ __launch_bounds__(256) void head_dgrad_batch_kernel(const HeadDgBatch bt) { head_dgrad_body(bt.k[blockIdx.y]); }
+
+static void fill_fwd(HeadFwdK& k, const abc_conv_desc* d) {
+    k.x = d->src.x; k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.w = d->w; k.bias = d->bias; k.y = (float*)d->y;
+    k.HW = d->Hg * d->Wg; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;
+    k.ctot = d->ctot_out; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
+    k.drop_p = d->src.drop_p; k.drop_seed = d->src.drop_seed;
+    k.bytesX = (unsigned)((int64_t)d->B * k.HW * d->src.ldx * 2);
+    k.bytesW = (unsigned)((int64_t)4 * d->Cout_pad * 32 * 2);
+}
+
+static void fill_dg(HeadDgK& k, const abc_conv_desc* d) {
+    k.dl = (const float*)d->src.x; k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.w = d->w; k.y = (bf16*)d->y;
+    k.HW = d->Hg * d->Wg; k.hc = d->Cin; k.CK = abc_conv_chunk(d->dtype_c, d->Cin);
+    k.ksteps = abc_roundup(d->Cin, k.CK) / 16; k.ldy = d->ldy; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
+    k.bytesDL = (unsigned)((int64_t)d->B * d->Cin * k.HW * 4);
+    k.bytesW = (unsigned)((int64_t)abc_roundup(d->Cin, k.CK) * 128 * 2);
+}
+
 }  // namespace
 
 int abc_head_fwd_ok(const abc_conv_desc* d) {
@@ -234,12 +263,7 @@ int abc_head_fwd_ok(const abc_conv_desc* d) {
 
 int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream) {
     HeadFwdK k;
-    k.x = d->src.x; k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.w = d->w; k.bias = d->bias; k.y = (float*)d->y;
-    k.HW = d->Hg * d->Wg; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;
-    k.ctot = d->ctot_out; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
-    k.drop_p = d->src.drop_p; k.drop_seed = d->src.drop_seed;
-    k.bytesX = (unsigned)((int64_t)d->B * k.HW * d->src.ldx * 2);
-    k.bytesW = (unsigned)((int64_t)4 * d->Cout_pad * 32 * 2);
+    fill_fwd(k, d);
     hipLaunchKernelGGL(head_fwd_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
     return abc_check_launch("head_fwd");
 }
@@ -256,11 +280,31 @@ int abc_head_dgrad_ok(const abc_conv_desc* d) {
 
 int abc_head_dgrad_launch(const abc_conv_desc* d, abc_stream_t stream) {
     HeadDgK k;
-    k.dl = (const float*)d->src.x; k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.w = d->w; k.y = (bf16*)d->y;
-    k.HW = d->Hg * d->Wg; k.hc = d->Cin; k.CK = abc_conv_chunk(d->dtype_c, d->Cin);
-    k.ksteps = abc_roundup(d->Cin, k.CK) / 16; k.ldy = d->ldy; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
-    k.bytesDL = (unsigned)((int64_t)d->B * d->Cin * k.HW * 4);
-    k.bytesW = (unsigned)((int64_t)abc_roundup(d->Cin, k.CK) * 128 * 2);
+    fill_dg(k, d);
     hipLaunchKernelGGL(head_dgrad_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
     return abc_check_launch("head_dgrad");
+}
+
+// All heads' 1x1 convolutions in one launch.  which = 0: forward (every descriptor must satisfy abc_head_fwd_ok),
+// 1: data gradient (abc_head_dgrad_ok); all with the same batch and map size.
+extern "C" int abc_heads_batch(const abc_conv_desc* descs, int32_t n, int32_t which, abc_stream_t stream) {
+    if (n < 1 || n > MAX_HEADS) return abc_fail(ABC_EINVAL, "heads_batch: 1..8 heads");
+    for (int i = 0; i < n; ++i) {
+        const abc_conv_desc* d = descs + i;
+        if (!(which ? abc_head_dgrad_ok(d) : abc_head_fwd_ok(d))) return abc_fail(ABC_EUNSUPPORTED, "heads_batch: a descriptor does not fit the heads' 1x1 kernels");
+        if (d->B != descs->B || d->Hg != descs->Hg || d->Wg != descs->Wg) return abc_fail(ABC_EINVAL, "heads_batch: all heads must share batch and map size");
+    }
+    const int npairs = descs->B * descs->Hg * descs->Wg / 64;
+    if (which == 0) {
+        HeadFwdBatch bt;
+        for (int i = 0; i < n; ++i) fill_fwd(bt.k[i], descs + i);
+        for (int i = n; i < MAX_HEADS; ++i) bt.k[i] = bt.k[0];
+        hipLaunchKernelGGL(head_fwd_batch_kernel, dim3(abc_cdiv(npairs, 4), n), dim3(256), 0, (hipStream_t)stream, bt);
+    } else {
+        HeadDgBatch bt;
+        for (int i = 0; i < n; ++i) fill_dg(bt.k[i], descs + i);
+        for (int i = n; i < MAX_HEADS; ++i) bt.k[i] = bt.k[0];
+        hipLaunchKernelGGL(head_dgrad_batch_kernel, dim3(abc_cdiv(npairs, 4), n), dim3(256), 0, (hipStream_t)stream, bt);
+    }
+    return abc_check_launch("heads_batch");
 }

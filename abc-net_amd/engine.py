@@ -169,7 +169,8 @@ class Engine:
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
                   grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
-                  accumulate=False):
+                  accumulate=False, collect=None):
+        """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch"""
         d = L.ConvDesc()
         src.fill(d.src)
         d.w, d.bias, d.y = w.data_ptr(), bias, y.data_ptr()
@@ -199,8 +200,31 @@ class Engine:
         meta = {"kernel": "%s<%s,%s,%s,CK%d,BN%d,S%d,MT%d>" % (kname, self._dn(src.dt), self._dn(self.dt), self._dn(y_dt), ck, bn, stride, mt),
                 "flops": 2.0 * npx * Cout * len(taps) * d.Cin,
                 "bytes": float(in_px * d.Cin * self._esz(src.dt) + npx * Cout * self._esz(y_dt))}
-        self._emit(ops, self.lib.abc_conv_fwd, d, what, meta=meta)
+        if collect is not None:
+            collect.append((d, what, meta))
+        else:
+            self._emit(ops, self.lib.abc_conv_fwd, d, what, meta=meta)
         return st, nblk
+
+    def emit_heads_batch(self, ops, items, which, what):
+        """the heads' 1x1 convolutions collected by emit_conv(collect=...) as ONE launch (abc_heads_batch) when every one of
+        them is served by the dedicated heads kernel (which = 0 forward / 1 data gradient), else one launch each"""
+        want = 3 if which == 0 else 4
+        ok = 1 <= len(items) <= 8 and all(self.lib.abc_conv_variant(C.byref(d)) == want for d, _w, _m in items) \
+            and not os.environ.get("ABC_NO_HEADS_BATCH")
+        if not ok:
+            for d, w, m in items:
+                self._emit(ops, self.lib.abc_conv_fwd, d, w, meta=m)
+            return
+        arr = (L.ConvDesc * len(items))()
+        for i, (d, _w, _m) in enumerate(items):
+            arr[i] = d
+        self.keep.append(arr)
+        self.keep.append([d for d, _w, _m in items])
+        lib, n = self.lib, len(items)
+        meta = {"kernel": "heads_%s_batch" % ("fwd" if which == 0 else "dgrad"), "flops": sum(m["flops"] for _d, _w, m in items),
+                "bytes": sum(m["bytes"] for _d, _w, m in items)}
+        ops.append((lambda _r, st, a=arr: lib.abc_heads_batch(a, n, which, st), None, what, (), meta))
 
     def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None, rowsum_to=None):
         """dual = (y_raw tensor, ld, channel offset, dY pointer, dY pixel stride): fuse the BatchNorm-backward correction into the load of P
@@ -433,6 +457,7 @@ class Engine:
         # the list forward() returns: one contiguous NCHW f32 map per head (unet.py:119), written directly
         self.logits = [self.new((self.B, hc, h, w), torch.float32) for hc in self.heads]
         self.head_recs, self.head2 = [], []
+        head_convs = []
         for i, hc in enumerate(self.heads):
             p = "out_modules.%d" % i
             rec, f = self.conv_bn(p + ".conv1", p + ".bn", trunk, 128, 3, (self.hfeat, self.hcoef, h, w, 128 * nh, 128 * i), 0.01)
@@ -443,8 +468,10 @@ class Engine:
             w2 = self.packed(1, 128, rows_pad)
             self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
             self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
-                           [(0, 0)], what="fwd %s.conv2" % p, planar_out=True)
+                           [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs)
             self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
+        # (the eight conv1 launches above write the eight slices of hfeat; the eight 1x1 convolutions go as one launch)
+        self.emit_heads_batch(self.fwd_ops, head_convs, 0, "fwd out_modules.*.conv2")
 
     # ------------------------------------------------------------------ backward plan
     def _bn_backward(self, ops, rec, same, pool, drop=None, defer=False):
@@ -564,7 +591,8 @@ class Engine:
         one = self.new((max(self.heads),), torch.float32, 1.0)
         zero = self.new((max(self.heads),), torch.float32, 0.0)
         dfeat = self.new((B, h, w, 128 * nh))
-        # ---- heads' 1x1 convs
+        # ---- heads' 1x1 convs (weight gradients one by one, the eight data gradients as one launch)
+        head_dgrads = []
         for r2 in self.head2:
             i, hc = r2.idx, r2.cout
             cs = self.chan_scale[self.head_off[i]:self.head_off[i] + hc]
@@ -579,7 +607,9 @@ class Engine:
                             {"kernel": "plane_sum", "flops": 0, "bytes": float(B * hc * h * w * 4)}))
             wd = self.packed(1, hc, 128)
             self.emit_pack(r2.cname + ".weight", wd, 1, hc, 128, 1, 128, hc)
-            self.emit_conv(ops, dl, wd, None, dfeat, self.dt, h, w, 128 * nh, 128 * i, 128, [(0, 0)], what="dgrad " + r2.cname)
+            self.emit_conv(ops, dl, wd, None, dfeat, self.dt, h, w, 128 * nh, 128 * i, 128, [(0, 0)], what="dgrad " + r2.cname,
+                           collect=head_dgrads)
+        self.emit_heads_batch(ops, head_dgrads, 1, "dgrad out_modules.*.conv2")
         # ---- heads' BN + conv1: per-head BN backward, ONE data-gradient conv over the 8x128 concatenated channels
         taps = taps_square(3)
         dyh = self.new((B, h, w, 128 * nh))

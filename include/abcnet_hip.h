@@ -265,6 +265,12 @@ typedef struct abc_adam_desc {
 } abc_adam_desc;
 int abc_adam_step(const abc_adam_desc* d, abc_stream_t stream);
 
+/* The heads' 1x1 convolutions (unet.py:70, out_modules[i].conv2) of ALL heads in one launch: descs[0..n) are the same
+ * descriptors abc_conv_fwd would take one by one (n <= 8, same batch and map size).  which = 0: forward into the NCHW
+ * f32 logits; which = 1: data gradient from the NCHW f32 dlogits.  ABC_EUNSUPPORTED when a descriptor is not served by
+ * the dedicated heads kernels (then call abc_conv_fwd per head). */
+int abc_heads_batch(const abc_conv_desc* descs, int32_t n, int32_t which, abc_stream_t stream);
+
 /* Inference NMS (img2smiles2.py:61-79) on the NCHW f32 head maps: atom/bond 3x3 peak
  * masks (logit > -1), |rho|, circular 3-tap omega peak mask; outputs NCHW f32 like the reference. */
 typedef struct abc_nms_desc {
