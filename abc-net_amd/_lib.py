@@ -20,7 +20,7 @@ vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_
 
 class ActSrc(C.Structure):
     _fields_ = [("x", vp), ("scale", vp), ("shift", vp), ("slope", vp), ("Hx", i32), ("Wx", i32), ("ldx", i32),
-                ("pool", i32), ("drop_p", f32), ("drop_seed", u32), ("planar", i32), ("ctot", i32)]
+                ("pool", i32), ("drop_p", f32), ("drop_seed", u32), ("planar", i32), ("ctot", i32), ("drop_salt", vp)]
 
 
 class ConvDesc(C.Structure):
@@ -49,7 +49,7 @@ class ActBwdDesc(C.Structure):
     _fields_ = [("y_raw", vp), ("ld_y", i32), ("dA_same", vp), ("ld_same", i32), ("dA_pool", vp), ("ld_pool", i32),
                 ("g", vp), ("ld_g", i32), ("partial", vp), ("scale", vp), ("shift", vp), ("slope", vp), ("mean", vp),
                 ("invstd", vp), ("dtype", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("cy_off", i32),
-                ("csame_off", i32), ("cpool_off", i32), ("drop_p", f32), ("drop_seed", u32), ("drop_ld", i32)]
+                ("csame_off", i32), ("cpool_off", i32), ("drop_p", f32), ("drop_seed", u32), ("drop_ld", i32), ("drop_salt", vp)]
 
 
 class BnBwdDesc(C.Structure):
@@ -197,6 +197,7 @@ SYMBOLS = {
     "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),
+    "abc_counter_add_u32": (C.c_int, [vp, u32, vp]),
     "abc_pool_act": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_sizeof": (C.c_int, [C.c_int]),
     "abc_last_error": (C.c_char_p, []),

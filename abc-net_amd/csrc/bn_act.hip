@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const abc_act_bwd_desc d) 
     const T* dp = (const T*)d.dA_pool;
     T* g = (T*)d.g;
     const float dscale = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+    const uint32_t dseed = d.drop_seed + ((d.drop_p > 0.f && d.drop_salt) ? *d.drop_salt : 0u);
 
     // 32-bit index arithmetic (checked on the host: fewer than 2^31 items); the vector count per pixel is a power of
     // two for every layer of the network -> shift instead of a division
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const abc_act_bwd_desc d) 
                 const float y = fmaf(x[j], sc[j], sh[j]);
                 float gg = da[j] * (y > 0.f ? 1.f : sl[j]);
                 if (d.drop_p > 0.f)
-                    gg = abc_drop_keep((uint32_t)(p * d.drop_ld + d.cy_off + c + j), d.drop_seed, d.drop_p) ? gg * dscale : 0.f;
+                    gg = abc_drop_keep((uint32_t)(p * d.drop_ld + d.cy_off + c + j), dseed, d.drop_p) ? gg * dscale : 0.f;
                 out[j] = gg;
                 a1[j] += gg;
                 a2[j] += gg * ((x[j] - mu[j]) * is[j]);

@@ -127,6 +127,7 @@ struct ActSrc {
     uint32_t drop_seed;
     int planar;           // 1: x is f32 channel-planar [B][ctot][Hx][Wx] (NCHW head maps); no pool / dropout
     int ctot;
+    const uint32_t* drop_salt;  // device scalar added to drop_seed (per-step counter), or null
 };
 
 // Stage a halo tile [HH][HW] pixels x CK channels (channels c0..c0+CK of src) into LDS in
@@ -153,6 +154,7 @@ __device__ inline void stage_halo(char* sA, int RS, int PS, int HH, int HW, int 
     }
     const InT* xb = (const InT*)s.x;
     const float dscale = (s.drop_p > 0.f) ? 1.0f / (1.0f - s.drop_p) : 1.0f;
+    const uint32_t dseed = s.drop_seed + ((s.drop_p > 0.f && s.drop_salt) ? *s.drop_salt : 0u);
     const int total = HH * HW * SEGS;
     for (int sidx = tid; sidx < total; sidx += nthreads) {
         const int pix = sidx / SEGS;
@@ -180,7 +182,7 @@ __device__ inline void stage_halo(char* sA, int RS, int PS, int HH, int HW, int 
                 if (s.drop_p > 0.f) {
 #pragma unroll
                     for (int j = 0; j < NV; ++j)
-                        v[j] = abc_drop_keep((uint32_t)(off + j), s.drop_seed, s.drop_p) ? v[j] * dscale : 0.f;
+                        v[j] = abc_drop_keep((uint32_t)(off + j), dseed, s.drop_p) ? v[j] * dscale : 0.f;
                 }
             } else {
                 float t[NV];

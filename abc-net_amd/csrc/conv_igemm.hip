@@ -542,7 +542,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     ConvK k;
     k.src.x = d->src.x; k.src.scale = d->src.scale; k.src.shift = d->src.shift; k.src.slope = d->src.slope;
     k.src.Hx = d->src.Hx; k.src.Wx = d->src.Wx; k.src.ldx = d->src.ldx; k.src.pool = d->src.pool;
-    k.src.drop_p = d->src.drop_p; k.src.drop_seed = d->src.drop_seed;
+    k.src.drop_p = d->src.drop_p; k.src.drop_seed = d->src.drop_seed; k.src.drop_salt = d->src.drop_salt;
     k.src.planar = d->src.planar; k.src.ctot = d->src.ctot;
     k.planar_out = d->planar_out; k.ctot_out = d->ctot_out;
     if (d->src.planar && (d->dtype_in != ABC_F32 || d->src.pool || d->src.drop_p > 0.f))

@@ -23,6 +23,7 @@ struct HeadFwdK {
     int HW, ldx, cin_off, Cout, Cout_pad, ctot, cout_off, npairs;
     float drop_p;
     uint32_t drop_seed;
+    const uint32_t* drop_salt;
     unsigned bytesX, bytesW;
 };
 
@@ -34,6 +35,7 @@ __device__ inline void head_fwd_body(const HeadFwdK& a) {
     const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX), rsW = abc_make_rsrc(a.w, a.bytesW);
     const bool tr = a.sc != nullptr;
     const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const uint32_t dseed = a.drop_seed + ((a.drop_p > 0.f && a.drop_salt) ? *a.drop_salt : 0u);
 
     // ---- B fragments of both pixel tiles: lane (pixel r, half h) takes channels 16 kk + 8 h .. + 8 of its pixel
     bf16x8 fb[2][8];
@@ -56,7 +58,7 @@ __device__ inline void head_fwd_body(const HeadFwdK& a) {
             }
             if (a.drop_p > 0.f) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(e0 + 16 * kk + j, a.drop_seed, a.drop_p) ? v[j] * dscale : 0.f;
+                for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(e0 + 16 * kk + j, dseed, a.drop_p) ? v[j] * dscale : 0.f;
             }
             fb[t][kk] = pack_frag<bf16>(v);
         }
@@ -234,7 +236,7 @@ static void fill_fwd(HeadFwdK& k, const abc_conv_desc* d) {
     k.x = d->src.x; k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.w = d->w; k.bias = d->bias; k.y = (float*)d->y;
     k.HW = d->Hg * d->Wg; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;
     k.ctot = d->ctot_out; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
-    k.drop_p = d->src.drop_p; k.drop_seed = d->src.drop_seed;
+    k.drop_p = d->src.drop_p; k.drop_seed = d->src.drop_seed; k.drop_salt = d->src.drop_salt;
     k.bytesX = (unsigned)((int64_t)d->B * k.HW * d->src.ldx * 2);
     k.bytesW = (unsigned)((int64_t)4 * d->Cout_pad * 32 * 2);
 }

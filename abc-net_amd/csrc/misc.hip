@@ -297,6 +297,13 @@ extern "C" int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream) {
     return abc_check_launch("nms_peaks");
 }
 
+__global__ void counter_add_kernel(uint32_t* p, uint32_t inc) { *p += inc; }
+extern "C" int abc_counter_add_u32(uint32_t* p, uint32_t inc, abc_stream_t stream) {
+    if (!p) return abc_fail(ABC_EINVAL, "counter_add: null");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p, inc);
+    return abc_check_launch("counter_add");
+}
+
 // sizeof() of every descriptor, so that the host binding can verify its mirror structs
 extern "C" int abc_sizeof(int which) {
     switch (which) {

@@ -362,6 +362,7 @@ struct HeadK {
     int HW, hc, ldq, cq_off, nchunks, nsplit, mtiles, Ca_pad;
     float drop_p;
     uint32_t drop_seed;
+    const uint32_t* drop_salt;
     unsigned bytesP, bytesQ;
 };
 
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
     }
     __syncthreads();
     const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const uint32_t dseed = a.drop_seed + ((a.drop_p > 0.f && a.drop_salt) ? *a.drop_salt : 0u);
     u32x4 qreg[4];
     const int CPI = a.HW / 128;  // chunks per image
     u32x4 areg0[16], areg1[16];  // two sets (current / next chunk) x [K-step x 2]: lane (r, h) holds dL[co][64 h + 8 kk + j]
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
             }
             if (a.drop_p > 0.f) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(eoff + j, a.drop_seed, a.drop_p) ? v[j] * dscale : 0.f;
+                for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(eoff + j, dseed, a.drop_p) ? v[j] * dscale : 0.f;
             }
             *(bf16x8*)(sQ + pix * HQ_PSW + part * 16) = pack_frag<bf16>(v);
         }
@@ -514,7 +516,7 @@ static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
     k.q = d->q.x; k.qsc = d->q.scale; k.qsh = d->q.shift; k.qsl = d->q.slope;
     k.partial = d->partial; k.rowsum = d->rowsum_partial; k.HW = d->Hg * d->Wg; k.hc = d->Ca; k.ldq = d->q.ldx; k.cq_off = d->cq_off;
     k.nchunks = d->B * k.HW / 128; k.nsplit = d->nsplit; k.mtiles = abc_cdiv(d->Ca, 32); k.Ca_pad = k.mtiles * 32;
-    k.drop_p = d->q.drop_p; k.drop_seed = d->q.drop_seed;
+    k.drop_p = d->q.drop_p; k.drop_seed = d->q.drop_seed; k.drop_salt = d->q.drop_salt;
     k.bytesP = (unsigned)((int64_t)d->B * d->Ca * k.HW * 4); k.bytesQ = (unsigned)((int64_t)d->B * k.HW * d->q.ldx * 2);
     static bool attr_done = false;
     if (!attr_done) {
@@ -847,7 +849,7 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     WgK k;
     auto cp = [](ActSrc& o, const abc_act_src& i) {
         o.x = i.x; o.scale = i.scale; o.shift = i.shift; o.slope = i.slope; o.Hx = i.Hx; o.Wx = i.Wx; o.ldx = i.ldx;
-        o.pool = i.pool; o.drop_p = i.drop_p; o.drop_seed = i.drop_seed; o.planar = i.planar; o.ctot = i.ctot;
+        o.pool = i.pool; o.drop_p = i.drop_p; o.drop_seed = i.drop_seed; o.planar = i.planar; o.ctot = i.ctot; o.drop_salt = i.drop_salt;
     };
     cp(k.p, d->p); cp(k.q, d->q);
     const int php = d->p.pool ? d->p.Hx / 2 : d->p.Hx, pwp = d->p.pool ? d->p.Wx / 2 : d->p.Wx;

@@ -23,6 +23,7 @@ from . import arch
 
 BN_EPS = 1e-5
 BN_MOM = 0.1
+DROP_STEP = 0x9E3779B9  # odd: the salted seed walks all 2^32 values
 def head_offsets(heads):
     """offset of each head inside the flat per-channel loss-scale array"""
     offs, o = [], 0
@@ -58,6 +59,7 @@ class Src:
     def __init__(self, t, dt, H, W, ld, coff, C, coef=None, pool=False, drop_p=0.0, drop_seed=0, producer=None, planar=False):
         self.t, self.dt, self.H, self.W, self.ld, self.coff, self.C = t, dt, H, W, ld, coff, C
         self.coef, self.pool, self.drop_p, self.drop_seed, self.producer = coef, pool, drop_p, drop_seed, producer
+        self.drop_salt = None  # device uint32 scalar added to drop_seed (the engine's per-step counter)
         self.planar = planar  # NCHW f32 [B][C][H][W] (head maps / their gradients)
 
     def lh(self):  # logical dims
@@ -72,6 +74,7 @@ class Src:
             a.scale = a.shift = a.slope = None
         a.Hx, a.Wx, a.ldx, a.pool = self.H, self.W, self.ld, 1 if self.pool else 0
         a.drop_p, a.drop_seed = self.drop_p, self.drop_seed
+        a.drop_salt = self.drop_salt.data_ptr() if (self.drop_salt is not None and self.drop_p > 0) else None
 
 
 class Rec:
@@ -102,6 +105,10 @@ class Engine:
         self.lay_p, self.lay_b, self.lay_c = layout
         self.drop_p = dropout_p if (train and variant == "unet") else 0.0
         self.drop_seed = 0x1234ABCD
+        # nn.Dropout draws a fresh mask every forward (unet.py:69).  The launch descriptors -- and a captured hipGraph --
+        # are static, so the step-dependence lives in HBM: a counter the forward plan bumps first thing (DROP_STEP per
+        # step), added to drop_seed by every kernel that applies or replays the mask
+        self.drop_salt = torch.zeros(1, dtype=torch.int32, device=device)
         self.head_off = head_offsets(self.heads)
         self.keep = []  # ctypes descriptors and tensors referenced by raw pointer
         self.pack_ops, self.fwd_ops, self.bwd_ops = [], [], []
@@ -112,6 +119,11 @@ class Engine:
         self._colsum_need = 0
         self._colsum_users = []
         self._build()
+
+    def dropout_seed(self, nth_forward):
+        """the hash seed the nth train-mode forward of this engine (1-based) draws its mask with (tests mirror the mask
+        with abcnet_amd.dropout.keep_mask)"""
+        return (self.drop_seed + nth_forward * DROP_STEP) & 0xFFFFFFFF
 
     # ------------------------------------------------------------------ memory helpers
     def P(self, name):
@@ -403,6 +415,10 @@ class Engine:
         S = [(H >> i, W >> i) for i in range(6)]
         self.img = self.new((B, 1, H, W), torch.float32)
         img_src = Src(self.img, L.F32, H, W, 1, 0, 1)
+        if self.drop_p > 0:
+            lib, sp = self.lib, self.drop_salt.data_ptr()
+            self.fwd_ops.append((lambda _r, st: lib.abc_counter_add_u32(sp, DROP_STEP, st), None, "dropout step", (),
+                                 {"kernel": "counter_add", "flops": 0, "bytes": 0}))
         x = self.double_conv("inc1", img_src, 16, 3)
         x1 = self.double_conv("inc2", x, 16, 3)
         x2 = self.double_conv("down1.maxpool_conv.1", self.pooled(x1), 32, 3)
@@ -463,7 +479,7 @@ class Engine:
             rec, f = self.conv_bn(p + ".conv1", p + ".bn", trunk, 128, 3, (self.hfeat, self.hcoef, h, w, 128 * nh, 128 * i), 0.01)
             rec.is_head = True
             self.head_recs.append(rec)
-            f.drop_p, f.drop_seed = self.drop_p, self.drop_seed
+            f.drop_p, f.drop_seed, f.drop_salt = self.drop_p, self.drop_seed, self.drop_salt
             rows_pad = -(-hc // 32) * 32
             w2 = self.packed(1, 128, rows_pad)
             self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
@@ -492,7 +508,7 @@ class Engine:
         d.mean, d.invstd = rec.mean.data_ptr(), rec.invstd.data_ptr()
         d.dtype, d.B, d.H, d.W, d.C, d.cy_off = self.dt, self.B, rec.H, rec.W, C_, rec.coff
         if drop is not None:
-            d.drop_p, d.drop_seed, d.drop_ld = drop[0], drop[1], rec.ld
+            d.drop_p, d.drop_seed, d.drop_ld, d.drop_salt = drop[0], drop[1], rec.ld, self.drop_salt.data_ptr()
         nblk = self.lib.abc_act_bwd_blocks(C.byref(d))
         part = self.new((nblk, 2, C_), torch.float32)
         d.partial = part.data_ptr()
@@ -663,7 +679,7 @@ class Engine:
         d.mean, d.invstd = rec.mean.data_ptr(), rec.invstd.data_ptr()
         d.dtype, d.B, d.H, d.W, d.C, d.cy_off = self.dt, self.B, rec.H, rec.W, C_, rec.coff
         if drop is not None:
-            d.drop_p, d.drop_seed, d.drop_ld = drop[0], drop[1], rec.ld
+            d.drop_p, d.drop_seed, d.drop_ld, d.drop_salt = drop[0], drop[1], rec.ld, self.drop_salt.data_ptr()
         nblk = self.lib.abc_act_bwd_blocks(C.byref(d))
         part = self.new((nblk, 2, C_), torch.float32)
         d.partial = part.data_ptr()

@@ -149,6 +149,31 @@ class Trainer:
     def loss_value(self):
         return self.loss.result()
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """everything a bit-exact resume needs: the model in the REFERENCE's state_dict layout (loads into
+        /root/reference/src/unet.py as is, train.py:435), plus what the reference does not save -- the Adam moments and
+        step counter, the learning rate, the dropout step counter and the running meters"""
+        sd = {"model": {k: v.clone() for k, v in self.model.state_dict().items()},
+              "adam_m": self.opt.m.clone(), "adam_v": self.opt.v.clone(), "adam_step": self.opt.step_t.clone(),
+              "lr": self.lr, "weight_decay": self.wd, "steps": self.steps, "drop_salt": self.eng.drop_salt.clone()}
+        if self.metrics is not None:
+            sd["meters"] = self.metrics.totals.clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        self.model.load_state_dict(sd["model"])
+        if sd["lr"] != self.lr or sd["weight_decay"] != self.wd:
+            self.wd = sd["weight_decay"]
+            self.reset_optimizer(sd["lr"])
+        self.opt.m.copy_(sd["adam_m"])
+        self.opt.v.copy_(sd["adam_v"])
+        self.opt.step_t.copy_(sd["adam_step"])
+        self.eng.drop_salt.copy_(sd["drop_salt"])   # the dropout stream continues where it stopped
+        self.steps = max(self.steps, 1) if self._graphs is not None else self.steps
+        if self.metrics is not None and "meters" in sd:
+            self.metrics.totals.copy_(sd["meters"])
+
     # ------------------------------------------------------------------ measurement
     def profile(self, iters=3):
         """Eager (no graph) steps with a HIP event pair around EVERY launch, recorded on the stream the

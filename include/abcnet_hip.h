@@ -52,6 +52,9 @@ typedef struct abc_act_src {
     int32_t planar;      /* 1: x is channel-planar f32 [B][ctot][Hx][Wx] (the reference's NCHW head maps and
                             their gradients, unet.py:119); ldx is ignored, no pool/dropout */
     int32_t ctot;
+    const uint32_t* drop_salt; /* device scalar added to drop_seed (NULL = 0): a counter the caller bumps once per step
+                                  (abc_counter_add_u32), so that a captured graph draws a fresh mask every replay, as
+                                  nn.Dropout does every forward (unet.py:69) */
 } abc_act_src;
 
 /* Generic tap-list convolution as implicit GEMM on MFMA.  One descriptor covers
@@ -155,6 +158,7 @@ typedef struct abc_act_bwd_desc {
     const float* scale; const float* shift; const float* slope; const float* mean; const float* invstd;
     int32_t dtype, B, H, W, C, cy_off, csame_off, cpool_off;
     float drop_p; uint32_t drop_seed; int32_t drop_ld; /* dropout index = pixel*drop_ld + cy_off + c */
+    const uint32_t* drop_salt;                         /* as abc_act_src.drop_salt: the SAME counter as the forward's */
 } abc_act_bwd_desc;
 int abc_act_bwd_blocks(const abc_act_bwd_desc* d);
 int abc_act_bwd(const abc_act_bwd_desc* d, abc_stream_t stream);
@@ -398,6 +402,8 @@ int abc_nhwc_to_nchw_f32(const float* src, int32_t ld, int32_t c_off, int32_t C,
 int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int32_t W, float* dst, int32_t ld,
                          int32_t c_off, abc_stream_t stream);
 int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream);
+/* *p += inc (one thread): the per-step dropout salt */
+int abc_counter_add_u32(uint32_t* p, uint32_t inc, abc_stream_t stream);
 
 /* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17, abc_raster_desc = 18):
  * lets a foreign-language binding check its mirror structs at load time */

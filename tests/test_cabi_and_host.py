@@ -61,8 +61,10 @@ def test_engine_plan_builds_without_gpu():
     lay = (m._lay_p, m._lay_b, m._lay_c)
     ev = Engine("unet", 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, lay, 2, 64, 64, "bf16", False, device="cpu")
     tr = Engine("unet", 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, lay, 2, 64, 64, "fp32", True, device="cpu")
-    # (bf16: the eight heads' 1x1 convolutions are one batched launch; the fp32 parity mode launches them one by one)
-    assert len(ev.bwd_ops) == 0 and len(ev.fwd_ops) + 7 == len(tr.fwd_ops) > 80 and len(tr.bwd_ops) > 200
+    # (bf16: the eight heads' 1x1 convolutions are one batched launch, the fp32 parity mode launches them one by one; the
+    #  training plan starts with the dropout-step counter)
+    assert len(ev.bwd_ops) == 0 and len(ev.fwd_ops) + 7 + 1 == len(tr.fwd_ops) > 80 and len(tr.bwd_ops) > 200
+    assert tr.fwd_ops[0][2] == "dropout step"
     assert sum(op[4]["flops"] for op in ev.fwd_ops) == sum(op[4]["flops"] for op in tr.fwd_ops)
     # every learnable tensor except the conv biases in front of a BatchNorm (exactly-zero gradient) and s
     # (written by the loss kernel) is finalised by some backward op

@@ -155,7 +155,7 @@ def test_fused_train_step_matches_oracle():
     tg = synthetic_targets(B, S // 4, seed=1)
     m = make_model(dropout_p=0.2)
     tr = Trainer(m, B, S, S, use_graph=False)
-    masks = head_keep_masks(B, S // 4, S // 4, 8, tr.eng.drop_seed, 0.2)
+    masks = head_keep_masks(B, S // 4, S // 4, 8, tr.eng.dropout_seed(1), 0.2)   # the mask of the first forward
     sd, total, weighted, _ = _oracle_grads(x, tg, dropout_masks=masks)
     sd64 = _oracle_grads(x, tg, dropout_masks=masks, dtype=torch.float64)[0]
     p0 = m._flat.data.clone()
@@ -401,3 +401,72 @@ def test_unet2_fused_train_step_matches_oracle():
     res = tr.loss_value()
     assert abs(res["total"] - total.item()) < 2e-4 * abs(total.item()), (res["total"], total.item())
     _check_grads(lambda n: m.grad_of(n), sd, sd64)
+
+
+def test_trainer_checkpoint_resume_is_bit_exact():
+    """Trainer.state_dict() / load_state_dict(): 2 steps + save + 2 steps == restore into a FRESH trainer + 2 steps, bit
+    for bit (every kernel of the step, the split-K reductions included, is order-deterministic); the model part of the
+    checkpoint is the reference's own state_dict layout"""
+    from abcnet_amd.train import Trainer
+    x, tg = synthetic_images(2, 64, seed=7), synthetic_targets(2, 16, seed=1)
+
+    def fresh():
+        m = make_model(dtype="bf16", dropout_p=0.2)
+        tr = Trainer(m, 2, 64, 64, use_graph=True, metrics=True)
+        tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+        return m, tr
+
+    m1, t1 = fresh()
+    for _ in range(2):
+        t1.step()
+    torch.cuda.synchronize()
+    ck = t1.state_dict()
+    assert list(ck["model"].keys()) == list(uo.filled_state("unet", 1, HEADS, seed=0).keys())
+    for _ in range(2):
+        t1.step()
+    m2, t2 = fresh()
+    t2.load_state_dict(ck)
+    for _ in range(2):
+        t2.step()
+    torch.cuda.synchronize()
+    assert torch.equal(m1._flat.data, m2._flat.data)
+    assert torch.equal(m1._flat_buf, m2._flat_buf) and torch.equal(m1._counters, m2._counters)
+    assert torch.equal(t1.opt.m, t2.opt.m) and torch.equal(t1.opt.v, t2.opt.v) and torch.equal(t1.opt.step_t, t2.opt.step_t)
+    assert torch.equal(t1.metrics.totals, t2.metrics.totals)
+    assert t1.loss_value()["total"] == t2.loss_value()["total"]
+
+
+def test_dropout_mask_changes_every_step_also_inside_a_graph():
+    """nn.Dropout (unet.py:69) draws a fresh mask per forward; the launch plan is static (and captured), so the step
+    dependence is a device counter: same weights + same input must give DIFFERENT train-mode logits on consecutive
+    forwards, eagerly and when replayed from the hipGraph, and each must be the oracle's under that step's mask"""
+    from abcnet_amd.dropout import head_keep_masks
+    B, S = 2, 64
+    x = synthetic_images(B, S, seed=7)
+    m = make_model(dropout_p=0.2)
+    m.train()
+    eng = m._engine_for(x.to(DEV), True)
+    st = torch.cuda.current_stream().cuda_stream
+    eng.img.copy_(x.to(DEV))
+    eng.run_pack(st)
+    outs = []
+    for step in range(1, 3):
+        eng.run_forward(st)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in eng.logits])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.run_forward(torch.cuda.current_stream().cuda_stream)
+    for step in range(3, 5):
+        g.replay()
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in eng.logits])
+    for a, b in zip(outs[:-1], outs[1:]):
+        assert (a[5] - b[5]).abs().max().item() > 1e-3      # consecutive forwards differ
+    # BN running statistics move between the forwards but batch statistics (train mode) do not: every forward is the
+    # oracle's forward under its own mask
+    sd0 = uo.filled_state("unet", 1, HEADS, seed=0)
+    for step, got in zip(range(1, 5), outs):
+        masks = head_keep_masks(B, S // 4, S // 4, 8, eng.dropout_seed(step), 0.2)
+        ref = uo.forward("unet", uo.clone_state(sd0), x, train=True, dropout_masks=masks)
+        assert max((a.cpu() - r).abs().max().item() for a, r in zip(got, ref)) < 1e-3, step
