@@ -25,7 +25,8 @@ struct StemK {
 // (the tap weights live in registers: NT * CPT of them)
 template <typename CT, typename OutT, int NT, int CPT>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
-    constexpr int NR = NT > 9 ? 5 : 4;
+    constexpr int SROWS = 4;                       // output rows per workgroup (STEM_ROWS below)
+    constexpr int NR = SROWS + (NT > 9 ? 4 : 2);    // image rows they need
     __shared__ float sx[NR][512 + 8];
     __shared__ float red[4][2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
     const int cg = tid % ncg, slot = tid / ncg;
     const int nslot = 256 / ncg;
     const int nrows = a.B * a.H;
+    // (H is a multiple of rows_per_wg: a workgroup's rows belong to one image)
     const int r0 = blockIdx.x * a.rows_per_wg, r1 = min(r0 + a.rows_per_wg, nrows);
     const int nxr = a.dy_max - a.dy_min + 1;
     float wv[NT][CPT], bv[CPT], s1[CPT], s2[CPT];
@@ -44,15 +46,18 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
 #pragma unroll
     for (int j = 0; j < CPT; ++j) { bv[j] = a.bias ? a.bias[cg * CPT + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
     OutT* yo = (OutT*)a.y;
+    // all image rows of the workgroup's output rows in ONE staging pass (a barrier pair per output row left the kernel
+    // latency-bound at 1.1 TB/s of stores)
+    const int b = r0 / a.H, y0 = r0 - b * a.H;
+    const int nload = (r1 - r0) + nxr - 1;
+    for (int i = tid; i < nload * (a.W + 8); i += 256) {
+        const int rr = i / (a.W + 8), xx = i - rr * (a.W + 8) - 4;
+        const int yy = y0 + a.dy_min + rr;
+        sx[rr][xx + 4] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? a.x[((size_t)b * a.H + yy) * a.W + xx] : 0.f;
+    }
+    __syncthreads();
     for (int row = r0; row < r1; ++row) {
-        const int b = row / a.H, y = row - b * a.H;
-        __syncthreads();
-        for (int i = tid; i < nxr * (a.W + 8); i += 256) {
-            const int rr = i / (a.W + 8), xx = i - rr * (a.W + 8) - 4;
-            const int yy = y + a.dy_min + rr;
-            sx[rr][xx + 4] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? a.x[((size_t)b * a.H + yy) * a.W + xx] : 0.f;
-        }
-        __syncthreads();
+        const int rl = row - r0;
         for (int x0 = slot; x0 < a.W; x0 += nslot) {
             float v[CPT];
 #pragma unroll
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t < a.ntaps) {
-                    const float xv = sx[a.ty[t]][x0 + 4 + a.tx[t]];
+                    const float xv = sx[rl + a.ty[t]][x0 + 4 + a.tx[t]];
 #pragma unroll
                     for (int j = 0; j < CPT; ++j) v[j] = fmaf(wv[t][j], xv, v[j]);
                 }
@@ -132,7 +137,7 @@ int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks) {
         dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax;
         dxmin = d->tap_dx[t] < dxmin ? d->tap_dx[t] : dxmin; dxmax = d->tap_dx[t] > dxmax ? d->tap_dx[t] : dxmax;
     }
-    if (dymax - dymin > (d->ntaps > 9 ? 4 : 3) || dxmin < -4 || dxmax > 4) return 0;
+    if (dymax - dymin > (d->ntaps > 9 ? 4 : 2) || dxmin < -4 || dxmax > 4 || d->Hg % STEM_ROWS) return 0;
     if (stat_blocks) *stat_blocks = abc_cdiv(d->B * d->Hg, STEM_ROWS);
     return 1;
 }

@@ -342,7 +342,9 @@ class Engine:
             lib = self.lib
             a = (self.P(bname + ".weight"), self.P(bname + ".bias"), self.Bf(bname + ".running_mean"),
                  self.Bf(bname + ".running_var"), rec.scale.data_ptr(), rec.shift.data_ptr(), cout, BN_EPS)
-            self.fwd_ops.append((lambda _r, st, a=a: lib.abc_bn_eval_coeffs(*a, st), None, "bn-eval " + bname, (), {"kernel": "bn_eval", "flops": 0, "bytes": 0}))
+            # eval-mode coefficients are functions of the parameters alone: they are refreshed with the weight packing
+            # (every call on the module path, once per weight load in InferenceRunner), not inside the forward plan
+            self.pack_ops.append((lambda _r, st, a=a: lib.abc_bn_eval_coeffs(*a, st), None, "bn-eval " + bname, (), {"kernel": "bn_eval", "flops": 0, "bytes": 0}))
         rec.stats, rec.nblk = stats, nblk
         self.recs.append(rec)
         out = Src(yt, self.dt, H, W, ld, coff, cout, coef=coef, producer=rec)

@@ -5,8 +5,8 @@
 
 One step = eval-mode forward (running-statistics BatchNorm folded into the consumers' loads, no dropout) + the
 peak-NMS kernel, on a batch already resident in HBM, replayed from one hipGraph.  The weights do not change between
-steps, so re-packing them (and the BatchNorm coefficients) happens in `refresh()`, not in the step; call it again
-after `load_state_dict`.  The SMILES assembly that follows in the reference (img2smiles2.py:104-344, RDKit) is out of
+steps, so re-packing them and deriving the eval-mode BatchNorm coefficients happens in `refresh()`, not in the step;
+call it again after `load_state_dict`.  The SMILES assembly that follows in the reference (img2smiles2.py:104-344, RDKit) is out of
 scope: the step ends with the four mask / |rho| maps the decoder reads.
 """
 from __future__ import annotations
@@ -48,7 +48,8 @@ class InferenceRunner:
         self.refresh()
 
     def refresh(self):
-        """re-pack the (changed) weights; the next step re-derives the BatchNorm coefficients itself"""
+        """re-pack the (changed) weights and re-derive the eval-mode BatchNorm coefficients (both functions of the
+        parameters alone; call again after load_state_dict)"""
         self.eng.run_pack(torch.cuda.current_stream().cuda_stream)
 
     def load_batch(self, imgs):
