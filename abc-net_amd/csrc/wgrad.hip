@@ -368,12 +368,13 @@ struct HeadK {
 
 constexpr int HQ_PSW = 320;  // pixel stride of the [pixel][128 channel] bf16 LDS image (wgrad Q layout)
 
-__global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
+__device__ inline void head_wgrad_body(const HeadK& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int mi = wave & 3, nh = wave >> 2;
     const int split = blockIdx.x, mg = blockIdx.y;
+    if (split >= a.nsplit || mg * 4 >= a.mtiles) return;   // (batched launch: the grid is sized for the largest head)
     const int mt = mg * 4 + mi;
     const bool active = mt < a.mtiles;
     const int co = mt * 32 + r;
@@ -500,6 +501,11 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) {
 }
 
 // dL planar f32 (x) activated NHWC bf16 features, 1x1, 128 b-channels, whole 128-pixel chunks per image
+__global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) { head_wgrad_body(a); }
+// all heads in one launch (blockIdx.z = head), as abc_heads_batch does for the forward and the data gradient
+struct HeadWgBatch { HeadK k[8]; };
+__global__ __launch_bounds__(512, 2) void head_wgrad_batch_kernel(const HeadWgBatch bt) { head_wgrad_body(bt.k[blockIdx.z]); }
+
 static bool head_ok(const abc_wgrad_desc* d) {
     if (getenv("ABC_WGRAD_NOHEAD")) return false;
     if (!d->p.planar || d->dtype_p != ABC_F32 || d->dtype_q != ABC_BF16 || d->dtype_c != ABC_BF16) return false;
@@ -510,14 +516,18 @@ static bool head_ok(const abc_wgrad_desc* d) {
     return bp < (int64_t(1) << 31) && bq < (int64_t(1) << 31) && (d->q.ldx % 8) == 0 && (d->cq_off % 8) == 0;
 }
 
-static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
-    HeadK k;
+static void head_fill(HeadK& k, const abc_wgrad_desc* d) {
     k.dl = (const float*)d->p.x; k.psc = d->p.scale; k.psh = d->p.shift; k.psl = d->p.slope;
     k.q = d->q.x; k.qsc = d->q.scale; k.qsh = d->q.shift; k.qsl = d->q.slope;
     k.partial = d->partial; k.rowsum = d->rowsum_partial; k.HW = d->Hg * d->Wg; k.hc = d->Ca; k.ldq = d->q.ldx; k.cq_off = d->cq_off;
     k.nchunks = d->B * k.HW / 128; k.nsplit = d->nsplit; k.mtiles = abc_cdiv(d->Ca, 32); k.Ca_pad = k.mtiles * 32;
     k.drop_p = d->q.drop_p; k.drop_seed = d->q.drop_seed; k.drop_salt = d->q.drop_salt;
     k.bytesP = (unsigned)((int64_t)d->B * d->Ca * k.HW * 4); k.bytesQ = (unsigned)((int64_t)d->B * k.HW * d->q.ldx * 2);
+}
+
+static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
+    HeadK k;
+    head_fill(k, d);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)head_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -796,6 +806,31 @@ static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipSt
 }  // namespace
 
 extern "C" int abc_wgrad_rowsum_ok(const abc_wgrad_desc* d) { return head_ok(d) ? 1 : 0; }
+
+// The heads' 1x1 weight gradients (unet.py:70 under autograd) of all heads in one launch: descs[0..n) as abc_wgrad takes
+// them one by one (each with its OWN partial / rowsum_partial slabs), n <= 8.  ABC_EUNSUPPORTED unless every one of them
+// is served by the heads kernel.
+extern "C" int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc_stream_t stream) {
+    if (n < 1 || n > 8) return abc_fail(ABC_EINVAL, "wgrad_heads_batch: 1..8 heads");
+    HeadWgBatch bt;
+    int gx = 0, gy = 0;
+    for (int i = 0; i < n; ++i) {
+        const abc_wgrad_desc* d = descs + i;
+        if (d->nsplit < 1 || d->ntaps != 1 || !head_ok(d)) return abc_fail(ABC_EUNSUPPORTED, "wgrad_heads_batch: not a heads' 1x1 weight gradient");
+        if (d->p.Hx != d->Hg || d->p.Wx != d->Wg || d->q.Hx != d->Hg || d->q.Wx != d->Wg) return abc_fail(ABC_EINVAL, "wgrad: dims mismatch");
+        head_fill(bt.k[i], d);
+        gx = bt.k[i].nsplit > gx ? bt.k[i].nsplit : gx;
+        gy = abc_cdiv(bt.k[i].mtiles, 4) > gy ? abc_cdiv(bt.k[i].mtiles, 4) : gy;
+    }
+    for (int i = n; i < 8; ++i) bt.k[i] = bt.k[0];
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)head_wgrad_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(head_wgrad_batch_kernel, dim3(gx, gy, n), dim3(512), 2 * 128 * HQ_PSW + 3 * 128 * 4, (hipStream_t)stream, bt);
+    return abc_check_launch("wgrad_heads_batch");
+}
 
 extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {
     if (head_ok(d) || c1_ok(d)) return 0;

@@ -238,10 +238,13 @@ class Engine:
                 "bytes": sum(m["bytes"] for _d, _w, m in items)}
         ops.append((lambda _r, st, a=arr: lib.abc_heads_batch(a, n, which, st), None, what, (), meta))
 
-    def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None, rowsum_to=None):
+    def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None, rowsum_to=None,
+                   collect=None):
         """dual = (y_raw tensor, ld, channel offset, dY pointer, dY pixel stride): fuse the BatchNorm-backward correction into the load of P
         (p = act_bwd output with coef = (ca, cc, cb)); returns False without emitting anything when the library does not
-        serve this descriptor that way"""
+        serve this descriptor that way.
+        collect: a list -- nothing is emitted; the launch and its reductions are appended as a dict for
+        emit_wgrad_heads_batch, and the split-K slabs get their OWN buffer (the batched heads run concurrently)"""
         dw_ptr = self.G(wname)
         d = L.WgradDesc()
         p.fill(d.p)
@@ -278,11 +281,17 @@ class Engine:
         wsk = self._ws_k = 1 - getattr(self, "_ws_k", 1)
         r = L.WgradReduceDesc()
         r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = nsplit, len(taps), Ca, Cb, ca_pad, cb_pad, dw_ptr, 0
-        self._ws_users += [(d, wsk), (r, wsk)]
+        if collect is not None:
+            own = self.new((need,), torch.float32)
+            d.partial = r.partial = own.data_ptr()
+        else:
+            self._ws_users += [(d, wsk), (r, wsk)]
         meta = {"ws": wsk, "kernel": "wgrad<%s,%s,%s,%dx%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), at_.value, bt_.value, stride),
                 "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
                 "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt))}
-        self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
+        post = []
+        if collect is None:
+            self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
         fused_rowsum = False
         if rowsum_to is not None and self.lib.abc_wgrad_rowsum_ok(C.byref(d)):
             # the heads' kernel also leaves per-split row sums of P = the conv's bias gradient (no separate pass over dL)
@@ -291,13 +300,41 @@ class Engine:
             r2 = L.WgradReduceDesc()
             r2.partial, r2.nsplit, r2.ntaps, r2.Ca, r2.Cb, r2.Ca_pad, r2.Cb_pad, r2.dw, r2.accumulate = rs.data_ptr(), nsplit, 1, Ca, 1, ca_pad, 1, self.G(rowsum_to), 0
             fused_rowsum = True
-        self._emit(ops, self.lib.abc_wgrad_reduce, r, what + " reduce", writes=(wname,) if wname else (),
-                   meta={"ws": wsk, "side": True, "kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)})
+        post.append((r, what + " reduce", (wname,) if wname else (),
+                     {"ws": wsk, "side": True, "kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)}))
         if fused_rowsum:
-            self._emit(ops, self.lib.abc_wgrad_reduce, r2, "dbias " + what[6:] + " reduce", writes=(rowsum_to,),
-                       meta={"kernel": "wgrad_reduce", "flops": 0, "bytes": float(nsplit * ca_pad * 4)})
-            return "rowsum"
-        return True
+            post.append((r2, "dbias " + what[6:] + " reduce", (rowsum_to,),
+                         {"kernel": "wgrad_reduce", "flops": 0, "bytes": float(nsplit * ca_pad * 4)}))
+        if collect is not None:
+            collect.append({"d": d, "what": what, "meta": meta, "post": post})
+        else:
+            for rd, w, wr, m in post:
+                self._emit(ops, self.lib.abc_wgrad_reduce, rd, w, writes=wr, meta=m)
+        return "rowsum" if fused_rowsum else True
+
+    def emit_wgrad_heads_batch(self, ops, items, what):
+        """the heads' 1x1 weight gradients collected by emit_wgrad(collect=...) as ONE launch (abc_wgrad_heads_batch) when the
+        heads kernel serves every one of them ((0, 0) tile), else one launch each; their slab reductions follow"""
+        def tile(d):
+            at_, bt_ = L.i32(), L.i32()
+            L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
+            return at_.value, bt_.value
+        ok = 1 <= len(items) <= 8 and all(tile(it["d"]) == (0, 0) for it in items) and not os.environ.get("ABC_NO_HEADS_BATCH")
+        if ok:
+            arr = (L.WgradDesc * len(items))()
+            for i, it in enumerate(items):
+                arr[i] = it["d"]
+            self.keep.append(arr)
+            lib, n = self.lib, len(items)
+            meta = {"kernel": "heads_wgrad_batch", "flops": sum(it["meta"]["flops"] for it in items), "bytes": sum(it["meta"]["bytes"] for it in items)}
+            ops.append((lambda _r, st, a=arr: lib.abc_wgrad_heads_batch(a, n, st), None, what, (), meta))
+        else:
+            for it in items:
+                self._emit(ops, self.lib.abc_wgrad, it["d"], it["what"], meta=it["meta"])
+        for it in items:
+            self.keep.append(it["d"])
+            for rd, w, wr, m in it["post"]:
+                self._emit(ops, self.lib.abc_wgrad_reduce, rd, w, writes=wr, meta=m)
 
     def emit_colsum(self, ops, t, dt, npix, ld, c_off, Cn, chan_scale, bname, what):
         out_ptr = self.G(bname)
@@ -610,13 +647,13 @@ class Engine:
         zero = self.new((max(self.heads),), torch.float32, 0.0)
         dfeat = self.new((B, h, w, 128 * nh))
         # ---- heads' 1x1 convs (weight gradients one by one, the eight data gradients as one launch)
-        head_dgrads = []
+        head_dgrads, head_wgrads = [], []
         for r2 in self.head2:
             i, hc = r2.idx, r2.cout
             cs = self.chan_scale[self.head_off[i]:self.head_off[i] + hc]
             dl = Src(self.dlogits[i], L.F32, h, w, 0, 0, hc, coef=(cs, zero, one), planar=True)
             got = self.emit_wgrad(ops, dl, r2.src, hc, 128, [(0, 0)], 1, r2.cname + ".weight", "wgrad " + r2.cname,
-                                  rowsum_to=r2.cname + ".bias")
+                                  rowsum_to=r2.cname + ".bias", collect=head_wgrads)
             if got != "rowsum":
                 lib = self.lib
                 psw = self.new((lib.abc_plane_sum_work(hc),), torch.float32)
@@ -627,6 +664,7 @@ class Engine:
             self.emit_pack(r2.cname + ".weight", wd, 1, hc, 128, 1, 128, hc)
             self.emit_conv(ops, dl, wd, None, dfeat, self.dt, h, w, 128 * nh, 128 * i, 128, [(0, 0)], what="dgrad " + r2.cname,
                            collect=head_dgrads)
+        self.emit_wgrad_heads_batch(ops, head_wgrads, "wgrad out_modules.*.conv2")
         self.emit_heads_batch(ops, head_dgrads, 1, "dgrad out_modules.*.conv2")
         # ---- heads' BN + conv1: per-head BN backward, ONE data-gradient conv over the 8x128 concatenated channels
         taps = taps_square(3)

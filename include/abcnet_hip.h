@@ -218,6 +218,8 @@ typedef struct abc_wgrad_reduce_desc {
     float* dw;    /* [Ca][Cb][ntaps] */
     int32_t accumulate; /* 1: add to dw instead of overwrite */
 } abc_wgrad_reduce_desc;
+/* the heads' 1x1 weight gradients of all heads in one launch (each descriptor with its own partial / rowsum slabs) */
+int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc_stream_t stream);
 int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream);
 
 /* Per-channel column sums of an NHWC tensor (bias gradients of convs that do not
