@@ -154,6 +154,8 @@ SYMBOLS = {
     "abc_pack_item_fill": (i64, [vp, P(PackDesc), i64]),
     "abc_pack_batch": (C.c_int, [vp, i32, i64, vp]),
     "abc_bn_finalize_fwd": (C.c_int, [P(BnFwdDesc), vp]),
+    "abc_bn_finalize_fwd_batch": (C.c_int, [vp, i32, vp]),
+    "abc_bn_finalize_bwd_batch": (C.c_int, [vp, i32, i32, vp]),
     "abc_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, f32, vp]),
     "abc_act_bwd_blocks": (C.c_int, [P(ActBwdDesc)]),
     "abc_act_bwd": (C.c_int, [P(ActBwdDesc), vp]),
@@ -167,6 +169,7 @@ SYMBOLS = {
     "abc_wgrad": (C.c_int, [P(WgradDesc), vp]),
     "abc_wgrad_reduce": (C.c_int, [P(WgradReduceDesc), vp]),
     "abc_wgrad_heads_batch": (C.c_int, [vp, i32, vp]),
+    "abc_wgrad_reduce_batch": (C.c_int, [vp, i32, vp]),
     "abc_colsum_blocks": (C.c_int, [i64]),
     "abc_colsum": (C.c_int, [vp, i32, i64, i32, i32, i32, vp, vp, vp, vp]),
     "abc_loss_blocks": (C.c_int, [P(LossDesc)]),

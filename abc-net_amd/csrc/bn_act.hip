@@ -23,14 +23,16 @@ __device__ inline double block_sum_f64(double v, double* sm) {
     return sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const abc_bn_fwd_desc d) {
+// pstride = floats between consecutive partial rows (the layer's own C, or the width of a shared partial buffer)
+__device__ inline void bn_finalize_fwd_body(const abc_bn_fwd_desc& d, int pstride) {
     __shared__ double sm[4];
     const int c = blockIdx.x;
+    if (c >= d.C) return;
     const int rows = d.rows == 4 ? 4 : 2;
     double s1 = 0.0, s2 = 0.0;
     for (int k = threadIdx.x; k < d.nblk; k += 256) {
-        s1 += (double)d.partial[((size_t)k * rows + 0) * d.C + c];
-        s2 += (double)d.partial[((size_t)k * rows + 1) * d.C + c];
+        s1 += (double)d.partial[((size_t)k * rows + 0) * pstride + c];
+        s2 += (double)d.partial[((size_t)k * rows + 1) * pstride + c];
     }
     s1 = block_sum_f64(s1, sm);
     s2 = block_sum_f64(s2, sm);
@@ -53,6 +55,12 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const abc_bn_fwd_d
     }
 }
 
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const abc_bn_fwd_desc d) { bn_finalize_fwd_body(d, d.C); }
+// several BatchNorms (the eight heads') in one launch: blockIdx.y = layer
+constexpr int MAX_BNB = 8;
+struct BnFwdBatch { abc_bn_fwd_desc d[MAX_BNB]; };
+__global__ __launch_bounds__(256) void bn_finalize_fwd_batch_kernel(const BnFwdBatch bt) { bn_finalize_fwd_body(bt.d[blockIdx.y], bt.d[blockIdx.y].C); }
+
 __global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
                                float* shift, int C, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,13 +70,14 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const abc_bn_bwd_desc d) {
+__device__ inline void bn_finalize_bwd_body(const abc_bn_bwd_desc& d, int pstride) {
     __shared__ double sm[4];
     const int c = blockIdx.x;
+    if (c >= d.C) return;
     double s1 = 0.0, s2 = 0.0;
     for (int k = threadIdx.x; k < d.nblk; k += 256) {
-        s1 += (double)d.partial[((size_t)k * 2 + 0) * d.C + c];
-        s2 += (double)d.partial[((size_t)k * 2 + 1) * d.C + c];
+        s1 += (double)d.partial[((size_t)k * 2 + 0) * pstride + c];
+        s2 += (double)d.partial[((size_t)k * 2 + 1) * pstride + c];
     }
     s1 = block_sum_f64(s1, sm);
     s2 = block_sum_f64(s2, sm);
@@ -86,6 +95,12 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const abc_bn_bwd_d
             d.cc[c] = gs * (d.mean[c] * is * k2 - k1);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const abc_bn_bwd_desc d) { bn_finalize_bwd_body(d, d.C); }
+struct BnBwdBatch { abc_bn_bwd_desc d[MAX_BNB]; int pstride; };
+__global__ __launch_bounds__(256) void bn_finalize_bwd_batch_kernel(const BnBwdBatch bt) {
+    bn_finalize_bwd_body(bt.d[blockIdx.y], bt.pstride > 0 ? bt.pstride : bt.d[blockIdx.y].C);
 }
 
 // ------------------------------------------------------------------ pass 1
@@ -387,6 +402,29 @@ extern "C" int abc_bn_finalize_fwd(const abc_bn_fwd_desc* d, abc_stream_t stream
     if (d->C < 1 || d->nblk < 1) return abc_fail(ABC_EINVAL, "bn_finalize_fwd: empty");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(d->C), dim3(256), 0, (hipStream_t)stream, *d);
     return abc_check_launch("bn_finalize_fwd");
+}
+
+// n <= 8 BatchNorm finalisations in one launch (the heads').  bwd: pstride > 0 = the layers' partial sums are column
+// slices of ONE [nblk][2][pstride] buffer (each descriptor's `partial` points at its first column), 0 = own buffers.
+extern "C" int abc_bn_finalize_fwd_batch(const abc_bn_fwd_desc* descs, int32_t n, abc_stream_t stream) {
+    if (n < 1 || n > MAX_BNB) return abc_fail(ABC_EINVAL, "bn_finalize_fwd_batch: 1..8 layers");
+    BnFwdBatch bt;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) { bt.d[i] = descs[i]; cmax = descs[i].C > cmax ? descs[i].C : cmax; if (descs[i].C < 1 || descs[i].nblk < 1) return abc_fail(ABC_EINVAL, "bn_finalize_fwd_batch: empty"); }
+    for (int i = n; i < MAX_BNB; ++i) bt.d[i] = descs[0];
+    hipLaunchKernelGGL(bn_finalize_fwd_batch_kernel, dim3(cmax, n), dim3(256), 0, (hipStream_t)stream, bt);
+    return abc_check_launch("bn_finalize_fwd_batch");
+}
+
+extern "C" int abc_bn_finalize_bwd_batch(const abc_bn_bwd_desc* descs, int32_t n, int32_t pstride, abc_stream_t stream) {
+    if (n < 1 || n > MAX_BNB) return abc_fail(ABC_EINVAL, "bn_finalize_bwd_batch: 1..8 layers");
+    BnBwdBatch bt;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) { bt.d[i] = descs[i]; cmax = descs[i].C > cmax ? descs[i].C : cmax; if (descs[i].C < 1 || descs[i].nblk < 1) return abc_fail(ABC_EINVAL, "bn_finalize_bwd_batch: empty"); }
+    for (int i = n; i < MAX_BNB; ++i) bt.d[i] = descs[0];
+    bt.pstride = pstride;
+    hipLaunchKernelGGL(bn_finalize_bwd_batch_kernel, dim3(cmax, n), dim3(256), 0, (hipStream_t)stream, bt);
+    return abc_check_launch("bn_finalize_bwd_batch");
 }
 
 extern "C" int abc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

@@ -660,6 +660,48 @@ __global__ __launch_bounds__(64) void wgrad_reduce_wave_kernel(const abc_wgrad_r
     }
 }
 
+// Several small reductions (the heads' 8 weight gradients and 8 bias row sums) in ONE launch: blockIdx.y = item; an item
+// whose output is small against its slab count goes wave-per-output (4 outputs per workgroup), the others thread-per-
+// output; summation orders are those of the single-item kernels, so results are bit-identical to them.
+constexpr int MAX_RB = 16;
+struct ReduceBatch { abc_wgrad_reduce_desc d[MAX_RB]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch bt) {
+    const abc_wgrad_reduce_desc& d = bt.d[blockIdx.y];
+    const int64_t n = (int64_t)d.ntaps * d.Ca * d.Cb;
+    const size_t slab = (size_t)d.Ca_pad * d.Cb_pad;
+    const size_t step = (size_t)d.ntaps * slab;
+    if (n <= 4096 && d.nsplit >= 128) {
+        const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (idx >= n) return;
+        const int bi = (int)(idx % d.Cb), ai = (int)((idx / d.Cb) % d.Ca), t = (int)(idx / ((int64_t)d.Cb * d.Ca));
+        const float* p = d.partial + (size_t)t * slab + (size_t)ai * d.Cb_pad + bi;
+        float s = 0.f;
+        for (int k = lane; k < d.nsplit; k += 64) s += p[(size_t)k * step];
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) {
+            float* o = d.dw + ((size_t)ai * d.Cb + bi) * d.ntaps + t;
+            *o = d.accumulate ? (*o + s) : s;
+        }
+        return;
+    }
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int bi = (int)(idx % d.Cb);
+    const int ai = (int)((idx / d.Cb) % d.Ca);
+    const int t = (int)(idx / ((int64_t)d.Cb * d.Ca));
+    const float* p = d.partial + (size_t)t * slab + (size_t)ai * d.Cb_pad + bi;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= d.nsplit; k += 4) {
+        s0 += p[(size_t)k * step]; s1 += p[(size_t)(k + 1) * step]; s2 += p[(size_t)(k + 2) * step]; s3 += p[(size_t)(k + 3) * step];
+    }
+    for (; k < d.nsplit; ++k) s0 += p[(size_t)k * step];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* o = d.dw + ((size_t)ai * d.Cb + bi) * d.ntaps + t;
+    *o = d.accumulate ? (*o + s) : s;
+}
+
 struct WGeom {
     int AT, BT, dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, lds, tgw, ngroups, nta, ntb, npatch,
         tiles_x, tiles_y, fast_p, fast_q, nbuf, PM, ts;
@@ -920,6 +962,21 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     if (d->dtype_p == ABC_F32 && d->dtype_q == ABC_BF16) return wdispatch<float, bf16, bf16>(k, g, d->stride, d->nsplit, st);
     if (d->dtype_p == ABC_BF16 && d->dtype_q == ABC_F32) return wdispatch<bf16, float, bf16>(k, g, d->stride, d->nsplit, st);
     return abc_fail(ABC_EUNSUPPORTED, "wgrad: dtype combination");
+}
+
+extern "C" int abc_wgrad_reduce_batch(const abc_wgrad_reduce_desc* descs, int32_t n, abc_stream_t stream) {
+    if (n < 1 || n > MAX_RB) return abc_fail(ABC_EINVAL, "wgrad_reduce_batch: 1..16 items");
+    ReduceBatch bt;
+    int64_t gx = 1;
+    for (int i = 0; i < n; ++i) {
+        bt.d[i] = descs[i];
+        const int64_t cnt = (int64_t)descs[i].ntaps * descs[i].Ca * descs[i].Cb;
+        const int64_t blocks = (cnt <= 4096 && descs[i].nsplit >= 128) ? (cnt + 3) / 4 : (cnt + 255) / 256;
+        gx = blocks > gx ? blocks : gx;
+    }
+    for (int i = n; i < MAX_RB; ++i) bt.d[i] = descs[0];
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, bt);
+    return abc_check_launch("wgrad_reduce_batch");
 }
 
 extern "C" int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream) {

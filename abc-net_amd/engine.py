@@ -331,9 +331,21 @@ class Engine:
         else:
             for it in items:
                 self._emit(ops, self.lib.abc_wgrad, it["d"], it["what"], meta=it["meta"])
-        for it in items:
-            self.keep.append(it["d"])
-            for rd, w, wr, m in it["post"]:
+        posts = [p for it in items for p in it["post"]]
+        self.keep.append([it["d"] for it in items])
+        if ok and len(posts) <= 16:
+            # the 8 weight-gradient and 8 bias row-sum reductions as one launch too
+            rarr = (L.WgradReduceDesc * len(posts))()
+            for i, (rd, _w, _wr, _m) in enumerate(posts):
+                rarr[i] = rd
+            self.keep.append(rarr)
+            self.keep.append([rd for rd, _w, _wr, _m in posts])
+            lib, nr = self.lib, len(posts)
+            writes = tuple(w for _rd, _w, wr, _m in posts for w in wr)
+            ops.append((lambda _r, st, a=rarr: lib.abc_wgrad_reduce_batch(a, nr, st), None, what + " reduce", writes,
+                        {"kernel": "wgrad_reduce_batch", "flops": 0, "bytes": sum(m["bytes"] for _rd, _w, _wr, m in posts)}))
+        else:
+            for rd, w, wr, m in posts:
                 self._emit(ops, self.lib.abc_wgrad_reduce, rd, w, writes=wr, meta=m)
 
     def emit_colsum(self, ops, t, dt, npix, ld, c_off, Cn, chan_scale, bname, what):
@@ -350,8 +362,11 @@ class Engine:
         ops.append((fn, None, what, (bname,), {"kernel": "colsum", "flops": 0, "bytes": float(npix * Cn * self._esz(dt))}))
 
     # ------------------------------------------------------------------ layers
-    def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None, stats_rows=2, force_stats=False):
-        """conv (+bias) -> raw output into dst=(tensor, coef, H, W, ld, coff); BN stats/coefficients"""
+    def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None, stats_rows=2, force_stats=False, stat_out=None,
+                collect_fin=None):
+        """conv (+bias) -> raw output into dst=(tensor, coef, H, W, ld, coff); BN stats/coefficients.
+        stat_out = (mean, invstd) tensors to use instead of fresh ones (slices of a shared array: the heads);
+        collect_fin: a list -- the train-mode finalisation is appended as (desc, what) instead of being emitted"""
         yt, coef, H, W, ld, coff = dst
         cin = src.C
         taps = taps_square(k)
@@ -365,7 +380,10 @@ class Engine:
         sc, sh, sl = coef
         sl[coff:coff + cout] = slope
         rec.scale, rec.shift, rec.slopes = sc[coff:coff + cout], sh[coff:coff + cout], sl[coff:coff + cout]
-        rec.mean, rec.invstd = self.new((cout,), torch.float32), self.new((cout,), torch.float32, 1.0)
+        if stat_out is not None:
+            rec.mean, rec.invstd = stat_out
+        else:
+            rec.mean, rec.invstd = self.new((cout,), torch.float32), self.new((cout,), torch.float32, 1.0)
         if self.train:
             d = L.BnFwdDesc()
             d.partial, d.nblk, d.C, d.count, d.rows = stats.data_ptr(), nblk, cout, float(self.B * H * W), stats_rows
@@ -374,7 +392,11 @@ class Engine:
             d.running_mean, d.running_var = self.Bf(bname + ".running_mean"), self.Bf(bname + ".running_var")
             d.num_batches_tracked = self.Cn(bname + ".num_batches_tracked")
             d.eps, d.momentum = BN_EPS, BN_MOM
-            self._emit(self.fwd_ops, self.lib.abc_bn_finalize_fwd, d, "bn " + bname)
+            if collect_fin is not None:
+                self.keep.append(d)
+                collect_fin.append((d, "bn " + bname))
+            else:
+                self._emit(self.fwd_ops, self.lib.abc_bn_finalize_fwd, d, "bn " + bname)
         else:
             lib = self.lib
             a = (self.P(bname + ".weight"), self.P(bname + ".bias"), self.Bf(bname + ".running_mean"),
@@ -512,10 +534,15 @@ class Engine:
         # the list forward() returns: one contiguous NCHW f32 map per head (unet.py:119), written directly
         self.logits = [self.new((self.B, hc, h, w), torch.float32) for hc in self.heads]
         self.head_recs, self.head2 = [], []
-        head_convs = []
+        head_convs, head_fins = [], []
+        # batch statistics of the eight heads' BatchNorms side by side (one act_bwd pass over all 8 x 128 channels)
+        self.hmean, self.hinvstd = self.new((128 * nh,), torch.float32), self.new((128 * nh,), torch.float32, 1.0)
+        batch_fin = nh <= 8 and not os.environ.get("ABC_NO_HEADS_BATCH")
         for i, hc in enumerate(self.heads):
             p = "out_modules.%d" % i
-            rec, f = self.conv_bn(p + ".conv1", p + ".bn", trunk, 128, 3, (self.hfeat, self.hcoef, h, w, 128 * nh, 128 * i), 0.01)
+            rec, f = self.conv_bn(p + ".conv1", p + ".bn", trunk, 128, 3, (self.hfeat, self.hcoef, h, w, 128 * nh, 128 * i), 0.01,
+                                  stat_out=(self.hmean[128 * i:128 * (i + 1)], self.hinvstd[128 * i:128 * (i + 1)]),
+                                  collect_fin=head_fins if batch_fin else None)
             rec.is_head = True
             self.head_recs.append(rec)
             f.drop_p, f.drop_seed, f.drop_salt = self.drop_p, self.drop_seed, self.drop_salt
@@ -525,6 +552,14 @@ class Engine:
             self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
                            [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs)
             self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
+        if head_fins:
+            arr = (L.BnFwdDesc * len(head_fins))()
+            for i, (d, _w) in enumerate(head_fins):
+                arr[i] = d
+            self.keep.append(arr)
+            lib, n = self.lib, len(head_fins)
+            self.fwd_ops.append((lambda _r, st, a=arr: lib.abc_bn_finalize_fwd_batch(a, n, st), None, "bn out_modules.*.bn", (),
+                                 {"kernel": "bn", "flops": 0, "bytes": 0}))
         # (the eight conv1 launches above write the eight slices of hfeat; the eight 1x1 convolutions go as one launch)
         self.emit_heads_batch(self.fwd_ops, head_convs, 0, "fwd out_modules.*.conv2")
 
@@ -670,9 +705,17 @@ class Engine:
         taps = taps_square(3)
         dyh = self.new((B, h, w, 128 * nh))
         wd_all = self.packed(9, 128 * nh, 128)
+        merged = None
+        if self.dt == L.BF16 and not os.environ.get("ABC_NO_HEAD_FUSE") and not os.environ.get("ABC_NO_HEADS_BATCH") and nh <= 8:
+            merged = self._heads_act_bwd_merged(ops, dfeat)
         for i, rec in enumerate(self.head_recs):
             drop = (self.drop_p, self.drop_seed) if self.drop_p > 0 else None
-            if self.dt == L.BF16 and not os.environ.get("ABC_NO_HEAD_FUSE"):
+            if merged is not None:
+                ok = self.emit_wgrad(ops, merged[i], rec.src, 128, 128, taps, 1, rec.cname + ".weight", "wgrad " + rec.cname,
+                                     dual=(rec.y, rec.ld, rec.coff, dyh.data_ptr() + 128 * i * dyh.element_size(), 128 * nh))
+                if not ok:
+                    raise RuntimeError("fused BN-backward apply was refused for " + rec.cname)
+            elif self.dt == L.BF16 and not os.environ.get("ABC_NO_HEAD_FUSE"):
                 # bf16: the weight-gradient kernel applies the BN-backward correction on load and writes dY into this
                 # head's channel slice of dyh (no separate apply pass)
                 gsrc, _apply = self._bn_backward(ops, rec, (dfeat, 128 * nh, 128 * i), None, drop=drop, defer=True)
@@ -688,6 +731,52 @@ class Engine:
         dy_all = Src(dyh, self.dt, h, w, 128 * nh, 0, 128 * nh)
         self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
         self.trunk.producer.grad_same = (dtrunk, 128, 0)
+
+    def _heads_act_bwd_merged(self, ops, dfeat):
+        """BN -> LeakyReLU -> Dropout backward of ALL heads as one pass over the 8 x 128 channels of hfeat / dfeat (their
+        coefficient and statistics arrays sit side by side), one batched finalisation; returns per head the Src of g with
+        the deferred-apply coefficients (as _bn_backward(defer=True))"""
+        nh = len(self.heads)
+        Ct = 128 * nh
+        r0 = self.head_recs[0]
+        B, H, W = self.B, r0.H, r0.W
+        g = self.new((B, H, W, Ct))
+        d = L.ActBwdDesc()
+        d.y_raw, d.ld_y = self.hfeat.data_ptr(), Ct
+        d.dA_same, d.ld_same, d.csame_off = dfeat.data_ptr(), Ct, 0
+        d.g, d.ld_g = g.data_ptr(), Ct
+        sc, sh, sl = self.hcoef
+        d.scale, d.shift, d.slope = sc.data_ptr(), sh.data_ptr(), sl.data_ptr()
+        d.mean, d.invstd = self.hmean.data_ptr(), self.hinvstd.data_ptr()
+        d.dtype, d.B, d.H, d.W, d.C, d.cy_off = self.dt, B, H, W, Ct, 0
+        if self.drop_p > 0:
+            d.drop_p, d.drop_seed, d.drop_ld, d.drop_salt = self.drop_p, self.drop_seed, Ct, self.drop_salt.data_ptr()
+        nblk = self.lib.abc_act_bwd_blocks(C.byref(d))
+        part = self.new((nblk, 2, Ct), torch.float32)
+        d.partial = part.data_ptr()
+        self._emit(ops, self.lib.abc_act_bwd, d, "act_bwd out_modules.*.bn",
+                   meta={"kernel": "act_bwd", "flops": 0, "bytes": float(B * H * W * Ct * self._esz(self.dt) * 3)})
+        arr = (L.BnBwdDesc * nh)()
+        out, writes = [], []
+        # the deferred-apply coefficients are indexed by the ABSOLUTE channel of g (abc_act_src): one array of 8 x 128 per
+        # quantity, every head's finalisation writing its own slice
+        ca_all, cb_all, cc_all = (self.new((Ct,), torch.float32) for _ in range(3))
+        for i, rec in enumerate(self.head_recs):
+            k1, k2, gs = (self.new((128,), torch.float32) for _ in range(3))
+            ca, cb, cc = (t[128 * i:128 * (i + 1)] for t in (ca_all, cb_all, cc_all))
+            f = arr[i]
+            f.partial, f.nblk, f.C, f.count = part.data_ptr() + 4 * 128 * i, nblk, 128, float(B * H * W)
+            f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
+            f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
+            f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+            f.mean, f.ca, f.cb, f.cc = rec.mean.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
+            writes += [rec.bname + ".weight", rec.bname + ".bias"]
+            out.append(Src(g, self.dt, H, W, Ct, 128 * i, 128, coef=(ca_all, cc_all, cb_all)))
+        self.keep.append(arr)
+        lib = self.lib
+        ops.append((lambda _r, st, a=arr: lib.abc_bn_finalize_bwd_batch(a, nh, Ct, st), None, "bn_bwd out_modules.*.bn", tuple(writes),
+                    {"kernel": "bn_bwd", "flops": 0, "bytes": 0}))
+        return out
 
     def _convT_backward(self, ops, rec):
         """ConvTranspose2d(k3,s2) backward: bias (column sums of dOut), weight (stride-2 wgrad), data (stride-2 gather)"""

@@ -139,6 +139,8 @@ typedef struct abc_bn_fwd_desc {
     float eps, momentum;
 } abc_bn_fwd_desc;
 int abc_bn_finalize_fwd(const abc_bn_fwd_desc* d, abc_stream_t stream);
+/* n <= 8 layers in one launch (the eight heads' BatchNorms, unet.py:67) */
+int abc_bn_finalize_fwd_batch(const abc_bn_fwd_desc* descs, int32_t n, abc_stream_t stream);
 /* eval mode: coefficients from running stats (model.eval(): img2smiles2.py:49) */
 int abc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* scale, float* shift, int32_t C, float eps, abc_stream_t stream);
@@ -172,6 +174,8 @@ typedef struct abc_bn_bwd_desc {
     const float* mean; float* ca; float* cb; float* cc;
 } abc_bn_bwd_desc;
 int abc_bn_finalize_bwd(const abc_bn_bwd_desc* d, abc_stream_t stream);
+/* n <= 8 layers in one launch; pstride > 0: their partial sums are column slices of one [nblk][2][pstride] buffer */
+int abc_bn_finalize_bwd_batch(const abc_bn_bwd_desc* descs, int32_t n, int32_t pstride, abc_stream_t stream);
 typedef struct abc_bn_apply_desc {
     void* g; int32_t ld_g; const void* y_raw; int32_t ld_y; int32_t cy_off;
     const float* mean; const float* invstd; const float* k1; const float* k2; const float* gscale;
@@ -221,6 +225,8 @@ typedef struct abc_wgrad_reduce_desc {
 /* the heads' 1x1 weight gradients of all heads in one launch (each descriptor with its own partial / rowsum slabs) */
 int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc_stream_t stream);
 int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream);
+/* up to 16 (small) reductions in one launch; results bit-identical to abc_wgrad_reduce item by item */
+int abc_wgrad_reduce_batch(const abc_wgrad_reduce_desc* descs, int32_t n, abc_stream_t stream);
 
 /* Per-channel column sums of an NHWC tensor (bias gradients of convs that do not
  * feed a BN: unet.py:44 up.bias, unet.py:70 conv2.bias), optional per-channel scale. */
