@@ -288,7 +288,9 @@ class Engine:
             self._ws_users += [(d, wsk), (r, wsk)]
         meta = {"ws": wsk, "kernel": "wgrad<%s,%s,%s,%dx%d,S%d>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), at_.value, bt_.value, stride),
                 "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
-                "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt))}
+                # both operands once, the split-K slabs this launch writes, and (DUAL) the y_raw it reads + the dY it writes
+                "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt)
+                               + need * 4 + (2 * self.B * gh * gw * Ca * self._esz(self.dt) if dual is not None else 0))}
         post = []
         if collect is None:
             self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
