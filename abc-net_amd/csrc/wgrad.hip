@@ -29,7 +29,7 @@ namespace {
 
 constexpr int MAXT_FAST = 9;  // taps per workgroup (accumulator budget: 9 x 16 VGPRs)
 constexpr int MAXT_SLOW = 5;  // the general loader needs the registers: fewer taps per workgroup, more tap groups
-constexpr int WTHR = 512;  // 8 waves
+constexpr int WTHR_HOST = 512;  // 8 waves (the default workgroup)
 
 struct WgK {
     ActSrc p, q;
@@ -55,24 +55,28 @@ __device__ inline bf16x8 tr_read8(const char* base0, const char* base1) {
 // prefetch registers it makes the register allocator spill inside the MFMA loop
 template <typename T, typename CT, int CW>
 __device__ inline void stage_slow(char* dst, int RS, int PS, int HH, int HW, int b, int iy0, int ix0, int Hin, int Win,
-                                                     const ActSrc* s, int c0, int tid, int cvalid) {
-    stage_halo<T, CT, CW>(dst, RS, PS, HH, HW, b, iy0, ix0, Hin, Win, *s, c0, tid, WTHR, cvalid);
+                                                     const ActSrc* s, int c0, int tid, int cvalid, int nthr) {
+    stage_halo<T, CT, CW>(dst, RS, PS, HH, HW, b, iy0, ix0, Hin, Win, *s, c0, tid, nthr, cvalid);
 }
 
 // TS ("tap split", one 32x32 tile pair, more than 9 taps -- unet2's 5x5 convolutions): the 8 waves split the TAPS instead
 // of the patch rows (wave w owns taps w, w + 8, w + 16, w + 24: <= 4 accumulators), every wave walks the whole patch, and
 // ONE workgroup pass covers all taps.  With the row split 25 taps ran as 3 tap groups (grid.y) that each re-staged both
 // operands: 596 MB fetched per launch against 302 MB algorithmic (profiles/r01_f_unet2_pmc_summary.json).
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false>
-__global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
+// NW = waves per workgroup: 8 (one workgroup per CU), or 4 with 2 x 2 tile pairs and a single LDS buffer, so that TWO
+// workgroups share a CU: more bytes of prefetch in flight per CU (the kernel is bound by memory-level parallelism, DESIGN.md
+// section 8) and one workgroup's commit phase under the other's MFMA block.
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
+    constexpr int WTHR = NW * 64;
     static_assert(!TS || (AT == 1 && BT == 1 && FAST && !K3 && !DUAL && sizeof(CT) == 2), "tap split: one bf16 tile pair on the prefetch path");
     constexpr int MAXT = TS ? 4 : (FAST ? MAXT_FAST : MAXT_SLOW);
-    constexpr int RSPLIT = TS ? 1 : 8 / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
+    constexpr int RSPLIT = TS ? 1 : NW / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
     constexpr int PROWS = 8 * PM;           // patch rows (x 16 columns)
     constexpr int ROWS = PROWS / RSPLIT;    // patch rows per wave
     constexpr int CWP = AT * 32, CWQ = BT * 32;
     constexpr int NPF_P = (PROWS * 16 * (CWP / Frag<CT>::NV) + WTHR - 1) / WTHR;
-    constexpr int NPF_Q = (PM > 1 || STRIDE == 2) ? 5 : ((sizeof(CT) == 2) ? 4 : 6);  // (stride 2: 17 x 33 halo pixels)
+    constexpr int NPF_Q = NW == 4 ? 6 : ((PM > 1 || STRIDE == 2) ? 5 : ((sizeof(CT) == 2) ? 4 : 6));  // (stride 2: 17 x 33 halo pixels)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int buf_bytes = a.sP_bytes + a.sQ_bytes;
     float* sCoefP = (float*)(smem + a.coef_off);
@@ -199,9 +203,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgK a) {
             }
             pq.commit(sQ, a.HW * PSWQ, PSWQ, gQ, coefQ ? sCoefQ : nullptr, a.cstrQ, tid, cvalQ);
         } else {
-            stage_slow<PT, CT, CWP>(sP, 16 * PSWP, PSWP, PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, &a.p, a.cp_off + ca0, tid, cvalP);
+            stage_slow<PT, CT, CWP>(sP, 16 * PSWP, PSWP, PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, &a.p, a.cp_off + ca0, tid, cvalP, WTHR);
             stage_slow<QT, CT, CWQ>(sQ, a.HW * PSWQ, PSWQ, a.HH, a.HW, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.Hq, a.Wq,
-                                    &a.q, a.cq_off + cb0, tid, cvalQ);
+                                    &a.q, a.cq_off + cb0, tid, cvalQ, WTHR);
         }
     };
 
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBat
 
 struct WGeom {
     int AT, BT, dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, lds, tgw, ngroups, nta, ntb, npatch,
-        tiles_x, tiles_y, fast_p, fast_q, nbuf, PM, ts;
+        tiles_x, tiles_y, fast_p, fast_q, nbuf, PM, ts, nw;
 };
 
 static int psw_for(int cw, int csz) {
@@ -749,7 +753,7 @@ static int wgeom_pm(const abc_wgrad_desc* d, WGeom* g, int pm) {
     const int64_t bytesP = (int64_t)d->B * d->p.Hx * d->p.Wx * d->p.ldx * (d->dtype_p == ABC_BF16 ? 2 : 4);
     const int64_t bytesQ = (int64_t)d->B * d->q.Hx * d->q.Wx * d->q.ldx * (d->dtype_q == ABC_BF16 ? 2 : 4);
     g->fast_p = (fast_ok(d->p, csz, lastP, bytesP) && g->HH * g->HW * g->HW < 65536) ? 1 : 0;
-    g->fast_q = (fast_ok(d->q, csz, lastQ, bytesQ) && abc_cdiv(g->HH * g->HW * segq, WTHR) <= ((pm > 1 || (d->stride == 2 && csz == 2)) ? 5 : (csz == 2 ? 4 : 6))) ? 1 : 0;
+    g->fast_q = (fast_ok(d->q, csz, lastQ, bytesQ) && abc_cdiv(g->HH * g->HW * segq, WTHR_HOST) <= ((pm > 1 || (d->stride == 2 && csz == 2)) ? 5 : (csz == 2 ? 4 : 6))) ? 1 : 0;
     g->ngroups = abc_cdiv(d->ntaps, (g->fast_p && g->fast_q) ? MAXT_FAST : MAXT_SLOW);
     g->tgw = abc_cdiv(d->ntaps, g->ngroups);
     return ABC_OK;
@@ -780,7 +784,24 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     else { g->AT = 1; g->BT = 1; }
     // narrow layers (one tile pair, 8-way row split) take 32-row patches when both operands can be prefetched:
     // 4 K-steps per wave between barriers instead of 1
-    g->ts = 0;
+    g->ts = 0; g->nw = 8;
+    // (experiment, ABC_WGRAD_NW4=1) wide bf16 3x3 layers as 4-wave workgroups on 2 x 2 tile pairs, two per CU
+    static const bool nw4 = getenv("ABC_WGRAD_NW4") != nullptr;
+    if (nw4 && g->AT == 4 && g->BT == 2 && d->ntaps == 9 && d->dtype_p == ABC_BF16 && d->dtype_q == ABC_BF16) {
+        g->AT = 2; g->BT = 2;
+        int rc = wgeom_pm(d, g, 1);
+        const int segq = 64 / 8;
+        if (rc == ABC_OK && g->fast_p && fast_ok(d->q, csz, d->Cb - (g->ntb - 1) * 64, (int64_t)d->B * d->q.Hx * d->q.Wx * d->q.ldx * 2) &&
+            abc_cdiv(g->HH * g->HW * segq, 256) <= 6) {
+            g->fast_q = 1; g->nw = 4; g->nbuf = 1;
+            g->coef_off = g->sP_bytes + g->sQ_bytes;
+            g->lds = g->coef_off + 3 * (64 + 64) * 4 + 256;
+            if (g->lds < 4 * 16 * 64 * 4) g->lds = 4 * 16 * 64 * 4;
+            g->ngroups = 1; g->tgw = d->ntaps;
+            return ABC_OK;
+        }
+        g->AT = 4; g->BT = 2;
+    }
     if (g->AT == 1 && g->BT == 1 && d->stride == 1 && csz == 2 && d->Hg % 32 == 0) {
         int rc = wgeom_pm(d, g, 4);
         if (rc == ABC_OK && g->fast_p && g->fast_q) return ABC_OK;
@@ -797,15 +818,15 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     return wgeom_pm(d, g, 1);
 }
 
-template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false>
+template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false, int NW = 8>
 static int wlaunch3(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
-    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3, DUAL, TS>;
+    auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3, DUAL, TS, NW>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(WTHR), g.lds, st, k);
+    hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(NW * 64), g.lds, st, k);
     return abc_check_launch("wgrad");
 }
 
@@ -831,6 +852,13 @@ template <typename PT, typename QT, typename CT>
 static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipStream_t st) {
     if constexpr (sizeof(CT) == 2) {
         if (g.AT == 4) return wlaunch<PT, QT, CT, 4, 2, 1>(k, g, nsplit, st);
+    }
+    if constexpr (sizeof(CT) == 2 && sizeof(PT) == 2 && sizeof(QT) == 2) {
+        if (g.AT == 2 && g.nw == 4) {
+            if (k.k3 && k.p2 != nullptr) return wlaunch3<PT, QT, CT, 2, 2, 1, true, 1, true, true, false, 4>(k, g, nsplit, st);
+            if (k.k3) return wlaunch3<PT, QT, CT, 2, 2, 1, true, 1, true, false, false, 4>(k, g, nsplit, st);
+            return wlaunch3<PT, QT, CT, 2, 2, 1, true, 1, false, false, false, 4>(k, g, nsplit, st);
+        }
     }
     if (g.AT == 2) return wlaunch<PT, QT, CT, 2, 2, 1>(k, g, nsplit, st);
     if constexpr (sizeof(CT) == 2) {
@@ -907,7 +935,8 @@ extern "C" int abc_wgrad_blocks(const abc_wgrad_desc* d) {
     if (c1_ok(d)) return 1;
     WGeom g;
     if (wgeom(d, &g)) return -1;
-    return g.nta * g.ntb * g.ngroups;
+    // (4-wave workgroups sit two to a CU: half as many CU-fills per split, so that the caller's nsplit doubles)
+    return g.nw == 4 ? (g.nta * g.ntb * g.ngroups + 1) / 2 : g.nta * g.ntb * g.ngroups;
 }
 
 extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
