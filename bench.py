@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--variant", default="unet", choices=["unet", "unet2"], help="unet.py (headline) or unet2.py (config 3)")
     ap.add_argument("--metrics", action="store_true", help="also update the 17 training meters of train.py:145-215 on the device every step")
+    ap.add_argument("--extract", action="store_true", help="(--mode infer) also build the atom / bond candidate lists of "
+                    "img2smiles2.py:113-191 on the device inside the step")
     ap.add_argument("--raster", action="store_true", help="rasterise the targets on the device every step from compact records "
                     "(utils.py:83-228 on the GPU) instead of keeping pre-rasterised maps resident")
     ap.add_argument("--no-graph", action="store_true")
@@ -155,7 +157,7 @@ def main():
     imgs = synthetic_images(a.batch, a.size, seed=7 + rank)
     if a.mode == "infer":
         from abcnet_amd.infer import InferenceRunner
-        tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph)
+        tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract)
         tr.load_batch(imgs.to(dev))
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics)
@@ -215,7 +217,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),
-                   "device_rasteriser": bool(a.raster)},
+                   "device_rasteriser": bool(a.raster), "device_extraction": bool(a.extract)},
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 
