@@ -72,7 +72,7 @@ class InferenceRunner:
         if self.use_graph and self._graph is None and self.steps >= 1:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._run(torch.cuda.current_stream().cuda_stream)
             self._graph = g
         if self._graph is not None:

@@ -113,11 +113,11 @@ class Trainer:
                 graphs.append(None)
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._run_segment(k)
             graphs.append(g)
         gopt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gopt):
+        with torch.cuda.graph(gopt, capture_error_mode="thread_local"):
             self.opt.step()
         self._graphs = (graphs, gopt)
 
