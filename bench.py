@@ -221,28 +221,34 @@ def main():
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 
-    if rank == 0 and not a.no_profile:
-        prof = tr.profile(iters=3)
-        tot = sum(r["ms"] for r in prof.values())
-        dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
-        r = prof[dom]
-        ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK[a.dtype], "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": pmc_traffic(dom, a.mode, a.variant),
-                           "algorithmic_mb_per_launch": round(r["bytes"] / r["calls"] / 1e6, 2),
-                           "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
-                           "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
-        out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("ABC_BENCH_TOP", 12))]}
-        if os.environ.get("ABC_BENCH_TOP"):
-            out["kernel_calls"] = {k: v["calls"] for k, v in prof.items()}
-        out["eager_step_ms_sum_of_kernels"] = round(tot, 3)
-        flops_step = sum(v["flops"] for v in prof.values())
-        bytes_step = sum(v["bytes"] for v in prof.values())
-        out["whole_step"] = {"algorithmic_tflop": round(flops_step / 1e12, 3), "algorithmic_gb": round(bytes_step / 1e9, 3),
-                             "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK[a.dtype], 4),
-                             "hbm_frac": round(bytes_step / (el / a.steps) / 1e9 / HBM_PEAK, 4)}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = (cpu_baseline if a.mode == "train" else cpu_baseline_infer)(a.size, variant=a.variant)
+    # (the instrumented pass and the CPU leg are reported beside the measurement; a failure there must not lose the line)
+    try:
+        if rank == 0 and not a.no_profile:
+            prof = tr.profile(iters=3)
+            tot = sum(r["ms"] for r in prof.values())
+            dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
+            r = prof[dom]
+            ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK[a.dtype], "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": pmc_traffic(dom, a.mode, a.variant),
+                               "algorithmic_mb_per_launch": round(r["bytes"] / r["calls"] / 1e6, 2),
+                               "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
+                               "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
+            out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("ABC_BENCH_TOP", 12))]}
+            if os.environ.get("ABC_BENCH_TOP"):
+                out["kernel_calls"] = {k: v["calls"] for k, v in prof.items()}
+            out["eager_step_ms_sum_of_kernels"] = round(tot, 3)
+            flops_step = sum(v["flops"] for v in prof.values())
+            bytes_step = sum(v["bytes"] for v in prof.values())
+            out["whole_step"] = {"algorithmic_tflop": round(flops_step / 1e12, 3), "algorithmic_gb": round(bytes_step / 1e9, 3),
+                                 "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK[a.dtype], 4),
+                                 "hbm_frac": round(bytes_step / (el / a.steps) / 1e9 / HBM_PEAK, 4)}
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = (cpu_baseline if a.mode == "train" else cpu_baseline_infer)(a.size, variant=a.variant)
+
+    except Exception as e:  # noqa: BLE001
+        if rank == 0:
+            out["report_error"] = "%s: %s" % (type(e).__name__, e)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
