@@ -458,3 +458,29 @@ def test_layout_roundtrip(lib):
     torch.cuda.synchronize()
     assert torch.equal(back.cpu(), x)
     assert torch.equal(nh[..., 5:42].cpu(), x.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [dict(C=32, ld=32, off=0), dict(C=64, ld=128, off=64, scale=True), dict(C=256, ld=512, off=256),
+                                  dict(C=14, ld=14, off=0), dict(C=128, ld=128, off=0, npix=777)])
+def test_colsum(lib, dt, case):
+    """abc_colsum: per-channel sums over pixels of a channel slice of an NHWC tensor (bias gradients of convT / 1x1
+    convs) -- vector kernel for 16-byte-aligned slices, scalar kernel otherwise (C = 14)"""
+    import ctypes as C_
+    g = torch.Generator().manual_seed(21)
+    C, ld, off = case["C"], case["ld"], case["off"]
+    npix = case.get("npix", 2 * 48 * 40)
+    x = q(torch.randn((npix, ld), generator=g), dt)
+    cs = (torch.rand(ld, generator=g) + 0.5) if case.get("scale") else None
+    ref = x[:, off:off + C].double().sum(0)
+    if cs is not None:
+        ref = ref * cs[off:off + C].double()
+    xd = x.to(U.tdt(dt)).to(U.DEV)
+    nb = lib.abc_colsum_blocks(npix)
+    work = torch.zeros(nb * C, dtype=torch.float32, device=U.DEV)
+    out = torch.zeros(C, dtype=torch.float32, device=U.DEV)
+    csd = None if cs is None else cs.to(U.DEV)
+    L.check(lib.abc_colsum(xd.data_ptr(), dt, npix, ld, off, C, None if csd is None else csd.data_ptr(), work.data_ptr(), out.data_ptr(),
+                           U.stream()), "colsum")
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-4
