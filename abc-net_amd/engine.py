@@ -423,10 +423,11 @@ class Engine:
         return b
 
     def pooled(self, s: Src):
-        """nn.MaxPool2d(2) (unet.py:30).  unet: materialised once by abc_pool_act, so that the level's first conv and
-        its weight gradient read a plain tensor on their prefetch paths; the gradient still routes to the producer
-        as a pooled one (via_pool).  unet2 keeps pooling on load (its residual path reads the same source)."""
-        if self.variant != "unet":
+        """nn.MaxPool2d(2) (unet.py:30, unet2.py:83): materialised once by abc_pool_act, so that the level's first conv, its
+        weight gradient (and, in unet2, the block's residual branch) read a plain tensor on their prefetch paths; the
+        gradient still routes to the producer as a pooled one (via_pool).  (unet2 pooled on load at first: its first
+        conv of every level and that conv's weight gradient then ran on the general loaders -- 0.37 ms for down1 alone.)"""
+        if os.environ.get("ABC_UNET2_POOL_ON_LOAD") and self.variant != "unet":
             return Src(s.t, s.dt, s.H, s.W, s.ld, s.coff, s.C, coef=s.coef, pool=True, producer=s.producer)
         Ho, Wo = s.H // 2, s.W // 2
         out = self.new((self.B, Ho, Wo, s.C))
@@ -1030,7 +1031,7 @@ class Engine:
             half = blk.cin // 2
             up_rec.grad_out = (d_x, blk.cin, half)
             skip_prod.grad_same = (d_x, blk.cin, 0)
-        elif src.pool:
+        elif src.pool or getattr(src, "via_pool", False):
             src.producer.grad_pool = (d_x, blk.cin, 0)
         else:
             src.producer.grad_same = (d_x, blk.cin, 0)
