@@ -25,7 +25,7 @@ struct StemK {
 // (the tap weights live in registers: NT * CPT of them)
 template <typename CT, typename OutT, int NT, int CPT>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
-    constexpr int SROWS = 4;                       // output rows per workgroup (STEM_ROWS below)
+    constexpr int SROWS = 8;                       // output rows per workgroup (STEM_ROWS below)
     constexpr int NR = SROWS + (NT > 9 ? 4 : 2);    // image rows they need
     __shared__ float sx[NR][512 + 8];
     __shared__ float red[4][2 * 64];
@@ -39,10 +39,13 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
     const int nxr = a.dy_max - a.dy_min + 1;
     float wv[NT][CPT], bv[CPT], s1[CPT], s2[CPT];
     const CT* wp = (const CT*)a.w;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) wv[t][j] = (t < a.ntaps) ? (float)wp[((size_t)t * a.Cout_pad + cg * CPT + j) * 16] : 0.f;
+    // the tap weights reach the registers through LDS: one cooperative pass over the <= 25 x 64 values per workgroup
+    // (every thread fetching its own 72 .. 100 values from global memory was a 72-deep latency chain per workgroup)
+    __shared__ float sw[NT * 64];
+    for (int i = tid; i < a.ntaps * a.Cout; i += 256) {
+        const int t = i / a.Cout, c = i - t * a.Cout;
+        sw[t * 64 + c] = (float)wp[((size_t)t * a.Cout_pad + c) * 16];
+    }
 #pragma unroll
     for (int j = 0; j < CPT; ++j) { bv[j] = a.bias ? a.bias[cg * CPT + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
     OutT* yo = (OutT*)a.y;
@@ -56,6 +59,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
         sx[rr][xx + 4] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? a.x[((size_t)b * a.H + yy) * a.W + xx] : 0.f;
     }
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) wv[t][j] = (t < a.ntaps) ? sw[t * 64 + cg * CPT + j] : 0.f;
     for (int row = r0; row < r1; ++row) {
         const int rl = row - r0;
         for (int x0 = slot; x0 < a.W; x0 += nslot) {
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
     }
 }
 
-constexpr int STEM_ROWS = 4;
+constexpr int STEM_ROWS = 8;
 
 }  // namespace
 
