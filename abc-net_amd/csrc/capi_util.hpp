@@ -5,3 +5,6 @@
 
 int abc_fail(int code, const char* msg);     // records msg, returns code
 int abc_check_launch(const char* what);      // hipGetLastError -> ABC_ELAUNCH
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per (kernel, device) --
+// `done` is the caller's per-kernel bitmask over device ordinals -- and report a refusal instead of failing later at launch
+int abc_allow_lds(const void* fn, int bytes, unsigned long long* done);

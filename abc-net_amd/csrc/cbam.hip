@@ -618,11 +618,8 @@ extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t
     if (d->work == nullptr) return abc_fail(ABC_EINVAL, "cbam_channel_bwd: work buffer of B * (C + 2 mid) floats required");
     const size_t sh = (size_t)d->B * (d->C + 2 * d->mid) * sizeof(float);
     if (sh > 150 * 1024) return abc_fail(ABC_EUNSUPPORTED, "cbam_channel_bwd: B * (C + 2 mid) floats exceed the LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)cbam_channel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)cbam_channel_bwd_kernel, 160 * 1024, &lds_ok)) return rc;
     // one (c, j) weight-gradient element per thread where possible: the per-element loops over the images are chains of
     // dependent global loads, so width beats depth (8 elements per thread cost 50 us per call)
     const int want = abc_cdiv(d->C * d->mid, 256);

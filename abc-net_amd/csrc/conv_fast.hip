@@ -526,11 +526,8 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0>
 int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WG);
-        attr_done = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)fn, LDS_WG, &lds_ok)) return rc;
     hipLaunchKernelGGL(fn, dim3(g.nwg), dim3(FT), g.lds, st, k);
     return abc_check_launch("conv_fast");
 }

@@ -455,11 +455,8 @@ static int conv_geom(const abc_conv_desc* d, Geom* g) {
 template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool FAST>
 static int launch_fs(const ConvK& k, const Geom& g, hipStream_t st) {
     auto fn = conv_igemm_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, FAST>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)fn, 160 * 1024, &lds_ok)) return rc;
     // persistent: one workgroup per CU walks the tiles
     const int nwg = g.grid < 256 ? g.grid : 256;
     hipLaunchKernelGGL(fn, dim3(nwg), dim3(NTHR), g.lds, st, k);

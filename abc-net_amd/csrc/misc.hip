@@ -11,6 +11,18 @@ int abc_fail(int code, const char* msg) {
     g_err[sizeof(g_err) - 1] = 0;
     return code;
 }
+int abc_allow_lds(const void* fn, int bytes, unsigned long long* done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev >= 0 && dev < 64 && ((*done >> dev) & 1ull)) return ABC_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) on device %d: %s", bytes, dev, hipGetErrorString(e));
+        return ABC_ELAUNCH;
+    }
+    if (dev >= 0 && dev < 64) *done |= 1ull << dev;
+    return ABC_OK;
+}
 int abc_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

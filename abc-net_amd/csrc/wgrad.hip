@@ -532,11 +532,8 @@ static void head_fill(HeadK& k, const abc_wgrad_desc* d) {
 static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
     HeadK k;
     head_fill(k, d);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)head_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)head_wgrad_kernel, 160 * 1024, &lds_ok)) return rc;
     hipLaunchKernelGGL(head_wgrad_kernel, dim3(d->nsplit, abc_cdiv(k.mtiles, 4)), dim3(512), 2 * 128 * HQ_PSW + 3 * 128 * 4, st, k);
     return abc_check_launch("head_wgrad");
 }
@@ -821,11 +818,8 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
 template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false, int NW = 8>
 static int wlaunch3(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
     auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3, DUAL, TS, NW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)fn, 160 * 1024, &lds_ok)) return rc;
     hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(NW * 64), g.lds, st, k);
     return abc_check_launch("wgrad");
 }
@@ -893,11 +887,8 @@ extern "C" int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc
         gy = abc_cdiv(bt.k[i].mtiles, 4) > gy ? abc_cdiv(bt.k[i].mtiles, 4) : gy;
     }
     for (int i = n; i < 8; ++i) bt.k[i] = bt.k[0];
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)head_wgrad_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)head_wgrad_batch_kernel, 160 * 1024, &lds_ok)) return rc;
     hipLaunchKernelGGL(head_wgrad_batch_kernel, dim3(gx, gy, n), dim3(512), 2 * 128 * HQ_PSW + 3 * 128 * 4, (hipStream_t)stream, bt);
     return abc_check_launch("wgrad_heads_batch");
 }

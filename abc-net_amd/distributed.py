@@ -12,24 +12,96 @@ is tested without GPUs.
 from __future__ import annotations
 
 import os
+import socket
+import subprocess
+import sys
+import time
 
-import torch
-import torch.distributed as dist
+# the host driver of this pool supports dmabuf IPC only; ROCr reads this when the process first touches the GPU, so it
+# has to be in the environment BEFORE any torch.cuda call (it is exported on the boxes already; rank_env() below hands
+# it to child ranks explicitly)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
-def init_process_group(backend=None, rank=None, world_size=None, master_addr="127.0.0.1", master_port=None):
-    """multi_gpu_train.py:44-45, with env-driven defaults (torchrun) instead of a fixed port"""
+def init_process_group(backend=None, rank=None, world_size=None, master_addr="127.0.0.1", master_port=None, device=None):
+    """multi_gpu_train.py:44-48 (init_process_group + torch.cuda.set_device(local_rank)), with env-driven defaults
+    (torchrun / launch_ranks) instead of a fixed port.  Selects this rank's GPU FIRST: every launch of the library goes
+    to the current device's stream, and RCCL wants one distinct device per rank.
+    device: explicit device index (testing: several ranks on one GPU over gloo); default LOCAL_RANK."""
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     rank = int(os.environ.get("RANK", 0)) if rank is None else rank
     world_size = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else world_size
     os.environ.setdefault("MASTER_ADDR", master_addr)
     os.environ.setdefault("MASTER_PORT", str(master_port or 29512))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", rank % max(ndev, 1)))
+        if not 0 <= device < ndev:
+            raise RuntimeError("rank %d wants GPU %d but only %d are visible" % (rank, device, ndev))
+        torch.cuda.set_device(device)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
     return rank, world_size
+
+
+def rank_dropout_seed(base, rank):
+    """dropout hash seed of data-parallel rank `rank` (rank 0 keeps `base`)"""
+    return (base ^ ((rank * 0x632BE5AB) & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank, world, port, base=None):
+    """environment of child rank `rank` (what torchrun would export), rendezvous on 127.0.0.1"""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def launch_ranks(argv, world, timeout=None, env=None, rank0_stdout=None):
+    """multi_gpu_train.py:30-36 (`mp.spawn(main_worker, nprocs=device_count)`) as FRESH child processes: one
+    `python argv...` per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set.  To be called from a parent that has
+    NOT touched the GPU (a process that has initialised HIP must never fork/exec ranks).  Rank 0's stdout is the
+    parent's (or `rank0_stdout`), the other ranks' stdout goes to stderr.  Returns the list of exit codes; when one rank
+    fails or the timeout passes, the remaining ranks are terminated (exact PIDs) and their code is reported as -15/-9."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        out = (rank0_stdout if rank0_stdout is not None else None) if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=rank_env(r, world, port, env), stdout=out))
+    t0 = time.time()
+    codes = [None] * world
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = any(c not in (None, 0) for c in codes)
+        late = timeout is not None and time.time() - t0 > timeout
+        if failed or late:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    return codes
 
 
 def sampler_indices(n, world, rank, epoch, seed=0, shuffle=True):
@@ -87,6 +159,7 @@ class GradReducer:
         self.g, self.buckets, self.group = flat_grad, buckets, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
+        self.dev = flat_grad.device
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self._pending = []
         self.by_ready = {}
@@ -99,7 +172,7 @@ class GradReducer:
         view = self.g[lo:hi]
         if self.cuda:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            ev.record(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
@@ -114,17 +187,30 @@ class GradReducer:
         if self.world == 1:
             return
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
         else:
             for w in self._pending:
                 w.wait()
             self._pending = []
 
 
-def broadcast_parameters(flat_params, flat_buffers=None, src=0, group=None):
+def broadcast_parameters(flat_params, flat_buffers=None, src=0, group=None, counters=None):
     """DDP constructor semantics (multi_gpu_train.py:52): rank 0's parameters and buffers win"""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     dist.broadcast(flat_params, src=src, group=group)
-    if flat_buffers is not None:
+    broadcast_buffers(flat_buffers, counters, src=src, group=group)
+
+
+def broadcast_buffers(flat_buffers, counters=None, src=0, group=None):
+    """DDP(broadcast_buffers=True) (the default multi_gpu_train.py:52 runs with): before every forward rank 0's BatchNorm
+    running statistics and num_batches_tracked replace every other rank's, so rank 0's trajectory is THE trajectory:
+    its checkpoint holds statistics that only ever saw rank 0's shard, and an eval forward on any rank uses them.
+    Train-mode arithmetic never reads the buffers, so doing this right before they are read (eval, state_dict) is
+    observably the same as doing it before every forward; Trainer(broadcast_buffers=...) offers both."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    if flat_buffers is not None and flat_buffers.numel():
         dist.broadcast(flat_buffers, src=src, group=group)
+    if counters is not None and counters.numel():
+        dist.broadcast(counters, src=src, group=group)

@@ -23,11 +23,16 @@ class InferenceRunner:
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("InferenceRunner needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
-        dev = device or next(model.parameters()).device
+        dev = torch.device(device or next(model.parameters()).device)
+        if dev.type != "cuda":
+            raise L.AbcNetHipError("InferenceRunner: the model must live on a GPU (got %s); abcnet_amd has no CPU fallback" % dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.dev = dev
         model.eval()
-        x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
-        self.eng = eng = model._engine_for(x0, False)
+        with torch.cuda.device(dev):
+            x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
+            self.eng = eng = model._engine_for(x0, False)
         lg = eng.logits
         self.atom_mask, self.bond_mask = torch.empty_like(lg[0]), torch.empty_like(lg[4])
         self.rho_abs, self.omega_mask = torch.empty_like(lg[6]), torch.empty_like(lg[7])
@@ -50,7 +55,8 @@ class InferenceRunner:
     def refresh(self):
         """re-pack the (changed) weights and re-derive the eval-mode BatchNorm coefficients (both functions of the
         parameters alone; call again after load_state_dict)"""
-        self.eng.run_pack(torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.device(self.dev):
+            self.eng.run_pack(torch.cuda.current_stream().cuda_stream)
 
     def load_batch(self, imgs):
         self.eng.img.copy_(imgs.reshape(self.eng.img.shape), non_blocking=True)
@@ -69,6 +75,10 @@ class InferenceRunner:
 
     def step(self):
         """forward + NMS on the batch in the static image buffer; results in .logits / .atom_mask / ..."""
+        with torch.cuda.device(self.dev):
+            self._step()
+
+    def _step(self):
         if self.use_graph and self._graph is None and self.steps >= 1:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -88,7 +98,8 @@ class InferenceRunner:
     def profile(self, iters=3):
         """eager steps with a HIP event pair around every launch on the launch stream (as Trainer.profile)"""
         eng = self.eng
-        stream = torch.cuda.current_stream()
+        torch.cuda.set_device(self.dev)
+        stream = torch.cuda.current_stream(self.dev)
         st = stream.cuda_stream
         acc = {}
         for _ in range(iters):

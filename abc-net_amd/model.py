@@ -17,6 +17,10 @@ Two ways in:
 
 All parameters live in ONE flat f32 arena (gradients, Adam moments likewise): the
 optimiser is a single kernel and the data-parallel all-reduce a few large buckets.
+The module tree mirrors the reference's (inc1.double_conv.0.weight, ...): its 159 (unet) /
+251 (unet2) nn.Parameters and the BatchNorm buffers are views into the arenas, so
+named_parameters(), per-tensor .grad after loss.backward(), torch.optim.Adam(model.parameters())
+and state_dict() behave as with unet.py:78-98.
 There is no CPU fallback: without the HIP library / a GPU the compute entry points raise.
 """
 from __future__ import annotations
@@ -39,17 +43,18 @@ def _kaiming_uniform_(t, fan_in, gen=None):
 
 
 class _UNetFn(torch.autograd.Function):
-    """forward(x) of the compatibility path; parameters are passed so autograd routes their grads"""
+    """forward(x) of the compatibility path; the reference-named parameters are passed so that autograd routes their
+    gradients to them (loss.backward() then fills p.grad of all 159 / 251 tensors, train.py:140)"""
 
     @staticmethod
-    def forward(ctx, model, x, flat):
+    def forward(ctx, model, x, *params):
         eng = model._engine_for(x, model.training)
-        st = torch.cuda.current_stream().cuda_stream
-        eng.img.copy_(x.reshape(eng.img.shape))
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        model._load_image(eng, x)
         eng.run_pack(st)
         eng.run_forward(st)
         outs = model._export_logits(eng, st)
-        ctx.model, ctx.eng = model, eng
+        ctx.model, ctx.eng, ctx.need_x = model, eng, x.requires_grad
         return tuple(outs)
 
     @staticmethod
@@ -57,17 +62,25 @@ class _UNetFn(torch.autograd.Function):
         model, eng = ctx.model, ctx.eng
         if not eng.train:
             raise RuntimeError("backward through an eval-mode forward is not supported")
-        st = torch.cuda.current_stream().cuda_stream
-        lib = eng.lib
-        # d(loss)/d(logits) arrives as the NCHW f32 maps the kernels consume directly: plain copies
-        for i, g in enumerate(gouts):
-            if g is None:
-                eng.dlogits[i].zero_()
-            else:
-                eng.dlogits[i].copy_(g)
-        eng.chan_scale.fill_(1.0)
-        eng.run_backward(st)
-        return None, None, model._flat_grad.clone()
+        if ctx.need_x:
+            raise RuntimeError("abcnet_amd: the gradient with respect to the input image is not produced")
+        with torch.cuda.device(eng.img.device):
+            st = torch.cuda.current_stream().cuda_stream
+            # d(loss)/d(logits) arrives as the NCHW f32 maps the kernels consume directly: plain copies
+            for i, g in enumerate(gouts):
+                if g is None:
+                    eng.dlogits[i].zero_()
+                else:
+                    eng.dlogits[i].copy_(g)
+            eng.chan_scale.fill_(1.0)
+            eng.run_backward(st)
+            g = model._flat_grad.clone()
+        return (None, None) + tuple(g[off:off + cnt].view(shape) for off, cnt, shape in model._param_slices)
+
+
+class _Node(nn.Module):
+    """a container of the reference's module tree (DoubleConv, Sequential, Conv2d, BatchNorm2d, ... by position): it only
+    holds the reference-named parameters and buffers, which are views into the model's flat arenas"""
 
 
 class UNetBase(nn.Module):
@@ -80,33 +93,81 @@ class UNetBase(nn.Module):
         self.heads = heads
         self.compute_dtype = dtype  # "fp32" (parity mode, exact-f32 MFMA) or "bf16" (throughput mode)
         self.dropout_p = dropout_p
+        self.dropout_seed_base = 0x1234ABCD
+        self.dropout_seed = self.dropout_seed_base   # a Trainer under torch.distributed mixes its rank in
         self._table = arch.state_table(self.VARIANT, in_channels, heads)
         self._lay_p, self._np = arch.arena_layout(self._table, "param")
         self._lay_b, self._nb = arch.arena_layout(self._table, "buffer")
         self._lay_c = OrderedDict((n, i) for i, (n, s, r) in enumerate(t for t in self._table if t[2] == "counter"))
-        self._flat = nn.Parameter(torch.zeros(self._np))
-        self.register_buffer("_flat_buf", torch.zeros(self._nb), persistent=False)
-        self.register_buffer("_counters", torch.zeros(len(self._lay_c), dtype=torch.int64), persistent=False)
+        # ONE flat f32 arena per role; the reference-named tensors registered below are views into them
+        self._flat = torch.zeros(self._np)
+        self._flat_buf = torch.zeros(self._nb)
+        self._counters = torch.zeros(len(self._lay_c), dtype=torch.int64)
         self._flat_grad = None
         self._engines = {}
-        self._opt = None
-        self._graphs = {}
+        self._leaves = []          # (name, holder module, attribute, role)
+        self._param_slices = []    # (offset, numel, shape) in parameters() order
+        for name, shape, role in self._table:
+            *path, attr = name.split(".")
+            mod = self
+            for seg in path:
+                nxt = mod._modules.get(seg)
+                if nxt is None:
+                    nxt = _Node()
+                    mod.add_module(seg, nxt)
+                mod = nxt
+            v = self._view(name)
+            if role == "param":
+                mod.register_parameter(attr, nn.Parameter(v))
+                off, cnt = self._lay_p[name]
+                self._param_slices.append((off, cnt, tuple(shape)))
+            else:
+                mod.register_buffer(attr, v)
+            self._leaves.append((name, mod, attr, role))
         self.reset_parameters()
 
     # ------------------------------------------------------------------ parameters
-    def _view(self, name):
+    def _shape_role(self, name):
         for n, shape, role in self._table:
             if n == name:
-                break
-        else:
-            raise KeyError(name)
+                return shape, role
+        raise KeyError(name)
+
+    def _view(self, name):
+        shape, role = self._shape_role(name)
         if role == "param":
             off, cnt = self._lay_p[name]
-            return self._flat.data[off:off + cnt].view(shape)
+            return self._flat[off:off + cnt].view(shape)
         if role == "buffer":
             off, cnt = self._lay_b[name]
             return self._flat_buf[off:off + cnt].view(shape)
         return self._counters[self._lay_c[name]]
+
+    def _rebind(self):
+        """point every registered parameter / buffer at its slice of the (moved) arenas"""
+        for name, mod, attr, role in self._leaves:
+            v = self._view(name)
+            if role == "param":
+                p = mod._parameters[attr]
+                p.data = v
+                p.grad = None
+            else:
+                mod._buffers[attr] = v
+
+    def _apply(self, fn, recurse=True):
+        """model.to(device) / .cuda(rank) (train.py:48, multi_gpu_train.py:49): the ARENAS move, the named tensors are
+        re-pointed at them (moving 159 tensors one by one would scatter them)"""
+        flat, buf = fn(self._flat), fn(self._flat_buf)
+        cnt = fn(self._counters)
+        if flat.dtype != torch.float32 or buf.dtype != torch.float32 or cnt.dtype != torch.int64:
+            raise L.AbcNetHipError("abcnet_amd keeps its parameters in float32 (the compute dtype is the constructor's dtype=)")
+        moved = flat.device != self._flat.device
+        self._flat, self._flat_buf, self._counters = flat, buf, cnt
+        if moved:
+            self._flat_grad = None
+            self._engines = {}
+        self._rebind()
+        return self
 
     def reset_parameters(self, seed=None):
         """torch default initialisation of the reference modules (unet.py:82-98): kaiming-uniform(a=sqrt 5)
@@ -124,6 +185,8 @@ class UNetBase(nn.Module):
         with torch.no_grad():
             for name, shape, role in self._table:
                 v = self._view(name)
+                if v.device.type != "cpu":
+                    raise L.AbcNetHipError("reset_parameters(): initialise on the host, then .to(device)")
                 if role == "param":
                     if name == "s":
                         v.copy_(torch.randn(10, generator=gen) / 100)
@@ -147,60 +210,51 @@ class UNetBase(nn.Module):
                 yield name, self._view(name)
 
     def grad_of(self, name):
+        """the fast path's gradient of a reference-named tensor (a view into the flat gradient arena the Trainer's
+        backward plan fills; the compatibility path fills p.grad of the named parameters instead)"""
         off, cnt = self._lay_p[name]
-        shape = [s for n, s, r in self._table if n == name][0]
-        return self._flat_grad[off:off + cnt].view(shape)
+        return self._flat_grad[off:off + cnt].view(self._shape_role(name)[0])
 
-    # state_dict in the reference's layout ------------------------------------------------
-    def _save_to_state_dict(self, destination, prefix, keep_vars):
-        for name, shape, role in self._table:
-            destination[prefix + name] = self._view(name).detach()
+    def flat_param_grads(self):
+        """p.grad of all named parameters concatenated in arena order (zeros where a parameter has none)"""
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.parameters()])
 
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-        names = set()
-        with torch.no_grad():
-            for name, shape, role in self._table:
-                names.add(name)
-                key = prefix + name
-                if key not in state_dict:
-                    missing_keys.append(key)
-                    continue
-                v = state_dict[key]
-                if tuple(v.shape) != tuple(shape):
-                    error_msgs.append("size mismatch for %s: %s vs %s" % (key, tuple(v.shape), tuple(shape)))
-                    continue
-                self._view(name).copy_(v)
-        for key in state_dict.keys():
-            if key.startswith(prefix) and key[len(prefix):] not in names:
-                unexpected_keys.append(key)
-
+    # state_dict: the registered tensors carry the reference's names, shapes and dtypes; copies go through the views
     def load_state_dict(self, state_dict, strict=True, assign=False):
-        """also accepts checkpoints saved from nn.DataParallel (keys prefixed 'module.', train.py:435)"""
+        """also accepts checkpoints saved from nn.DataParallel / DDP (keys prefixed 'module.', train.py:435,
+        img2smiles2.py:43-44)"""
+        if assign:
+            raise L.AbcNetHipError("load_state_dict(assign=True) would detach the parameters from the arena")
         if state_dict and all(k.startswith("module.") for k in state_dict.keys()):
             state_dict = OrderedDict((k[7:], v) for k, v in state_dict.items())
         return super().load_state_dict(state_dict, strict=strict)
-
-    def __getattr__(self, name):
-        if name == "s":  # model.module.s[i] in the reference loss (train.py:127-135)
-            off, cnt = self.__dict__["_lay_p"]["s"]
-            return self._flat[off:off + cnt]
-        return super().__getattr__(name)
 
     # ------------------------------------------------------------------ engines
     def _engine_for(self, x, train):
         if not x.is_cuda:
             raise L.AbcNetHipError("abcnet_amd runs on an MI355X only (got a %s tensor); there is no CPU fallback" % x.device)
+        if x.device != self._flat.device:
+            # (this is also what a replica made by multi-device nn.DataParallel runs into: its engines, graphs and arenas
+            #  cannot be replicated -- use one process per GPU, abcnet_amd.distributed / multi_gpu_train.py's way)
+            raise L.AbcNetHipError("input on %s but the model lives on %s; multi-device nn.DataParallel is not supported -- "
+                                   "run one process per GPU (abcnet_amd.distributed.launch_ranks / torchrun)" % (x.device, self._flat.device))
         B, Cc, H, W = x.shape
-        key = (B, H, W, bool(train), self.compute_dtype)
+        if Cc != self.n_channels:
+            raise ValueError("expected %d input channels, got %d" % (self.n_channels, Cc))
+        key = (B, H, W, bool(train), self.compute_dtype, self.dropout_seed)
         eng = self._engines.get(key)
-        if eng is None or eng.params.data_ptr() != self._flat.data.data_ptr():
+        if eng is None or eng.params.data_ptr() != self._flat.data_ptr():
             if self._flat_grad is None or self._flat_grad.device != x.device:
-                self._flat_grad = torch.zeros_like(self._flat.data)
-            eng = Engine(self.VARIANT, self.n_channels, self.heads, self._flat.data, self._flat_grad, self._flat_buf,
-                         self._counters, (self._lay_p, self._lay_b, self._lay_c), B, H, W, self.compute_dtype, train,
-                         dropout_p=self.dropout_p, device=x.device)
+                self._flat_grad = torch.zeros_like(self._flat)
+            with torch.cuda.device(x.device):
+                eng = Engine(self.VARIANT, self.n_channels, self.heads, self._flat, self._flat_grad, self._flat_buf,
+                             self._counters, (self._lay_p, self._lay_b, self._lay_c), B, H, W, self.compute_dtype, train,
+                             dropout_p=self.dropout_p, device=x.device, drop_seed=self.dropout_seed)
             self._engines[key] = eng
         return eng
+
+    def _load_image(self, eng, x):
+        eng.img.copy_(x.reshape(eng.img.shape))
 
     def _export_logits(self, eng, st):
         # the kernels already wrote the reference's NCHW f32 maps; hand out copies because the engine
@@ -209,24 +263,26 @@ class UNetBase(nn.Module):
 
     def forward(self, x):
         if torch.is_grad_enabled() and self.training:
-            outs = _UNetFn.apply(self, x, self._flat)
+            outs = _UNetFn.apply(self, x, *self.parameters())
         else:
             eng = self._engine_for(x, self.training)
-            st = torch.cuda.current_stream().cuda_stream
-            eng.img.copy_(x.reshape(eng.img.shape))
-            eng.run_pack(st)
-            eng.run_forward(st)
-            outs = self._export_logits(eng, st)
+            with torch.cuda.device(x.device):
+                st = torch.cuda.current_stream().cuda_stream
+                self._load_image(eng, x)
+                eng.run_pack(st)
+                eng.run_forward(st)
+                outs = self._export_logits(eng, st)
         return list(outs)
 
     # ------------------------------------------------------------------ fast path
     def forward_logits(self, x):
         """the engine's own NCHW f32 head maps (valid until the next call), no copies"""
         eng = self._engine_for(x, self.training)
-        st = torch.cuda.current_stream().cuda_stream
-        eng.img.copy_(x.reshape(eng.img.shape))
-        eng.run_pack(st)
-        eng.run_forward(st)
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream().cuda_stream
+            self._load_image(eng, x)
+            eng.run_pack(st)
+            eng.run_forward(st)
         return eng.logits, eng
 
     def nms(self, x):

@@ -9,6 +9,7 @@ Plain torch CPU ops, seeded; independent of the oracle.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 
@@ -85,3 +86,41 @@ def correlated_logits(targets, seed: int = 19, centre_noise: float = 1.2):
         (t_rho + 0.5 * rn(60).double()).float(),
         torch.round((5.0 * t_om.float() - 2.5 + rn(60)) * 4) / 4,
     ]
+
+
+def random_annotations(n_atoms, n_bonds, seed, size=512):
+    """seeded annotation strings in the reference's format, covering the branches: unknown and two-letter elements,
+    3- and 4-field atoms, hs in {-1,0,1,2}, all bond orders and stereo codes, both directions, vertical bonds
+    (delta_x == 0), border positions (x or y == 0 / last), overlapping neighbourhoods, omega bins 0 and 29"""
+    rng = np.random.RandomState(seed)
+    elems = ['C', 'N', 'O', 'P', 'F', 'Cl', 'S', 'Br', 'B', 'Se', 'I', 'H', 'Si', 'Xx', 'c', 'n']
+    atoms = []
+    for i in range(n_atoms):
+        x, y = int(rng.randint(0, size)), int(rng.randint(0, size))
+        if i % 7 == 0:
+            x = [0, size - 1, 3, size - 4][(i // 7) % 4]
+        if i % 11 == 0:
+            y = [0, size - 1][(i // 11) % 2]
+        s = "%s:%d,%d,%d" % (elems[int(rng.randint(0, len(elems)))], x, y, int(rng.choice([0, 0, 0, 1, -1, 2])))
+        if rng.rand() < 0.7:
+            s += ",%d" % int(rng.choice([0, 1, 2, -1]))
+        atoms.append(s)
+    bonds = []
+    for i in range(n_bonds):
+        x, y = int(rng.randint(0, size)), int(rng.randint(0, size))
+        if i % 9 == 0:
+            x = [0, size - 1][(i // 9) % 2]
+        dx, dy = int(rng.randint(-40, 41)), int(rng.randint(-40, 41))
+        if i % 5 == 0:
+            dx = 0
+        if i % 13 == 0:
+            dy = 0
+        if dx == 0 and dy == 0:
+            dy = 7
+        if i % 17 == 0:
+            dx, dy = 1, -40   # steep: omega bin 0
+        if i % 19 == 0:
+            dx, dy = 1, 40    # omega bin 29
+        bonds.append("%d:%d,%d,%d,%d,%d,%d" % (int(rng.choice([1, 2, 3, 4, 7])), x, y, dx, dy, int(rng.choice([0, 0, 1, 5, 6])),
+                                                int(rng.choice([0, 1]))))
+    return ";".join(atoms) + ";", ";".join(bonds) + ";"

@@ -20,18 +20,35 @@ from .ops import FusedAdam, FusedLoss, FusedMetrics
 
 class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
-                 process_group=None, device=None, metrics=False):
+                 process_group=None, device=None, metrics=False, broadcast_buffers="lazy"):
+        """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
+        mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
+        as DDP does; "lazy" (default): right before they are read (state_dict(), sync_buffers()), which is observably the
+        same because train-mode arithmetic never reads them; False: never (each rank keeps its own shard's statistics)."""
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("Trainer needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
-        dev = device or next(model.parameters()).device
+        dev = torch.device(device or next(model.parameters()).device)
+        if dev.type != "cuda":
+            raise L.AbcNetHipError("Trainer: the model must live on a GPU (got %s); abcnet_amd has no CPU fallback" % dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.dev = dev
-        model.train()
-        x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
-        self.eng = model._engine_for(x0, True)
-        eng = self.eng
-        self.world = torch.distributed.get_world_size(process_group) if torch.distributed.is_initialized() else 1
+        dist_on = torch.distributed.is_initialized()
+        self.world = torch.distributed.get_world_size(process_group) if dist_on else 1
+        self.rank = torch.distributed.get_rank(process_group) if dist_on else 0
         self.group = process_group
+        if broadcast_buffers not in ("step", "lazy", False):
+            raise ValueError("broadcast_buffers must be 'step', 'lazy' or False")
+        self.broadcast_buffers = broadcast_buffers if self.world > 1 else False
+        # every rank draws its OWN dropout masks, as the unseeded processes of multi_gpu_train.py:36 do (rank 0 keeps the
+        # single-process stream)
+        model.dropout_seed = D.rank_dropout_seed(model.dropout_seed_base, self.rank)
+        model.train()
+        with torch.cuda.device(dev):
+            x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
+            self.eng = model._engine_for(x0, True)
+        eng = self.eng
         h, w = eng.h, eng.w
         B = batch
         shapes = [(B, 1, h, w), (B, 14, h, w), (B, 3, h, w), (B, 2, h, w), (B, 1, h, w), (B, 6, 60, h, w), (B, 60, h, w), (B, 60, h, w)]
@@ -102,7 +119,7 @@ class Trainer:
         return segs
 
     def _run_segment(self, k):
-        st = torch.cuda.current_stream().cuda_stream
+        st = torch.cuda.current_stream(self.dev).cuda_stream
         for fn in self._segments[k]:
             fn(st)
 
@@ -122,8 +139,20 @@ class Trainer:
         self._graphs = (graphs, gopt)
 
     # ------------------------------------------------------------------ step
+    def sync_buffers(self):
+        """rank 0's BatchNorm running statistics / num_batches_tracked to every rank (DDP broadcast_buffers)"""
+        if self.world > 1:
+            with torch.cuda.device(self.dev):
+                D.broadcast_buffers(self.model._flat_buf, self.model._counters, group=self.group)
+
     def step(self):
         """one optimisation step on the batch currently in the static buffers"""
+        with torch.cuda.device(self.dev):
+            if self.broadcast_buffers == "step":
+                D.broadcast_buffers(self.model._flat_buf, self.model._counters, group=self.group)
+            self._step()
+
+    def _step(self):
         if self.use_graph and self._graphs is None and self.steps >= 1:
             torch.cuda.synchronize()
             self._capture()
@@ -154,9 +183,12 @@ class Trainer:
         """everything a bit-exact resume needs: the model in the REFERENCE's state_dict layout (loads into
         /root/reference/src/unet.py as is, train.py:435), plus what the reference does not save -- the Adam moments and
         step counter, the learning rate, the dropout step counter and the running meters"""
+        if self.broadcast_buffers:
+            self.sync_buffers()   # every rank's checkpoint holds rank 0's BatchNorm buffers, as under DDP
         sd = {"model": {k: v.clone() for k, v in self.model.state_dict().items()},
               "adam_m": self.opt.m.clone(), "adam_v": self.opt.v.clone(), "adam_step": self.opt.step_t.clone(),
-              "lr": self.lr, "weight_decay": self.wd, "steps": self.steps, "drop_salt": self.eng.drop_salt.clone()}
+              "lr": self.lr, "weight_decay": self.wd, "steps": self.steps, "drop_salt": self.eng.drop_salt.clone(),
+              "drop_seed": self.eng.drop_seed}
         if self.metrics is not None:
             sd["meters"] = self.metrics.totals.clone()
         return sd
@@ -169,7 +201,11 @@ class Trainer:
         self.opt.m.copy_(sd["adam_m"])
         self.opt.v.copy_(sd["adam_v"])
         self.opt.step_t.copy_(sd["adam_step"])
-        self.eng.drop_salt.copy_(sd["drop_salt"])   # the dropout stream continues where it stopped
+        # the dropout stream continues where it stopped; the seed itself is baked into the launch descriptors, so a
+        # checkpoint written under another seed (another rank's) is continued through the device-side salt
+        delta = (int(sd.get("drop_seed", self.eng.drop_seed)) - self.eng.drop_seed) & 0xFFFFFFFF
+        salt = (int(sd["drop_salt"].item()) + delta) & 0xFFFFFFFF
+        self.eng.drop_salt.fill_(salt - (1 << 32) if salt >= (1 << 31) else salt)
         self.steps = max(self.steps, 1) if self._graphs is not None else self.steps
         if self.metrics is not None and "meters" in sd:
             self.metrics.totals.copy_(sd["meters"])
@@ -179,7 +215,8 @@ class Trainer:
         """Eager (no graph) steps with a HIP event pair around EVERY launch, recorded on the stream the
         kernels are launched on.  Returns {kernel: {calls, ms, flops, bytes}} per step (averaged)."""
         eng = self.eng
-        stream = torch.cuda.current_stream()
+        torch.cuda.set_device(self.dev)
+        stream = torch.cuda.current_stream(self.dev)
         st = stream.cuda_stream
         groups = [eng.pack_ops, eng.fwd_ops, None, eng.bwd_ops]
         acc = {}

@@ -2,7 +2,9 @@
 """Headline benchmark (BASELINE.json): training images/sec of unet.py at 384x384, bf16, batch 16 per GPU.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N>1, either: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (ranks come from the env)
+       or:     python bench.py --gpus N ...   -- then THIS process only starts N fresh rank processes (before it has
+               touched the GPU; multi_gpu_train.py:30-36's mp.spawn) and exits non-zero unless all N joined.
 
 A step = pack weights + forward + fused loss + backward + gradient all-reduce (N>1) + fused Adam on one
 batch of synthetic inputs already resident in HBM (data: Bernoulli ink images + rasterised random
@@ -97,6 +99,28 @@ def pmc_traffic(kernel, mode="train", variant="unet"):
     return None if rec is None else rec["bytes_per_launch"]
 
 
+def experiment_knobs():
+    """ABC_* environment variables other than this script's own hooks: switches of the library / engine that change
+    WHICH kernels run.  A benchmark line measured under one is not the product's: refused unless --allow-knobs, and
+    then echoed into the JSON line."""
+    own = ("ABC_BENCH_",)
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("ABC_") and not k.startswith(own)}
+
+
+def launch_ranks(a):
+    """--gpus N without a launcher: start the N ranks ourselves.  This parent never initialises HIP
+    (torch.cuda.device_count() does not, on this image); the children are fresh interpreters."""
+    sys.path.insert(0, ROOT)
+    import abcnet_amd  # noqa: F401
+    from abcnet_amd import distributed as D
+    ndev = torch.cuda.device_count()
+    if "ABC_BENCH_DEVICE" not in os.environ and ndev < a.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (a.gpus, ndev))
+    codes = D.launch_ranks([os.path.abspath(__file__)] + sys.argv[1:], a.gpus, timeout=float(os.environ.get("ABC_BENCH_TIMEOUT", 3000)))
+    if any(c != 0 for c in codes):
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (a.gpus, codes))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +140,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--allow-knobs", action="store_true", help="run although ABC_* experiment switches are set (they are echoed)")
     a = ap.parse_args()
+    knobs = experiment_knobs()
+    if knobs and not a.allow_knobs:
+        raise SystemExit("bench.py: experiment switches are set (%s); unset them or pass --allow-knobs" % ", ".join(knobs))
     if a.size is None:
         a.size = 384 if a.mode == "train" else 512
     if a.batch is None:
@@ -125,7 +153,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return launch_ranks(a)
+    if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -145,14 +177,18 @@ def main():
     else:
         from abcnet_amd.unet import UNet
 
+    backend = None
     if world > 1:
-        D.init_process_group(backend=os.environ.get("ABC_BENCH_BACKEND"), rank=rank, world_size=world)
+        D.init_process_group(backend=os.environ.get("ABC_BENCH_BACKEND"), rank=rank, world_size=world, device=local)
+        backend = dist.get_backend()
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit("--gpus %d but %d ranks joined" % (a.gpus, dist.get_world_size()))
 
     model = UNet(1, HEADS, dtype=a.dtype)
     model.reset_parameters(seed=1234)  # identical random init on every rank (and re-broadcast below)
     model = model.to(dev)
     if world > 1:
-        D.broadcast_parameters(model._flat.data, model._flat_buf)
+        D.broadcast_parameters(model._flat, model._flat_buf, counters=model._counters)
     # each rank owns its shard of the synthetic stream (weak scaling: fixed batch per GPU)
     imgs = synthetic_images(a.batch, a.size, seed=7 + rank)
     if a.mode == "infer":
@@ -166,7 +202,7 @@ def main():
         if a.raster:
             # the data path a real loader would use: a few KB of records per batch, maps built where the loss reads them
             from abcnet_amd.raster import TargetRasterizer, parse_record
-            from oracle.raster_oracle import random_annotations   # (test-data generator only: seeded annotation strings)
+            from abcnet_amd.synthetic import random_annotations   # seeded annotation strings in the reference's format
             rz = TargetRasterizer(a.batch, a.size // 4, max_atoms=64, max_bonds=64, targets=tr.targets)
             rz.load([parse_record(*random_annotations(30, 32, 900 + 16 * rank + i, size=a.size), h=a.size // 4) for i in range(a.batch)])
             _step = tr.step
@@ -196,14 +232,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
     loss = tr.loss_value()["total"] if a.mode == "train" else float(tr.atom_mask.sum().item())
-    if a.mode == "train" and world > 1 and os.environ.get("ABC_BENCH_CHECK"):
-        # replicas must hold identical parameters after the averaged updates
-        chk = model._flat.data.double().sum().reshape(1)
+    if a.mode == "train" and world > 1:
+        # replicas must hold identical parameters after the averaged updates (cheap: one 8-byte all-gather after the clock stopped)
+        chk = model._flat.double().sum().reshape(1)
         both = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(both, chk)
-        if rank == 0:
-            print("replica checksums", [b.item() for b in both], file=sys.stderr)
-            assert all(abs(b.item() - both[0].item()) == 0.0 for b in both), "replicas diverged"
+        if not all(b.item() == both[0].item() for b in both):
+            raise SystemExit("replicas diverged: parameter checksums %s" % [b.item() for b in both])
 
     if a.mode == "train":
         metric = "training images/sec (%dx%d, b%d/GPU)" % (a.size, a.size, a.batch)
@@ -213,11 +248,11 @@ def main():
         workload = "img2smiles2.py heat-map path on %s.py (eval forward + peak NMS), %dx%d, batch %d/GPU" % (a.variant, a.size, a.size, a.batch)
     out = {
         "metric": metric, "value": round(world * a.batch * a.steps / el, 2), "unit": "images/sec",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
+        "n_gpus": world, "ranks_joined": dist.get_world_size() if world > 1 else 1, "backend": backend, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),
-                   "device_rasteriser": bool(a.raster), "device_extraction": bool(a.extract)},
+                   "device_rasteriser": bool(a.raster), "device_extraction": bool(a.extract), "env_knobs": knobs},
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 

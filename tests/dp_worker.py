@@ -1,0 +1,71 @@
+"""One data-parallel rank of tests/test_gpu_00_dataparallel.py (started by abcnet_amd.distributed.launch_ranks, i.e. the
+way multi_gpu_train.py:30-53 starts main_worker: one fresh process per rank, init_process_group, model on its GPU,
+parameters of rank 0 everywhere, then the training loop).
+
+    python dp_worker.py OUT_DIR VARIANT DTYPE SIZE BATCH STEPS BUCKET_MB
+
+RCCL ("nccl") when every rank has a GPU of its own; on a one-GPU box the ranks share device 0 and exchange over gloo
+(ABC_DP_SHARED_DEVICE=1), which runs the same bucketed all-reduce between the same hipGraph segments."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import abcnet_amd  # noqa: E402,F401
+from abcnet_amd import distributed as D  # noqa: E402
+from abcnet_amd.synthetic import synthetic_images, synthetic_targets  # noqa: E402
+from abcnet_amd.train import Trainer  # noqa: E402
+
+HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
+
+
+def main():
+    out, variant, dtype, size, batch, steps, bucket_mb = sys.argv[1:8]
+    size, batch, steps, bucket_mb = int(size), int(batch), int(steps), float(bucket_mb)
+    shared = os.environ.get("ABC_DP_SHARED_DEVICE") == "1"
+    rank, world = D.init_process_group(backend="gloo" if shared else "nccl", device=0 if shared else None)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if variant == "unet2":
+        from abcnet_amd.unet2 import UNet
+    else:
+        from abcnet_amd.unet import UNet
+    model = UNet(1, HEADS, dtype=dtype, dropout_p=0.2)
+    model.reset_parameters(seed=1000 + rank)       # DIFFERENT on every rank: the broadcast below must make rank 0's win
+    with torch.no_grad():                            # non-trivial BatchNorm buffers too
+        model._flat_buf.add_(0.01 * (rank + 1))
+    model = model.to(dev)
+    D.broadcast_parameters(model._flat, model._flat_buf, counters=model._counters)   # DDP constructor, multi_gpu_train.py:52
+    p0 = model._flat.clone()
+    tr = Trainer(model, batch, size, size, use_graph=True, bucket_mb=bucket_mb, broadcast_buffers="lazy")
+    x = synthetic_images(batch, size, seed=7 + rank)
+    tg = synthetic_targets(batch, size // 4, seed=1 + rank)
+    tr.load_batch(x.to(dev), [t.to(dev) for t in tg])
+    res = {"rank": rank, "world": world, "backend": dist.get_backend(), "p0": p0.cpu(), "n_buckets": len(tr.buckets),
+           "n_segments": len(tr._segments), "drop_seed": tr.eng.drop_seed}
+    tr.step()                                        # eager
+    torch.cuda.synchronize()
+    res["grad_step1"] = model._flat_grad.cpu().clone()      # mean over ranks of the per-rank gradients
+    res["loss_step1"] = tr.loss_value()["total"]
+    lm = D.reduce_mean(torch.tensor([res["loss_step1"]], dtype=torch.float64, device=dev), world)   # multi_gpu_train.py:116
+    res["loss_mean_step1"] = lm.item()
+    for _ in range(steps - 1):                       # captured: one hipGraph per segment between two all-reduce launches
+        tr.step()
+    torch.cuda.synchronize()
+    res["graphs"] = tr._graphs is not None
+    res["params"] = model._flat.cpu().clone()
+    res["buffers_own"] = model._flat_buf.cpu().clone()      # this rank's own running statistics (its shard's)
+    ck = tr.state_dict()                             # "lazy": rank 0's buffers arrive here
+    res["buffers_ckpt"] = torch.cat([ck["model"][k].reshape(-1).float().cpu() for k in ck["model"] if "running_" in k])
+    res["nbt_ckpt"] = int(ck["model"]["inc1.double_conv.1.num_batches_tracked"])
+    res["adam_m"] = tr.opt.m.cpu().clone()
+    torch.save(res, os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

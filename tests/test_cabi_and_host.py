@@ -179,3 +179,59 @@ def test_gloo_world2_bucketed_allreduce_and_broadcast():
     assert all(r[1] for r in res), "bucketed all-reduce != sum over ranks"
     assert all(r[2] == 0.0 for r in res), "rank 0 parameters must win the broadcast"
     assert all(abs(r[3] - 1.5) < 1e-6 for r in res)
+
+
+_RANK_SCRIPT = """
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import abcnet_amd
+from abcnet_amd import distributed as D
+mode = sys.argv[1]
+rank, world = D.init_process_group(backend="gloo")
+assert (rank, world) == (int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+assert t.item() == world * (world + 1) / 2
+if mode == "fail" and rank == 1:
+    sys.exit(3)
+if mode == "fail":
+    time.sleep(600)     # must be ended by the launcher once rank 1 has failed
+print("rank", rank, "ok")
+"""
+
+
+def test_launch_ranks_starts_fresh_processes_and_reports_failures(tmp_path):
+    """multi_gpu_train.py:30-36 (mp.spawn of main_worker) as fresh child processes: every rank joins the group; when one
+    rank fails the others are ended and the failure is reported (bench.py --gpus N turns that into a non-zero exit)"""
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % ROOT)
+    out = open(tmp_path / "rank0.out", "w")
+    assert D.launch_ranks([str(script), "ok"], 2, timeout=300, rank0_stdout=out) == [0, 0]
+    out.close()
+    assert "rank 0 ok" in open(tmp_path / "rank0.out").read()
+    import time
+    t0 = time.time()
+    codes = D.launch_ranks([str(script), "fail"], 2, timeout=300)
+    assert codes[1] == 3 and codes[0] not in (0, None) and time.time() - t0 < 120
+
+
+def test_bench_refuses_more_gpus_than_visible_and_experiment_knobs():
+    """`python bench.py --gpus N` without a launcher must start N ranks or fail -- never print a 1-GPU line as N GPUs"""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout
+    if torch.cuda.device_count() < 2:
+        assert "GPU(s) visible" in r.stderr
+    env["ABC_CONV_NOWD"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "experiment switches" in r.stderr
+
+
+def test_rank_dropout_seeds_differ_and_rank0_keeps_the_base():
+    base = 0x1234ABCD
+    seeds = [D.rank_dropout_seed(base, r) for r in range(8)]
+    assert seeds[0] == base and len(set(seeds)) == 8 and all(0 <= s < 2 ** 32 for s in seeds)

@@ -1,0 +1,109 @@
+"""GPU parity test of the N > 1 path (multi_gpu_train.py:24-53,62-66,72-75,114-119):
+two FRESH rank processes run the data-parallel training step -- parameters of rank 0 broadcast, per-rank image shards,
+per-rank dropout masks, bucketed gradient all-reduce launched between hipGraph segments of the backward plan, fused
+Adam -- and this process then checks
+
+  * the averaged gradient of step 1 == mean of the two single-process gradients (computed here, one rank at a time),
+  * replica parameters (and Adam moments) bit-identical after 3 steps, and != the initial ones,
+  * rank 0's parameters / BatchNorm buffers win (DDP constructor + broadcast_buffers semantics),
+  * the loss mean over ranks (reduce_mean) == mean of the single-process losses.
+
+The ranks use RCCL (backend "nccl") when the box has a GPU per rank; on a one-GPU box they share device 0 and exchange
+over gloo -- the same GradReducer / segment / graph code.  This file sorts first on purpose: the rank processes must be
+started BEFORE this process initialises HIP (a process that holds a GPU context must not fork/exec others on this pool).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import abcnet_amd  # noqa: E402,F401
+from abcnet_amd import distributed as D  # noqa: E402
+from abcnet_amd.synthetic import synthetic_images, synthetic_targets  # noqa: E402
+
+HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _single_process_grad(variant, dtype, p0, rank, size, batch):
+    """what rank `rank` computes on its own shard without any exchange (lr = 0: parameters stay put)"""
+    from abcnet_amd.train import Trainer
+    if variant == "unet2":
+        from abcnet_amd.unet2 import UNet
+    else:
+        from abcnet_amd.unet import UNet
+    m = UNet(1, HEADS, dtype=dtype, dropout_p=0.2)
+    m.dropout_seed_base = D.rank_dropout_seed(m.dropout_seed_base, rank)   # the masks rank `rank` drew
+    m = m.to("cuda")
+    m._flat.copy_(p0)
+    tr = Trainer(m, batch, size, size, lr=0.0, use_graph=False)
+    x = synthetic_images(batch, size, seed=7 + rank)
+    tg = synthetic_targets(batch, size // 4, seed=1 + rank)
+    tr.load_batch(x.to("cuda"), [t.to("cuda") for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    return m._flat_grad.cpu().clone(), tr.loss_value()["total"], tr.eng.drop_seed
+
+
+CASES = [("unet", "bf16"), ("unet2", "fp32")]
+WORLD, SIZE, BATCH, STEPS = 2, 64, 2, 3
+
+
+@pytest.fixture(scope="module")
+def rank_runs(tmp_path_factory):
+    """both cases' rank processes, run to completion before this process initialises HIP"""
+    if torch.cuda.is_initialized():
+        pytest.skip("the rank processes must be started before this process touches the GPU: run this file first / alone")
+    ndev = torch.cuda.device_count()      # (does not initialise HIP on this image)
+    assert ndev >= 1, "needs an MI355X"
+    env = dict(os.environ)
+    if ndev < WORLD:
+        env["ABC_DP_SHARED_DEVICE"] = "1"
+    runs = {}
+    for variant, dtype in CASES:
+        out = str(tmp_path_factory.mktemp("dp_%s_%s" % (variant, dtype)))
+        codes = D.launch_ranks([os.path.join(HERE, "dp_worker.py"), out, variant, dtype, str(SIZE), str(BATCH), str(STEPS), "4"],
+                               WORLD, timeout=900, env=env, rank0_stdout=sys.stderr)
+        assert codes == [0] * WORLD, "%s %s: rank exit codes %s" % (variant, dtype, codes)
+        runs[(variant, dtype)] = [torch.load(os.path.join(out, "rank%d.pt" % i), weights_only=False) for i in range(WORLD)]
+    return runs, ndev
+
+
+@pytest.mark.parametrize("variant,dtype", CASES)
+def test_two_ranks_average_gradients_and_stay_identical(variant, dtype, rank_runs):
+    runs, ndev = rank_runs
+    world, size, batch, steps = WORLD, SIZE, BATCH, STEPS
+    r = runs[(variant, dtype)]
+    assert [x["world"] for x in r] == [world] * world
+    assert all(x["backend"] == ("nccl" if ndev >= world else "gloo") for x in r)
+    assert r[0]["n_buckets"] >= 3 and r[0]["n_segments"] >= 3 and all(x["graphs"] for x in r)   # several all-reduces inside backward
+    # rank 0's initial parameters everywhere
+    assert torch.equal(r[0]["p0"], r[1]["p0"])
+    # per-rank dropout streams
+    assert r[0]["drop_seed"] != r[1]["drop_seed"]
+    # ---- averaged gradient == mean of the single-process gradients
+    g, losses = [], []
+    for k in range(world):
+        gk, lk, seed = _single_process_grad(variant, dtype, r[0]["p0"], k, size, batch)
+        assert seed == r[k]["drop_seed"]
+        assert abs(lk - r[k]["loss_step1"]) <= 1e-9 * abs(lk), (k, lk, r[k]["loss_step1"])
+        g.append(gk)
+        losses.append(lk)
+    want = (g[0].double() + g[1].double()) / 2
+    for k in range(world):
+        got = r[k]["grad_step1"].double()
+        err = (got - want).abs().max().item()
+        # the 1/world factor is folded into d(loss)/d(logits) (a power of two: exact), the sum of two floats rounds once
+        assert err <= 1e-6 * want.abs().max().item(), (k, err, want.abs().max().item())
+    assert torch.equal(r[0]["grad_step1"], r[1]["grad_step1"])
+    assert abs(r[0]["loss_mean_step1"] - sum(losses) / world) <= 1e-9 * abs(sum(losses) / world)
+    # ---- replicas stay bit-identical, and they did move
+    assert torch.equal(r[0]["params"], r[1]["params"]) and torch.equal(r[0]["adam_m"], r[1]["adam_m"])
+    assert not torch.equal(r[0]["params"], r[0]["p0"])
+    # ---- BatchNorm buffers: every rank accumulates its own shard's statistics, the checkpoint holds rank 0's
+    assert not torch.equal(r[0]["buffers_own"], r[1]["buffers_own"])
+    assert torch.equal(r[0]["buffers_ckpt"], r[1]["buffers_ckpt"])
+    assert r[0]["nbt_ckpt"] == r[1]["nbt_ckpt"] == steps

@@ -134,15 +134,76 @@ def test_compat_path_autograd_matches_oracle():
     m.train()
     preds = m(x.to(DEV))
     loss, _, _ = loss_oracle.abc_loss(preds, [t.to(DEV) for t in tg], m.s)  # torch ops on device = the reference's loss code
+    opt = torch.optim.Adam(m.parameters(), lr=2.5e-4, weight_decay=1e-8)   # train.py:55 on the 159 named tensors
+    opt.zero_grad()
     loss.backward()
     assert abs(loss.item() - total.item()) < 1e-4 * abs(total.item())
-    flat = m._flat.grad
+    named = dict(m.named_parameters())
+    assert list(named) == [k for k, v in sd.items() if v.requires_grad] and len(named) == 159
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in named.values())
+    _check_grads(lambda name: named[name].grad, sd, sd64)
+    # optimizer.step() (train.py:141) on the named tensors moves the arena the kernels read, as the oracle's Adam does
+    from oracle import adam_oracle
+    before = {k: v.detach().clone() for k, v in named.items()}
+    opt.step()
+    for name in ("out_modules.5.conv2.weight", "dconv1.double_conv.1.weight", "up2.up.weight", "s"):
+        p = before[name].cpu().reshape(-1).clone()
+        n = p.numel()
+        adam_oracle.adam_step(p, named[name].grad.cpu().reshape(-1), torch.zeros(n), torch.zeros(n), 1)
+        assert (named[name].detach().cpu().reshape(-1) - p).abs().max().item() < 1e-6, name
+        off, cnt = m._lay_p[name]
+        assert torch.equal(m._flat[off:off + cnt], named[name].detach().reshape(-1)), "parameter is not a view of the arena"
+    with torch.no_grad():
+        m.eval()
+        y2 = m(x.to(DEV))
+    assert all(torch.isfinite(t).all() for t in y2)
 
-    def get(name):
-        off, n = m._lay_p[name]
-        return flat[off:off + n].view(sd[name].shape)
 
-    _check_grads(get, sd, sd64)
+def test_named_parameters_follow_the_arena_across_devices():
+    """unet.py:78-98 surface: 159 named tensors / 10,698,575 values, state_dict round trip, .to(device) keeps them views of
+    ONE arena, per-tensor optimiser groups work"""
+    m = UNet(1, HEADS)
+    assert sum(p.numel() for p in m.parameters()) == 10698575 and len(list(m.parameters())) == 159
+    m = m.to(DEV)
+    base = m._flat.data_ptr()
+    for (name, p), (off, cnt, shape) in zip(m.named_parameters(), m._param_slices):
+        assert p.is_cuda and p.data_ptr() == base + 4 * off and tuple(p.shape) == shape, name
+    # per-layer learning rates (anything per-tensor) work on the named tensors
+    groups = [{"params": [p for n, p in m.named_parameters() if n.startswith("out_modules")], "lr": 1e-3},
+              {"params": [p for n, p in m.named_parameters() if not n.startswith("out_modules")], "lr": 1e-4}]
+    torch.optim.Adam(groups)
+    with pytest.raises(L.AbcNetHipError):
+        m.half()
+    with pytest.raises(L.AbcNetHipError):
+        m(torch.zeros(1, 1, 64, 64))   # CPU tensor: no fallback
+
+
+def test_three_input_channels_match_oracle():
+    """unet.py:122-134 builds UNet(in_channels=3, ...): the first convolution reads the NCHW image channel-planar"""
+    B, S = 2, 64
+    x = synthetic_images(B, S, seed=7, in_channels=3)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    sd0 = uo.filled_state("unet", 3, HEADS, seed=0)
+    m = UNet(3, HEADS, dtype="fp32", dropout_p=0.0)
+    m.load_state_dict(sd0)
+    m = m.to(DEV)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        with torch.no_grad():
+            ys = m(x.to(DEV))
+            ref = uo.forward("unet", uo.clone_state(sd0), x, train=(mode == "train"))
+        err = max((y.cpu() - r).abs().max().item() for y, r in zip(ys, ref))
+        assert err < 1e-3, (mode, err)
+    m.train()
+    preds = m(x.to(DEV))
+    loss, _, _ = loss_oracle.abc_loss(preds, [t.to(DEV) for t in tg], m.s)
+    loss.backward()
+    sd = uo.clone_state(sd0, requires_grad=True)
+    total, _, _ = loss_oracle.abc_loss(uo.forward("unet", sd, x, train=True), tg, sd["s"])
+    total.backward()
+    g, r = dict(m.named_parameters())["inc1.double_conv.0.weight"].grad.cpu(), sd["inc1.double_conv.0.weight"].grad
+    assert g.shape == (16, 3, 3, 3)
+    assert (g - r).norm().item() <= 2e-2 * r.norm().item(), ((g - r).norm().item(), r.norm().item())
 
 
 def test_fused_train_step_matches_oracle():
