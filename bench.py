@@ -159,6 +159,10 @@ def main():
         return launch_ranks(a)
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    # stdout carries ONE JSON line; anything libraries print meanwhile (gloo / RCCL banners) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # (testing hooks: ABC_BENCH_DEVICE pins every rank to one device and ABC_BENCH_BACKEND=gloo replaces RCCL, so that
@@ -284,8 +288,11 @@ def main():
     except Exception as e:  # noqa: BLE001
         if rank == 0:
             out["report_error"] = "%s: %s" % (type(e).__name__, e)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     if world > 1:
         dist.destroy_process_group()
 
