@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("w", vp), ("dst", vp), ("mode", i32), ("dtype_c", i32), ("Cout", i32), ("Cin", i32), ("kh", i32),
                 ("kw", i32), ("py", i32), ("px", i32), ("rows_pad", i32), ("red_pad", i32), ("red_total", i32),
-                ("red_off", i32), ("ck", i32)]
+                ("red_off", i32), ("ck", i32), ("rows_total", i32), ("rows_off", i32)]
 
 
 class BnFwdDesc(C.Structure):
@@ -154,7 +154,7 @@ SYMBOLS = {
     "abc_pack_item_fill": (i64, [vp, P(PackDesc), i64]),
     "abc_pack_batch": (C.c_int, [vp, i32, i64, vp]),
     "abc_bn_finalize_fwd": (C.c_int, [P(BnFwdDesc), vp]),
-    "abc_bn_finalize_fwd_batch": (C.c_int, [vp, i32, vp]),
+    "abc_bn_finalize_fwd_batch": (C.c_int, [vp, i32, i32, vp]),
     "abc_bn_finalize_bwd_batch": (C.c_int, [vp, i32, i32, vp]),
     "abc_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, f32, vp]),
     "abc_act_bwd_blocks": (C.c_int, [P(ActBwdDesc)]),
@@ -201,6 +201,7 @@ SYMBOLS = {
     "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),
+    "abc_concat_f32": (C.c_int, [vp, vp, i32, vp, vp]),
     "abc_counter_add_u32": (C.c_int, [vp, u32, vp]),
     "abc_pool_act": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_sizeof": (C.c_int, [C.c_int]),

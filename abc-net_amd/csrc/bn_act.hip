@@ -59,8 +59,10 @@ __device__ inline void bn_finalize_fwd_body(const abc_bn_fwd_desc& d, int pstrid
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const abc_bn_fwd_desc d) { bn_finalize_fwd_body(d, d.C); }
 // several BatchNorms (the eight heads') in one launch: blockIdx.y = layer
 constexpr int MAX_BNB = 8;
-struct BnFwdBatch { abc_bn_fwd_desc d[MAX_BNB]; };
-__global__ __launch_bounds__(256) void bn_finalize_fwd_batch_kernel(const BnFwdBatch bt) { bn_finalize_fwd_body(bt.d[blockIdx.y], bt.d[blockIdx.y].C); }
+struct BnFwdBatch { abc_bn_fwd_desc d[MAX_BNB]; int pstride; };
+__global__ __launch_bounds__(256) void bn_finalize_fwd_batch_kernel(const BnFwdBatch bt) {
+    bn_finalize_fwd_body(bt.d[blockIdx.y], bt.pstride > 0 ? bt.pstride : bt.d[blockIdx.y].C);
+}
 
 __global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float* scale,
                                float* shift, int C, float eps) {
@@ -446,12 +448,13 @@ extern "C" int abc_bn_finalize_fwd(const abc_bn_fwd_desc* d, abc_stream_t stream
 
 // n <= 8 BatchNorm finalisations in one launch (the heads').  bwd: pstride > 0 = the layers' partial sums are column
 // slices of ONE [nblk][2][pstride] buffer (each descriptor's `partial` points at its first column), 0 = own buffers.
-extern "C" int abc_bn_finalize_fwd_batch(const abc_bn_fwd_desc* descs, int32_t n, abc_stream_t stream) {
+extern "C" int abc_bn_finalize_fwd_batch(const abc_bn_fwd_desc* descs, int32_t n, int32_t pstride, abc_stream_t stream) {
     if (n < 1 || n > MAX_BNB) return abc_fail(ABC_EINVAL, "bn_finalize_fwd_batch: 1..8 layers");
     BnFwdBatch bt;
     int cmax = 0;
     for (int i = 0; i < n; ++i) { bt.d[i] = descs[i]; cmax = descs[i].C > cmax ? descs[i].C : cmax; if (descs[i].C < 1 || descs[i].nblk < 1) return abc_fail(ABC_EINVAL, "bn_finalize_fwd_batch: empty"); }
     for (int i = n; i < MAX_BNB; ++i) bt.d[i] = descs[0];
+    bt.pstride = pstride;
     hipLaunchKernelGGL(bn_finalize_fwd_batch_kernel, dim3(cmax, n), dim3(256), 0, (hipStream_t)stream, bt);
     return abc_check_launch("bn_finalize_fwd_batch");
 }

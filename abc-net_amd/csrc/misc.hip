@@ -65,7 +65,8 @@ __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunk
         } else {  // ConvTranspose2d dgrad: row = cin, reduce over cout, 9 taps
             if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
         }
-        dst[(((size_t)t * nch_total + ch_off + c) * d.rows_pad + n) * CK + k] = (CT)v;
+        const int rtot = d.rows_total > 0 ? d.rows_total : d.rows_pad;
+        dst[(((size_t)t * nch_total + ch_off + c) * rtot + d.rows_off + n) * CK + k] = (CT)v;
     }
 }
 
@@ -94,7 +95,8 @@ __device__ inline void pack_one(const PackItem& it, unsigned r) {
         if (n < (unsigned)d.Cin && rc < (unsigned)d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
     }
     const unsigned nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
-    const size_t o = (((size_t)t * nch_total + ch_off + c) * rows + n) * CK + k;
+    const unsigned rtot = d.rows_total > 0 ? (unsigned)d.rows_total : rows;
+    const size_t o = (((size_t)t * nch_total + ch_off + c) * rtot + (unsigned)d.rows_off + n) * CK + k;
     if (it.is_bf16) ((bf16*)d.dst)[o] = (bf16)v; else ((float*)d.dst)[o] = v;
 }
 
@@ -310,6 +312,28 @@ extern "C" int abc_nms_peaks(const abc_nms_desc* d, abc_stream_t stream) {
 }
 
 __global__ void counter_add_kernel(uint32_t* p, uint32_t inc) { *p += inc; }
+struct ConcatArgs { const float* src[16]; int32_t first[17]; };
+__global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a, int n, float* dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.first[n]) return;
+    int j = 0;
+    while (j + 1 < n && a.first[j + 1] <= i) ++j;
+    dst[i] = a.src[j][i - a.first[j]];
+}
+extern "C" int abc_concat_f32(const float* const* srcs, const int32_t* counts, int32_t n, float* dst, abc_stream_t stream) {
+    if (n < 1 || n > 16) return abc_fail(ABC_EINVAL, "concat_f32: 1..16 arrays");
+    ConcatArgs a;
+    a.first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (counts[i] < 0 || srcs[i] == nullptr) return abc_fail(ABC_EINVAL, "concat_f32: null / negative entry");
+        a.src[i] = srcs[i]; a.first[i + 1] = a.first[i] + counts[i];
+    }
+    for (int i = n; i < 16; ++i) { a.src[i] = srcs[0]; a.first[i + 1] = a.first[n]; }
+    if (a.first[n] == 0) return ABC_OK;
+    hipLaunchKernelGGL(concat_kernel, dim3(abc_cdiv(a.first[n], 256)), dim3(256), 0, (hipStream_t)stream, a, n, dst);
+    return abc_check_launch("concat_f32");
+}
+
 extern "C" int abc_counter_add_u32(uint32_t* p, uint32_t inc, abc_stream_t stream) {
     if (!p) return abc_fail(ABC_EINVAL, "counter_add: null");
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p, inc);

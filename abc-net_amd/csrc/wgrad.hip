@@ -84,7 +84,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    int id = blockIdx.x;
+    // blocks with equal (blockIdx.x % 8) share an XCD and its L2: give each XCD a contiguous range of logical ids, so that
+    // the nta x ntb workgroups of one split -- which re-read the same P / Q patches -- hit in L2 instead of going out again
+    int id = abc_xcd_remap(blockIdx.x, gridDim.x);
     const int bt = id % a.ntb; id /= a.ntb;
     const int at = id % a.nta; id /= a.nta;
     const int split = id;

@@ -166,8 +166,10 @@ class Engine:
     def _esz(self, dt):
         return 2 if dt == L.BF16 else 4
 
-    def emit_pack(self, wname, dst, mode, Cout, Cin, k, rows_pad, red_real, red_total=None, red_off=0, py=0, px=0):
+    def emit_pack(self, wname, dst, mode, Cout, Cin, k, rows_pad, red_real, red_total=None, red_off=0, py=0, px=0, rows_total=0,
+                  rows_off=0):
         d = L.PackDesc()
+        d.rows_total, d.rows_off = rows_total, rows_off
         d.w, d.dst, d.mode, d.dtype_c = self.P(wname), dst.data_ptr(), mode, self.dt
         d.Cout, d.Cin, d.kh, d.kw, d.py, d.px = Cout, Cin, k, k, py, px
         total = red_real if red_total is None else red_total
@@ -366,18 +368,23 @@ class Engine:
 
     # ------------------------------------------------------------------ layers
     def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None, stats_rows=2, force_stats=False, stat_out=None,
-                collect_fin=None):
+                collect_fin=None, shared=None):
         """conv (+bias) -> raw output into dst=(tensor, coef, H, W, ld, coff); BN stats/coefficients.
         stat_out = (mean, invstd) tensors to use instead of fresh ones (slices of a shared array: the heads);
-        collect_fin: a list -- the train-mode finalisation is appended as (desc, what) instead of being emitted"""
+        collect_fin: a list -- the train-mode finalisation is appended as (desc, what) instead of being emitted;
+        shared = (stats, nblk): the convolution itself was emitted by the caller as part of a wider one whose statistics
+        partials are [nblk][rows][ld] -- this layer's columns start at coff"""
         yt, coef, H, W, ld, coff = dst
         cin = src.C
         taps = taps_square(k)
         rows_pad = -(-cout // 32) * 32
-        wf = self.packed(len(taps), cin, rows_pad)
-        self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin)
-        stats, nblk = self.emit_conv(self.fwd_ops, src, wf, self.P(cname + ".bias"), yt, self.dt, H, W, ld, coff, cout, taps,
-                                     stats=self.train or force_stats, what="fwd " + cname, stats_rows=stats_rows)
+        if shared is not None:
+            stats, nblk = shared
+        else:
+            wf = self.packed(len(taps), cin, rows_pad)
+            self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin)
+            stats, nblk = self.emit_conv(self.fwd_ops, src, wf, self.P(cname + ".bias"), yt, self.dt, H, W, ld, coff, cout, taps,
+                                         stats=self.train or force_stats, what="fwd " + cname, stats_rows=stats_rows)
         rec = Rec(kind="conv", cname=cname, bname=bname, src=src, cin=cin, cout=cout, k=k, taps=taps, y=yt, H=H, W=W, ld=ld,
                   coff=coff, coef=coef, slope=slope)
         sc, sh, sl = coef
@@ -389,7 +396,7 @@ class Engine:
             rec.mean, rec.invstd = self.new((cout,), torch.float32), self.new((cout,), torch.float32, 1.0)
         if self.train:
             d = L.BnFwdDesc()
-            d.partial, d.nblk, d.C, d.count, d.rows = stats.data_ptr(), nblk, cout, float(self.B * H * W), stats_rows
+            d.partial, d.nblk, d.C, d.count, d.rows = stats.data_ptr() + (4 * coff if shared is not None else 0), nblk, cout, float(self.B * H * W), stats_rows
             d.gamma, d.beta = self.P(bname + ".weight"), self.P(bname + ".bias")
             d.scale, d.shift, d.mean, d.invstd = rec.scale.data_ptr(), rec.shift.data_ptr(), rec.mean.data_ptr(), rec.invstd.data_ptr()
             d.running_mean, d.running_var = self.Bf(bname + ".running_mean"), self.Bf(bname + ".running_var")
@@ -551,11 +558,17 @@ class Engine:
         # batch statistics of the eight heads' BatchNorms side by side (one act_bwd pass over all 8 x 128 channels)
         self.hmean, self.hinvstd = self.new((128 * nh,), torch.float32), self.new((128 * nh,), torch.float32, 1.0)
         batch_fin = nh <= 8 and not os.environ.get("ABC_NO_HEADS_BATCH")
+        # the eight conv1's (unet.py:66,116-118: the same 128-channel trunk into 8 x 128 channels) as ONE 128 -> 8 x 128
+        # convolution: the input halo tile is shared by the 8 n-blocks of a pixel tile (same XCD, its L2), and 8 x 768 tiles
+        # fill the 512 workgroup slots 12.0 times instead of 8 x 1.5
+        shared = None
+        if batch_fin and self.dt == L.BF16 and trunk.C == 128 and not os.environ.get("ABC_NO_HEADS_CONV1_MERGE"):
+            shared = self._heads_conv1_merged(trunk, h, w)
         for i, hc in enumerate(self.heads):
             p = "out_modules.%d" % i
             rec, f = self.conv_bn(p + ".conv1", p + ".bn", trunk, 128, 3, (self.hfeat, self.hcoef, h, w, 128 * nh, 128 * i), 0.01,
                                   stat_out=(self.hmean[128 * i:128 * (i + 1)], self.hinvstd[128 * i:128 * (i + 1)]),
-                                  collect_fin=head_fins if batch_fin else None)
+                                  collect_fin=head_fins if batch_fin else None, shared=shared)
             rec.is_head = True
             self.head_recs.append(rec)
             f.drop_p, f.drop_seed, f.drop_salt = self.drop_p, self.drop_seed, self.drop_salt
@@ -571,10 +584,30 @@ class Engine:
                 arr[i] = d
             self.keep.append(arr)
             lib, n = self.lib, len(head_fins)
-            self.fwd_ops.append((lambda _r, st, a=arr: lib.abc_bn_finalize_fwd_batch(a, n, st), None, "bn out_modules.*.bn", (),
+            pstride = 128 * nh if shared is not None else 0
+            self.fwd_ops.append((lambda _r, st, a=arr: lib.abc_bn_finalize_fwd_batch(a, n, pstride, st), None, "bn out_modules.*.bn", (),
                                  {"kernel": "bn", "flops": 0, "bytes": 0}))
         # (the eight conv1 launches above write the eight slices of hfeat; the eight 1x1 convolutions go as one launch)
         self.emit_heads_batch(self.fwd_ops, head_convs, 0, "fwd out_modules.*.conv2")
+
+    def _heads_conv1_merged(self, trunk: Src, h, w):
+        """pack the eight conv1 weights one below the other ([tap][chunk][8 x 128][CK]), gather their biases, emit the one
+        convolution into hfeat; returns (stats partials [nblk][2][8 x 128] or None, nblk)"""
+        nh = len(self.heads)
+        Ct = 128 * nh
+        taps = taps_square(3)
+        wf = self.packed(len(taps), 128, Ct)
+        for i in range(nh):
+            self.emit_pack("out_modules.%d.conv1.weight" % i, wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i)
+        bias_all = self.new((Ct,), torch.float32)
+        srcs = (C.c_void_p * nh)(*[self.P("out_modules.%d.conv1.bias" % i) for i in range(nh)])
+        counts = (C.c_int32 * nh)(*([128] * nh))
+        self.keep += [srcs, counts]
+        lib, bp = self.lib, bias_all.data_ptr()
+        self.pack_ops.append((lambda _r, st: lib.abc_concat_f32(srcs, counts, nh, bp, st), None, "gather out_modules.*.conv1.bias", (),
+                              {"kernel": "concat", "flops": 0, "bytes": 0}))
+        return self.emit_conv(self.fwd_ops, trunk, wf, bp, self.hfeat, self.dt, h, w, Ct, 0, Ct, taps, stats=self.train,
+                              what="fwd out_modules.*.conv1")
 
     # ------------------------------------------------------------------ backward plan
     def _bn_backward(self, ops, rec, same, pool, drop=None, defer=False):
@@ -721,9 +754,13 @@ class Engine:
         merged = None
         if self.dt == L.BF16 and not os.environ.get("ABC_NO_HEAD_FUSE") and not os.environ.get("ABC_NO_HEADS_BATCH") and nh <= 8:
             merged = self._heads_act_bwd_merged(ops, dfeat)
+        one_wgrad = merged is not None and not os.environ.get("ABC_NO_HEADS_WGRAD_MERGE") and \
+            self._heads_conv1_wgrad_merged(ops, merged, dyh, taps)
         for i, rec in enumerate(self.head_recs):
             drop = (self.drop_p, self.drop_seed) if self.drop_p > 0 else None
-            if merged is not None:
+            if one_wgrad:
+                pass
+            elif merged is not None:
                 ok = self.emit_wgrad(ops, merged[i], rec.src, 128, 128, taps, 1, rec.cname + ".weight", "wgrad " + rec.cname,
                                      dual=(rec.y, rec.ld, rec.coff, dyh.data_ptr() + 128 * i * dyh.element_size(), 128 * nh))
                 if not ok:
@@ -744,6 +781,63 @@ class Engine:
         dy_all = Src(dyh, self.dt, h, w, 128 * nh, 0, 128 * nh)
         self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
         self.trunk.producer.grad_same = (dtrunk, 128, 0)
+
+    def _heads_conv1_wgrad_merged(self, ops, merged, dyh, taps):
+        """The eight heads' conv1 weight gradients (unet.py:66, 8 x [128,128,3,3]) as ONE weight gradient with 8 x 128
+        a-channels: the eight share their Q operand (the trunk activation), their P operands sit side by side in g / hfeat,
+        so one launch of 8 x 2 tiles x 16 splits reads Q once per XCD, writes an eighth of the split-K slabs (16 instead
+        of 128 slabs per head) and runs 72 instead of 9 patches per workgroup.  The slab reduction scatters the eight
+        row blocks to the eight parameters' gradients (one batched launch).  False when the library does not serve the
+        fused BatchNorm-backward load for this descriptor (the caller then emits one launch per head)."""
+        nh = len(self.heads)
+        Ct = 128 * nh
+        r0 = self.head_recs[0]
+        q = r0.src
+        g0 = merged[0]
+        p = Src(g0.t, self.dt, g0.H, g0.W, Ct, 0, Ct, coef=g0.coef)
+        d = L.WgradDesc()
+        p.fill(d.p)
+        q.fill(d.q)
+        d.dtype_p, d.dtype_q, d.dtype_c = p.dt, q.dt, self.dt
+        gh, gw = p.lh()
+        d.B, d.Hg, d.Wg, d.Hq, d.Wq = self.B, gh, gw, gh, gw
+        d.cp_off, d.cq_off, d.Ca, d.Cb, d.stride = 0, q.coff, Ct, 128, 1
+        L.set_taps(d, taps)
+        d.p2, d.ld_p2, d.cp2_off, d.p_dual, d.p_out, d.ld_pout = self.hfeat.data_ptr(), Ct, 0, 1, dyh.data_ptr(), Ct
+        if not self.lib.abc_wgrad_fuses_apply(C.byref(d)):
+            return False
+        ca_pad, cb_pad = L.i32(), L.i32()
+        L.check(self.lib.abc_wgrad_pads(C.byref(d), C.byref(ca_pad), C.byref(cb_pad)), "wgrad_pads")
+        ca_pad, cb_pad = ca_pad.value, cb_pad.value
+        per_split = self.lib.abc_wgrad_blocks(C.byref(d))
+        npatch = self.B * (-(-gh // 8)) * (-(-gw // 16))
+        nsplit = max(1, min(max(1, npatch // 2), 256 // per_split))
+        d.nsplit = nsplit
+        need = nsplit * len(taps) * ca_pad * cb_pad
+        slabs = self.new((need,), torch.float32)
+        d.partial = slabs.data_ptr()
+        at_, bt_ = L.i32(), L.i32()
+        L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
+        esz = self._esz(self.dt)
+        npx = self.B * gh * gw
+        meta = {"kernel": "wgrad<%s,%s,%s,%dx%d,S1>" % (self._dn(p.dt), self._dn(q.dt), self._dn(self.dt), at_.value, bt_.value),
+                "flops": 2.0 * npx * Ct * 128 * len(taps),
+                # g + y_raw read, dY written, Q read once, the slabs written
+                "bytes": float(3 * npx * Ct * esz + npx * 128 * self._esz(q.dt) + need * 4)}
+        self._emit(ops, self.lib.abc_wgrad, d, "wgrad out_modules.*.conv1", meta=meta)
+        rarr = (L.WgradReduceDesc * nh)()
+        writes = []
+        for i, rec in enumerate(self.head_recs):
+            r = rarr[i]
+            r.partial = slabs.data_ptr() + 4 * 128 * i * cb_pad      # this head's 128 rows of every slab
+            r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad = nsplit, len(taps), 128, 128, ca_pad, cb_pad
+            r.dw, r.accumulate = self.G(rec.cname + ".weight"), 0
+            writes.append(rec.cname + ".weight")
+        self.keep.append(rarr)
+        lib = self.lib
+        ops.append((lambda _r, st, a=rarr: lib.abc_wgrad_reduce_batch(a, nh, st), None, "wgrad out_modules.*.conv1 reduce", tuple(writes),
+                    {"kernel": "wgrad_reduce_batch", "flops": 0, "bytes": float(need * 4 + Ct * 128 * len(taps) * 4)}))
+        return True
 
     def _heads_act_bwd_merged(self, ops, dfeat):
         """BN -> LeakyReLU -> Dropout backward of ALL heads as one pass over the 8 x 128 channels of hfeat / dfeat (their

@@ -220,7 +220,7 @@ class Trainer:
         st = stream.cuda_stream
         groups = [eng.pack_ops, eng.fwd_ops, None, eng.bwd_ops]
         acc = {}
-        by_op = os.environ.get("ABC_PROFILE_OPS")  # (diagnostics: one row per launch label instead of per kernel)
+        by_op = os.environ.get("ABC_BENCH_OPS")  # (diagnostics: one row per launch label instead of per kernel)
         for _ in range(iters):
             marks = []
             for ops in groups:

@@ -118,6 +118,10 @@ typedef struct abc_pack_desc {
                           gradient is ONE conv over the concatenated 8x128 channels) */
     int32_t red_off;   /* where this weight's reduction channels start in dst (multiple of CK) */
     int32_t ck;        /* K-chunk of dst: abc_conv_chunk(dtype_c, red_total) */
+    int32_t rows_total; /* 0, or the row count of the whole dst (>= rows_off + rows_pad): several weights may be packed one
+                          below the other along the ROW (output-channel) axis -- the 8 heads' conv1 (unet.py:66,116-118) run
+                          as ONE 128 -> 8 x 128 convolution over the shared trunk activation */
+    int32_t rows_off;  /* where this weight's rows start in dst */
 } abc_pack_desc;
 int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream);
 /* batched form: the caller builds a table of abc_pack_item_bytes()-sized entries with abc_pack_item_fill (host
@@ -139,8 +143,10 @@ typedef struct abc_bn_fwd_desc {
     float eps, momentum;
 } abc_bn_fwd_desc;
 int abc_bn_finalize_fwd(const abc_bn_fwd_desc* d, abc_stream_t stream);
-/* n <= 8 layers in one launch (the eight heads' BatchNorms, unet.py:67) */
-int abc_bn_finalize_fwd_batch(const abc_bn_fwd_desc* descs, int32_t n, abc_stream_t stream);
+/* n <= 8 layers in one launch (the eight heads' BatchNorms, unet.py:67).  pstride > 0: the layers' stat partials are column
+ * slices of ONE [nblk][rows][pstride] buffer (each descriptor's `partial` points at its first column: the heads' conv1
+ * run as one convolution); 0: own buffers of width C */
+int abc_bn_finalize_fwd_batch(const abc_bn_fwd_desc* descs, int32_t n, int32_t pstride, abc_stream_t stream);
 /* eval mode: coefficients from running stats (model.eval(): img2smiles2.py:49) */
 int abc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* scale, float* shift, int32_t C, float eps, abc_stream_t stream);
@@ -410,6 +416,9 @@ int abc_nhwc_to_nchw_f32(const float* src, int32_t ld, int32_t c_off, int32_t C,
 int abc_nchw_to_nhwc_f32(const float* src, int32_t C, int32_t B, int32_t H, int32_t W, float* dst, int32_t ld,
                          int32_t c_off, abc_stream_t stream);
 int abc_fill_f32(float* p, float v, int64_t n, abc_stream_t stream);
+/* dst = srcs[0][0:counts[0]] ++ srcs[1][0:counts[1]] ++ ... (n <= 16 device arrays; `srcs` / `counts` are HOST arrays read at
+ * call time): the eight heads' conv1 biases (unet.py:66) side by side for the one merged convolution */
+int abc_concat_f32(const float* const* srcs, const int32_t* counts, int32_t n, float* dst, abc_stream_t stream);
 /* *p += inc (one thread): the per-step dropout salt */
 int abc_counter_add_u32(uint32_t* p, uint32_t inc, abc_stream_t stream);
 

@@ -63,10 +63,13 @@ def test_engine_plan_builds_without_gpu():
     tr = Engine("unet", 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, lay, 2, 64, 64, "fp32", True, device="cpu")
     # (bf16: the eight heads' 1x1 convolutions are one batched launch, the fp32 parity mode launches them one by one; the
     #  training plan starts with the dropout-step counter)
-    # eval: the 34 BatchNorm coefficient refreshes ride with the weight packing, not in the forward plan
-    assert len(ev.pack_ops) == 34 + 1 and len(tr.pack_ops) == 1
-    # (train adds 34 BatchNorm finalisations, the heads' eight as one batched launch)
-    assert len(ev.bwd_ops) == 0 and len(ev.fwd_ops) + (34 - 7) + 7 + 1 == len(tr.fwd_ops) > 80 and len(tr.bwd_ops) > 200
+    # eval: the 34 BatchNorm coefficient refreshes ride with the weight packing, not in the forward plan; bf16 also gathers
+    # the eight conv1 biases of the heads for their ONE merged 128 -> 8 x 128 convolution
+    assert len(ev.pack_ops) == 34 + 1 + 1 and len(tr.pack_ops) == 1
+    assert sum(1 for op in ev.fwd_ops if "out_modules" in op[2] and "conv1" in op[2]) == 1
+    assert sum(1 for op in tr.fwd_ops if "out_modules" in op[2] and "conv1" in op[2]) == 8
+    # (train adds 34 BatchNorm finalisations, the heads' eight as one batched launch; fp32 keeps the 8 conv1 launches)
+    assert len(ev.bwd_ops) == 0 and len(ev.fwd_ops) + 7 + (34 - 7) + 7 + 1 == len(tr.fwd_ops) > 80 and len(tr.bwd_ops) > 200
     assert tr.fwd_ops[0][2] == "dropout step"
     assert sum(op[4]["flops"] for op in ev.fwd_ops) == sum(op[4]["flops"] for op in tr.fwd_ops)
     # every learnable tensor except the conv biases in front of a BatchNorm (exactly-zero gradient) and s

@@ -484,3 +484,58 @@ def test_colsum(lib, dt, case):
                            U.stream()), "colsum")
     torch.cuda.synchronize()
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-4
+
+
+def test_conv_rows_packed_side_by_side_and_concat(lib):
+    """abc_pack_desc.rows_total / rows_off + abc_concat_f32: three convolutions over the same input as ONE convolution whose
+    packed weight holds their rows one below the other (how the eight heads' conv1, unet.py:66,116-118, run), per-block
+    BatchNorm partials in one [nblk][2][3 x 128] buffer finalised with a column stride (abc_bn_finalize_fwd_batch)"""
+    dt = L.BF16
+    g = torch.Generator().manual_seed(77)
+    B, Cin, Cout, n, H, W = 2, 128, 128, 3, 24, 32
+    x = q(torch.randn((B, Cin, H, W), generator=g), dt)
+    ws = [torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5 for _ in range(n)]
+    bs = [torch.randn(Cout, generator=g) for _ in range(n)]
+    Ct = n * Cout
+    ck = lib.abc_conv_chunk(dt, Cin)
+    wp = torch.zeros(9 * Cin * Ct, dtype=torch.bfloat16, device=U.DEV)
+    keep = []
+    for i in range(n):
+        wd = ws[i].to(U.DEV)
+        keep.append(wd)
+        d = L.PackDesc()
+        d.w, d.dst, d.mode, d.dtype_c = wd.data_ptr(), wp.data_ptr(), 0, dt
+        d.Cout, d.Cin, d.kh, d.kw = Cout, Cin, 3, 3
+        d.rows_pad, d.red_pad, d.red_total, d.red_off, d.ck = Cout, Cin, Cin, 0, ck
+        d.rows_total, d.rows_off = Ct, Cout * i
+        L.check(lib.abc_pack_conv_weights(C.byref(d), U.stream()), "pack")
+    bd = [b.to(U.DEV) for b in bs]
+    bias_all = torch.zeros(Ct, device=U.DEV)
+    srcs = (C.c_void_p * n)(*[b.data_ptr() for b in bd])
+    counts = (C.c_int32 * n)(*([Cout] * n))
+    L.check(lib.abc_concat_f32(srcs, counts, n, bias_all.data_ptr(), U.stream()), "concat")
+    assert torch.equal(bias_all.cpu(), torch.cat(bs))
+    xd = U.nhwc(x, dt)
+    y, st = U.conv(lib, xd, dt, dt, B, H, W, Cin, 0, Cin, wp, bias_all, Ct, taps_square(3), H, W, stats=True)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, q(torch.cat(ws), dt), torch.cat(bs), padding=1)
+    got = U.to_nchw(y)
+    assert U.relerr(got, ref) < U.tol(dt), U.relerr(got, ref)
+    # the three layers' statistics from column slices of the one partial buffer
+    nblk = st.shape[0]
+    outs = [[torch.zeros(Cout, device=U.DEV) for _ in range(4)] for _ in range(n)]
+    gam = torch.ones(Cout, device=U.DEV)
+    bet = torch.zeros(Cout, device=U.DEV)
+    arr = (L.BnFwdDesc * n)()
+    for i in range(n):
+        f = arr[i]
+        f.partial, f.nblk, f.C, f.count, f.rows = st.data_ptr() + 4 * Cout * i, nblk, Cout, float(B * H * W), 2
+        f.gamma, f.beta = gam.data_ptr(), bet.data_ptr()
+        f.scale, f.shift, f.mean, f.invstd = (t.data_ptr() for t in outs[i])
+        f.eps, f.momentum = 1e-5, 0.1
+    L.check(lib.abc_bn_finalize_fwd_batch(arr, n, Ct, U.stream()), "bn_fwd_batch")
+    torch.cuda.synchronize()
+    for i in range(n):
+        r = ref[:, Cout * i:Cout * (i + 1)].double()
+        np.testing.assert_allclose(outs[i][2].cpu().numpy(), r.mean((0, 2, 3)).numpy(), atol=2e-2)
+        np.testing.assert_allclose(outs[i][3].cpu().numpy(), (1.0 / torch.sqrt(r.var((0, 2, 3), unbiased=False) + 1e-5)).numpy(), rtol=3e-2)
