@@ -1051,6 +1051,8 @@ class Engine:
             dz = self.new((B, H, W, Cc))
             du, dst = self.f32buf(B, H, W), self.f32buf(B, H, W, 2)
             d_avgz, d_maxz = self.f32buf(B, Cc), self.f32buf(B, Cc)
+            # (kept for the in-situ parity tests: every backward kernel's output against torch autograd on these tensors)
+            blk.bw = {"g": g, "dz": dz, "du": du, "dst": dst, "d_avgz": d_avgz, "d_maxz": d_maxz}
 
             def pix(blk=blk, g=g, dz=dz, du=du, dst=dst, d_avgz=d_avgz, d_maxz=d_maxz):
                 d = blk.pix()

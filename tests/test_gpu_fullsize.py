@@ -1,0 +1,182 @@
+"""GPU parity at the configurations the benchmark measures (BASELINE.json configs 2, 3 and 5), in the dtype it measures
+them in (bf16):
+
+  config 2 / 3: ONE train step of unet.py / unet2.py at 384x384, batch 16, bf16 -- loss, head logits and every
+                parameter's gradient against the fp32 ORACLE (CPU) on the same batch, same weights, same dropout mask;
+  config 5    : the img2smiles2.py heat-map path at 512x512, batch 64, bf16 -- logits and the NMS masks of a sample of
+                the batch against the oracle's eval forward + oracle NMS.
+
+bf16 cannot meet the 1e-3 fp32 gate (the reference itself moves by 0.3-0.5 in its train-mode logits under bf16
+autocast), so these tests hold the throughput mode to MEASURED bounds: tests/golden/
+bf16_deviation.json is the output of `python tests/test_gpu_fullsize.py --measure` on an MI355X (committed; it also
+carries, beside each number, the deviation of the ORACLE ITSELF run under torch.autocast(bfloat16) on the same batch),
+and a test fails when the HIP path deviates from the fp32 oracle by more than 1.5x what was measured -- or by more
+than the oracle's own autocast run does, where that is recorded.
+"""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import abcnet_amd  # noqa: E402,F401
+from abcnet_amd.synthetic import synthetic_images, synthetic_targets  # noqa: E402
+from oracle import loss_oracle, nms_oracle  # noqa: E402
+from oracle import unet_oracle as uo  # noqa: E402
+
+HEADS = uo.HEADS
+DEV = "cuda"
+PRE_BN_BIAS = ("double_conv.0.bias", "double_conv.3.bias", "conv1.bias")
+BOUNDS = os.path.join(HERE, "golden", "bf16_deviation.json")
+
+
+def _model(variant, dtype, dropout_p):
+    if variant == "unet2":
+        from abcnet_amd.unet2 import UNet
+    else:
+        from abcnet_amd.unet import UNet
+    m = UNet(1, HEADS, dtype=dtype, dropout_p=dropout_p)
+    m.load_state_dict(uo.filled_state(variant, 1, HEADS, seed=0))
+    return m.to(DEV)
+
+
+def _grad_stats(get, ref_sd):
+    """per-parameter relative L2 deviation of the gradient; returns (worst, median, name of worst, whole-model relative L2)"""
+    rels, num, den = [], 0.0, 0.0
+    for name, t in ref_sd.items():
+        if t.grad is None or name.endswith(PRE_BN_BIAS):
+            continue
+        ref = t.grad.double()
+        got = get(name).double().cpu()
+        e, n = (got - ref).norm().item(), ref.norm().item()
+        rels.append((e / (n + 1e-30), name))
+        num += e * e
+        den += n * n
+    rels.sort()
+    return rels[-1][0], rels[len(rels) // 2][0], rels[-1][1], (num / den) ** 0.5
+
+
+def measure_train(variant, with_autocast=False):
+    """one bf16 train step at the benchmark shape vs the fp32 oracle (and, optionally, the oracle under bf16 autocast)"""
+    from abcnet_amd.dropout import head_keep_masks
+    from abcnet_amd.train import Trainer
+    B, S = 16, 384
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    drop = 0.2 if variant == "unet" else 0.0      # unet2's heads have no Dropout (unet2.py:116-126)
+    m = _model(variant, "bf16", drop)
+    tr = Trainer(m, B, S, S, lr=0.0, use_graph=False)
+    masks = head_keep_masks(B, S // 4, S // 4, 8, tr.eng.dropout_seed(1), 0.2) if drop > 0 else None
+    tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    hip_loss = tr.loss_value()["total"]
+    hip_logits = [t.cpu().clone() for t in tr.eng.logits]
+
+    def oracle(autocast):
+        sd = uo.clone_state(uo.filled_state(variant, 1, HEADS, seed=0), requires_grad=True)
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                preds = uo.forward(variant, sd, x, train=True, dropout_masks=masks)
+            preds = [p.float() for p in preds]
+        else:
+            preds = uo.forward(variant, sd, x, train=True, dropout_masks=masks)
+        total, _, _ = loss_oracle.abc_loss(preds, tg, sd["s"])
+        total.backward()
+        return sd, total.item(), [p.detach() for p in preds]
+
+    sd, ref_loss, ref_logits = oracle(False)
+    worst, med, wname, whole = _grad_stats(lambda n: m.grad_of(n), sd)
+    out = {"loss_rel": abs(hip_loss - ref_loss) / abs(ref_loss), "loss_hip": hip_loss, "loss_oracle_fp32": ref_loss,
+           "logits_linf": max((a - b).abs().max().item() for a, b in zip(hip_logits, ref_logits)),
+           "grad_rel_l2_worst": worst, "grad_rel_l2_median": med, "grad_worst_param": wname, "grad_rel_l2_whole_model": whole}
+    if with_autocast:
+        sda, la, lga = oracle(True)
+        w2, m2, n2, wh2 = _grad_stats(lambda n: sda[n].grad, sd)
+        out["oracle_autocast"] = {"loss_rel": abs(la - ref_loss) / abs(ref_loss),
+                                  "logits_linf": max((a - b).abs().max().item() for a, b in zip(lga, ref_logits)),
+                                  "grad_rel_l2_worst": w2, "grad_rel_l2_median": m2, "grad_worst_param": n2,
+                                  "grad_rel_l2_whole_model": wh2}
+    return out
+
+
+SAMPLE = (0, 21, 42, 63)
+
+
+def measure_infer():
+    """config 5: eval forward + NMS at 512x512, batch 64, bf16; a sample of the batch against the oracle"""
+    from abcnet_amd.infer import InferenceRunner
+    B, S = 64, 512
+    x = synthetic_images(B, S, seed=7)
+    m = _model("unet", "bf16", 0.2)
+    run = InferenceRunner(m, B, S, S, use_graph=True)
+    run.load_batch(x.to(DEV))
+    run.step()
+    run.step()      # the second step is the captured graph
+    torch.cuda.synchronize()
+    idx = torch.tensor(SAMPLE)
+    with torch.no_grad():
+        ref = uo.forward("unet", uo.filled_state("unet", 1, HEADS, seed=0), x[idx], train=False)
+        ra, rb, rr, ro = nms_oracle.nms(ref[0], ref[4], ref[6], ref[7])
+    got = [t[idx.to(DEV)].cpu() for t in run.logits]
+    linf = max((a - b).abs().max().item() for a, b in zip(got, ref))
+    flips = lambda g, r: int((g[idx.to(DEV)].cpu() != r).sum().item())
+    # decisions of the device NMS on the DEVICE's logits equal the oracle NMS applied to those same logits: bit-exact
+    da, db, dr, do = nms_oracle.nms(got[0], got[4], got[6], got[7])
+    exact = (torch.equal(run.atom_mask[idx.to(DEV)].cpu(), da) and torch.equal(run.bond_mask[idx.to(DEV)].cpu(), db)
+             and torch.equal(run.omega_mask[idx.to(DEV)].cpu(), do) and torch.equal(run.rho_abs[idx.to(DEV)].cpu(), dr))
+    n_pix = len(SAMPLE) * (S // 4) ** 2
+    return {"logits_linf": linf, "atom_mask_flips": flips(run.atom_mask, ra), "bond_mask_flips": flips(run.bond_mask, rb),
+            "omega_mask_flips": flips(run.omega_mask, ro), "pixels": n_pix, "omega_entries": 60 * n_pix,
+            "atom_peaks_oracle": int(ra.sum().item()), "omega_peaks_oracle": int(ro.sum().item()),
+            "nms_on_device_logits_exact": bool(exact)}
+
+
+def _bounds():
+    with open(BOUNDS) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("variant", ["unet", "unet2"])
+def test_bf16_train_step_at_benchmark_config(variant):
+    b = _bounds()["train_" + variant]
+    got = measure_train(variant)
+    report = {k: got[k] for k in ("loss_rel", "logits_linf", "grad_rel_l2_worst", "grad_rel_l2_median", "grad_rel_l2_whole_model")}
+    for k, v in report.items():
+        assert v <= 1.5 * b[k] + 1e-12, (variant, k, v, b[k], got["grad_worst_param"])
+    # and never worse than what the reference arithmetic itself does under bf16 autocast (recorded beside the bound),
+    # for the quantities where that comparison is meaningful end to end
+    ac = b["oracle_autocast"]
+    assert got["loss_rel"] <= max(ac["loss_rel"], 1.5 * b["loss_rel"])
+    assert got["grad_rel_l2_whole_model"] <= max(ac["grad_rel_l2_whole_model"], 1.5 * b["grad_rel_l2_whole_model"])
+
+
+def test_bf16_inference_at_benchmark_config():
+    b = _bounds()["infer_unet"]
+    got = measure_infer()
+    assert got["nms_on_device_logits_exact"], "device NMS != oracle NMS on the device's own logits"
+    assert got["logits_linf"] <= 1.5 * b["logits_linf"], (got["logits_linf"], b["logits_linf"])
+    for k in ("atom_mask_flips", "bond_mask_flips", "omega_mask_flips"):
+        assert got[k] <= 1.5 * b[k] + 8, (k, got[k], b[k])
+
+
+if __name__ == "__main__":
+    if "--measure" in sys.argv:
+        import time
+        out = sys.argv[sys.argv.index("--measure") + 1] if len(sys.argv) > sys.argv.index("--measure") + 1 else BOUNDS
+        res = {"how": "python tests/test_gpu_fullsize.py --measure on an MI355X (bf16, the shapes of BASELINE.json configs 2, 3, 5); "
+                      "deviations are against the fp32 oracle on the same inputs; oracle_autocast = the oracle itself under "
+                      "torch.autocast('cpu', bfloat16) against its own fp32 run; host threads: %d" % torch.get_num_threads()}
+        for key, fn in (("infer_unet", measure_infer), ("train_unet", lambda: measure_train("unet", True)),
+                        ("train_unet2", lambda: measure_train("unet2", True))):
+            t0 = time.time()
+            res[key] = fn()
+            print(key, "%.1f s" % (time.time() - t0), json.dumps(res[key]), flush=True)
+            with open(out, "w") as f:
+                json.dump(res, f, indent=1)

@@ -570,3 +570,94 @@ def test_batched_heads_equal_one_by_one_launches(variant, monkeypatch):
             assert rel <= 1e-5, (name, rel)       # 1x1 convs and BN parameters of the heads: upstream of any bf16 re-rounding
         else:
             assert rel <= 1e-1, (name, rel)   # (worst seen: 2.4e-2 unet, 5.6e-2 unet2 -- the first block, ~60 bf16 roundings away)
+
+
+@pytest.mark.parametrize("prefix", ["dconv2", "dconv1", "up1.conv", "inc2", "down2.maxpool_conv.1"])
+def test_unet2_block_is_exact_in_situ(prefix):
+    """Flip-free parity of unet2's CBAM + residual block (unet2.py:6-74), every abc_cbam_* entry by its own output: one
+    fused step (fp32, lr = 0), then torch ops / autograd on the ENGINE's tensors of one block --
+      forward : ca (abc_cbam_channel_fwd), [mean, max] over channels (abc_cbam_spatial_stats), sa (abc_cbam_conv7_fwd),
+                relu(sa * ca * z + r) (abc_cbam_apply_fwd);
+      backward: g = dOut * [out > 0] and du (abc_cbam_bwd1), d[mean, max] + the 7x7 weight / bias gradients
+                (abc_cbam_conv7_bwd), the MLP gradients and the pool gradients (abc_cbam_bwd2 + abc_cbam_channel_bwd),
+                d(y2) after abc_cbam_bwd3 + BatchNorm backward, BN2's dgamma / dbeta.
+    Blocks with an identity residual (dconv2, dconv1, inc2), a 1x1 residual over the concat (up1.conv, 512 -> 256) and a
+    pooled consumer + pooled input (down2)."""
+    import torch.nn.functional as F
+    from abcnet_amd.train import Trainer
+    B, S = 2, 64
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    m = make_model(dropout_p=0.0, variant="unet2")
+    tr = Trainer(m, B, S, S, lr=0.0, use_graph=False)
+    tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    eng = tr.eng
+    blk = [u for k, u in eng.units2 if k == "blk" and u.prefix == prefix][0]
+    rec2 = blk.rec2
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    p = prefix + ".double_conv"
+    mlp = p + ".5.channel_attention.shared_MLP"
+    c7 = p + ".5.spatial_attention.conv2d"
+    C_, H, W = blk.cout, blk.H, blk.W
+
+    def nchw(t):
+        return t.float().permute(0, 3, 1, 2).contiguous()
+
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    y2 = leaf(nchw(rec2.y[..., rec2.coff:rec2.coff + C_]))
+    gamma, beta = leaf(sd[rec2.bname + ".weight"]), leaf(sd[rec2.bname + ".bias"])
+    w1, b1, w2, b2 = (leaf(sd[mlp + k]) for k in (".0.weight", ".0.bias", ".2.weight", ".2.bias"))
+    w7, b7 = leaf(sd[c7 + ".weight"]), leaf(sd[c7 + ".bias"])
+    rt, ld_r, c_r, pooled_r = blk.res
+    r_full = nchw(rt[..., c_r:c_r + C_])
+    if pooled_r:
+        r_full = F.max_pool2d(r_full, 2)
+    r = leaf(r_full)
+    z = F.batch_norm(y2, None, None, gamma, beta, training=True, eps=1e-5)
+    zc = (y2.detach() * rec2.scale.view(1, -1, 1, 1) + rec2.shift.view(1, -1, 1, 1))
+    assert (z.detach() - zc).abs().max().item() <= 2e-5 * zc.abs().max().item()
+
+    def mlp_f(v):
+        return F.linear(F.relu(F.linear(v, w1, b1)), w2, b2)
+
+    # (unet2.py:9-10,19-21: AdaptiveAvgPool2d(1) / AdaptiveMaxPool2d(1); unet2.py:31-33: torch.mean / torch.max over channels)
+    ca = torch.sigmoid(mlp_f(F.adaptive_avg_pool2d(z, 1).flatten(1)) + mlp_f(F.adaptive_max_pool2d(z, 1).flatten(1)))
+    o1 = ca[:, :, None, None] * z
+    st = torch.cat([torch.mean(o1, dim=1, keepdim=True), torch.max(o1, dim=1, keepdim=True)[0]], 1)
+    sa = torch.sigmoid(F.conv2d(st, w7, b7, padding=3))
+    out = F.relu(sa * o1 + r)
+
+    def close(got, ref, tol=2e-5, what=""):
+        err = (got.float() - ref.float()).abs().max().item()
+        assert err <= tol * ref.float().abs().max().item() + 1e-9, (prefix, what, err, ref.float().abs().max().item())
+
+    close(blk.ca, ca.detach(), what="ca")
+    close(blk.st.permute(0, 3, 1, 2), st.detach(), what="st")
+    close(blk.sa.unsqueeze(1), sa.detach(), what="sa")
+    got_out = nchw(blk.out[..., blk.coff_out:blk.coff_out + C_])
+    close(got_out, out.detach(), what="out")
+    # ---- backward: the engine's own d(out)
+    dOut = torch.zeros_like(out)
+    if blk.grad_same is not None:
+        t, ld, co = blk.grad_same
+        dOut = dOut + nchw(t[..., co:co + C_])
+    if blk.grad_pool is not None:
+        t, ld, co = blk.grad_pool
+        oo = got_out.detach().clone().requires_grad_(True)      # route through the max-pool of the ENGINE's output
+        F.max_pool2d(oo, 2).backward(nchw(t[..., co:co + C_]))
+        dOut = dOut + oo.grad
+    # decisions (relu mask) from the engine's own output, so that no last-bit difference can flip one
+    mask = (got_out > 0).float()
+    (sa * o1 + r).backward(dOut * mask)
+    bw = blk.bw
+    close(nchw(bw["g"]), dOut * mask, what="g")
+    close(nchw(bw["g"]), r.grad, what="d_residual")
+    close(nchw(bw["dz"]), y2.grad, tol=1e-4, what="d_y2")
+    close(m.grad_of(c7 + ".weight"), w7.grad, tol=1e-4, what="dw7")
+    close(m.grad_of(c7 + ".bias"), b7.grad, tol=1e-4, what="db7")
+    for k, t in ((".0.weight", w1), (".0.bias", b1), (".2.weight", w2), (".2.bias", b2)):
+        close(m.grad_of(mlp + k), t.grad, tol=1e-4, what="mlp" + k)
+    close(m.grad_of(rec2.bname + ".weight"), gamma.grad, tol=1e-4, what="dgamma2")
+    close(m.grad_of(rec2.bname + ".bias"), beta.grad, tol=1e-4, what="dbeta2")
