@@ -30,13 +30,13 @@ class ConvDesc(C.Structure):
                 ("Hout", i32), ("Wout", i32), ("ldy", i32), ("cout_off", i32), ("Cout", i32), ("Cout_pad", i32),
                 ("stride", i32), ("om", i32), ("oy0", i32), ("ox0", i32), ("ntaps", i32),
                 ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("stats_rows", i32), ("accumulate", i32),
-                ("planar_out", i32), ("ctot_out", i32)]
+                ("planar_out", i32), ("ctot_out", i32), ("out_act", i32), ("out_slope", f32)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [("w", vp), ("dst", vp), ("mode", i32), ("dtype_c", i32), ("Cout", i32), ("Cin", i32), ("kh", i32),
                 ("kw", i32), ("py", i32), ("px", i32), ("rows_pad", i32), ("red_pad", i32), ("red_total", i32),
-                ("red_off", i32), ("ck", i32), ("rows_total", i32), ("rows_off", i32)]
+                ("red_off", i32), ("ck", i32), ("rows_total", i32), ("rows_off", i32), ("row_scale", vp)]
 
 
 class BnFwdDesc(C.Structure):
@@ -157,6 +157,7 @@ SYMBOLS = {
     "abc_bn_finalize_fwd_batch": (C.c_int, [vp, i32, i32, vp]),
     "abc_bn_finalize_bwd_batch": (C.c_int, [vp, i32, i32, vp]),
     "abc_bn_eval_coeffs": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, f32, vp]),
+    "abc_bn_eval_fold": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, f32, vp]),
     "abc_act_bwd_blocks": (C.c_int, [P(ActBwdDesc)]),
     "abc_act_bwd": (C.c_int, [P(ActBwdDesc), vp]),
     "abc_bn_finalize_bwd": (C.c_int, [P(BnBwdDesc), vp]),

@@ -73,6 +73,15 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] - rm[c] * sc;
 }
 
+__global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, const float* cb, float* scale,
+                                    float* bias_out, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    bias_out[c] = ((cb ? cb[c] : 0.f) - rm[c]) * sc + beta[c];
+}
+
 __device__ inline void bn_finalize_bwd_body(const abc_bn_bwd_desc& d, int pstride) {
     __shared__ double sm[4];
     const int c = blockIdx.x;
@@ -475,6 +484,13 @@ extern "C" int abc_bn_eval_coeffs(const float* gamma, const float* beta, const f
     hipLaunchKernelGGL(bn_eval_kernel, dim3(abc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
                        running_var, scale, shift, C, eps);
     return abc_check_launch("bn_eval_coeffs");
+}
+
+extern "C" int abc_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                const float* conv_bias, float* scale, float* bias_out, int32_t C, float eps, abc_stream_t stream) {
+    hipLaunchKernelGGL(bn_eval_fold_kernel, dim3(abc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, conv_bias, scale, bias_out, C, eps);
+    return abc_check_launch("bn_eval_fold");
 }
 
 extern "C" int abc_bn_finalize_bwd(const abc_bn_bwd_desc* d, abc_stream_t stream) {

@@ -47,6 +47,7 @@ struct FastK {
     int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS, magic;
     int tiles_x, tiles_y, nblocks_n, ntiles;
     int sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, stats_rows, accumulate, b_static, stg_off, red_off, dbg, stagger;
+    int out_act; float out_slope;   // epilogue activation (BatchNorm folded into the weights: eval mode)
     unsigned bytesA, bytesW;
     long long* prof;  // debugging: per-workgroup phase timestamps (null in production)
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
@@ -145,9 +146,23 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     };
 
     __syncthreads();  // tap offsets + coefficient table visible
-
     bool first_tile = true;
-    for (int tile = abc_xcd_remap(blockIdx.x, gridDim.x); tile < a.ntiles; tile += gridDim.x) {
+    // tile of this workgroup in round k (-1: none).  Full rounds: logical id + k * grid (XCD-contiguous ids).  The last,
+    // partial round is dealt out in equal contiguous runs per XCD (the grid of a persistent launch is a multiple of 8), so
+    // that it keeps all eight XCDs busy instead of filling the first ones.
+    const int lid = abc_xcd_remap(blockIdx.x, gridDim.x);
+    auto tile_of = [&](int k) -> int {
+        const int G = (int)gridDim.x, base = k * G;
+        if (base + G <= a.ntiles) return base + lid;
+        const int R = a.ntiles - base;
+        if (R <= 0) return -1;
+        if (G & 7) return lid < R ? base + lid : -1;
+        const int per = G >> 3, x = lid / per, i = lid - x * per;
+        const int q = R >> 3, rem = R & 7;
+        const int cnt = q + (x < rem ? 1 : 0), b0 = x * q + (x < rem ? x : rem);
+        return i < cnt ? base + b0 + i : -1;
+    };
+    for (int round = 0, tile = tile_of(0); tile >= 0; tile = tile_of(++round)) {
         int id = tile;
         const int nb = id % a.nblocks_n; id /= a.nblocks_n;
         const int mblock = id;
@@ -169,7 +184,9 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 
         // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile).
         // Persistent (resident-weight) workgroups prefetched this tile's halo during the previous tile.
-        if (!STATIC || first_tile) {
+        // (WD workgroups are persistent too when there are more tiles than workgroup slots: the next tile's first halo chunk
+        //  is issued during the last chunk of this tile, see the main loop)
+        if (!(STATIC || WD != 0) || first_tile) {
             apre.setup(gA, a.RS, PS, b, iy0, ix0, a.cin_off, tid);
             apre.issue(rsA, 0u);
         }
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         const unsigned chunk_stride = (unsigned)(a.Cout_pad * CK) * (unsigned)sizeof(CT);
         // (the wave's n-offset sits in the VGPR part: everything in the scalar offset must be provably wave-uniform, or
         //  the compiler wraps every load in a readfirstlane loop)
-        const unsigned bq_voff = (unsigned)((wn * TN * 32 + r) * CKB + h * LHB);
+        const unsigned bq_voff = (a.dbg & 128) ? 0u : (unsigned)((wn * TN * 32 + r) * CKB + h * LHB);
         auto bq_load = [&](int slot, int c, int t) {
             const unsigned soff = w_n0 + (unsigned)t * tap_stride + (unsigned)c * chunk_stride;
 #pragma unroll
@@ -230,8 +247,8 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         if constexpr (STATIC) {
             // narrow layers are bound by the latency of one tile (10 KB in, 8 KB out, 18 MFMAs per wave): start the
             // next tile's halo now, it lands under this tile's MFMAs and stores
-            const int nt = tile + (int)gridDim.x;
-            if (nt < a.ntiles) {
+            const int nt = tile_of(round + 1);
+            if (nt >= 0) {
                 int id2 = nt / a.nblocks_n;
                 const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
                 const int ty2 = id2 % a.tiles_y; id2 /= a.tiles_y;
@@ -249,7 +266,20 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
             for (int c = 0; c < a.nchunks; ++c) {
                 const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
                 const bool more = c + 1 < a.nchunks;
-                if (more) apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
+                if (more) {
+                    apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
+                } else {
+                    // last chunk: the staging registers are free -> the NEXT tile's first halo chunk lands under this
+                    // chunk's MFMAs and the epilogue (a workgroup's prologue measured 5 of its 30 us, with no MFMA issued)
+                    const int nt = tile_of(round + 1);
+                    if (nt >= 0) {
+                        int id2 = nt / a.nblocks_n;
+                        const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
+                        const int ty2 = id2 % a.tiles_y; id2 /= a.tiles_y;
+                        apre.setup(gA, a.RS, PS, id2, ty2 * (2 * MT) * STRIDE + a.dy_min, tx2 * 16 * STRIDE + a.dx_min, a.cin_off, tid);
+                        apre.issue(rsA, 0u);
+                    }
+                }
                 frag_t fa0[TM], fa1[TM];
                 // (tap offsets from the kernel arguments: scalar registers, no LDS round trip in front of the fragment reads)
                 {
@@ -422,7 +452,8 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     for (int k = 0; k < 16; ++k) {
                         const float v = acc[i][j][k] + bv[j];
                         s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
-                        *(OutT*)(wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT)) = (OutT)v;
+                        const float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                        *(OutT*)(wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT)) = (OutT)vo;
                     }
                 }
                 lds_wave_sync();
@@ -460,7 +491,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
                     const float v = acc[i][j][k] + bv[j];
                     if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
-                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)v;
+                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)(a.out_act ? fmaxf(v, a.out_slope * v) : v);
                 }
             }
             lds_wave_sync();
@@ -707,7 +738,9 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->tiles_x = abc_cdiv(d->Wg, 16);
     g->tiles_y = abc_cdiv(d->Hg, prow);
     g->ntiles = g->nbn * g->tiles_x * g->tiles_y * d->B;
-    g->nwg = g->b_static ? (g->ntiles < 768 ? g->ntiles : 768) : g->ntiles;   // persistent: three workgroups per CU
+    // persistent workgroups: three per CU with resident weights; two per CU (512 slots) on the weights-direct loop when
+    // there are more tiles than slots (measured on one box, same run: 6144 tiles 482 -> 463 us, 5632 tiles 473 -> 448 us)
+    g->nwg = g->b_static ? (g->ntiles < 768 ? g->ntiles : 768) : ((g->wd && g->ntiles > 512 && !getenv("ABC_CONV_NOPERSIST")) ? 512 : g->ntiles);
     g->eligible = 1;
     return ABC_OK;
 }
@@ -726,6 +759,7 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     k.sA_bytes = g.sA_bytes; k.a_bufs = g.a_bufs; k.sB_off = g.a_bufs * g.sA_bytes; k.sB_bytes = g.sB_bytes;
     k.tap_off = g.tap_off; k.coef_off = g.coef_off; k.cstride = g.cstride; k.stats_rows = d->stats_rows;
     k.accumulate = d->accumulate; k.b_static = g.b_static; k.stg_off = g.stg_off; k.red_off = g.red_off;
+    k.out_act = d->out_act; k.out_slope = d->out_slope;
     { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     k.prof = g_prof;
     { const char* e = getenv("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }

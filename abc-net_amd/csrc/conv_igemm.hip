@@ -39,7 +39,8 @@ struct ConvK {
     int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad;
     int om, oy0, ox0;
     int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS;
-    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles, b_static, stg_off, stats_rows, accumulate, magic;
+    int tiles_x, tiles_y, nblocks_n, sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, planar_out, ctot_out, fast_a, dbg, ntiles, b_static, stg_off, stats_rows, accumulate, magic, out_act;
+    float out_slope;
     unsigned bytesA, bytesW;
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
 };
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
                     const int gy = cur_gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = cur_gx0 + (rit & 15);
                     const float v = acc[i][j][k] + bv[j];
                     if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
-                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)v;
+                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)(a.out_act ? fmaxf(v, a.out_slope * v) : v);
                 }
             }
             __syncthreads();
@@ -554,7 +555,8 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     k.tiles_x = g.tiles_x; k.tiles_y = g.tiles_y; k.nblocks_n = g.nbn; k.sA_bytes = g.sA_bytes; k.a_bufs = g.a_bufs;
     k.sB_off = g.a_bufs * g.sA_bytes; k.coef_off = g.coef_off; k.cstride = g.cstride;
     k.sB_bytes = g.sB_bytes; k.tap_off = g.tap_off; k.fast_a = g.fast_a; k.ntiles = g.grid; k.b_static = g.b_static; k.stg_off = g.stg_off;
-    k.stats_rows = d->stats_rows; k.accumulate = d->accumulate;
+    k.stats_rows = d->stats_rows; k.accumulate = d->accumulate; k.out_act = d->out_act; k.out_slope = d->out_slope;
+    if (d->out_act && d->planar_out) return abc_fail(ABC_EUNSUPPORTED, "conv: out_act needs an NHWC output");
     if (d->accumulate && d->planar_out) return abc_fail(ABC_EUNSUPPORTED, "conv: accumulate needs an NHWC output");
     k.magic = 65536 / g.HW + 1;
     k.bytesA = (unsigned)((int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4));

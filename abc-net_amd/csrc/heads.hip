@@ -255,7 +255,7 @@ int abc_head_fwd_ok(const abc_conv_desc* d) {
     if (getenv("ABC_CONV_NOHEAD")) return 0;
     if (!d->planar_out || d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
     if (d->Cin != 128 || d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_F32) return 0;
-    if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr) return 0;
+    if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr || d->out_act) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
     if ((d->src.ldx % 8) || (d->cin_off % 8) || d->Cout_pad % 32) return 0;
     // (all offsets in the kernel are unsigned 32-bit bytes: a batch-64 512x512 feature buffer of 8 x 128 channels is 2^31)
@@ -274,7 +274,7 @@ int abc_head_dgrad_ok(const abc_conv_desc* d) {
     if (getenv("ABC_CONV_NOHEAD")) return 0;
     if (!d->src.planar || d->dtype_in != ABC_F32 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16 || d->planar_out) return 0;
     if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
-    if (d->Cout != 128 || d->Cout_pad != 128 || d->cin_off != 0 || d->src.ctot != d->Cin || d->bias != nullptr || d->stats != nullptr || d->accumulate) return 0;
+    if (d->Cout != 128 || d->Cout_pad != 128 || d->cin_off != 0 || d->src.ctot != d->Cin || d->bias != nullptr || d->stats != nullptr || d->accumulate || d->out_act) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
     if ((d->ldy % 8) || (d->cout_off % 8)) return 0;
     return (int64_t)d->B * d->Cin * d->Hg * d->Wg * 4 < (int64_t(1) << 31);

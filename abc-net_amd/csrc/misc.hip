@@ -65,6 +65,7 @@ __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunk
         } else {  // ConvTranspose2d dgrad: row = cin, reduce over cout, 9 taps
             if (n < d.Cin && rc < d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
         }
+        if (d.row_scale != nullptr && (d.mode == 0 || d.mode == 2) && n < d.Cout) v *= d.row_scale[n];
         const int rtot = d.rows_total > 0 ? d.rows_total : d.rows_pad;
         dst[(((size_t)t * nch_total + ch_off + c) * rtot + d.rows_off + n) * CK + k] = (CT)v;
     }
@@ -94,6 +95,7 @@ __device__ inline void pack_one(const PackItem& it, unsigned r) {
     } else {
         if (n < (unsigned)d.Cin && rc < (unsigned)d.Cout) v = d.w[((size_t)n * d.Cout + rc) * 9 + t];
     }
+    if (d.row_scale != nullptr && (d.mode == 0 || d.mode == 2) && n < (unsigned)d.Cout) v *= d.row_scale[n];
     const unsigned nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
     const unsigned rtot = d.rows_total > 0 ? (unsigned)d.rows_total : rows;
     const size_t o = (((size_t)t * nch_total + ch_off + c) * rtot + (unsigned)d.rows_off + n) * CK + k;

@@ -17,7 +17,8 @@ struct StemK {
     const float* bias;
     void* y;
     float* stats;
-    int B, H, W, Cout, Cout_pad, ldy, cout_off, ntaps, dy_min, dy_max, rows_per_wg;
+    int B, H, W, Cout, Cout_pad, ldy, cout_off, ntaps, dy_min, dy_max, rows_per_wg, out_act;
+    float out_slope;
     int8_t ty[25], tx[25];
 };
 
@@ -79,6 +80,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemK a) {
             }
 #pragma unroll
             for (int j = 0; j < CPT; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            if (a.out_act) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) v[j] = fmaxf(v[j], a.out_slope * v[j]);
+            }
             OutT* dst = yo + ((size_t)row * a.W + x0) * a.ldy + a.cout_off + cg * CPT;
             if constexpr (CPT == 4) {
                 if constexpr (sizeof(OutT) == 2) {
@@ -153,7 +158,7 @@ int abc_conv_stem_launch(const abc_conv_desc* d, abc_stream_t stream) {
     StemK k;
     k.x = (const float*)d->src.x; k.w = d->w; k.bias = d->bias; k.y = d->y; k.stats = d->stats;
     k.B = d->B; k.H = d->Hg; k.W = d->Wg; k.Cout = d->Cout; k.Cout_pad = d->Cout_pad; k.ldy = d->ldy; k.cout_off = d->cout_off;
-    k.ntaps = d->ntaps; k.rows_per_wg = STEM_ROWS;
+    k.ntaps = d->ntaps; k.rows_per_wg = STEM_ROWS; k.out_act = d->out_act; k.out_slope = d->out_slope;
     int dymin = 127, dymax = -127;
     for (int t = 0; t < d->ntaps; ++t) { dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax; }
     k.dy_min = dymin; k.dy_max = dymax;

@@ -88,7 +88,7 @@ class Rec:
 
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
-                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD):
+                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False):
         if variant not in ("unet", "unet2"):
             raise NotImplementedError("variant %r" % variant)
         if H % 32 or W % 32:
@@ -99,6 +99,12 @@ class Engine:
         self.lib = L.load()
         self.variant, self.heads, self.B, self.H, self.W = variant, list(heads), B, H, W
         self.train = train
+        # eval-mode graph with every BatchNorm folded into the convolution in front of it: the weights are
+        # packed times gamma / sqrt(running_var + eps), the bias becomes (b - running_mean) * that + beta, the conv's epilogue
+        # applies the activation, and every consumer loads a finished tensor with the identity transform
+        self.fold = bool(fold_bn)
+        if self.fold and (train or variant != "unet"):
+            raise ValueError("fold_bn is the eval-mode graph of unet.py")
         self.dt = L.BF16 if dtype == "bf16" else L.F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         self.dev = device
@@ -167,9 +173,10 @@ class Engine:
         return 2 if dt == L.BF16 else 4
 
     def emit_pack(self, wname, dst, mode, Cout, Cin, k, rows_pad, red_real, red_total=None, red_off=0, py=0, px=0, rows_total=0,
-                  rows_off=0):
+                  rows_off=0, row_scale=None):
         d = L.PackDesc()
         d.rows_total, d.rows_off = rows_total, rows_off
+        d.row_scale = row_scale
         d.w, d.dst, d.mode, d.dtype_c = self.P(wname), dst.data_ptr(), mode, self.dt
         d.Cout, d.Cin, d.kh, d.kw, d.py, d.px = Cout, Cin, k, k, py, px
         total = red_real if red_total is None else red_total
@@ -184,9 +191,12 @@ class Engine:
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
                   grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
-                  accumulate=False, collect=None):
-        """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch"""
+                  accumulate=False, collect=None, out_slope=None):
+        """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch;
+        out_slope: not None -> the epilogue stores max(v, out_slope * v) (folded-BatchNorm eval graph)"""
         d = L.ConvDesc()
+        if out_slope is not None:
+            d.out_act, d.out_slope = 1, out_slope
         src.fill(d.src)
         d.w, d.bias, d.y = w.data_ptr(), bias, y.data_ptr()
         d.stats = None
@@ -378,6 +388,8 @@ class Engine:
         cin = src.C
         taps = taps_square(k)
         rows_pad = -(-cout // 32) * 32
+        if self.fold:
+            return self._conv_bn_folded(cname, bname, src, cout, k, dst, slope, shared)
         if shared is not None:
             stats, nblk = shared
         else:
@@ -418,6 +430,32 @@ class Engine:
         self.recs.append(rec)
         out = Src(yt, self.dt, H, W, ld, coff, cout, coef=coef, producer=rec)
         return rec, out
+
+    def _fold_coeffs(self, cname, bname, cout, scale_t, bias_t):
+        """pack-time op: scale_t = gamma / sqrt(running_var + eps), bias_t = (conv bias - running_mean) * scale_t + beta"""
+        lib = self.lib
+        a = (self.P(bname + ".weight"), self.P(bname + ".bias"), self.Bf(bname + ".running_mean"), self.Bf(bname + ".running_var"),
+             self.P(cname + ".bias"), scale_t.data_ptr(), bias_t.data_ptr(), cout, BN_EPS)
+        self.pack_ops.append((lambda _r, st, a=a: lib.abc_bn_eval_fold(*a, st), None, "bn-fold " + bname, (),
+                              {"kernel": "bn_fold", "flops": 0, "bytes": 0}))
+
+    def _conv_bn_folded(self, cname, bname, src, cout, k, dst, slope, shared):
+        """eval-mode conv + BatchNorm + activation as ONE convolution (see __init__): returns (rec, Src with no transform)"""
+        yt, coef, H, W, ld, coff = dst
+        cin = src.C
+        taps = taps_square(k)
+        rows_pad = -(-cout // 32) * 32
+        if shared is None:
+            fs, fb = self.new((cout,), torch.float32, 1.0), self.new((cout,), torch.float32)
+            self._fold_coeffs(cname, bname, cout, fs, fb)
+            wf = self.packed(len(taps), cin, rows_pad)
+            self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin, row_scale=fs.data_ptr())
+            self.emit_conv(self.fwd_ops, src, wf, fb.data_ptr(), yt, self.dt, H, W, ld, coff, cout, taps, what="fwd " + cname,
+                           out_slope=slope)
+        rec = Rec(kind="conv", cname=cname, bname=bname, src=src, cin=cin, cout=cout, k=k, taps=taps, y=yt, H=H, W=W, ld=ld,
+                  coff=coff, coef=None, slope=slope)
+        self.recs.append(rec)
+        return rec, Src(yt, self.dt, H, W, ld, coff, cout, coef=None, producer=rec)
 
     def double_conv(self, prefix, src, cout, k, dst_b=None):
         H, W = src.lh()
@@ -467,7 +505,7 @@ class Engine:
                 phases.append(wp)
         rec = Rec(kind="convT", cname=name + ".up", src=low, cin=cin, cout=half, H=Hs, W=Ws, ld=Ctot, coff=half, y=cat)
         self.recs.append(rec)
-        cat_src = Src(cat, self.dt, Hs, Ws, Ctot, 0, Ctot, coef=cat_coef, producer=("cat", None))
+        cat_src = Src(cat, self.dt, Hs, Ws, Ctot, 0, Ctot, coef=None if self.fold else cat_coef, producer=("cat", None))
         if self.variant == "unet2":
             cat_src.cat = (skip_producer, rec)
             self.units2.append(("convT", rec))
@@ -597,9 +635,19 @@ class Engine:
         Ct = 128 * nh
         taps = taps_square(3)
         wf = self.packed(len(taps), 128, Ct)
+        bias_all = self.new((Ct,), torch.float32)
+        if self.fold:
+            scale_all = self.new((Ct,), torch.float32, 1.0)
+            for i in range(nh):
+                p = "out_modules.%d" % i
+                self._fold_coeffs(p + ".conv1", p + ".bn", 128, scale_all[128 * i:128 * (i + 1)], bias_all[128 * i:128 * (i + 1)])
+                self.emit_pack(p + ".conv1.weight", wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i,
+                               row_scale=scale_all[128 * i:128 * (i + 1)].data_ptr())
+            self.emit_conv(self.fwd_ops, trunk, wf, bias_all.data_ptr(), self.hfeat, self.dt, h, w, Ct, 0, Ct, taps,
+                           what="fwd out_modules.*.conv1", out_slope=0.01)
+            return None, 0
         for i in range(nh):
             self.emit_pack("out_modules.%d.conv1.weight" % i, wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i)
-        bias_all = self.new((Ct,), torch.float32)
         srcs = (C.c_void_p * nh)(*[self.P("out_modules.%d.conv1.bias" % i) for i in range(nh)])
         counts = (C.c_int32 * nh)(*([128] * nh))
         self.keep += [srcs, counts]

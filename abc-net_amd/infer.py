@@ -3,8 +3,8 @@
     model.eval(); preds = model(imgs)                       (img2smiles2.py:56-59)
     3x3 / circular 3-tap local-max masks, |rho|             (img2smiles2.py:61-79)
 
-One step = eval-mode forward (running-statistics BatchNorm folded into the consumers' loads, no dropout) + the
-peak-NMS kernel, on a batch already resident in HBM, replayed from one hipGraph.  The weights do not change between
+One step = eval-mode forward (running-statistics BatchNorm folded into the convolution weights / biases at refresh()
+time, activations in the convolutions' epilogues, no dropout) + the peak-NMS kernel, on a batch already resident in HBM, replayed from one hipGraph.  The weights do not change between
 steps, so re-packing them and deriving the eval-mode BatchNorm coefficients happens in `refresh()`, not in the step;
 call it again after `load_state_dict`.  The SMILES assembly that follows in the reference (img2smiles2.py:104-344, RDKit) is out of
 scope: the step ends with the four mask / |rho| maps the decoder reads.
@@ -19,7 +19,11 @@ from . import _lib as L
 
 
 class InferenceRunner:
-    def __init__(self, model, batch, height, width, use_graph=True, device=None, extract=False, cap_atoms=512, cap_bonds=16384):
+    def __init__(self, model, batch, height, width, use_graph=True, device=None, extract=False, cap_atoms=512, cap_bonds=16384,
+                 fold_bn=None):
+        """fold_bn: run the eval graph with every BatchNorm folded into the convolution in front of it and the activation in
+        that convolution's epilogue (weights re-packed times gamma / sqrt(running_var + eps) by refresh()); default: on for
+        unet.py, off for unet2.py (whose CBAM reads the un-activated BatchNorm output)"""
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("InferenceRunner needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
@@ -32,7 +36,10 @@ class InferenceRunner:
         model.eval()
         with torch.cuda.device(dev):
             x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
-            self.eng = eng = model._engine_for(x0, False)
+            if fold_bn is None:
+                fold_bn = model.VARIANT == "unet"
+            self.fold_bn = bool(fold_bn)
+            self.eng = eng = model._engine_for(x0, False, fold_bn=self.fold_bn)
         lg = eng.logits
         self.atom_mask, self.bond_mask = torch.empty_like(lg[0]), torch.empty_like(lg[4])
         self.rho_abs, self.omega_mask = torch.empty_like(lg[6]), torch.empty_like(lg[7])

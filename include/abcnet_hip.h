@@ -88,6 +88,10 @@ typedef struct abc_conv_desc {
     int32_t planar_out;  /* 1: y is channel-planar f32 [B][ctot_out][Hout][Wout] (NCHW logits written directly by
                             the heads' 1x1 conv: the list forward() returns needs no layout pass); ldy ignored */
     int32_t ctot_out;
+    int32_t out_act;     /* 1: the epilogue stores max(v, out_slope * v) instead of v (v = result + bias): with BatchNorm folded into
+                            the weights / bias (eval mode: abc_pack_desc.row_scale, abc_bn_eval_fold) the output is the ACTIVATED
+                            tensor and its consumers load it with the identity transform; the statistics stay those of v */
+    float out_slope;     /* 0 = ReLU, 0.01 = LeakyReLU */
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
@@ -122,6 +126,8 @@ typedef struct abc_pack_desc {
                           below the other along the ROW (output-channel) axis -- the 8 heads' conv1 (unet.py:66,116-118) run
                           as ONE 128 -> 8 x 128 convolution over the shared trunk activation */
     int32_t rows_off;  /* where this weight's rows start in dst */
+    const float* row_scale; /* NULL, or one factor per output row (modes 0 and 2: per output channel): eval-mode BatchNorm folded
+                               into the convolution in front of it, w'[n][..] = w[n][..] * gamma[n] / sqrt(running_var[n] + eps) */
 } abc_pack_desc;
 int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream);
 /* batched form: the caller builds a table of abc_pack_item_bytes()-sized entries with abc_pack_item_fill (host
@@ -150,6 +156,12 @@ int abc_bn_finalize_fwd_batch(const abc_bn_fwd_desc* descs, int32_t n, int32_t p
 /* eval mode: coefficients from running stats (model.eval(): img2smiles2.py:49) */
 int abc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float* scale, float* shift, int32_t C, float eps, abc_stream_t stream);
+
+/* eval mode with the BatchNorm folded into the convolution in front of it (img2smiles2.py:49 inference graph): the per-row
+ * weight factor scale[c] = gamma / sqrt(running_var + eps) (-> abc_pack_desc.row_scale) and the folded bias
+ * bias_out[c] = (conv_bias[c] - running_mean[c]) * scale[c] + beta[c]; conv_bias may be NULL */
+int abc_bn_eval_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                     const float* conv_bias, float* scale, float* bias_out, int32_t C, float eps, abc_stream_t stream);
 
 /* Backward of [BN -> act -> (dropout) -> (maxpool)] in two passes (autograd of
  * unet.py:13-17,30,67-69):

@@ -109,13 +109,14 @@ def measure_train(variant, with_autocast=False):
 SAMPLE = (0, 21, 42, 63)
 
 
-def measure_infer():
-    """config 5: eval forward + NMS at 512x512, batch 64, bf16; a sample of the batch against the oracle"""
+def measure_infer(fold_bn=True):
+    """config 5: eval forward + NMS at 512x512, batch 64, bf16 (the BatchNorm-folded graph the benchmark runs); a sample of
+    the batch against the oracle"""
     from abcnet_amd.infer import InferenceRunner
     B, S = 64, 512
     x = synthetic_images(B, S, seed=7)
     m = _model("unet", "bf16", 0.2)
-    run = InferenceRunner(m, B, S, S, use_graph=True)
+    run = InferenceRunner(m, B, S, S, use_graph=True, fold_bn=fold_bn)
     run.load_batch(x.to(DEV))
     run.step()
     run.step()      # the second step is the captured graph
@@ -132,7 +133,7 @@ def measure_infer():
     exact = (torch.equal(run.atom_mask[idx.to(DEV)].cpu(), da) and torch.equal(run.bond_mask[idx.to(DEV)].cpu(), db)
              and torch.equal(run.omega_mask[idx.to(DEV)].cpu(), do) and torch.equal(run.rho_abs[idx.to(DEV)].cpu(), dr))
     n_pix = len(SAMPLE) * (S // 4) ** 2
-    return {"logits_linf": linf, "atom_mask_flips": flips(run.atom_mask, ra), "bond_mask_flips": flips(run.bond_mask, rb),
+    return {"fold_bn": bool(fold_bn), "logits_linf": linf, "atom_mask_flips": flips(run.atom_mask, ra), "bond_mask_flips": flips(run.bond_mask, rb),
             "omega_mask_flips": flips(run.omega_mask, ro), "pixels": n_pix, "omega_entries": 60 * n_pix,
             "atom_peaks_oracle": int(ra.sum().item()), "omega_peaks_oracle": int(ro.sum().item()),
             "nms_on_device_logits_exact": bool(exact)}
@@ -173,7 +174,7 @@ if __name__ == "__main__":
         res = {"how": "python tests/test_gpu_fullsize.py --measure on an MI355X (bf16, the shapes of BASELINE.json configs 2, 3, 5); "
                       "deviations are against the fp32 oracle on the same inputs; oracle_autocast = the oracle itself under "
                       "torch.autocast('cpu', bfloat16) against its own fp32 run; host threads: %d" % torch.get_num_threads()}
-        for key, fn in (("infer_unet", measure_infer), ("train_unet", lambda: measure_train("unet", True)),
+        for key, fn in (("infer_unet", measure_infer), ("infer_unet_unfolded", lambda: measure_infer(False)), ("train_unet", lambda: measure_train("unet", True)),
                         ("train_unet2", lambda: measure_train("unet2", True))):
             t0 = time.time()
             res[key] = fn()

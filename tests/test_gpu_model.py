@@ -367,7 +367,7 @@ def test_inference_runner_graph_matches_module_path():
     from abcnet_amd.infer import InferenceRunner
     m = make_model()
     m.eval()
-    run = InferenceRunner(m, 2, 128, 128, use_graph=True)
+    run = InferenceRunner(m, 2, 128, 128, use_graph=True, fold_bn=False)   # (the module path keeps BatchNorm on load: same arithmetic)
     for seed in (7, 8, 9):   # step 0 eager, step 1 captures, step 2 replays
         x = synthetic_images(2, 128, seed=seed)
         run.load_batch(x.to(DEV))
@@ -661,3 +661,43 @@ def test_unet2_block_is_exact_in_situ(prefix):
         close(m.grad_of(mlp + k), t.grad, tol=1e-4, what="mlp" + k)
     close(m.grad_of(rec2.bname + ".weight"), gamma.grad, tol=1e-4, what="dgamma2")
     close(m.grad_of(rec2.bname + ".bias"), beta.grad, tol=1e-4, what="dbeta2")
+
+
+@pytest.mark.parametrize("dtype,size,tol", [("fp32", 64, 1e-3), ("bf16", 128, 0.08)])
+def test_folded_inference_graph_matches_oracle(dtype, size, tol):
+    """the eval graph with every BatchNorm folded into the convolution in front of it (weights packed times
+    gamma / sqrt(running_var + eps), bias (b - running_mean) * that + beta, activation in the conv's epilogue, consumers load
+    finished tensors) gives the reference's eval forward (img2smiles2.py:49,56-59): fp32 within the 1e-3 gate, bf16 within
+    the bound of the un-folded bf16 graph; and the NMS on top is the oracle's NMS of these logits, bit for bit"""
+    from abcnet_amd.infer import InferenceRunner
+    B = 2
+    x = synthetic_images(B, size, seed=7)
+    m = make_model(dtype)
+    run = InferenceRunner(m, B, size, size, use_graph=True, fold_bn=True)
+    assert run.fold_bn and all(op[4]["kernel"] != "bn_eval" for op in run.eng.pack_ops)
+    run.load_batch(x.to(DEV))
+    run.step()
+    run.step()   # captured graph
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = uo.forward("unet", uo.filled_state("unet", 1, HEADS, seed=0), x, train=False)
+    worst = max((y.cpu() - r).abs().max().item() for y, r in zip(run.logits, ref))
+    assert worst < tol, worst
+    plain = InferenceRunner(m, B, size, size, use_graph=False, fold_bn=False)
+    plain.load_batch(x.to(DEV))
+    plain.step()
+    torch.cuda.synchronize()
+    dev = max((a - b).abs().max().item() for a, b in zip(run.logits, plain.logits))
+    assert dev < tol, dev
+    got = [t.cpu() for t in run.logits]
+    da, db, dr, do = nms_oracle.nms(got[0], got[4], got[6], got[7])
+    assert torch.equal(run.atom_mask.cpu(), da) and torch.equal(run.bond_mask.cpu(), db) and torch.equal(run.omega_mask.cpu(), do)
+    # new weights: refresh() re-folds
+    sd = uo.filled_state("unet", 1, HEADS, seed=3)
+    m.load_state_dict(sd)
+    run.refresh()
+    run.step()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref2 = uo.forward("unet", sd, x, train=False)
+    assert max((y.cpu() - r).abs().max().item() for y, r in zip(run.logits, ref2)) < tol
