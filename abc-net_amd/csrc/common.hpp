@@ -365,20 +365,66 @@ struct HaloFetch {
         const int n = (cvalid + NV - 1) / NV;
         return (n >= SEGS || (n & (n - 1))) ? SEGS : n;
     }
+    // live_segs() is a power of two (SEGS is, and fewer live segments are only used when their count is): every `/ live`
+    // and `% live` below is a shift / mask.  As runtime integer divisions (~20 VALU instructions each, per segment, per patch)
+    // the address arithmetic of one weight-gradient patch cost 2.4 us per workgroup -- more than its 72 MFMAs per wave.
+    static_assert((SEGS & (SEGS - 1)) == 0, "segments per pixel must be a power of two");
+    __device__ static inline int live_shift(int live) { return 31 - __builtin_clz((unsigned)live); }
 
-    __device__ inline void issue(__amdgpu_buffer_rsrc_t rs, const HaloGeom& g, int b, int iy0, int ix0, int c0, int tid_, int cvalid) {
+    // Two-phase form of issue(): prepare() computes every segment's byte offset (the address arithmetic, integer divisions
+    // included), fire() is NMAX buffer loads and nothing else.  A caller with several fetchers prepares ALL of them, then
+    // fires all of them: in the one-phase form hipcc, at ~250 VGPRs, computes the next offset in registers that an
+    // already-issued load is going to write and has to put `s_waitcnt vmcnt(N)` -- a full memory round trip -- between
+    // the loads of one batch (measured on the weight-gradient kernel: loads and MFMAs did not overlap at all).
+    unsigned voff[NMAX];
+    __device__ inline void prepare(const HaloGeom& g, int b, int iy0, int ix0, int c0, int tid_, int cvalid) {
         const int tid = abc_launder(tid_);
-        // live segments per pixel: with fewer valid channels than the tile is wide (and a power-of-two count) the threads
-        // are spread over the live segments only -- the padding is zeroed once by the caller and never touched
-        const int live = live_segs(cvalid);
-        const int part = tid % live;
+        const int live = live_segs(cvalid), lsh = live_shift(live);
+        const int part = tid & (live - 1);
         const int total = g.HH * g.HW * live;
         const int base = ((b * g.Hx + iy0) * g.Wx + ix0) * g.ldx + c0 + part * NV;
         inb = 0;
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) {
             const int sidx = tid + i * NTHR;
-            const int pix = sidx / live;
+            const int pix = sidx >> lsh;
+            const int hy = (pix * g.magic) >> 16, hx = pix - hy * g.HW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = sidx < total && part * NV < cvalid && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+            voff[i] = ok ? (unsigned)(base + (hy * g.Wx + hx) * g.ldx) * (unsigned)sizeof(InT) : 0x80000000u;
+            inb |= ok ? (1u << i) : 0u;
+        }
+    }
+    __device__ inline void fire(__amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) raw[i].ld(rs, voff[i]);
+    }
+    // the loads whose index (counted from `first` across a caller's fetchers) is congruent to `phase` modulo `nphase`:
+    // a batch spread over the K-steps of the MFMA block (all arguments compile-time constants after unrolling)
+    __device__ inline void fire_slice(__amdgpu_buffer_rsrc_t rs, int first, int phase, int nphase) {
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+            if ((first + i) % nphase == phase) raw[i].ld(rs, voff[i]);
+    }
+    __device__ inline void prepare_none() {
+        inb = 0;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) voff[i] = 0x80000000u;   // out of range: the loads return zeros, no memory traffic
+    }
+
+    __device__ inline void issue(__amdgpu_buffer_rsrc_t rs, const HaloGeom& g, int b, int iy0, int ix0, int c0, int tid_, int cvalid) {
+        const int tid = abc_launder(tid_);
+        // live segments per pixel: with fewer valid channels than the tile is wide (and a power-of-two count) the threads
+        // are spread over the live segments only -- the padding is zeroed once by the caller and never touched
+        const int live = live_segs(cvalid), lsh = live_shift(live);
+        const int part = tid & (live - 1);
+        const int total = g.HH * g.HW * live;
+        const int base = ((b * g.Hx + iy0) * g.Wx + ix0) * g.ldx + c0 + part * NV;
+        inb = 0;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) {
+            const int sidx = tid + i * NTHR;
+            const int pix = sidx >> lsh;
             const int hy = (pix * g.magic) >> 16, hx = pix - hy * g.HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             const bool ok = sidx < total && part * NV < cvalid && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
@@ -390,8 +436,8 @@ struct HaloFetch {
     // lcoef = LDS table [3][cstride] of (scale, shift, slope), index = channel relative to the workgroup's first one
     __device__ inline void commit(char* sA, int RS, int PS, const HaloGeom& g, const float* lcoef, int cstride, int tid_, int cvalid) {
         const int tid = abc_launder(tid_);
-        const int live = live_segs(cvalid);
-        const int part = tid % live;
+        const int live = live_segs(cvalid), lsh = live_shift(live);
+        const int part = tid & (live - 1);
         const int cch = part * NV;
         const int total = g.HH * g.HW * live;
         float sc[NV], sh[NV], sl[NV];
@@ -404,7 +450,7 @@ struct HaloFetch {
         for (int i = 0; i < NMAX; ++i) {
             const int sidx = tid + i * NTHR;
             if (sidx < total) {
-                const int pix = sidx / live;
+                const int pix = sidx >> lsh;
                 const int hy = (pix * g.magic) >> 16, hx = pix - hy * g.HW;
                 char* dst = sA + hy * RS + hx * PS + part * 16;
                 if constexpr (sizeof(InT) == sizeof(CT)) {

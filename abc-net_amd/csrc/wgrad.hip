@@ -159,14 +159,48 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
         const int ty_i = pid % a.tiles_y; pid /= a.tiles_y;
         b = pid; gy0 = ty_i * PROWS; gx0 = tx_i * 16;
     };
-    auto issue = [&](int patch) {
+    // SPREAD: the next patch's loads are not issued as one batch in front of the MFMA block but a few at a time between
+    // its K-steps.  A CU's memory pipeline holds far less than a patch (55 .. 87 KB from 8 waves): the waves of a batch sat
+    // in their load instructions until most of the data had come back, so loads and MFMAs never overlapped (ablations on the
+    // eight heads' merged weight gradient: loads only 193 us, MFMAs only 214 us, both 329 us, with the commit 571 us).
+    constexpr bool SPREAD = FAST && K3 && sizeof(CT) == 2 && !TS && ROWS >= 4;
+    auto prepare = [&](int patch, bool live) {
         int b, gy0, gx0;
         patch_origin(patch, b, gy0, gx0);
         if constexpr (FAST) {
-            pp.issue(rsP, gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
-            if constexpr (DUAL) pp2.issue(rsP2, gP2, b, gy0, gx0, a.cp2_off + ca0, tid, cvalP);
-            pq.issue(rsQ, gQ, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.cq_off + cb0, tid, cvalQ);
+            // all address arithmetic first (see HaloFetch::prepare)
+            if (live) {
+                pp.prepare(gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
+                if constexpr (DUAL) pp2.prepare(gP2, b, gy0, gx0, a.cp2_off + ca0, tid, cvalP);
+                pq.prepare(gQ, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.cq_off + cb0, tid, cvalQ);
+            } else {
+                pp.prepare_none();
+                if constexpr (DUAL) pp2.prepare_none();
+                pq.prepare_none();
+            }
         }
+    };
+    auto fire_all = [&]() {
+        if constexpr (FAST) {
+            __builtin_amdgcn_sched_barrier(0);
+            pp.fire(rsP);
+            if constexpr (DUAL) pp2.fire(rsP2);
+            pq.fire(rsQ);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // (over the FIRST half of the K-steps, so that the last load has the second half to come back in)
+    constexpr int NPH = ROWS / 2;
+    auto fire_slice = [&](int phase) {   // phase < NPH
+        if constexpr (FAST) {
+            pp.fire_slice(rsP, 0, phase, NPH);
+            if constexpr (DUAL) pp2.fire_slice(rsP2, NPF_P, phase, NPH);
+            pq.fire_slice(rsQ, DUAL ? 2 * NPF_P : NPF_P, phase, NPH);
+        }
+    };
+    auto issue = [&](int patch) {
+        prepare(patch, true);
+        fire_all();
     };
     auto commit = [&](int patch, char* buf) {
         int b, gy0, gx0;
@@ -176,9 +210,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
         if constexpr (FAST) {
             if constexpr (DUAL) {
                 constexpr int NV = Frag<CT>::NV;
-                const int SEGS = pp.live_segs(cvalP);   // same thread -> segment mapping as HaloFetch::issue
+                const int SEGS = pp.live_segs(cvalP);   // same thread -> segment mapping as HaloFetch::issue (a power of two)
+                const int ssh = pp.live_shift(SEGS);
                 const int lt = abc_launder(tid);
-                const int part = lt % SEGS, cch = part * NV;
+                const int part = lt & (SEGS - 1), cch = part * NV;
                 const bool chan = cch < cvalP;
                 float ka[NV], kb[NV], kc[NV];
 #pragma unroll
@@ -188,7 +223,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
                 for (int i = 0; i < NPF_P; ++i) {
                     const int sidx = lt + i * WTHR;
                     if (sidx < PROWS * 16 * SEGS) {
-                        const int pix = sidx / SEGS, hy = pix >> 4, hx = pix & 15;
+                        const int pix = sidx >> ssh, hy = pix >> 4, hx = pix & 15;
                         float v1[NV], v2[NV];
                         pp.raw[i].get(v1); pp2.raw[i].get(v2);
                         const bool in = chan && ((pp.inb >> i) & 1u);
@@ -224,11 +259,16 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
     for (int it = -1; it < 0 || patch < a.npatch; ++it, patch += a.nsplit) {
         const int next = patch + a.nsplit;
         const bool has_next = next < a.npatch;
-        if (has_next && !(a.dbg & 1)) issue(next);
+        if constexpr (SPREAD) {
+            prepare(has_next ? next : patch, has_next);
+            if (it < 0) fire_all();     // prologue: nothing to hide behind
+        } else {
+            if (has_next && !(a.dbg & 1)) issue(next);
+        }
         if (it >= 0 && !(a.dbg & 4)) {
             const char* sP = smem + ((a.nbuf == 2) ? (it & 1) * buf_bytes : 0);
             const char* sQ = sP + a.sP_bytes;
-#pragma unroll 1
+#pragma unroll(SPREAD ? ROWS : 1)
             for (int rr = 0; rr < ROWS; ++rr) {
                 const int row = row_lo + rr;
                 if constexpr (sizeof(CT) == 2 && FAST && K3) {
@@ -254,6 +294,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
 #pragma unroll
                         for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[t], acc[t], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (SPREAD) {
+                            if (rr < NPH) fire_slice(rr);   // (unconditional: without a next patch the offsets are out of range)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 } else if constexpr (sizeof(CT) == 2) {
                     // lane supplies the address of pixel k = 8h + 4q + ((lane&15)>>2), 4 channels
@@ -373,7 +417,15 @@ struct HeadK {
 };
 
 constexpr int HQ_PSW = 320;  // pixel stride of the [pixel][128 channel] bf16 LDS image (wgrad Q layout)
+constexpr int HP_RSW = 272;  // row stride of the [dL row][128 pixel] bf16 LDS image: 16 consecutive rows = 16 distinct 16-byte bank slots
+constexpr int HEAD_PBUF = 128 * HP_RSW, HEAD_QBUF = 128 * HQ_PSW;
+constexpr int HEAD_LDS = 2 * (HEAD_PBUF + HEAD_QBUF) + 3 * 128 * 4;
 
+// dL used to go global -> registers with each lane reading ITS row (256 contiguous bytes per chunk): 64 lanes = 64 rows
+// 36 KB apart, i.e. 64 cache lines touched per load instruction for 16 useful bytes each -- the kernel ran at the texture
+// addresser's line rate, 7.9 us per 128-pixel chunk (1.7 TB/s for all heads together).  Now both operands are loaded
+// coalesced (a wave instruction = two whole 512-byte rows of dL) one chunk ahead, transformed, and written to LDS as bf16:
+// dL as [row][pixel] (the A fragment of a K-step is one ds_read_b128), the features as [pixel][channel] (read transposed).
 __device__ inline void head_wgrad_body(const HeadK& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -383,10 +435,6 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
     if (split >= a.nsplit || mg * 4 >= a.mtiles) return;   // (batched launch: the grid is sized for the largest head)
     const int mt = mg * 4 + mi;
     const bool active = mt < a.mtiles;
-    const int co = mt * 32 + r;
-    const bool co_ok = active && co < a.hc;
-    const float psc = (co_ok && a.psc) ? a.psc[co] : 1.f, psh = (co_ok && a.psh) ? a.psh[co] : 0.f,
-                psl = (co_ok && a.psl) ? a.psl[co] : 1.f;
     const bool ptrans = a.psc != nullptr;
     const int c0 = (int)((long long)split * a.nchunks / a.nsplit), c1 = (int)((long long)(split + 1) * a.nchunks / a.nsplit);
 
@@ -394,26 +442,42 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
     // Q staging: 128 pixels x 16 segments of 8 channels over 512 threads -> 4 per thread, same channel segment always
     const int part = tid & 15, pix0 = tid >> 4;  // segment i: pixel pix0 + 32 i
     const bool qtrans = a.qsc != nullptr;
-    float* sCoef = (float*)(smem + 2 * 128 * HQ_PSW);  // [3][128]: re-read at every commit (registers go to the dL prefetch)
+    float* sCoef = (float*)(smem + 2 * (HEAD_PBUF + HEAD_QBUF));  // [3][128]
     if (qtrans && tid < 128) {
         sCoef[tid] = a.qsc[a.cq_off + tid]; sCoef[128 + tid] = a.qsh[a.cq_off + tid]; sCoef[256 + tid] = a.qsl[a.cq_off + tid];
+    }
+    // P staging: 128 rows x 32 segments of 4 pixels -> 8 per thread; segment i of a thread: row prow0 + 16 i, pixels 4 pseg ..
+    const int pseg = tid & 31, prow0 = tid >> 5;
+    float psc[8], psh[8], psl[8], rsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int co = mg * 128 + prow0 + 16 * i;
+        const bool ok = co < a.hc;
+        psc[i] = (ok && ptrans) ? a.psc[co] : 1.f; psh[i] = (ok && ptrans) ? a.psh[co] : 0.f; psl[i] = (ok && ptrans) ? a.psl[co] : 1.f;
+        rsum[i] = 0.f;
     }
     __syncthreads();
     const float dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const uint32_t dseed = a.drop_seed + ((a.drop_p > 0.f && a.drop_salt) ? *a.drop_salt : 0u);
-    u32x4 qreg[4];
+    // TWO chunks of prefetch in flight (two named register sets): with one, an iteration was the loaded HBM latency
+    // (~4 us for 96 KB per CU) plus the commit -- the 16 MFMAs per wave of a chunk hide nothing.  Loads are issued
+    // unconditionally (past the last chunk with an out-of-range offset: zeros, no traffic) so that vmcnt stays exact.
+    u32x4 qreg0[4], preg0[8], qreg1[4], preg1[8];
     const int CPI = a.HW / 128;  // chunks per image
-    u32x4 areg0[16], areg1[16];  // two sets (current / next chunk) x [K-step x 2]: lane (r, h) holds dL[co][64 h + 8 kk + j]
-    auto issue = [&](int c, u32x4 (&as)[16]) {
+    auto issue = [&](int c, u32x4 (&qreg)[4], u32x4 (&preg)[8]) {
+        const bool live = c < c1;
         const int b = c / CPI, pp0 = (c - b * CPI) * 128;
-        const unsigned qoff = (unsigned)(((unsigned)(c * 128 + pix0) * (unsigned)a.ldq + (unsigned)(a.cq_off + part * 8)) * 2u);
+        const unsigned qoff = live ? (unsigned)(((unsigned)(c * 128 + pix0) * (unsigned)a.ldq + (unsigned)(a.cq_off + part * 8)) * 2u) : 0x80000000u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, qoff + (unsigned)(i * 32 * a.ldq * 2), 0, 0);
-        const unsigned poff = co_ok ? (unsigned)((((unsigned)(b * a.hc + co)) * (unsigned)a.HW + (unsigned)(pp0 + 64 * h)) * 4u) : 0x80000000u;
+        for (int i = 0; i < 4; ++i) qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, live ? qoff + (unsigned)(i * 32 * a.ldq * 2) : qoff, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) as[k] = __builtin_amdgcn_raw_buffer_load_b128(rsP, poff + (unsigned)(k * 16), 0, 0);
+        for (int i = 0; i < 8; ++i) {
+            const int co = mg * 128 + prow0 + 16 * i;
+            const unsigned poff = (live && co < a.hc) ? (unsigned)((((unsigned)(b * a.hc + co)) * (unsigned)a.HW + (unsigned)(pp0 + 4 * pseg)) * 4u) : 0x80000000u;
+            preg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsP, poff, 0, 0);
+        }
     };
-    auto commit = [&](int c, char* sQ) {
+    auto commit = [&](int c, char* sP, char* sQ, const u32x4 (&qreg)[4], const u32x4 (&preg)[8]) {
         float qsc[8], qsh[8], qsl[8];
         if (qtrans) {
 #pragma unroll
@@ -436,6 +500,22 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
             }
             *(bf16x8*)(sQ + pix * HQ_PSW + part * 16) = pack_frag<bf16>(v);
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = mg * 128 + prow0 + 16 * i < a.hc;
+            float f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = __uint_as_float(preg[i][j]);
+                if (ptrans) f[j] = abc_act(f[j], psc[i], psh[i], psl[i]);
+                if (!ok) f[j] = 0.f;
+            }
+            rsum[i] += (f[0] + f[1]) + (f[2] + f[3]);   // sum over pixels of the transformed dL = the conv's bias gradient
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16)f[j];
+            *(bf16x4*)(sP + (prow0 + 16 * i) * HP_RSW + pseg * 8) = o;
+        }
     };
 
     f32x16 acc[2];
@@ -446,21 +526,13 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
 
     const int sub = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     const int qlane = (64 * h + ((lane & 15) >> 2)) * HQ_PSW + sub * 2;  // + 8 kk pixels + b-tile * 64 bytes
-    constexpr int QBUF = 128 * HQ_PSW;
+    // K order inside a chunk: MFMA K-step kk covers pixels {64 h + 8 kk + j}: the same pixel set for both operands
+    const int plane = (mi * 32 + r) * HP_RSW + (64 * h) * 2;              // + 8 kk pixels
 
-    float rsum = 0.f;  // this lane's share of sum_p P[co][p] (the conv's bias gradient), nh == 0 waves only
-    auto compute = [&](const u32x4 (&cur)[16], const char* sQ) {
+    auto compute = [&](const char* sP, const char* sQ) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(cur[2 * kk][j]); f[4 + j] = __uint_as_float(cur[2 * kk + 1][j]); }
-            if (ptrans) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = abc_act(f[j], psc, psh, psl);
-            }
-            if (nh == 0) rsum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
-            const bf16x8 fa = pack_frag<bf16>(f);
+            const bf16x8 fa = *(const bf16x8*)(sP + plane + kk * 16);
             const char* qb = sQ + qlane + kk * 8 * HQ_PSW + nh * 128;
             const bf16x8 fb0 = tr_read8(qb, qb + 4 * HQ_PSW);
             const bf16x8 fb1 = tr_read8(qb + 64, qb + 64 + 4 * HQ_PSW);
@@ -469,29 +541,36 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
         }
     };
 
-    if (c0 < c1) {
-        issue(c0, areg0);
-        commit(c0, smem);
-    }
+    constexpr int BUF = HEAD_PBUF + HEAD_QBUF;
+    char* const b0 = smem;
+    char* const b1 = smem + BUF;
+    issue(c0, qreg0, preg0);
+    issue(c0 + 1, qreg1, preg1);
+    if (c0 < c1) commit(c0, b0, b0 + HEAD_PBUF, qreg0, preg0);
     __syncthreads();
-    // two chunks per trip so that the register sets have fixed names: even chunks (relative) live in areg0 / LDS
-    // buffer 0, odd ones in areg1 / buffer 1
+    // even chunks (relative) live in LDS buffer 0 and come from register set 0, odd ones buffer 1 / set 1
     for (int c = c0; c < c1; c += 2) {
-        const bool n1 = c + 1 < c1, n2 = c + 2 < c1;
-        if (n1) issue(c + 1, areg1);
-        if (active) compute(areg0, smem);
-        if (n1) commit(c + 1, smem + QBUF);
+        issue(c + 2, qreg0, preg0);
+        if (active) compute(b0, b0 + HEAD_PBUF);
+        if (c + 1 < c1) commit(c + 1, b1, b1 + HEAD_PBUF, qreg1, preg1);
         __syncthreads();
-        if (n1) {
-            if (n2) issue(c + 2, areg0);
-            if (active) compute(areg1, smem + QBUF);
-            if (n2) commit(c + 2, smem);
+        if (c + 1 < c1) {
+            issue(c + 3, qreg1, preg1);
+            if (active) compute(b1, b1 + HEAD_PBUF);
+            if (c + 2 < c1) commit(c + 2, b0, b0 + HEAD_PBUF, qreg0, preg0);
             __syncthreads();
         }
     }
-    if (active && nh == 0 && a.rowsum != nullptr) {
-        rsum += __shfl_xor(rsum, 32);   // the two pixel halves of the row
-        if (h == 0) a.rowsum[(size_t)split * a.Ca_pad + mt * 32 + r] = co_ok ? rsum : 0.f;
+    if (a.rowsum != nullptr) {
+        // a row's 32 segments sit in the 32 lanes of one half-wave
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = rsum[i];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            const int row = mg * 128 + prow0 + 16 * i;
+            if (pseg == 0 && row < a.Ca_pad) a.rowsum[(size_t)split * a.Ca_pad + row] = v;
+        }
     }
     if (active) {
 #pragma unroll
@@ -536,7 +615,7 @@ static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
     head_fill(k, d);
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)head_wgrad_kernel, 160 * 1024, &lds_ok)) return rc;
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3(d->nsplit, abc_cdiv(k.mtiles, 4)), dim3(512), 2 * 128 * HQ_PSW + 3 * 128 * 4, st, k);
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(d->nsplit, abc_cdiv(k.mtiles, 4)), dim3(512), HEAD_LDS, st, k);
     return abc_check_launch("head_wgrad");
 }
 
@@ -891,7 +970,7 @@ extern "C" int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc
     for (int i = n; i < 8; ++i) bt.k[i] = bt.k[0];
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)head_wgrad_batch_kernel, 160 * 1024, &lds_ok)) return rc;
-    hipLaunchKernelGGL(head_wgrad_batch_kernel, dim3(gx, gy, n), dim3(512), 2 * 128 * HQ_PSW + 3 * 128 * 4, (hipStream_t)stream, bt);
+    hipLaunchKernelGGL(head_wgrad_batch_kernel, dim3(gx, gy, n), dim3(512), HEAD_LDS, (hipStream_t)stream, bt);
     return abc_check_launch("wgrad_heads_batch");
 }
 

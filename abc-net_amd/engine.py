@@ -252,7 +252,7 @@ class Engine:
         ops.append((lambda _r, st, a=arr: lib.abc_heads_batch(a, n, which, st), None, what, (), meta))
 
     def emit_wgrad(self, ops, p: Src, q: Src, Ca, Cb, taps, stride, wname, what, cp_off=None, cq_off=None, dual=None, rowsum_to=None,
-                   collect=None):
+                   collect=None, nsplit=None):
         """dual = (y_raw tensor, ld, channel offset, dY pointer, dY pixel stride): fuse the BatchNorm-backward correction into the load of P
         (p = act_bwd output with coef = (ca, cc, cb)); returns False without emitting anything when the library does not
         serve this descriptor that way.
@@ -280,12 +280,15 @@ class Engine:
         ca_pad, cb_pad = ca_pad.value, cb_pad.value
         per_split = self.lib.abc_wgrad_blocks(C.byref(d))
         npatch = self.B * (-(-gh // 8)) * (-(-gw // 16))
+        nsplit_arg = nsplit
         # one 8-wave workgroup per CU is resident: a single round of ~256 workgroups keeps the split-K slabs small
         nsplit = max(1, min(max(1, npatch // 2), 256 // per_split))
         at_, bt_ = L.i32(), L.i32()
         L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
         if (at_.value, bt_.value) == (0, 1):   # one-channel kernel: 256-thread workgroups streaming dY, several per CU
             nsplit = min(self.B * gh, 1024)
+        elif nsplit_arg is not None and (at_.value, bt_.value) == (0, 0):
+            nsplit = max(1, min(nsplit_arg, self.B * gh * gw // 128))   # the heads' kernel splits whole 128-pixel chunks
         d.nsplit = nsplit
         need = nsplit * len(taps) * ca_pad * cb_pad
         self._ws_need = max(self._ws_need, need)
@@ -777,12 +780,20 @@ class Engine:
         dfeat = self.new((B, h, w, 128 * nh))
         # ---- heads' 1x1 convs (weight gradients one by one, the eight data gradients as one launch)
         head_dgrads, head_wgrads = [], []
+        # K-splits of the heads' batched 1x1 weight gradient: ONE round of ~256 workgroups over all heads, instead of 256 splits
+        # per head = 8 rounds of workgroups that each lived for 4 chunks and wrote a 64 KB slab.  Shared out by the measured
+        # cost of a 128-pixel chunk: ~4 us for the feature tile alone, ~9 us with 128 rows of dL beside it (the rows of the
+        # channel-planar dL are 36 KB apart: 128 concurrent 512-byte streams per workgroup, poor DRAM page locality)
+        units = [-(-(-(-hc // 32)) // 4) for hc in self.heads]
+        cost = [4.0 + 5.2 * (hc / u) / 128.0 for hc, u in zip(self.heads, units)]
+        tot = sum(u * c for u, c in zip(units, cost))
+        head_splits = [max(1, int(256 * c / tot)) for c in cost] if not os.environ.get("ABC_NO_HEADS_BATCH") else [None] * nh
         for r2 in self.head2:
             i, hc = r2.idx, r2.cout
             cs = self.chan_scale[self.head_off[i]:self.head_off[i] + hc]
             dl = Src(self.dlogits[i], L.F32, h, w, 0, 0, hc, coef=(cs, zero, one), planar=True)
             got = self.emit_wgrad(ops, dl, r2.src, hc, 128, [(0, 0)], 1, r2.cname + ".weight", "wgrad " + r2.cname,
-                                  rowsum_to=r2.cname + ".bias", collect=head_wgrads)
+                                  rowsum_to=r2.cname + ".bias", collect=head_wgrads, nsplit=head_splits[i])
             if got != "rowsum":
                 lib = self.lib
                 psw = self.new((lib.abc_plane_sum_work(hc),), torch.float32)

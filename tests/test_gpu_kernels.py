@@ -196,7 +196,16 @@ def test_head_wgrad_fused_activation(lib, Cn, nsplit):
     assert (at.value, bt.value) == (0, 0)  # the head kernel took it
     part = torch.full((nsplit * ca.value * cb.value,), float("nan"), dtype=torch.float32, device=U.DEV)
     d.partial = part.data_ptr()
+    # per-split row sums of the transformed dL ride along: the conv's bias gradient (f32 sums, before the bf16 rounding)
+    assert lib.abc_wgrad_rowsum_ok(C.byref(d)) == 1
+    rs = torch.full((nsplit, ca.value), float("nan"), dtype=torch.float32, device=U.DEV)
+    d.rowsum_partial = rs.data_ptr()
     L.check(lib.abc_wgrad(C.byref(d), U.stream()), "wgrad")
+    torch.cuda.synchronize()
+    want_b = (dl * scale.view(1, -1, 1, 1)).double().sum((0, 2, 3))
+    got_b = rs.double().sum(0).cpu()
+    assert torch.isfinite(rs).all() and (got_b[:Cn] - want_b).abs().max().item() <= 1e-5 * want_b.abs().max().item() + 1e-6
+    assert (got_b[Cn:] == 0).all()
     dw = torch.zeros((Cn, Cin, 1), dtype=torch.float32, device=U.DEV)
     r = L.WgradReduceDesc()
     r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), nsplit, 1, Cn, Cin, ca.value, cb.value, dw.data_ptr(), 0
