@@ -286,6 +286,34 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const abc_act_bwd_desc d) 
             }
         }
     }
+    if (pooled && ((d.H | d.W) & 1)) {
+        // odd height / width (input sizes that are not multiples of 32): MaxPool2d(2) floors, so the last row / column
+        // belongs to no window -- its gradient is the full-resolution source alone (or zero)
+        const int wodd = d.W & 1, hodd = d.H & 1;
+        const int ncol = wodd ? d.H : 0;                 // pixels (y, W - 1)
+        const int nrow = hodd ? 2 * Ww : 0;              // pixels (H - 1, x < 2 Ww)
+        const unsigned nl = (unsigned)(ncol + nrow);
+        const unsigned n2 = (unsigned)d.B * nl * (unsigned)ncv;
+        for (unsigned it = blockIdx.x * 256u + tid; it < n2; it += st32) {
+            unsigned l = pow2 ? (it >> lg) : (it / (unsigned)ncv);
+            const int b = (int)(l / nl);
+            l -= (unsigned)b * nl;
+            const int y = (int)l < ncol ? (int)l : d.H - 1, x = (int)l < ncol ? d.W - 1 : (int)l - ncol;
+            const size_t p = ((size_t)b * d.H + y) * d.W + x;
+            float xv[N], da[N], out[N];
+            ldv<T, N>(yr + p * d.ld_y + d.cy_off + c, xv);
+            if (ds != nullptr) ldv<T, N>(ds + p * d.ld_same + d.csame_off + c, da);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float yv = fmaf(xv[j], sc[j], sh[j]);
+                const float gg = (ds != nullptr ? da[j] : 0.f) * (yv > 0.f ? 1.f : sl[j]);
+                out[j] = gg;
+                a1[j] += gg;
+                a2[j] += gg * ((xv[j] - mu[j]) * is[j]);
+            }
+            stv<N>(g + p * d.ld_g + c, out);
+        }
+    }
     // block reduction per channel: threads with equal (tid % ncv) share a channel vector
 #pragma unroll
     for (int j = 0; j < N; ++j) { red[tid][j] = a1[j]; red[tid][N + j] = a2[j]; }
@@ -504,7 +532,7 @@ static int act_bwd_check(const abc_act_bwd_desc* d) {
     if (d->C % N) return abc_fail(ABC_EINVAL, "act_bwd: C must be a multiple of the vector width");
     const int ncv = d->C / N;
     if (ncv > 256 || (256 % ncv)) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: C/vec must divide 256");
-    if (d->dA_pool && ((d->H & 1) || (d->W & 1))) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: pooled dims must be even");
+    if (d->dA_pool && (((d->H | d->W) & 1) && d->drop_p > 0.f)) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: odd pooled dims with dropout");
     if (!d->dA_pool && !d->dA_same) return abc_fail(ABC_EINVAL, "act_bwd: no gradient source");
     if ((d->ld_y | d->ld_g | d->cy_off) % N) return abc_fail(ABC_EINVAL, "act_bwd: alignment");
     if ((int64_t)d->B * d->H * d->W * ncv >= (int64_t(1) << 31)) return abc_fail(ABC_EUNSUPPORTED, "act_bwd: tensor too large for 32-bit indexing");
@@ -615,7 +643,8 @@ __global__ __launch_bounds__(256) void pool_act_kernel(const InT* x, const float
 
 extern "C" int abc_pool_act(const abc_act_src* src, int32_t dtype_in, int32_t c_off, int32_t C, int32_t B, void* out, int32_t dtype_out,
                             int32_t ld_out, abc_stream_t stream) {
-    if (C % 8 || c_off % 8 || src->ldx % 8 || ld_out % 8 || (src->Hx & 1) || (src->Wx & 1)) return abc_fail(ABC_EINVAL, "pool_act: alignment");
+    // (odd Hx / Wx: MaxPool2d(2) floors -- the last row / column is dropped, unet.py:30 on sizes that are not multiples of 32)
+    if (C % 8 || c_off % 8 || src->ldx % 8 || ld_out % 8 || src->Hx < 2 || src->Wx < 2) return abc_fail(ABC_EINVAL, "pool_act: alignment");
     if (src->planar || src->drop_p > 0.f) return abc_fail(ABC_EUNSUPPORTED, "pool_act: planar / dropout source");
     const int64_t nseg = (int64_t)B * (src->Hx / 2) * (src->Wx / 2) * (C / 8);
     const dim3 grid((unsigned)((nseg + 255) / 256));

@@ -42,15 +42,34 @@ def taps_mirror(taps):
     return [(-dy, -dx) for dy, dx in taps]
 
 
-def convT_phase_taps(py, px):
-    """input offsets of the taps of output parity (py,px) of ConvTranspose2d(k3,s2) after the
-    crop of the first row/col (unet.py:51-57); order matches abc_pack_conv_weights mode 2"""
-    ys = [0] if py == 0 else [1, 0]  # py=1: ky=0 -> iy=a+1, ky=2 -> iy=a
-    xs = [0] if px == 0 else [1, 0]
-    return [(dy, dx) for dy in ys for dx in xs]
+def convT_phase_taps(py, px, crop_y=True, crop_x=True):
+    """input offsets of the taps of output parity (py,px) of ConvTranspose2d(k3,s2) after the reference's pad / crop
+    (unet.py:51-57); order matches abc_pack_conv_weights mode 2 for the pack parity convT_pack_parity() names.
+
+    Per axis: the 2n+1 outputs o = 2i + k (k = 0..2) meet a skip tensor of size s.  s = 2n (every level when the input size
+    is a multiple of 32): diff = -1, F.pad crops the FIRST row -> output o' = o - 1, parity 0 takes k = 1 at i = a, parity 1
+    takes k = 0 at i = a + 1 and k = 2 at i = a.  s = 2n + 1 (odd levels of other input sizes): nothing is cropped ->
+    parity 0 takes k = 0 at i = a and k = 2 at i = a - 1, parity 1 takes k = 1 at i = a."""
+    def axis(p, crop):
+        if crop:
+            return [0] if p == 0 else [1, 0]
+        return [0, -1] if p == 0 else [0]
+    return [(dy, dx) for dy in axis(py, crop_y) for dx in axis(px, crop_x)]
 
 
-TAPS_CONVT_DGRAD = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+def convT_pack_parity(p, crop):
+    """which kernel rows abc_pack_conv_weights mode 2 has to pick for output parity p: pack parity 1 = (k = 0, k = 2),
+    pack parity 0 = (k = 1)"""
+    return p if crop else 1 - p
+
+
+def convT_dgrad_taps(crop_y=True, crop_x=True):
+    """dX[i] = sum_k dOut[2 i + k - c] W[k] with c = 1 where the first row / column was cropped, 0 where not"""
+    cy, cx = (1 if crop_y else 0), (1 if crop_x else 0)
+    return [(ky - cy, kx - cx) for ky in range(3) for kx in range(3)]
+
+
+TAPS_CONVT_DGRAD = convT_dgrad_taps()
 
 
 class Src:
@@ -91,8 +110,10 @@ class Engine:
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False):
         if variant not in ("unet", "unet2"):
             raise NotImplementedError("variant %r" % variant)
-        if H % 32 or W % 32:
-            raise ValueError("H and W must be multiples of 32 (got %dx%d)" % (H, W))
+        if H < 32 or W < 32:
+            raise ValueError("H and W must be at least 32 (five 2x2 poolings; got %dx%d)" % (H, W))
+        if (H % 32 or W % 32) and variant != "unet":
+            raise ValueError("unet2: H and W must be multiples of 32 (got %dx%d)" % (H, W))
         if in_channels < 1:
             raise ValueError("in_channels must be positive")
         self.in_channels = in_channels
@@ -495,18 +516,26 @@ class Engine:
         half = Ctot // 2
         cin = low.C
         lh, lw = low.lh()
-        assert (2 * lh, 2 * lw) == (Hs, Ws)
+        # unet.py:51-56: the 2n+1 outputs are padded by diff = s - (2n+1), i.e. the first row / column is cropped where the
+        # skip tensor has 2n rows (always, for input sizes that are multiples of 32) and nothing where it has 2n+1
+        if Hs - 2 * lh not in (0, 1) or Ws - 2 * lw not in (0, 1):
+            raise ValueError("skip tensor %dx%d does not fit the transposed conv of %dx%d" % (Hs, Ws, lh, lw))
+        crop_y, crop_x = Hs == 2 * lh, Ws == 2 * lw
         rows_pad = -(-half // 32) * 32
         phases = []
         for py in (0, 1):
             for px in (0, 1):
-                taps = convT_phase_taps(py, px)
+                taps = convT_phase_taps(py, px, crop_y, crop_x)
                 wp = self.packed(len(taps), cin, rows_pad)
-                self.emit_pack(name + ".up.weight", wp, 2, half, cin, 3, rows_pad, cin, py=py, px=px)
+                self.emit_pack(name + ".up.weight", wp, 2, half, cin, 3, rows_pad, cin, py=convT_pack_parity(py, crop_y),
+                               px=convT_pack_parity(px, crop_x))
+                # output rows 2a + py < Hs: without the crop the even parity has one row more than the input
+                gh, gw = (Hs - py + 1) // 2, (Ws - px + 1) // 2
                 self.emit_conv(self.fwd_ops, low, wp, self.P(name + ".up.bias"), cat, self.dt, Hs, Ws, Ctot, half, half, taps,
-                               grid=(lh, lw), om=2, oy0=py, ox0=px, what="fwd %s.up phase %d%d" % (name, py, px))
+                               grid=(gh, gw), om=2, oy0=py, ox0=px, what="fwd %s.up phase %d%d" % (name, py, px))
                 phases.append(wp)
-        rec = Rec(kind="convT", cname=name + ".up", src=low, cin=cin, cout=half, H=Hs, W=Ws, ld=Ctot, coff=half, y=cat)
+        rec = Rec(kind="convT", cname=name + ".up", src=low, cin=cin, cout=half, H=Hs, W=Ws, ld=Ctot, coff=half, y=cat,
+                  taps_bwd=convT_dgrad_taps(crop_y, crop_x))
         self.recs.append(rec)
         cat_src = Src(cat, self.dt, Hs, Ws, Ctot, 0, Ctot, coef=None if self.fold else cat_coef, producer=("cat", None))
         if self.variant == "unet2":
@@ -951,13 +980,13 @@ class Engine:
         hs, ws = rec.H, rec.W
         dOut = Src(dcat, self.dt, hs, ws, ld, coff, rec.cout)
         self.emit_colsum(ops, dcat, self.dt, B * hs * ws, ld, coff, rec.cout, None, rec.cname + ".bias", "dbias " + rec.cname)
-        self.emit_wgrad(ops, rec.src, dOut, rec.cin, rec.cout, TAPS_CONVT_DGRAD, 2, rec.cname + ".weight", "wgrad " + rec.cname)
+        self.emit_wgrad(ops, rec.src, dOut, rec.cin, rec.cout, rec.taps_bwd, 2, rec.cname + ".weight", "wgrad " + rec.cname)
         lh, lw = rec.src.lh()
         rows_pad = -(-rec.cin // 32) * 32
         wd = self.packed(9, rec.cout, rows_pad)
         self.emit_pack(rec.cname + ".weight", wd, 3, rec.cout, rec.cin, 3, rows_pad, rec.cout)
         dsrc = self.new((B, lh, lw, rec.cin))
-        self.emit_conv(ops, dOut, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, TAPS_CONVT_DGRAD, stride=2,
+        self.emit_conv(ops, dOut, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, rec.taps_bwd, stride=2,
                        what="dgrad " + rec.cname)
         rec.src.producer.grad_same = (dsrc, rec.cin, 0)
 

@@ -21,6 +21,8 @@ What is produced (all float32 unless noted):
   raster_128.npz           the 8 target maps of utils.py:83-228 for seeded annotation strings (sparse)
   decode_128.npz           atom / bond candidate lists of img2smiles2.py:113-191 for seeded head maps
   adam.npz                 one torch.optim.Adam step (train.py:55 settings)
+  shapes_unet.npz          unet.py at an input size that is not a multiple of 32 (72x88, 104x40) and with 3 input channels:
+                           head-map samples / statistics (eval, train) and gradient norms under a surrogate loss
   meta.json                state_dict key/shape lists, parameter counts
 """
 import json
@@ -146,6 +148,43 @@ def grad_goldens(variant):
         res["head/" + k] = g.reshape(-1)[:64].double().numpy()
     np.savez(os.path.join(HERE, "grads_%s_512.npz" % variant), **res)
     print("wrote grads", variant, loss.item())
+
+
+def shape_goldens():
+    """unet.py on the shapes its general code paths exist for: an input whose size is NOT a multiple of 32 (the pad / crop of
+    unet.py:51-56 then crops on some levels and not on others) and in_channels = 3 (unet.py:122-134's own self-check).
+    Stored: strided samples + statistics of the eight head maps in eval and train mode, and (train mode) the gradient
+    norms / leading samples of a few parameters under the surrogate loss sum_i mean(head_i ** 2)."""
+    mod = ref_module("unet")
+    res = {}
+    for tag, cin, H, W in (("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40)):
+        sd = uo.filled_state("unet", cin, HEADS, seed=0)
+        x = synthetic_images(2, max(H, W), seed=7, in_channels=cin)[:, :, :H, :W].contiguous()
+        for mode in ("eval", "train"):
+            m = mod.UNet(cin, HEADS)
+            m.load_state_dict(sd, strict=True)
+            for om in m.out_modules:
+                om.drop.p = 0.0
+            m.train(mode == "train")
+            ys = m(x)
+            for i, y in enumerate(ys):
+                res["%s_%s_head%d_shape" % (tag, mode, i)] = np.array(y.shape)
+                res["%s_%s_head%d_sample" % (tag, mode, i)] = sample(y)
+                res["%s_%s_head%d_stats" % (tag, mode, i)] = np.array(
+                    [y.min().item(), y.max().item(), y.double().mean().item(), y.double().norm().item()])
+            if mode == "train":
+                loss = sum((y ** 2).mean() for y in ys)
+                loss.backward()
+                res["%s_loss" % tag] = np.array(loss.item())
+                named = dict(m.named_parameters())
+                for k in ("inc1.double_conv.0.weight", "down3.maxpool_conv.1.double_conv.3.weight", "up1.up.weight", "up2.up.weight",
+                          "up3.up.weight", "up2.up.bias", "up2.conv.double_conv.0.weight", "dconv2.double_conv.4.weight",
+                          "out_modules.5.conv2.weight"):
+                    g = named[k].grad
+                    res["%s_gnorm/%s" % (tag, k)] = np.array(g.double().norm().item())
+                    res["%s_ghead/%s" % (tag, k)] = g.reshape(-1)[:64].double().numpy()
+    np.savez(os.path.join(HERE, "shapes_unet.npz"), **res)
+    print("wrote shapes")
 
 
 def loss_goldens():
@@ -312,10 +351,11 @@ def meta():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("metrics", "decode", "raster"):   # (added after the other fixtures: regenerate one alone)
-        {"metrics": metrics_goldens, "decode": decode_goldens, "raster": raster_goldens}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("metrics", "decode", "raster", "shapes"):   # (added after the other fixtures: regenerate one alone)
+        {"metrics": metrics_goldens, "decode": decode_goldens, "raster": raster_goldens, "shapes": shape_goldens}[sys.argv[1]]()
         sys.exit(0)
     meta()
+    shape_goldens()
     metrics_goldens()
     decode_goldens()
     raster_goldens()

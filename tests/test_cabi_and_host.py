@@ -83,13 +83,28 @@ def test_engine_plan_builds_without_gpu():
     assert abs(per_img_384 - 52.86e9) / 52.86e9 < 0.02
 
 
-def test_non_multiple_of_32_is_refused():
-    from abcnet_amd.engine import Engine
+def test_sizes_that_are_not_multiples_of_32_build_for_unet_only():
+    """unet.py:51-56: the transposed convs meet skip tensors of 2n or 2n+1 rows; the plan lowers both (per axis: crop the first
+    row, or not).  unet2's CBAM passes keep the multiple-of-32 restriction; below 32 pixels five poolings leave nothing."""
+    from abcnet_amd.engine import Engine, convT_phase_taps, convT_pack_parity
     from abcnet_amd.unet import UNet
+    from abcnet_amd.unet2 import UNet as UNet2
     m = UNet(1, HEADS)
-    m._flat_grad = torch.zeros_like(m._flat.data)
+    m._flat_grad = torch.zeros_like(m._flat)
+    lay = (m._lay_p, m._lay_b, m._lay_c)
+    e = Engine("unet", 1, HEADS, m._flat, m._flat_grad, m._flat_buf, m._counters, lay, 1, 72, 88, "fp32", True, device="cpu")
+    assert (e.h, e.w) == (18, 22) and [tuple(t.shape[2:]) for t in e.logits] == [(18, 22)] * 8
+    ups = {r.cname: r for r in e.recs if r.kind == "convT"}
+    # 72: 72 36 18 9 4 2 -> up1 (2 -> 4: crop), up2 (4 -> 9: no crop), up3 (9 -> 18: crop); 88: 88 44 22 11 5 2 -> no crop, no crop, crop
+    assert ups["up1.up"].taps_bwd[0] == (-1, 0) and ups["up2.up"].taps_bwd[0] == (0, 0) and ups["up3.up"].taps_bwd[0] == (-1, -1)
+    assert convT_phase_taps(0, 1, crop_y=False, crop_x=True) == [(0, 1), (0, 0), (-1, 1), (-1, 0)]
+    assert convT_pack_parity(0, False) == 1 and convT_pack_parity(1, True) == 1
     with pytest.raises(ValueError):
-        Engine("unet", 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, (m._lay_p, m._lay_b, m._lay_c), 1, 100, 96,
+        Engine("unet", 1, HEADS, m._flat, m._flat_grad, m._flat_buf, m._counters, lay, 1, 31, 96, "fp32", False, device="cpu")
+    m2 = UNet2(1, HEADS)
+    m2._flat_grad = torch.zeros_like(m2._flat)
+    with pytest.raises(ValueError):
+        Engine("unet2", 1, HEADS, m2._flat, m2._flat_grad, m2._flat_buf, m2._counters, (m2._lay_p, m2._lay_b, m2._lay_c), 1, 100, 96,
                "fp32", False, device="cpu")
 
 

@@ -701,3 +701,44 @@ def test_folded_inference_graph_matches_oracle(dtype, size, tol):
     with torch.no_grad():
         ref2 = uo.forward("unet", sd, x, train=False)
     assert max((y.cpu() - r).abs().max().item() for y, r in zip(run.logits, ref2)) < tol
+
+
+@pytest.mark.parametrize("tag,cin,H,W", [("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40)])
+def test_general_shapes_match_reference_golden_and_oracle(tag, cin, H, W, golden_dir):
+    """the reference's general code paths on the HIP kernels: input sizes that are not multiples of 32 (unet.py:51-56: per level
+    and axis the transposed conv's first row is cropped, or nothing is; MaxPool2d floors) and in_channels = 3
+    (unet.py:122-134).  fp32 logits within the 1e-3 gate of the reference-generated golden and of the oracle, eval and train;
+    gradients of the reference loop body (loss.backward() through the module) against the oracle's autograd"""
+    gold = np.load(os.path.join(golden_dir, "shapes_unet.npz"))
+    x = synthetic_images(2, max(H, W), seed=7, in_channels=cin)[:, :, :H, :W].contiguous()
+    sd0 = uo.filled_state("unet", cin, HEADS, seed=0)
+    m = UNet(cin, HEADS, dtype="fp32", dropout_p=0.0)
+    m.load_state_dict(sd0)
+    m = m.to(DEV)
+    for mode in ("eval", "train"):
+        m.load_state_dict(sd0)
+        m.train(mode == "train")
+        with torch.no_grad():
+            ys = m(x.to(DEV))
+            ref = uo.forward("unet", uo.clone_state(sd0), x, train=(mode == "train"))
+        for i, (y, r) in enumerate(zip(ys, ref)):
+            assert tuple(y.shape) == tuple(r.shape) == tuple(gold["%s_%s_head%d_shape" % (tag, mode, i)])
+            assert (y.cpu() - r).abs().max().item() < 1e-3, (tag, mode, i)
+            f = y.cpu().reshape(-1)
+            step = max(f.numel() // 257, 1)
+            np.testing.assert_allclose(f[::step][:257].double().numpy(), gold["%s_%s_head%d_sample" % (tag, mode, i)], atol=1e-3)
+    # gradients under the golden's surrogate loss, through autograd of the drop-in module
+    m.load_state_dict(sd0)
+    m.train()
+    ys = m(x.to(DEV))
+    loss = sum((y ** 2).mean() for y in ys)
+    loss.backward()
+    assert abs(loss.item() - gold["%s_loss" % tag].item()) <= 1e-4 * abs(gold["%s_loss" % tag].item())
+    sd = uo.clone_state(sd0, requires_grad=True)
+    sum((y ** 2).mean() for y in uo.forward("unet", sd, x, train=True)).backward()
+    named = dict(m.named_parameters())
+    for k in ("inc1.double_conv.0.weight", "down3.maxpool_conv.1.double_conv.3.weight", "up1.up.weight", "up2.up.weight", "up3.up.weight",
+              "up2.up.bias", "up2.conv.double_conv.0.weight", "dconv2.double_conv.4.weight", "out_modules.5.conv2.weight"):
+        g, r = named[k].grad.cpu().double(), sd[k].grad.double()
+        assert (g - r).norm().item() <= 2e-2 * r.norm().item() + 1e-12, (tag, k, (g - r).norm().item(), r.norm().item())
+        assert abs(g.norm().item() - gold["%s_gnorm/%s" % (tag, k)].item()) <= 2e-2 * gold["%s_gnorm/%s" % (tag, k)].item() + 1e-12
