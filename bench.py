@@ -28,6 +28,14 @@ import torch.distributed as dist  # noqa: E402
 HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
 MFMA_PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md
 HBM_PEAK = 8000.0  # GB/s
+# SURVEY.md section 8(d) / BASELINE.md section 3: per-layer roofline rate R = 1 / sum_l max(bytes_l / 8 TB/s, flops_l / 2.5 PF) in
+# images/s per GPU (bf16, every conv reads its input and writes its output once, train = 3 x forward + loss + Adam bytes),
+# with the algorithmic bytes and flops per image it is built from; keyed (mode, variant, size)
+SURVEY_ROOFLINE = {
+    ("train", "unet", 384): {"R_img_s": 10800.0, "mb_per_img": 527.0, "gflop_per_img": 158.6},
+    ("train", "unet2", 384): {"R_img_s": 8400.0, "mb_per_img": 685.0, "gflop_per_img": 223.6},
+    ("infer", "unet", 512): {"R_img_s": 19800.0, "mb_per_img": 277.0, "gflop_per_img": 93.98},
+}
 
 
 def cpu_baseline(size, seconds_budget=25.0, variant="unet"):
@@ -260,6 +268,14 @@ def main():
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 
+    sr = SURVEY_ROOFLINE.get((a.mode, a.variant, a.size))
+    if sr is not None and a.dtype == "bf16":
+        per_gpu = out["value"] / world
+        out["survey_roofline"] = {"R_img_s_per_gpu": sr["R_img_s"], "frac": round(per_gpu / sr["R_img_s"], 4),
+                                  "hbm_frac": round(per_gpu * sr["mb_per_img"] * 1e6 / (HBM_PEAK * 1e9), 4),
+                                  "mfma_frac": round(per_gpu * sr["gflop_per_img"] * 1e9 / (MFMA_PEAK["bf16"] * 1e12), 4),
+                                  "source": "SURVEY.md section 8(d): measured img/s per GPU / per-layer roofline rate, and the two plain "
+                                            "fractions (algorithmic bytes/img x img/s / 8 TB/s, algorithmic flops/img x img/s / 2.5 PF)"}
     # (the instrumented pass and the CPU leg are reported beside the measurement; a failure there must not lose the line)
     try:
         if rank == 0 and not a.no_profile:
@@ -276,6 +292,10 @@ def main():
             out["kernel_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("ABC_BENCH_TOP", 12))]}
             if os.environ.get("ABC_BENCH_TOP"):
                 out["kernel_calls"] = {k: v["calls"] for k, v in prof.items()}
+                # per launch: algorithmic GFLOP and MB of every kernel label (the plan's own accounting; profiles/ joins it
+                # with the PMC bytes)
+                out["kernel_algorithmic"] = {k: [round(v["flops"] / max(v["calls"], 1) / 1e9, 3), round(v["bytes"] / max(v["calls"], 1) / 1e6, 2)]
+                                             for k, v in prof.items()}
             out["eager_step_ms_sum_of_kernels"] = round(tot, 3)
             flops_step = sum(v["flops"] for v in prof.values())
             bytes_step = sum(v["bytes"] for v in prof.values())

@@ -35,7 +35,7 @@ for w in ${WORKLOADS:-unet unet2 infer}; do
   case $w in
     unet) A="--variant unet --steps 20 --warmup 3";; unet2) A="--variant unet2 --steps 20 --warmup 3";; infer) A="--mode infer --steps 10 --warmup 3";;
   esac
-  python3 bench.py $A > $O/${TAG}_${w}_bench.json 2> $O/${TAG}_${w}_bench.err
+  ABC_BENCH_TOP=400 python3 bench.py $A > $O/${TAG}_${w}_bench.json 2> $O/${TAG}_${w}_bench.err
   echo "$w bench done"
 done
 ls -la $O

@@ -9,8 +9,10 @@
   --sq    : `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
              SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace ...` pass
 
-A row = one (kernel instantiation, grid size) pair, i.e. one launch SHAPE (the dominant conv label alone covers 16 .. 292 us
-launches).  Columns, all per launch (mean over the launches of that shape in the pass):
+A row = one launch SHAPE: the launches of one (kernel instantiation, grid size) pair whose durations lie within 15 % of each
+other, told apart by their position in the step's launch sequence (the dominant conv label alone covers 16 .. 340 us
+launches, and the persistent kernels use one grid size for every layer).  Columns, all per launch (mean over the launches of
+that shape in the pass):
 
   us           duration from the counter-free pass (profiled passes run 2-3 % slower: never mix them, MI355X_MICROARCH.md DVFS item 2)
   hbm_mb       FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024     (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)
@@ -78,40 +80,49 @@ def key(row):
     return (row["Kernel_Name"], int(row.get("Grid_Size", row.get("Grid_Size_X", 0)) or 0))
 
 
-def durations(d):
-    acc = {}
-    for r in read_rows(d, "*kernel_trace.csv"):
-        k = key(r)
-        a = acc.setdefault(k, [0, 0.0])
-        a[0] += 1
-        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0
-    return {k: (n, s / n) for k, (n, s) in acc.items()}
+def steps_in(rows):
+    """number of steps a pass ran: launches of the once-per-step Adam kernel (train) or NMS kernel (inference)"""
+    for probe in ("adam_kernel", "nms_kernel"):
+        n = sum(1 for r in rows if probe in r["Kernel_Name"])
+        if n:
+            return n
+    return 1
 
 
-def counters(d):
-    """{(kernel, grid): {counter: mean per launch}} ; also the profiled pass's own mean duration under '_us'"""
-    acc = {}
-    seen = {}
-    for r in read_rows(d, "*counter_collection.csv"):
-        k = key(r)
-        a = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
-        if "Start_Timestamp" in r and r.get("Start_Timestamp"):
-            seen[(k, r.get("Dispatch_Id"))] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0
-    out = {k: {c: s / n for c, (n, s) in cs.items()} for k, cs in acc.items()}
-    if not seen:
-        for r in read_rows(d, "*kernel_trace.csv"):
-            seen[(key(r), r.get("Dispatch_Id"))] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0
-    dur = {}
-    for (k, _), us in seen.items():
-        a = dur.setdefault(k, [0, 0.0])
-        a[0] += 1
-        a[1] += us
-    for k, (n, s) in dur.items():
-        if k in out:
-            out[k]["_us"] = s / n
+def by_ordinal(rows, value):
+    """{(kernel, grid): {ordinal within a step: [n, sum]}}: the launch sequence of a step is the same in every pass, so the
+    i-th launch of a (kernel, grid) pair within a step is the same layer everywhere -- that is what separates the SHAPES a
+    persistent kernel (one grid size for every layer) is launched on"""
+    rows = sorted(rows, key=lambda r: int(r.get("Start_Timestamp") or r.get("Dispatch_Id") or 0))
+    nsteps = steps_in(rows)
+    seq = {}
+    for r in rows:
+        seq.setdefault(key(r), []).append(r)
+    out = {}
+    for k, rs in seq.items():
+        per = max(len(rs) // nsteps, 1) if len(rs) % nsteps == 0 else len(rs)   # (setup-time launches: one ordinal each)
+        o = out.setdefault(k, {})
+        for i, r in enumerate(rs):
+            a = o.setdefault(i % per, [0, 0.0])
+            a[0] += 1
+            a[1] += value(r)
     return out
+
+
+def dur_us(r):
+    return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0
+
+
+def shape_clusters(ordinals):
+    """ordinals {ord: [n, sum_us]} -> list of ordinal lists: launches whose mean durations lie within 15 % of each other"""
+    items = sorted((s / n, o) for o, (n, s) in ordinals.items())
+    clusters, first = [], None
+    for us, o in items:
+        if first is None or us > 1.15 * first:
+            clusters.append([])
+            first = us
+        clusters[-1].append(o)
+    return clusters
 
 
 def main():
@@ -122,37 +133,66 @@ def main():
     while i < len(args):
         opt[args[i].lstrip("-")] = args[i + 1]
         i += 2
-    dur = durations(opt["trace"])
-    fetch = counters(opt["fetch"]) if "fetch" in opt else {}
-    write = counters(opt["write"]) if "write" in opt else {}
-    sq = counters(opt["sq"]) if "sq" in opt else {}
-    total_us = sum(n * us for n, us in dur.values())
+    trace = by_ordinal(read_rows(opt["trace"], "*kernel_trace.csv"), dur_us)
+    passes = {}
+    for name, counters_wanted in (("fetch", ("FETCH_SIZE",)), ("write", ("WRITE_SIZE",)),
+                                  ("sq", ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                                          "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"))):
+        if name not in opt:
+            continue
+        rows = read_rows(opt[name], "*counter_collection.csv")
+        ktr = {r.get("Dispatch_Id"): r for r in read_rows(opt[name], "*kernel_trace.csv")}
+        for c in counters_wanted:
+            sel = [r for r in rows if r["Counter_Name"] == c]
+            for r in sel:   # timestamps for the ordering (and the pass's own duration) come from its kernel trace
+                t = ktr.get(r.get("Dispatch_Id"))
+                if t is not None:
+                    r["Start_Timestamp"], r["End_Timestamp"] = t["Start_Timestamp"], t["End_Timestamp"]
+            passes[c] = by_ordinal(sel, lambda r: float(r["Counter_Value"]))
+            if c == "GRBM_GUI_ACTIVE":
+                passes["_sq_us"] = by_ordinal(sel, dur_us)
+    total_us = sum(s for o in trace.values() for n, s in o.values())
     rows = []
-    for k, (n, us) in dur.items():
-        r = {"kernel": short(k[0]), "grid": k[1], "launches": n, "us": round(us, 2), "share": round(n * us / total_us, 4)}
-        f, w = fetch.get(k, {}).get("FETCH_SIZE"), write.get(k, {}).get("WRITE_SIZE")
-        if f is not None and w is not None:
-            mb = (f * 1024 * 2 + w * 1024) / 1e6
-            r.update(fetch_mb=round(f * 1024 * 2 / 1e6, 2), write_mb=round(w * 1024 / 1e6, 2), hbm_mb=round(mb, 2),
-                     hbm_gbs=round(mb / us * 1e3, 1), hbm_frac=round(mb / us * 1e3 / PEAK_HBM_GBS, 4))
-        s = sq.get(k)
-        if s and "SQ_VALU_MFMA_BUSY_CYCLES" in s:
-            r["mfma_util"] = round(s["SQ_VALU_MFMA_BUSY_CYCLES"] / (us * 1e-6 * NOMINAL_HZ * SIMDS), 4)
-            if "GRBM_GUI_ACTIVE" in s and "_us" in s:
-                r["clk_ghz"] = round(s["GRBM_GUI_ACTIVE"] / 8.0 / (s["_us"] * 1e-6) / 1e9, 3)
-            wc = s.get("SQ_WAVE_CYCLES")
-            if wc:
-                for name, c in (("wait", "SQ_WAIT_ANY"), ("stall", "SQ_WAIT_INST_ANY"), ("active", "SQ_ACTIVE_INST_ANY")):
-                    if c in s:
-                        r[name] = round(s[c] / wc, 3)
-        rows.append(r)
+    for k, ords in trace.items():
+        for cl in shape_clusters(ords):
+            n = sum(ords[o][0] for o in cl)
+            us = sum(ords[o][1] for o in cl) / n
+            r = {"kernel": short(k[0]), "grid": k[1], "launches": n, "launches_per_step": len(cl), "us": round(us, 2), "share": round(n * us / total_us, 4)}
+
+            def mean(counter):
+                p = passes.get(counter, {}).get(k)
+                if not p:
+                    return None
+                tot = [p[o] for o in cl if o in p]
+                nn = sum(t[0] for t in tot)
+                return sum(t[1] for t in tot) / nn if nn else None
+
+            f, w = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+            if f is not None and w is not None:
+                mb = (f * 1024 * 2 + w * 1024) / 1e6
+                r.update(fetch_mb=round(f * 1024 * 2 / 1e6, 2), write_mb=round(w * 1024 / 1e6, 2), hbm_mb=round(mb, 2),
+                         hbm_gbs=round(mb / us * 1e3, 1), hbm_frac=round(mb / us * 1e3 / PEAK_HBM_GBS, 4))
+            mf = mean("SQ_VALU_MFMA_BUSY_CYCLES")
+            if mf is not None:
+                r["mfma_util"] = round(mf / (us * 1e-6 * NOMINAL_HZ * SIMDS), 4)
+                gui, squs = mean("GRBM_GUI_ACTIVE"), mean("_sq_us")
+                if gui is not None and squs:
+                    r["clk_ghz"] = round(gui / 8.0 / (squs * 1e-6) / 1e9, 3)
+                wc = mean("SQ_WAVE_CYCLES")
+                if wc:
+                    for name, c in (("wait", "SQ_WAIT_ANY"), ("stall", "SQ_WAIT_INST_ANY"), ("active", "SQ_ACTIVE_INST_ANY")):
+                        v = mean(c)
+                        if v is not None:
+                            r[name] = round(v / wc, 3)
+            rows.append(r)
     rows.sort(key=lambda r: -r["share"])
     with open(prefix + ".json", "w") as f:
         json.dump({"total_us_per_pass": round(total_us, 1), "rows": rows,
-                   "columns": "see profiles/kernel_table.py; mfma_util is against the nominal 2.4 GHz x 1024 SIMD matrix-pipe cycles "
+                   "columns": "see profiles/kernel_table.py; a row = the launches of one kernel instantiation and grid whose durations lie "
+                              "within 15 % (one launch SHAPE); mfma_util is against the nominal 2.4 GHz x 1024 SIMD matrix-pipe cycles "
                               "(= fraction of the 2.5 PFLOP/s dense bf16 peak for bf16 MFMAs), hbm_frac against 8 TB/s"}, f, indent=1)
-    top = int(opt.get("top", 40))
-    cols = ["kernel", "grid", "launches", "us", "share", "hbm_mb", "hbm_gbs", "hbm_frac", "mfma_util", "clk_ghz", "wait", "stall", "active"]
+    top = int(opt.get("top", 48))
+    cols = ["kernel", "grid", "launches_per_step", "us", "share", "hbm_mb", "hbm_gbs", "hbm_frac", "mfma_util", "clk_ghz", "wait", "stall", "active"]
     with open(prefix + ".md", "w") as f:
         f.write("| " + " | ".join(cols) + " |\n|" + "---|" * len(cols) + "\n")
         for r in rows[:top]:

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json (what bench.py reports as roofline.traffic) from the per-shape kernel tables of one round:
+
+    python profiles/make_pmc_traffic.py TAG        (reads profiles/TAG_{unet,unet2,infer}_kernel_table.json and
+                                                    profiles/TAG_{..}_bench.json, rewrites profiles/pmc_traffic.json)
+
+Per bench.py kernel label (one kernel instantiation; its launches of all shapes): mean HBM bytes per launch from the
+FETCH_SIZE / WRITE_SIZE passes (corrected as profiles/kernel_table.py says) beside the ALGORITHMIC bytes per launch of the
+engine's own plan (bench.py `kernel_algorithmic`), and their ratio."""
+import json
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+T = {"bf16": "bf16", "float": "f32"}
+
+
+def label_of(kernel):
+    m = re.match(r"(conv_fast|conv_igemm)_kernel<(\w+),(\w+),(\w+),(\d+),(\d+),(\d+),(\d+)", kernel)
+    if m:
+        k, a, b, c, ck, bn, s, mt = m.groups()
+        return "%s<%s,%s,%s,CK%s,BN%s,S%s,MT%s>" % (k, T[a], T[b], T[c], ck, bn, s, mt)
+    m = re.match(r"wgrad_kernel<(\w+),(\w+),(\w+),(\d+),(\d+),(\d+)", kernel)
+    if m:
+        a, b, c, at, bt, s = m.groups()
+        return "wgrad<%s,%s,%s,%sx%s,S%s>" % (T[a], T[b], T[c], at, bt, s)
+    return None
+
+
+def main(tag):
+    out = {}
+    for mode, variant, w in (("train", "unet", "unet"), ("train", "unet2", "unet2"), ("infer", "unet", "infer")):
+        tp = os.path.join(HERE, "%s_%s_kernel_table.json" % (tag, w))
+        bp = os.path.join(HERE, "%s_%s_bench.json" % (tag, w))
+        if not os.path.exists(tp):
+            continue
+        rows = json.load(open(tp))["rows"]
+        algo = {}
+        if os.path.exists(bp):
+            algo = json.load(open(bp)).get("kernel_algorithmic", {})
+        acc = {}
+        for r in rows:
+            lab = label_of(r["kernel"])
+            if lab is None or "hbm_mb" not in r:
+                continue
+            a = acc.setdefault(lab, [0, 0.0, 0.0, 0.0, 0.0])
+            a[0] += r["launches"]
+            a[1] += r["launches"] * r["hbm_mb"] * 1e6
+            a[2] += r["launches"] * r["fetch_mb"] * 1e6
+            a[3] += r["launches"] * r["write_mb"] * 1e6
+            a[4] += r["launches"] * r["us"]
+        for lab, (n, by, fb, wb, us) in acc.items():
+            e = {"bytes_per_launch": int(by / n), "fetch_bytes": int(fb / n), "write_bytes": int(wb / n), "launches_in_pass": n,
+                 "avg_launch_us": round(us / n, 2), "achieved_hbm_gbs": round(by / us / 1e3, 1),
+                 "source": "profiles/%s_%s_kernel_table.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate --kernel-trace-only "
+                           "passes; FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024; mean over every launch of the instantiation)" % (tag, w)}
+            if lab in algo:
+                e["algorithmic_bytes_per_launch"] = int(algo[lab][1] * 1e6)
+                e["traffic_over_algorithmic"] = round(by / n / (algo[lab][1] * 1e6), 3) if algo[lab][1] else None
+                e["algorithmic_gflop_per_launch"] = algo[lab][0]
+            out["%s:%s:%s" % (mode, variant, lab)] = e
+    with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote pmc_traffic.json with %d entries" % len(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
