@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("w", vp), ("dst", vp), ("mode", i32), ("dtype_c", i32), ("Cout", i32), ("Cin", i32), ("kh", i32),
                 ("kw", i32), ("py", i32), ("px", i32), ("rows_pad", i32), ("red_pad", i32), ("red_total", i32),
-                ("red_off", i32), ("ck", i32), ("rows_total", i32), ("rows_off", i32), ("row_scale", vp)]
+                ("red_off", i32), ("ck", i32), ("rows_total", i32), ("rows_off", i32), ("layout", i32), ("row_scale", vp)]
 
 
 class BnFwdDesc(C.Structure):
@@ -145,6 +145,7 @@ P = C.POINTER
 SYMBOLS = {
     "abc_conv_stat_blocks": (C.c_int, [P(ConvDesc)]),
     "abc_conv_variant": (C.c_int, [vp]),
+    "abc_conv_weight_layout": (C.c_int, [vp]),
     "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),
     "abc_conv_chunk": (C.c_int, [C.c_int, C.c_int]),
     "abc_heads_batch": (C.c_int, [vp, i32, i32, vp]),

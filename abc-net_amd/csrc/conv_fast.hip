@@ -219,14 +219,15 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         const unsigned chunk_stride = (unsigned)(a.Cout_pad * CK) * (unsigned)sizeof(CT);
         // (the wave's n-offset sits in the VGPR part: everything in the scalar offset must be provably wave-uniform, or
         //  the compiler wraps every load in a readfirstlane loop)
-        const unsigned bq_voff = (a.dbg & 128) ? 0u : (unsigned)((wn * TN * 32 + r) * CKB + h * LHB);
+        // (abc_pack_desc.layout 1: a 32-row block is [kk][h][r][16 bytes] -- the 64 lanes of one load read 1 KB back to back)
+        const unsigned bq_voff = (unsigned)(wn * TN * 32 * CKB + h * 512 + r * 16);
         auto bq_load = [&](int slot, int c, int t) {
             const unsigned soff = w_n0 + (unsigned)t * tap_stride + (unsigned)c * chunk_stride;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
-                    bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 16), soff, 0);
+                    bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 1024), soff, 0);
         };
         if constexpr (WD != 0) {
 #pragma unroll

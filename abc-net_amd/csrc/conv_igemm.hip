@@ -519,6 +519,12 @@ extern "C" int abc_conv_variant(const abc_conv_desc* d) {
     return 0;
 }
 
+extern "C" int abc_conv_weight_layout(const abc_conv_desc* d) {
+    if (abc_conv_stem_ok(d, nullptr) || abc_head_fwd_ok(d) || abc_head_dgrad_ok(d)) return 0;
+    abc_fast_geom f;
+    return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible && f.wd) ? 1 : 0;   // the weights-direct loop of conv_fast.hip
+}
+
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
     { int nb = 0; if (abc_conv_stem_ok(d, &nb)) return nb; }
     abc_fast_geom f;

@@ -37,6 +37,15 @@ extern "C" int abc_version(void) { return 100; }
 namespace {
 
 // ------------------------------------------------------------------ weight packing
+// element offset of (slice = tap * chunks + chunk, row, k) in a packed weight of `rows` rows per slice
+__host__ __device__ inline size_t abc_pack_offset(size_t slice, int rows, int row, int CK, int k, int layout) {
+    if (layout == 1) {   // bf16, CK = 32: [row / 32][kk][h][row % 32][8 elements] inside the slice (see abc_pack_desc.layout)
+        const int h = k >> 4, kk = (k >> 3) & 1, e = k & 7;
+        return (slice * rows + (size_t)(row & ~31)) * CK + (size_t)(((kk * 2 + h) * 32 + (row & 31)) * 8 + e);
+    }
+    return (slice * rows + row) * CK + k;
+}
+
 // dst[t][chunk][row][k], element type CT; see abc_pack_desc in the public header.
 template <typename CT>
 __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunks) {
@@ -67,7 +76,7 @@ __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunk
         }
         if (d.row_scale != nullptr && (d.mode == 0 || d.mode == 2) && n < d.Cout) v *= d.row_scale[n];
         const int rtot = d.rows_total > 0 ? d.rows_total : d.rows_pad;
-        dst[(((size_t)t * nch_total + ch_off + c) * rtot + d.rows_off + n) * CK + k] = (CT)v;
+        dst[abc_pack_offset((size_t)t * nch_total + ch_off + c, rtot, d.rows_off + n, CK, k, d.layout)] = (CT)v;
     }
 }
 
@@ -98,7 +107,7 @@ __device__ inline void pack_one(const PackItem& it, unsigned r) {
     if (d.row_scale != nullptr && (d.mode == 0 || d.mode == 2) && n < (unsigned)d.Cout) v *= d.row_scale[n];
     const unsigned nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
     const unsigned rtot = d.rows_total > 0 ? (unsigned)d.rows_total : rows;
-    const size_t o = (((size_t)t * nch_total + ch_off + c) * rtot + (unsigned)d.rows_off + n) * CK + k;
+    const size_t o = abc_pack_offset((size_t)t * nch_total + ch_off + c, (int)rtot, (int)((unsigned)d.rows_off + n), (int)CK, (int)k, d.layout);
     if (it.is_bf16) ((bf16*)d.dst)[o] = (bf16)v; else ((float*)d.dst)[o] = v;
 }
 
@@ -241,6 +250,8 @@ extern "C" int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream
     }
     const int CK = d->ck;
     if (CK != abc_conv_chunk(d->dtype_c, d->red_total)) return abc_fail(ABC_EINVAL, "pack: ck does not match red_total");
+    if (d->layout != 0 && (d->layout != 1 || d->dtype_c != ABC_BF16 || CK != 32 || (d->rows_total > 0 ? d->rows_total : d->rows_pad) % 32 || d->rows_off % 32))
+        return abc_fail(ABC_EINVAL, "pack: layout 1 needs bf16, CK = 32, whole 32-row blocks");
     if (d->red_pad % CK || d->red_pad < red || d->red_off % CK || d->red_off + d->red_pad > abc_roundup(d->red_total, CK))
         return abc_fail(ABC_EINVAL, "pack: red_pad/red_off");
     const int nchunks = d->red_pad / CK;
@@ -272,6 +283,9 @@ extern "C" int64_t abc_pack_item_fill(void* item, const abc_pack_desc* d, int64_
     const int CK = d->ck;
     if (CK != abc_conv_chunk(d->dtype_c, d->red_total) || d->red_pad % CK || d->red_pad < red || d->red_off % CK ||
         d->red_off + d->red_pad > abc_roundup(d->red_total, CK)) { abc_fail(ABC_EINVAL, "pack: red_pad/red_off/ck"); return -1; }
+    if (d->layout != 0 && (d->layout != 1 || d->dtype_c != ABC_BF16 || CK != 32 || (d->rows_total > 0 ? d->rows_total : d->rows_pad) % 32 || d->rows_off % 32)) {
+        abc_fail(ABC_EINVAL, "pack: layout 1 needs bf16, CK = 32, whole 32-row blocks"); return -1;
+    }
     PackItem* it = (PackItem*)item;
     it->d = *d; it->CK = CK; it->ntaps = ntaps; it->nchunks = d->red_pad / CK; it->is_bf16 = d->dtype_c == ABC_BF16; it->first = first;
     return (int64_t)ntaps * it->nchunks * d->rows_pad * CK;

@@ -141,6 +141,7 @@ class Engine:
         self.keep = []  # ctypes descriptors and tensors referenced by raw pointer
         self.pack_ops, self.fwd_ops, self.bwd_ops = [], [], []
         self._pack_descs = []
+        self._w_layout = {}   # packed weight buffer -> abc_pack_desc.layout its consuming conv wants
         self.recs = []
         self._ws_need = 0
         self._ws_users = []
@@ -237,6 +238,7 @@ class Engine:
         if stats:
             st = self.new((nblk, stats_rows, Cout), torch.float32)
             d.stats = st.data_ptr()
+        self._w_layout[d.w] = self.lib.abc_conv_weight_layout(C.byref(d))
         bn_, mt_, ck_ = L.i32(), L.i32(), L.i32()
         L.check(self.lib.abc_conv_tile(C.byref(d), C.byref(bn_), C.byref(mt_), C.byref(ck_)), "conv_tile")
         bn, mt, ck = bn_.value, mt_.value, ck_.value
@@ -599,6 +601,7 @@ class Engine:
         host = (C.c_char * (isz * len(self._pack_descs)))()
         first = 0
         for i, pd in enumerate(self._pack_descs):
+            pd.layout = self._w_layout.get(pd.dst, 0)
             n = lib.abc_pack_item_fill(C.addressof(host) + i * isz, C.byref(pd), first)
             if n < 0:
                 L.check(-1, "pack_item_fill")

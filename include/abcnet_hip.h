@@ -126,10 +126,17 @@ typedef struct abc_pack_desc {
                           below the other along the ROW (output-channel) axis -- the 8 heads' conv1 (unet.py:66,116-118) run
                           as ONE 128 -> 8 x 128 convolution over the shared trunk activation */
     int32_t rows_off;  /* where this weight's rows start in dst */
+    int32_t layout;    /* 0: rows of CK elements, [tap][chunk][row][CK].  1 (bf16, CK = 32 only; abc_conv_weight_layout() says which
+                          convolution wants it): inside every block of 32 rows x 64 bytes the bytes are ordered
+                          [kk = 16-byte half of a lane's 32 bytes][h = lane half][r = row][16 bytes], so that ONE fragment load of
+                          the weights-direct conv loop (64 lanes x 16 bytes) reads 1 KB of consecutive bytes = 8 whole cache
+                          lines instead of touching 16 */
     const float* row_scale; /* NULL, or one factor per output row (modes 0 and 2: per output channel): eval-mode BatchNorm folded
                                into the convolution in front of it, w'[n][..] = w[n][..] * gamma[n] / sqrt(running_var[n] + eps) */
 } abc_pack_desc;
 int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream);
+/* abc_pack_desc.layout the kernel that serves this convolution reads its weights in */
+int abc_conv_weight_layout(const abc_conv_desc* d);
 /* batched form: the caller builds a table of abc_pack_item_bytes()-sized entries with abc_pack_item_fill (host
  * memory, `first` = running element offset), copies it to the device once, and packs all weights of a step in ONE launch */
 int abc_pack_item_bytes(void);

@@ -65,6 +65,11 @@ def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, 
     d.Hg, d.Wg, d.Hout, d.Wout, d.ldy, d.cout_off, d.Cout, d.Cout_pad = gh, gw, Hout, Wout, ldy, cout_off, Cout, -(-Cout // 32) * 32
     d.stride, d.om, d.oy0, d.ox0 = stride, om, oy0, ox0
     L.set_taps(d, taps)
+    if lib.abc_conv_weight_layout(C.byref(d)) == 1:
+        # the kernel serving this descriptor reads abc_pack_desc.layout 1: re-order the row-major packing here (an independent
+        # statement of the permutation; abc_pack_conv_weights' own layout-1 path is held to it in test_gpu_kernels.py)
+        wp = wp.view(-1, 32, 2, 2, 8).permute(0, 3, 2, 1, 4).contiguous().view(-1)
+        d.w = wp.data_ptr()
     st = None
     if stats:
         nblk = lib.abc_conv_stat_blocks(C.byref(d))

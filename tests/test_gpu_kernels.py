@@ -548,3 +548,27 @@ def test_conv_rows_packed_side_by_side_and_concat(lib):
         r = ref[:, Cout * i:Cout * (i + 1)].double()
         np.testing.assert_allclose(outs[i][2].cpu().numpy(), r.mean((0, 2, 3)).numpy(), atol=2e-2)
         np.testing.assert_allclose(outs[i][3].cpu().numpy(), (1.0 / torch.sqrt(r.var((0, 2, 3), unbiased=False) + 1e-5)).numpy(), rtol=3e-2)
+
+
+def test_pack_layout_for_the_weights_direct_loop(lib):
+    """abc_pack_desc.layout 1 (what abc_conv_weight_layout() asks for on the 3x3 weights-direct conv loop) is the row-major
+    packing with every 32-row x 64-byte block re-ordered [kk][h][row][16 bytes]; forward and data-gradient modes, a second
+    weight packed below the first (rows_off)"""
+    dt = L.BF16
+    g = torch.Generator().manual_seed(5)
+    Cout, Cin = 96, 64
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / 24).to(U.DEV)
+    for mode, rows, red in ((0, Cout, Cin), (1, Cin, Cout)):
+        rows_pad = -(-rows // 32) * 32
+        ref = U.pack(lib, w, mode, dt, Cout, Cin, 3, rows_pad, red)
+        ck = lib.abc_conv_chunk(dt, red)
+        red_pad = -(-red // ck) * ck
+        got = torch.zeros_like(ref)
+        d = L.PackDesc()
+        d.w, d.dst, d.mode, d.dtype_c = w.data_ptr(), got.data_ptr(), mode, dt
+        d.Cout, d.Cin, d.kh, d.kw = Cout, Cin, 3, 3
+        d.rows_pad, d.red_pad, d.red_total, d.red_off, d.ck, d.layout = rows_pad, red_pad, red, 0, ck, 1
+        L.check(lib.abc_pack_conv_weights(C.byref(d), U.stream()), "pack")
+        torch.cuda.synchronize()
+        want = ref.view(-1, 32, 2, 2, 8).permute(0, 3, 2, 1, 4).contiguous().view(-1)
+        assert torch.equal(got, want), mode
