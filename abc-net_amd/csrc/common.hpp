@@ -395,6 +395,14 @@ struct HaloFetch {
             inb |= ok ? (1u << i) : 0u;
         }
     }
+    // the same segments of a SECOND tensor with the same pixel stride (the BatchNorm-fused weight gradient reads g and y_raw
+    // of one layer side by side): every offset differs from the other fetcher's by one constant
+    template <typename Other>
+    __device__ inline void prepare_like(const Other& o, unsigned delta_bytes) {
+        inb = o.inb;
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) voff[i] = (o.voff[i] >> 31) ? 0x80000000u : o.voff[i] + delta_bytes;
+    }
     __device__ inline void fire(__amdgpu_buffer_rsrc_t rs) {
 #pragma unroll
         for (int i = 0; i < NMAX; ++i) raw[i].ld(rs, voff[i]);

@@ -171,7 +171,13 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
             // all address arithmetic first (see HaloFetch::prepare)
             if (live) {
                 pp.prepare(gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
-                if constexpr (DUAL) pp2.prepare(gP2, b, gy0, gx0, a.cp2_off + ca0, tid, cvalP);
+                if constexpr (DUAL) {
+                    // (g and y_raw: same patch, same segments; with equal pixel strides the offsets differ by a constant)
+                    if (a.ld_p2 == a.p.ldx && a.p.Hx == a.Hg && a.p.Wx == a.Wg)
+                        pp2.prepare_like(pp, (unsigned)((a.cp2_off - a.cp_off) * (int)sizeof(PT)));
+                    else
+                        pp2.prepare(gP2, b, gy0, gx0, a.cp2_off + ca0, tid, cvalP);
+                }
                 pq.prepare(gQ, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.cq_off + cb0, tid, cvalQ);
             } else {
                 pp.prepare_none();
