@@ -10,6 +10,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Timing ablations (ABC_*_DBG bit masks that skip phases of a kernel: results invalid) and in-kernel phase timestamps exist
+// only in a debug build (ABC_KERNEL_DEBUG=1 ./build_hip.sh); the production library compiles them out.
+#ifdef ABC_KERNEL_DEBUG
+#define ABC_DBG(x) (x)
+#define ABC_PROF(p) (p)
+#else
+#define ABC_DBG(x) 0
+#define ABC_PROF(p) ((long long*)nullptr)
+#endif
+
 #define ABC_MAX_TAPS 49
 #define ABC_WAVE 64
 

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    long long* prof = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
+    long long* prof = ABC_PROF(a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr);
     if (prof && tid == 0) { prof[0] = wall_clock64(); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); prof[6] = ((long long)xcc << 32) | hw; }
 
     if (tid < a.ntaps) sTap[tid] = a.ty[tid] * a.RS + a.tx[tid] * PS;
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         return i < cnt ? base + b0 + i : -1;
     };
     for (int round = 0, tile = tile_of(0); tile >= 0; tile = tile_of(++round)) {
+        if (prof && tid == 0) { prof[5] = wall_clock64(); prof[7] = round; }
         int id = tile;
         const int nb = id % a.nblocks_n; id /= a.nblocks_n;
         const int mblock = id;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     // (unconditional: past the last stage the offsets run off the buffer and the loads return zeros;
                     //  a conditional issue would make the compiler drain ALL loads before every commit)
                     if constexpr (!STATIC) issue_next(breg[d]);
-                    if (g == 0 && c + 1 < a.nchunks && !(a.dbg & 2)) apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
+                    if (g == 0 && c + 1 < a.nchunks && !(ABC_DBG(a.dbg) & 2)) apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
 
                     {
                         const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                         // fragment reads software-pipelined one K-step ahead of the MFMAs (two named register sets;
                         // every read unconditional -- the step after the last re-reads the last tap -- so that the
                         // compiler can count lgkmcnt exactly instead of draining the LDS queue before each MFMA group)
-                        const int ntl = (a.dbg & 4) ? 0 : tcnt;
+                        const int ntl = (ABC_DBG(a.dbg) & 4) ? 0 : tcnt;
                         if constexpr (NR == 2) {
                             frag_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
                             int aoff = sTap[t0];
@@ -401,9 +402,9 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     }
 
                     if constexpr (!STATIC) {
-                        if (has_next && !(a.dbg & 8)) b_commit(breg[1 - d], gn, sB + (1 - d) * a.sB_bytes);
+                        if (has_next && !(ABC_DBG(a.dbg) & 8)) b_commit(breg[1 - d], gn, sB + (1 - d) * a.sB_bytes);
                     }
-                    if (closes && !(a.dbg & 16)) {
+                    if (closes && !(ABC_DBG(a.dbg) & 16)) {
                         if (a.a_bufs == 2) {
                             apre.commit(sA + (cn & 1) * a.sA_bytes, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
                         } else {
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         // sum, sum of squares, convert, one ds_write per value with an immediate offset; max / min in a second sweep
         // only when unet2's CBAM asks for them; the general path keeps every check.
         const bool whole = (gy0 + 2 * MT <= a.Hg) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok;
-        if (a.dbg & 64) {
+        if (ABC_DBG(a.dbg) & 64) {
         } else if (whole) {
             char* wbase = stg + 4 * h * ROWB + r * (int)sizeof(OutT);
             const int lrow = lane / SEG_PER_ROW, lsg = lane % SEG_PER_ROW;   // this lane's (pixel row, segment) in the store sweep

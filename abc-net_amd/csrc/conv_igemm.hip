@@ -191,14 +191,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
         if (gn == a.ngroups) { gn = 0; cn = c + 1; }
         const bool has_next = (s + 1 < nstages);
         const bool new_chunk = has_next && (gn == 0);
-        if (has_next && !(a.dbg & 1)) b_issue(cn, gn);
+        if (has_next && !(ABC_DBG(a.dbg) & 1)) b_issue(cn, gn);
         if (s == nstages - 1 && more) {
             decode(next_tile);
             if (!a.b_static) b_issue(0, 0);
             if constexpr (FAST) apre.issue(rsA, gA, b, iy0, ix0, a.cin_off, tid, 1 << 30);
         }
         if constexpr (FAST) {
-            if (new_chunk && !(a.dbg & 2)) apre.issue(rsA, gA, b, iy0, ix0, a.cin_off + cn * CK, tid, 1 << 30);
+            if (new_chunk && !(ABC_DBG(a.dbg) & 2)) apre.issue(rsA, gA, b, iy0, ix0, a.cin_off + cn * CK, tid, 1 << 30);
         }
 
         // ---- MFMA over the taps of this stage
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
             const char* sBc = sB + (s & 1) * a.sB_bytes;
             const int t0 = g * a.tg;
             const int tcnt = min(a.tg, a.ntaps - t0);
-            for (int tl = 0; tl < ((a.dbg & 4) ? 0 : tcnt); ++tl) {
+            for (int tl = 0; tl < ((ABC_DBG(a.dbg) & 4) ? 0 : tcnt); ++tl) {
                 const int aoff = sTap[t0 + tl];
                 const int boff = tl * BN * PS;
 #pragma unroll
@@ -225,12 +225,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
             }
         }
 
-        if (has_next && !(a.dbg & 8)) b_commit(gn, sB + ((s + 1) & 1) * a.sB_bytes);
+        if (has_next && !(ABC_DBG(a.dbg) & 8)) b_commit(gn, sB + ((s + 1) & 1) * a.sB_bytes);
         if (new_chunk) {
             if (a.a_bufs == 2) {
                 // the other halo buffer was last read in chunk c-1: free since the barrier that ended it
                 if constexpr (FAST) {
-                    if (!(a.dbg & 16)) apre.commit(sA + (cn & 1) * a.sA_bytes, a.RS, PS, gA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid, 1 << 30);
+                    if (!(ABC_DBG(a.dbg) & 16)) apre.commit(sA + (cn & 1) * a.sA_bytes, a.RS, PS, gA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid, 1 << 30);
                 }
             } else {
                 __syncthreads();  // every wave is done reading this chunk's halo
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
         bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
     }
     const bool planar = (sizeof(OutT) == 4) && a.planar_out;
-    if (a.dbg & 64) {
+    if (ABC_DBG(a.dbg) & 64) {
     } else if (!planar) {
         constexpr int TW = TN * 32;                       // channels of this wave's tile row
         constexpr int ROWB = TW * (int)sizeof(OutT) + 16;  // padded LDS row (bytes)
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
             }
         }
     }
-    if (a.stats != nullptr && !(a.dbg & 128)) {
+    if (a.stats != nullptr && !(ABC_DBG(a.dbg) & 128)) {
         __syncthreads();  // LDS reuse
         float* red = (float*)(smem + a.stg_off);  // [WM][4][BN]
         const int rows = a.stats_rows == 4 ? 4 : 2;

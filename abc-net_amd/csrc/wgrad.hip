@@ -269,9 +269,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
             prepare(has_next ? next : patch, has_next);
             if (it < 0) fire_all();     // prologue: nothing to hide behind
         } else {
-            if (has_next && !(a.dbg & 1)) issue(next);
+            if (has_next && !(ABC_DBG(a.dbg) & 1)) issue(next);
         }
-        if (it >= 0 && !(a.dbg & 4)) {
+        if (it >= 0 && !(ABC_DBG(a.dbg) & 4)) {
             const char* sP = smem + ((a.nbuf == 2) ? (it & 1) * buf_bytes : 0);
             const char* sQ = sP + a.sP_bytes;
 #pragma unroll(SPREAD ? ROWS : 1)
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
             }
             if (a.nbuf == 1) __syncthreads();  // single buffer: everyone is done reading before it is refilled
         }
-        if (has_next && !(a.dbg & 2)) commit(next, smem + ((a.nbuf == 2) ? ((it + 1) & 1) * buf_bytes : 0));
+        if (has_next && !(ABC_DBG(a.dbg) & 2)) commit(next, smem + ((a.nbuf == 2) ? ((it + 1) & 1) * buf_bytes : 0));
         __syncthreads();
     }
 

@@ -5,6 +5,12 @@ cd "$(dirname "$0")/abc-net_amd/csrc"
 OUT=../libabcnet_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 [ -n "$ABC_RESOURCE_USAGE" ] && FLAGS="$FLAGS -Rpass-analysis=kernel-resource-usage"
+# debug build: phase-skipping ablations (ABC_CONV_DBG / ABC_WGRAD_DBG) and in-kernel phase timestamps (scratch/prof_*.py)
+FLAVOUR=production
+[ -n "$ABC_KERNEL_DEBUG" ] && FLAGS="$FLAGS -DABC_KERNEL_DEBUG=1" && FLAVOUR=debug
+# (objects of the other flavour must not be linked: rebuild the kernels that differ when the flavour changes)
+[ "$(cat .build_flavour 2>/dev/null)" != "$FLAVOUR" ] && rm -f conv_fast.o conv_igemm.o wgrad.o
+echo $FLAVOUR > .build_flavour
 OBJS=""
 pids=""
 for f in conv_igemm conv_fast stem heads wgrad bn_act loss misc cbam metrics extract raster; do
