@@ -1192,9 +1192,9 @@ class Engine:
                        meta={"kernel": "cbam_bwd3", "flops": 0, "bytes": float(npx * Cc * esz * 3)})
             # BN2 backward on d_z, then the second conv
             rec2, rec1 = blk.rec2, blk.rec1
-            # (fusing the BN-backward apply into the weight gradient's load, as unet does, measured neutral here: bn_apply
-            #  -0.27 ms, dual weight gradients +0.33 ms per step -- ABC_UNET2_DEFER=1 to try again)
-            defer2 = bool(os.environ.get("ABC_UNET2_DEFER"))
+            # (the BN-backward apply fused into the weight gradient's load, as unet does: neutral in round 1 -- bn_apply -0.27 ms,
+            #  dual weight gradients +0.33 ms -- +0.9 % since the weight-gradient kernel's prefetch got cheaper: 1231 -> 1242 img/s)
+            defer2 = not os.environ.get("ABC_UNET2_NO_DEFER")
             dY2 = self._bn_finish(ops, rec2, part3, nb3, dz, defer=defer2)
             dA1 = self._conv_backward(ops, rec2, dY2)
             rec1.grad_same = (dA1, rec1.cout, 0)
