@@ -55,7 +55,7 @@ class ActBwdDesc(C.Structure):
 class BnBwdDesc(C.Structure):
     _fields_ = [("partial", vp), ("nblk", i32), ("C", i32), ("count", f64), ("gamma", vp), ("invstd", vp),
                 ("dgamma", vp), ("dbeta", vp), ("k1", vp), ("k2", vp), ("gscale", vp),
-                ("mean", vp), ("ca", vp), ("cb", vp), ("cc", vp)]
+                ("mean", vp), ("ca", vp), ("cb", vp), ("cc", vp), ("in_scale", vp)]
 
 
 class BnApplyDesc(C.Structure):
@@ -137,8 +137,18 @@ class RasterDesc(C.Structure):
                 ("n_atoms", vp), ("bonds", vp), ("n_bonds", vp), ("rho", vp)]
 
 
+class HeadsFusedDesc(C.Structure):
+    _fields_ = [("feat", vp), ("ld", i32), ("scale", vp), ("shift", vp), ("slope", vp), ("mean", vp), ("invstd", vp),
+                ("drop_p", f32), ("drop_seed", u32), ("drop_salt", vp), ("w2", vp * 8), ("b2", vp * 8), ("w2_pack", vp),
+                ("logits", vp * 8), ("t_atom", vp), ("t_types", vp), ("t_charges", vp), ("t_hs", vp), ("t_bond", vp),
+                ("t_btypes", vp), ("t_rho", vp), ("t_omega", vp), ("dl", vp), ("g", vp), ("bn_partial", vp), ("loss_partial", vp),
+                ("B", i32), ("h", i32), ("w", i32), ("chan_scale", vp), ("chan_off", i32 * 8), ("dw2", vp * 8), ("db2", vp * 8),
+                ("wgrad_work", vp)]
+
+
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
-            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc, ExtractDesc, RasterDesc]
+            LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc, ExtractDesc, RasterDesc,
+            HeadsFusedDesc]
 
 # every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
@@ -149,6 +159,15 @@ SYMBOLS = {
     "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),
     "abc_conv_chunk": (C.c_int, [C.c_int, C.c_int]),
     "abc_heads_batch": (C.c_int, [vp, i32, i32, vp]),
+    "abc_heads_fused_pack_bytes": (i64, []),
+    "abc_heads_fused_chunks": (C.c_int, [P(HeadsFusedDesc)]),
+    "abc_heads_fused_dl_elems": (i64, [P(HeadsFusedDesc)]),
+    "abc_heads_fused_wgrad_floats": (i64, [P(HeadsFusedDesc)]),
+    "abc_heads_fused_rows": (C.c_int, [i32]),
+    "abc_heads_fused_chan_of_row": (C.c_int, [i32, i32]),
+    "abc_heads_fused_pack": (C.c_int, [P(HeadsFusedDesc), vp]),
+    "abc_heads_fused_fwd_bwd": (C.c_int, [P(HeadsFusedDesc), vp]),
+    "abc_heads_fused_wgrad": (C.c_int, [P(HeadsFusedDesc), vp]),
     "abc_conv_tile": (C.c_int, [P(ConvDesc), P(i32), P(i32), P(i32)]),
     "abc_pack_conv_weights": (C.c_int, [P(PackDesc), vp]),
     "abc_pack_item_bytes": (C.c_int, []),

@@ -94,6 +94,8 @@ __device__ inline void bn_finalize_bwd_body(const abc_bn_bwd_desc& d, int pstrid
     s1 = block_sum_f64(s1, sm);
     s2 = block_sum_f64(s2, sm);
     if (threadIdx.x == 0) {
+        const float fin = d.in_scale != nullptr ? *d.in_scale : 1.f;   // the producer's gradient lacked this factor
+        s1 *= (double)fin; s2 *= (double)fin;
         if (d.dbeta != nullptr) d.dbeta[c] = (float)s1;
         if (d.dgamma != nullptr) d.dgamma[c] = (float)s2;
         d.k1[c] = (float)(s1 / d.count);
@@ -102,7 +104,7 @@ __device__ inline void bn_finalize_bwd_body(const abc_bn_bwd_desc& d, int pstrid
         d.gscale[c] = gs;
         if (d.ca != nullptr) {
             const float k1 = (float)(s1 / d.count), k2 = (float)(s2 / d.count), is = d.invstd[c];
-            d.ca[c] = gs;
+            d.ca[c] = gs * fin;
             d.cb[c] = -gs * k2 * is;
             d.cc[c] = gs * (d.mean[c] * is * k2 - k1);
         }

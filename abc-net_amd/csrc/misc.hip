@@ -378,6 +378,7 @@ extern "C" int abc_sizeof(int which) {
         case 16: return (int)sizeof(abc_metrics_desc);
         case 17: return (int)sizeof(abc_extract_desc);
         case 18: return (int)sizeof(abc_raster_desc);
+        case 19: return (int)sizeof(abc_heads_fused_desc);
         default: return -1;
     }
 }

@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "../../include/abcnet_hip.h"
 #include "capi_util.hpp"
+#include "heads_fused.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -420,6 +421,7 @@ struct HeadK {
     uint32_t drop_seed;
     const uint32_t* drop_salt;
     unsigned bytesP, bytesQ;
+    int cpad_blk;    // BLK: dl = bf16 [chunk][cpad_blk rows][128 pixels], written by the fused heads kernel (heads_fused.hip)
 };
 
 constexpr int HQ_PSW = 320;  // pixel stride of the [pixel][128 channel] bf16 LDS image (wgrad Q layout)
@@ -432,6 +434,7 @@ constexpr int HEAD_LDS = 2 * (HEAD_PBUF + HEAD_QBUF) + 3 * 128 * 4;
 // addresser's line rate, 7.9 us per 128-pixel chunk (1.7 TB/s for all heads together).  Now both operands are loaded
 // coalesced (a wave instruction = two whole 512-byte rows of dL) one chunk ahead, transformed, and written to LDS as bf16:
 // dL as [row][pixel] (the A fragment of a K-step is one ds_read_b128), the features as [pixel][channel] (read transposed).
+template <bool BLK>
 __device__ inline void head_wgrad_body(const HeadK& a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -476,11 +479,21 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
         const unsigned qoff = live ? (unsigned)(((unsigned)(c * 128 + pix0) * (unsigned)a.ldq + (unsigned)(a.cq_off + part * 8)) * 2u) : 0x80000000u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, live ? qoff + (unsigned)(i * 32 * a.ldq * 2) : qoff, 0, 0);
+        if constexpr (BLK) {
+            // the chunk's 128 rows are ONE contiguous 32 KB block: 16-byte piece q = tid + 512 i = (row q >> 4, pixels 8 (q & 15) ..)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = mg * 128 + (tid >> 4) + 32 * i;
+                const unsigned poff = (live && row < a.cpad_blk) ? (unsigned)((((unsigned)c * (unsigned)a.cpad_blk + (unsigned)row) * 128u + 8u * (tid & 15)) * 2u) : 0x80000000u;
+                preg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsP, poff, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int co = mg * 128 + prow0 + 16 * i;
             const unsigned poff = (live && co < a.hc) ? (unsigned)((((unsigned)(b * a.hc + co)) * (unsigned)a.HW + (unsigned)(pp0 + 4 * pseg)) * 4u) : 0x80000000u;
             preg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsP, poff, 0, 0);
+        }
         }
     };
     auto commit = [&](int c, char* sP, char* sQ, const u32x4 (&qreg)[4], const u32x4 (&preg)[8]) {
@@ -505,6 +518,18 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
                 for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(eoff + j, dseed, a.drop_p) ? v[j] * dscale : 0.f;
             }
             *(bf16x8*)(sQ + pix * HQ_PSW + part * 16) = pack_frag<bf16>(v);
+        }
+        if constexpr (BLK) {
+            // already bf16 in the operand layout: a copy, with the row sums (bias gradient) on the way
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float f = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f += __uint_as_float(preg[i][j] << 16) + __uint_as_float(preg[i][j] & 0xFFFF0000u);
+                rsum[i] += f;
+                *(u32x4*)(sP + ((tid >> 4) + 32 * i) * HP_RSW + (tid & 15) * 16) = preg[i];
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -567,7 +592,17 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
             __syncthreads();
         }
     }
-    if (a.rowsum != nullptr) {
+    if (BLK && a.rowsum != nullptr) {
+        // a row's 16 pieces sit in 16 consecutive lanes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rsum[i];
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            const int row = mg * 128 + (tid >> 4) + 32 * i;
+            if ((tid & 15) == 0 && row < a.Ca_pad) a.rowsum[(size_t)split * a.Ca_pad + row] = v;
+        }
+    } else if (a.rowsum != nullptr) {
         // a row's 32 segments sit in the 32 lanes of one half-wave
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -592,10 +627,38 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
 }
 
 // dL planar f32 (x) activated NHWC bf16 features, 1x1, 128 b-channels, whole 128-pixel chunks per image
-__global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) { head_wgrad_body(a); }
+__global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) { head_wgrad_body<false>(a); }
 // all heads in one launch (blockIdx.z = head), as abc_heads_batch does for the forward and the data gradient
 struct HeadWgBatch { HeadK k[8]; };
-__global__ __launch_bounds__(512, 2) void head_wgrad_batch_kernel(const HeadWgBatch bt) { head_wgrad_body(bt.k[blockIdx.z]); }
+__global__ __launch_bounds__(512, 2) void head_wgrad_batch_kernel(const HeadWgBatch bt) { head_wgrad_body<false>(bt.k[blockIdx.z]); }
+// ... with d(logits) from the fused heads kernel's blocked bf16 buffer (abc_heads_fused_wgrad)
+__global__ __launch_bounds__(512, 2) void head_wgrad_blocked_kernel(const HeadWgBatch bt) { head_wgrad_body<true>(bt.k[blockIdx.z]); }
+
+// slabs of the blocked weight gradient -> conv2.weight.grad / conv2.bias.grad of every head: packed rows back to channels
+// (hf_row_of_chan), times the head's loss factor (abc_loss_finalize's chan_scale), slab order fixed
+struct HeadFusedRedK {
+    const float* partial[HF_NH]; const float* rowsum[HF_NH];
+    float* dw[HF_NH]; float* db[HF_NH];
+    const float* chan_scale;
+    int nsplit[HF_NH], chan_off[HF_NH];
+};
+__global__ __launch_bounds__(128) void head_fused_reduce_kernel(const HeadFusedRedK a) {
+    const int head = blockIdx.y, ch = blockIdx.x, ci = threadIdx.x;
+    if (ch >= hf_ch(head)) return;
+    const int cpad = hf_tiles(head) * 32, row = hf_row_of_chan(head, ch);
+    const float cs = a.chan_scale[a.chan_off[head] + ch];
+    const float* p = a.partial[head] + (size_t)row * 128 + ci;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 2 <= a.nsplit[head]; k += 2) { s0 += p[(size_t)k * cpad * 128]; s1 += p[(size_t)(k + 1) * cpad * 128]; }
+    if (k < a.nsplit[head]) s0 += p[(size_t)k * cpad * 128];
+    a.dw[head][ch * 128 + ci] = (s0 + s1) * cs;
+    if (ci == 0) {
+        float b = 0.f;
+        for (int q = 0; q < a.nsplit[head]; ++q) b += a.rowsum[head][(size_t)q * cpad + row];
+        a.db[head][ch] = b * cs;
+    }
+}
 
 static bool head_ok(const abc_wgrad_desc* d) {
     if (getenv("ABC_WGRAD_NOHEAD")) return false;
@@ -614,6 +677,7 @@ static void head_fill(HeadK& k, const abc_wgrad_desc* d) {
     k.nchunks = d->B * k.HW / 128; k.nsplit = d->nsplit; k.mtiles = abc_cdiv(d->Ca, 32); k.Ca_pad = k.mtiles * 32;
     k.drop_p = d->q.drop_p; k.drop_seed = d->q.drop_seed; k.drop_salt = d->q.drop_salt;
     k.bytesP = (unsigned)((int64_t)d->B * d->Ca * k.HW * 4); k.bytesQ = (unsigned)((int64_t)d->B * k.HW * d->q.ldx * 2);
+    k.cpad_blk = 0;
 }
 
 static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
@@ -978,6 +1042,73 @@ extern "C" int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc
     if (int rc = abc_allow_lds((const void*)head_wgrad_batch_kernel, 160 * 1024, &lds_ok)) return rc;
     hipLaunchKernelGGL(head_wgrad_batch_kernel, dim3(gx, gy, n), dim3(512), HEAD_LDS, (hipStream_t)stream, bt);
     return abc_check_launch("wgrad_heads_batch");
+}
+
+// K-splits of the blocked weight gradient: ONE round of ~256 workgroups (the kernel holds 150 KB of LDS) shared out over the
+// heads by the cost of a 128-pixel chunk (the feature tile is staged and activated once per workgroup, the d(logits) rows on top)
+static void hf_splits(int nchunk, int* nsplit) {
+    double cost[HF_NH], tot = 0;
+    int units[HF_NH];
+    for (int i = 0; i < HF_NH; ++i) {
+        units[i] = abc_cdiv(hf_tiles(i), 4);
+        cost[i] = 4.0 + 1.5 * (double)hf_tiles(i) / units[i] / 4.0;
+        tot += units[i] * cost[i];
+    }
+    for (int i = 0; i < HF_NH; ++i) {
+        int n = (int)(256.0 * cost[i] / tot);
+        n = n < 1 ? 1 : n;
+        nsplit[i] = n > nchunk ? nchunk : n;
+    }
+}
+
+extern "C" int64_t abc_heads_fused_wgrad_floats(const abc_heads_fused_desc* d) {
+    int ns[HF_NH];
+    hf_splits(d->B * d->h * d->w / 128, ns);
+    int64_t n = 0;
+    for (int i = 0; i < HF_NH; ++i) n += (int64_t)ns[i] * hf_tiles(i) * 32 * (128 + 1);
+    return n;
+}
+
+// conv2.weight.grad / conv2.bias.grad of all heads from the fused kernel's blocked d(logits) (unet.py:70 under autograd):
+// dW2[c][ci] = factor_c * sum_p dL[c][p] * act(feat[p][ci]); run after abc_loss_finalize (chan_scale)
+extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t stream) {
+    const int HW = d->h * d->w, nchunk = d->B * HW / 128;
+    if (HW % 128 || d->ld % 8 || (int64_t)d->B * HW * d->ld * 2 >= (int64_t(1) << 31))
+        return abc_fail(ABC_EUNSUPPORTED, "heads_fused_wgrad: whole 128-pixel chunks, feature buffer below 2 GB");
+    int ns[HF_NH];
+    hf_splits(nchunk, ns);
+    HeadWgBatch bt;
+    HeadFusedRedK rk;
+    float* ws = d->wgrad_work;
+    size_t row0 = 0;
+    int gx = 0, gy = 0;
+    for (int i = 0; i < HF_NH; ++i) {
+        HeadK& k = bt.k[i];
+        const int cpad = hf_tiles(i) * 32;
+        k.dl = (const float*)((const bf16*)d->dl + row0 * (size_t)nchunk * 128);
+        k.psc = k.psh = k.psl = nullptr;
+        k.q = d->feat; k.qsc = d->scale; k.qsh = d->shift; k.qsl = d->slope;
+        k.partial = ws; ws += (size_t)ns[i] * cpad * 128;
+        k.rowsum = ws; ws += (size_t)ns[i] * cpad;
+        k.HW = HW; k.hc = hf_ch(i); k.ldq = d->ld; k.cq_off = 128 * i; k.nchunks = nchunk; k.nsplit = ns[i];
+        k.mtiles = hf_tiles(i); k.Ca_pad = cpad;
+        k.drop_p = d->drop_p; k.drop_seed = d->drop_seed; k.drop_salt = d->drop_salt;
+        k.bytesP = (unsigned)((size_t)nchunk * cpad * 128 * 2); k.bytesQ = (unsigned)((int64_t)d->B * HW * d->ld * 2);
+        k.cpad_blk = cpad;
+        if ((size_t)nchunk * cpad * 128 * 2 >= (size_t(1) << 31)) return abc_fail(ABC_EUNSUPPORTED, "heads_fused_wgrad: d(logits) block above 2 GB");
+        gx = ns[i] > gx ? ns[i] : gx;
+        gy = abc_cdiv(k.mtiles, 4) > gy ? abc_cdiv(k.mtiles, 4) : gy;
+        rk.partial[i] = k.partial; rk.rowsum[i] = k.rowsum; rk.dw[i] = d->dw2[i]; rk.db[i] = d->db2[i];
+        rk.nsplit[i] = ns[i]; rk.chan_off[i] = d->chan_off[i];
+        row0 += cpad;
+    }
+    rk.chan_scale = d->chan_scale;
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)head_wgrad_blocked_kernel, 160 * 1024, &lds_ok)) return rc;
+    hipLaunchKernelGGL(head_wgrad_blocked_kernel, dim3(gx, gy, HF_NH), dim3(512), HEAD_LDS, (hipStream_t)stream, bt);
+    if (int rc = abc_check_launch("heads_fused_wgrad")) return rc;
+    hipLaunchKernelGGL(head_fused_reduce_kernel, dim3(360, HF_NH), dim3(128), 0, (hipStream_t)stream, rk);
+    return abc_check_launch("heads_fused_wgrad_reduce");
 }
 
 extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {

@@ -197,6 +197,9 @@ typedef struct abc_bn_bwd_desc {
      *   dY = ca*g + cb*y_raw + cc,  ca = gscale, cb = -gscale*k2*invstd, cc = gscale*(mean*invstd*k2 - k1),
      * for consumers that apply it on load (abc_wgrad_desc.p_dual) instead of a separate abc_bn_apply_bwd pass */
     const float* mean; float* ca; float* cb; float* cc;
+    /* optional device scalar: the partial sums are of g / in_scale -- a producer that could not know a global factor of
+     * its gradient yet (the fused heads kernel: the loss normalisers are batch sums); folded into the sums and into ca */
+    const float* in_scale;
 } abc_bn_bwd_desc;
 int abc_bn_finalize_bwd(const abc_bn_bwd_desc* d, abc_stream_t stream);
 /* n <= 8 layers in one launch; pstride > 0: their partial sums are column slices of one [nblk][2][pstride] buffer */
@@ -307,6 +310,46 @@ int abc_adam_step(const abc_adam_desc* d, abc_stream_t stream);
  * f32 logits; which = 1: data gradient from the NCHW f32 dlogits.  ABC_EUNSUPPORTED when a descriptor is not served by
  * the dedicated heads kernels (then call abc_conv_fwd per head). */
 int abc_heads_batch(const abc_conv_desc* descs, int32_t n, int32_t which, abc_stream_t stream);
+
+/* The heads' second half of a TRAINING step in one pass (bf16): out_modules[i].conv2 forward (unet.py:70, 116-118), the
+ * activation + loss block with d(loss)/d(logits) (train.py:95-125, as abc_loss_fwd_bwd), conv2's data gradient, the
+ * backward of Dropout and LeakyReLU (unet.py:67-69) and BatchNorm-backward partial sums, for the eight heads
+ * [1,14,3,2,1,360,60,60] (train.py:47).  Replaces abc_heads_batch(which = 0) + abc_loss_fwd_bwd + abc_heads_batch(which
+ * = 1) + abc_act_bwd; abc_heads_fused_wgrad replaces abc_wgrad_heads_batch.  Order of a step:
+ *   abc_heads_fused_pack (weights changed) -> abc_heads_fused_fwd_bwd -> abc_loss_finalize(loss_partial, 2 x chunks blocks)
+ *   -> abc_heads_fused_wgrad, abc_bn_finalize_bwd(_batch) with in_scale = chan_scale + chan_off[i] and partial = bn_partial.
+ * Everything the kernel writes is the gradient of each loss term's NUMERATOR (the normalisers are batch sums): g and the
+ * BatchNorm sums lack the head's factor chan_scale[chan_off[i]], which the two consumers above apply. */
+typedef struct abc_heads_fused_desc {
+    const void* feat; int32_t ld;       /* raw conv1 outputs of all heads, NHWC bf16 [B*h*w][ld]; head i = channels [128 i, 128 i + 128) */
+    const float* scale; const float* shift; const float* slope;   /* [ld]: BatchNorm + LeakyReLU applied on load */
+    const float* mean; const float* invstd;                        /* [ld]: batch statistics (for xhat) */
+    float drop_p; uint32_t drop_seed; const uint32_t* drop_salt;   /* Dropout after the activation (abc_act_src) */
+    const float* w2[8]; const float* b2[8];   /* conv2.weight [C_i][128], conv2.bias [C_i] (reference layout, f32) */
+    void* w2_pack;                      /* abc_heads_fused_pack_bytes() bytes, written by abc_heads_fused_pack */
+    float* logits[8];                   /* out: NCHW f32 [B][C_i][h][w] (unet.py:119) */
+    const float* t_atom; const float* t_types; const float* t_charges; const float* t_hs; const float* t_bond;
+    const float* t_btypes; const double* t_rho; const double* t_omega;   /* targets, as abc_loss_desc */
+    void* dl;                           /* out: d(numerator)/d(logits), bf16, abc_heads_fused_dl_elems() elements:
+                                           per head [chunk][packed rows][128 pixels] (row order: abc_heads_fused_chan_of_row) */
+    void* g;                            /* out: NHWC bf16 [B*h*w][ld]: gradient w.r.t. the BatchNorm outputs, without the head's factor */
+    float* bn_partial;                  /* out: [abc_heads_fused_chunks()][2][ld]: sum g, sum g * xhat */
+    double* loss_partial;               /* out: [2 * abc_heads_fused_chunks()][16], the layout abc_loss_finalize reduces */
+    int32_t B, h, w;                    /* h * w a multiple of 128 */
+    /* abc_heads_fused_wgrad only: */
+    const float* chan_scale; int32_t chan_off[8];   /* abc_loss_finalize's factors, first channel of head i */
+    float* dw2[8]; float* db2[8];       /* out: conv2.weight.grad [C_i][128], conv2.bias.grad [C_i] */
+    float* wgrad_work;                  /* abc_heads_fused_wgrad_floats() floats */
+} abc_heads_fused_desc;
+int64_t abc_heads_fused_pack_bytes(void);
+int abc_heads_fused_chunks(const abc_heads_fused_desc* d);
+int64_t abc_heads_fused_dl_elems(const abc_heads_fused_desc* d);
+int64_t abc_heads_fused_wgrad_floats(const abc_heads_fused_desc* d);
+int abc_heads_fused_rows(int32_t head);                       /* packed rows of a head (multiple of 32) */
+int abc_heads_fused_chan_of_row(int32_t head, int32_t row);   /* channel of a packed row, -1 = padding */
+int abc_heads_fused_pack(const abc_heads_fused_desc* d, abc_stream_t stream);
+int abc_heads_fused_fwd_bwd(const abc_heads_fused_desc* d, abc_stream_t stream);
+int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t stream);
 
 /* Inference NMS (img2smiles2.py:61-79) on the NCHW f32 head maps: atom/bond 3x3 peak
  * masks (logit > -1), |rho|, circular 3-tap omega peak mask; outputs NCHW f32 like the reference. */
