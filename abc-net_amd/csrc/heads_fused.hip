@@ -30,6 +30,7 @@
 #include "capi_util.hpp"
 #include "loss_math.hpp"
 #include "heads_fused.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -53,7 +54,7 @@ struct HFK {
     const double *t_rho, *t_omega;
     float* bnpart;      // [nchunk][2][ld]
     double* losspart;   // [2 nchunk][16]
-    int HW, nchunk;
+    int HW, nchunk, dbg;
     HFHead hd[HF_NH];
 };
 
@@ -171,8 +172,9 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
                     z[k] = v[8 * gi + k];
                     const size_t at = pl(360, k * 60 + o);
                     t[k] = a.t_btypes[at];
-                    hd.logits[at] = z[k];
+                    if (!(ABC_DBG(a.dbg) & 2)) hd.logits[at] = z[k];
                 }
+                if (ABC_DBG(a.dbg) & 1) { for (int k = 0; k < 6; ++k) dz[k] = z[k] * t[k]; dn = t[0]; } else
                 num += (double)class_focal<6>(z, t, nullptr, dz, &dn);
                 den += (double)dn;
                 c.dnl[(2 * mt + gi) * 64 + lane] = dn;
@@ -239,7 +241,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
         bf16x8 bq[2];
         bq[0] = pack_frag<bf16>(dlv);
         bq[1] = pack_frag<bf16>(dlv + 8);
-        {
+        if (!(ABC_DBG(a.dbg) & 4)) {
             char* tl = c.ot;
 #pragma unroll
             for (int k = 0; k < 16; ++k) *(bf16*)(tl + ((k & 3) + 8 * (k >> 2) + 4 * h) * TROW + r * 2) = bq[k >> 3][k & 7];
@@ -253,6 +255,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
             lds_sync();
         }
         // ---- data gradient: dA[ci][p] += sum over the tile's 32 rows; K-step u = registers 8 u .. 8 u + 7 of both halves
+        if (!(ABC_DBG(a.dbg) & 8))
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -265,7 +268,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
     // ---- dA -> g: transpose through the wave's LDS tile ([32 pixels][128 channels]) so that a lane owns 8 consecutive
     // channels of a pixel (16-byte loads of the raw feature, 16-byte stores of g); LeakyReLU' and the dropout mask from
     // the raw feature; per-channel sums for BatchNorm's backward
-    {
+    if (!(ABC_DBG(a.dbg) & 16)) {
         char* ot = c.ot;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -443,6 +446,7 @@ extern "C" int abc_heads_fused_fwd_bwd(const abc_heads_fused_desc* d, abc_stream
     k.t_btypes = d->t_btypes; k.t_rho = d->t_rho; k.t_omega = d->t_omega;
     k.bnpart = d->bn_partial; k.losspart = d->loss_partial;
     k.HW = d->h * d->w; k.nchunk = abc_heads_fused_chunks(d);
+    { const char* e = getenv("ABC_HF_DBG"); k.dbg = e ? atoi(e) : 0; }
     size_t row0 = 0;
     for (int i = 0; i < HF_NH; ++i) {
         const int cpad = hf_tiles(i) * 32;

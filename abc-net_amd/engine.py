@@ -107,7 +107,7 @@ class Rec:
 
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
-                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False):
+                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False):
         if variant not in ("unet", "unet2"):
             raise NotImplementedError("variant %r" % variant)
         if H < 32 or W < 32:
@@ -128,6 +128,12 @@ class Engine:
             raise ValueError("fold_bn is the eval-mode graph of unet.py")
         self.dt = L.BF16 if dtype == "bf16" else L.F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        # the fused train step's heads (csrc/heads_fused.hip): conv2 forward + loss + the way back to the BatchNorm outputs as
+        # one pass.  Needs the loss in the plan (so: the Trainer asks for it; a module-style forward() cannot use it), bf16,
+        # the reference's eight heads and whole 128-pixel chunks; settled in _build_heads
+        self.want_fused_heads = bool(fused_heads) and train and dtype == "bf16" and not os.environ.get("ABC_NO_HEADS_FUSED") \
+            and not os.environ.get("ABC_NO_HEADS_BATCH") and not os.environ.get("ABC_NO_HEAD_FUSE")
+        self.hf = None
         self.dev = device
         self.params, self.grads, self.buffers, self.counters = params, grads, buffers, counters
         self.lay_p, self.lay_b, self.lay_c = layout
@@ -637,6 +643,8 @@ class Engine:
         shared = None
         if batch_fin and self.dt == L.BF16 and trunk.C == 128 and not os.environ.get("ABC_NO_HEADS_CONV1_MERGE"):
             shared = self._heads_conv1_merged(trunk, h, w)
+        fused = self.want_fused_heads and shared is not None and self.heads == [1, 14, 3, 2, 1, 360, 60, 60] and (h * w) % 128 == 0 \
+            and self.B * h * w * 128 * nh < (1 << 30)
         for i, hc in enumerate(self.heads):
             p = "out_modules.%d" % i
             rec, f = self.conv_bn(p + ".conv1", p + ".bn", trunk, 128, 3, (self.hfeat, self.hcoef, h, w, 128 * nh, 128 * i), 0.01,
@@ -645,11 +653,12 @@ class Engine:
             rec.is_head = True
             self.head_recs.append(rec)
             f.drop_p, f.drop_seed, f.drop_salt = self.drop_p, self.drop_seed, self.drop_salt
-            rows_pad = -(-hc // 32) * 32
-            w2 = self.packed(1, 128, rows_pad)
-            self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
-            self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
-                           [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs)
+            if not fused:
+                rows_pad = -(-hc // 32) * 32
+                w2 = self.packed(1, 128, rows_pad)
+                self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
+                self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
+                               [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs)
             self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
         if head_fins:
             arr = (L.BnFwdDesc * len(head_fins))()
@@ -660,8 +669,44 @@ class Engine:
             pstride = 128 * nh if shared is not None else 0
             self.fwd_ops.append((lambda _r, st, a=arr: lib.abc_bn_finalize_fwd_batch(a, n, pstride, st), None, "bn out_modules.*.bn", (),
                                  {"kernel": "bn", "flops": 0, "bytes": 0}))
+        if fused:
+            self._heads_fused_setup()
+            return
         # (the eight conv1 launches above write the eight slices of hfeat; the eight 1x1 convolutions go as one launch)
         self.emit_heads_batch(self.fwd_ops, head_convs, 0, "fwd out_modules.*.conv2")
+
+    def _heads_fused_setup(self):
+        """descriptor + buffers of the fused heads pass (abc_heads_fused_*): the conv2 forward leaves the forward plan -- the
+        Trainer runs abc_heads_fused_fwd_bwd + abc_loss_finalize between forward and backward (ops.FusedHeadsLoss, which also
+        binds the targets) -- and the backward plan starts from its outputs (_heads_backward)"""
+        lib, nh, B, h, w = self.lib, len(self.heads), self.B, self.h, self.w
+        Ct = 128 * nh
+        d = L.HeadsFusedDesc()
+        sc, sh, sl = self.hcoef
+        d.feat, d.ld = self.hfeat.data_ptr(), Ct
+        d.scale, d.shift, d.slope = sc.data_ptr(), sh.data_ptr(), sl.data_ptr()
+        d.mean, d.invstd = self.hmean.data_ptr(), self.hinvstd.data_ptr()
+        d.drop_p, d.drop_seed = self.drop_p, self.drop_seed
+        d.drop_salt = self.drop_salt.data_ptr() if self.drop_p > 0 else None
+        d.B, d.h, d.w = B, h, w
+        nchunk = lib.abc_heads_fused_chunks(C.byref(d))
+        self.hf_pack = self.new((lib.abc_heads_fused_pack_bytes() // 4 + 4,), torch.float32)
+        self.hf_dl = self.new((lib.abc_heads_fused_dl_elems(C.byref(d)),), torch.bfloat16)
+        self.hf_g = self.new((B, h, w, Ct))
+        self.hf_bnpart = self.new((nchunk, 2, Ct), torch.float32)
+        self.hf_losspart = torch.zeros((2 * nchunk, 16), dtype=torch.float64, device=self.dev)
+        self.chan_scale = self.new((sum(self.heads),), torch.float32, 0.0)
+        self.hf_work = self.new((lib.abc_heads_fused_wgrad_floats(C.byref(d)),), torch.float32)
+        d.w2_pack, d.dl, d.g = self.hf_pack.data_ptr(), self.hf_dl.data_ptr(), self.hf_g.data_ptr()
+        d.bn_partial, d.loss_partial = self.hf_bnpart.data_ptr(), self.hf_losspart.data_ptr()
+        d.chan_scale, d.wgrad_work = self.chan_scale.data_ptr(), self.hf_work.data_ptr()
+        for i in range(nh):
+            p = "out_modules.%d.conv2" % i
+            d.w2[i], d.b2[i], d.logits[i] = self.P(p + ".weight"), self.P(p + ".bias"), self.logits[i].data_ptr()
+            d.dw2[i], d.db2[i], d.chan_off[i] = self.G(p + ".weight"), self.G(p + ".bias"), self.head_off[i]
+        self.hf, self.hf_chunks = d, nchunk
+        self.pack_ops.append((lambda _r, st: lib.abc_heads_fused_pack(C.byref(d), st), None, "pack out_modules.*.conv2", (),
+                              {"kernel": "heads_fused_pack", "flops": 0, "bytes": 0}))
 
     def _heads_conv1_merged(self, trunk: Src, h, w):
         """pack the eight conv1 weights one below the other ([tap][chunk][8 x 128][CK]), gather their biases, emit the one
@@ -804,6 +849,8 @@ class Engine:
     def _heads_backward(self, ops):
         B, h, w = self.B, self.h, self.w
         nh = len(self.heads)
+        if self.hf is not None:
+            return self._heads_backward_fused(ops)
         self.dlogits = [self.new((B, hc, h, w), torch.float32) for hc in self.heads]
         nchan = sum(self.heads)
         self.chan_scale = self.new((nchan,), torch.float32, 0.0)
@@ -870,6 +917,48 @@ class Engine:
             self.emit_pack(rec.cname + ".weight", wd_all, 1, 128, 128, 3, 128, 128, red_total=128 * nh, red_off=128 * i)
         dtrunk = self.new((B, h, w, 128))
         dy_all = Src(dyh, self.dt, h, w, 128 * nh, 0, 128 * nh)
+        self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
+        self.trunk.producer.grad_same = (dtrunk, 128, 0)
+
+    def _heads_backward_fused(self, ops):
+        """backward plan behind the fused heads pass: conv2's weight / bias gradients from the blocked d(logits), the eight
+        BatchNorm finalisations from the pass's partial sums (times the head's loss factor), then conv1 as in the unfused plan"""
+        B, h, w = self.B, self.h, self.w
+        nh = len(self.heads)
+        Ct = 128 * nh
+        lib, d = self.lib, self.hf
+        npx = B * h * w
+        writes = tuple(n for i in range(nh) for n in ("out_modules.%d.conv2.weight" % i, "out_modules.%d.conv2.bias" % i))
+        ops.append((lambda _r, st: lib.abc_heads_fused_wgrad(C.byref(d), st), None, "wgrad out_modules.*.conv2", writes,
+                    {"kernel": "heads_fused_wgrad", "flops": 2.0 * npx * sum(self.heads) * 128,
+                     "bytes": float(npx * Ct * 2 + self.hf_dl.numel() * 2 + self.hf_work.numel() * 4)}))
+        arr = (L.BnBwdDesc * nh)()
+        merged, bwrites = [], []
+        ca_all, cb_all, cc_all = (self.new((Ct,), torch.float32) for _ in range(3))
+        for i, rec in enumerate(self.head_recs):
+            k1, k2, gs = (self.new((128,), torch.float32) for _ in range(3))
+            ca, cb, cc = (t[128 * i:128 * (i + 1)] for t in (ca_all, cb_all, cc_all))
+            f = arr[i]
+            f.partial, f.nblk, f.C, f.count = self.hf_bnpart.data_ptr() + 4 * 128 * i, self.hf_chunks, 128, float(npx)
+            f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
+            f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
+            f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
+            f.mean, f.ca, f.cb, f.cc = rec.mean.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
+            f.in_scale = self.chan_scale.data_ptr() + 4 * self.head_off[i]
+            bwrites += [rec.bname + ".weight", rec.bname + ".bias"]
+            merged.append(Src(self.hf_g, self.dt, h, w, Ct, 128 * i, 128, coef=(ca_all, cc_all, cb_all)))
+        self.keep.append(arr)
+        ops.append((lambda _r, st, a=arr: lib.abc_bn_finalize_bwd_batch(a, nh, Ct, st), None, "bn_bwd out_modules.*.bn", tuple(bwrites),
+                    {"kernel": "bn_bwd", "flops": 0, "bytes": 0}))
+        taps = taps_square(3)
+        dyh = self.new((B, h, w, Ct))
+        wd_all = self.packed(9, Ct, 128)
+        if not self._heads_conv1_wgrad_merged(ops, merged, dyh, taps):
+            raise RuntimeError("fused heads: the merged conv1 weight gradient was refused")
+        for i, rec in enumerate(self.head_recs):
+            self.emit_pack(rec.cname + ".weight", wd_all, 1, 128, 128, 3, 128, 128, red_total=Ct, red_off=128 * i)
+        dtrunk = self.new((B, h, w, 128))
+        dy_all = Src(dyh, self.dt, h, w, Ct, 0, Ct)
         self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
         self.trunk.producer.grad_same = (dtrunk, 128, 0)
 

@@ -18,13 +18,7 @@ class FusedLoss:
         lib = eng.lib
         self.eng, self.lib = eng, lib
         self.targets = targets  # keep alive
-        exp = [(eng.B, 1), (eng.B, 14), (eng.B, 3), (eng.B, 2), (eng.B, 1), (eng.B, 6, 60), (eng.B, 60), (eng.B, 60)]
-        dts = [torch.float32] * 6 + [torch.float64] * 2
-        for t, e, dt in zip(targets, exp, dts):
-            if tuple(t.shape) != tuple(e) + (eng.h, eng.w) or t.dtype != dt or not t.is_contiguous():
-                raise ValueError("target %s %s does not match the contract %s %s" % (tuple(t.shape), t.dtype, e, dt))
-        if eng.heads != [1, 14, 3, 2, 1, 360, 60, 60]:
-            raise ValueError("the fused loss is defined for heads [1,14,3,2,1,360,60,60] (train.py:47)")
+        self._check_targets(eng, targets)
         d = L.LossDesc()
         for i in range(8):
             d.logits[i], d.dlogits[i] = eng.logits[i].data_ptr(), eng.dlogits[i].data_ptr()
@@ -44,6 +38,16 @@ class FusedLoss:
         f.grad_scale = grad_scale
         self.d, self.f = d, f
 
+    @staticmethod
+    def _check_targets(eng, targets):
+        exp = [(eng.B, 1), (eng.B, 14), (eng.B, 3), (eng.B, 2), (eng.B, 1), (eng.B, 6, 60), (eng.B, 60), (eng.B, 60)]
+        dts = [torch.float32] * 6 + [torch.float64] * 2
+        for t, e, dt in zip(targets, exp, dts):
+            if tuple(t.shape) != tuple(e) + (eng.h, eng.w) or t.dtype != dt or not t.is_contiguous():
+                raise ValueError("target %s %s does not match the contract %s %s" % (tuple(t.shape), t.dtype, e, dt))
+        if eng.heads != [1, 14, 3, 2, 1, 360, 60, 60]:
+            raise ValueError("the fused loss is defined for heads [1,14,3,2,1,360,60,60] (train.py:47)")
+
     def run(self, stream):
         L.check(self.lib.abc_loss_fwd_bwd(C.byref(self.d), stream), "loss_fwd_bwd")
         L.check(self.lib.abc_loss_finalize(C.byref(self.f), stream), "loss_finalize")
@@ -56,6 +60,35 @@ class FusedLoss:
             r[n] = o[1 + i].item()
             r["raw_" + n] = o[9 + i].item()
         return r
+
+
+class FusedHeadsLoss(FusedLoss):
+    """The fused train step's heads (engine built with fused_heads=True): out_modules[i].conv2 + activation + loss +
+    d(logits) + the gradient back to the heads' BatchNorm outputs in one pass (abc_heads_fused_fwd_bwd), then the same
+    finalisation as FusedLoss.  Same interface."""
+
+    def __init__(self, eng, targets, s_ptr, ds_ptr, grad_scale=1.0):
+        lib = eng.lib
+        self.eng, self.lib = eng, lib
+        self.targets = targets
+        self._check_targets(eng, targets)
+        d = eng.hf
+        (d.t_atom, d.t_types, d.t_charges, d.t_hs, d.t_bond, d.t_btypes, d.t_rho, d.t_omega) = (t.data_ptr() for t in targets)
+        self.nblk = 2 * eng.hf_chunks
+        self.partial = eng.hf_losspart
+        self.out = torch.zeros(17, dtype=torch.float64, device=eng.logits[0].device)
+        f = L.LossFinDesc()
+        f.partial, f.nblk, f.s, f.ds, f.out = self.partial.data_ptr(), self.nblk, s_ptr, ds_ptr, self.out.data_ptr()
+        f.chan_scale, f.nchan = eng.chan_scale.data_ptr(), eng.chan_scale.numel()
+        for i in range(8):
+            f.chan_off[i] = eng.head_off[i]
+            f.head_c[i] = eng.heads[i]
+        f.grad_scale = grad_scale
+        self.d, self.f = d, f
+
+    def run(self, stream):
+        L.check(self.lib.abc_heads_fused_fwd_bwd(C.byref(self.d), stream), "heads_fused_fwd_bwd")
+        L.check(self.lib.abc_loss_finalize(C.byref(self.f), stream), "loss_finalize")
 
 
 METER_NAMES = [

@@ -15,12 +15,12 @@ import torch
 
 from . import _lib as L
 from . import distributed as D
-from .ops import FusedAdam, FusedLoss, FusedMetrics
+from .ops import FusedAdam, FusedHeadsLoss, FusedLoss, FusedMetrics
 
 
 class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
-                 process_group=None, device=None, metrics=False, broadcast_buffers="lazy"):
+                 process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True):
         """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
         mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
         as DDP does; "lazy" (default): right before they are read (state_dict(), sync_buffers()), which is observably the
@@ -47,7 +47,8 @@ class Trainer:
         model.train()
         with torch.cuda.device(dev):
             x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
-            self.eng = model._engine_for(x0, True)
+            # (fused_heads: the heads' 1x1 convolutions, the loss and the way back as one pass where the engine can -- bf16)
+            self.eng = model._engine_for(x0, True, fused_heads=fused_heads)
         eng = self.eng
         h, w = eng.h, eng.w
         B = batch
@@ -55,8 +56,8 @@ class Trainer:
         dts = [torch.float32] * 6 + [torch.float64] * 2
         self.targets = [torch.zeros(s, dtype=dt, device=dev) for s, dt in zip(shapes, dts)]
         off_s, _ = model._lay_p["s"]
-        self.loss = FusedLoss(eng, self.targets, model._flat.data.data_ptr() + 4 * off_s, model._flat_grad.data_ptr() + 4 * off_s,
-                              grad_scale=1.0 / self.world)
+        self.loss = (FusedHeadsLoss if eng.hf is not None else FusedLoss)(
+            eng, self.targets, model._flat.data.data_ptr() + 4 * off_s, model._flat_grad.data_ptr() + 4 * off_s, grad_scale=1.0 / self.world)
         # train.py:145-215: the 17 meters, updated every step on the device (no host round trips); off by default
         self.metrics = FusedMetrics(eng.logits, self.targets) if metrics else None
         self.lr, self.wd = lr, weight_decay
@@ -229,7 +230,11 @@ class Trainer:
                     e0.record(stream)
                     self.loss.run(st)
                     e1.record(stream)
-                    marks.append(("loss_fwd_bwd+finalize", 0.0, float(eng.B * eng.h * eng.w * (501 * 4 * 2 + 381 * 4 + 120 * 8)), e0, e1))
+                    if eng.hf is not None:   # features read twice, targets, logits + blocked d(logits) + g written
+                        marks.append(("heads_fused+finalize", 2.0 * 2 * eng.B * eng.h * eng.w * 128 * 501,
+                                      float(eng.B * eng.h * eng.w * (1024 * 2 * 3 + 501 * 4 + 768 * 2 + 381 * 4 + 120 * 8)), e0, e1))
+                    else:
+                        marks.append(("loss_fwd_bwd+finalize", 0.0, float(eng.B * eng.h * eng.w * (501 * 4 * 2 + 381 * 4 + 120 * 8)), e0, e1))
                     continue
                 for fn, ref, what, _w, meta in ops:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 FLAVOUR=production
 [ -n "$ABC_KERNEL_DEBUG" ] && FLAGS="$FLAGS -DABC_KERNEL_DEBUG=1" && FLAVOUR=debug
 # (objects of the other flavour must not be linked: rebuild the kernels that differ when the flavour changes)
-[ "$(cat .build_flavour 2>/dev/null)" != "$FLAVOUR" ] && rm -f conv_fast.o conv_igemm.o wgrad.o
+[ "$(cat .build_flavour 2>/dev/null)" != "$FLAVOUR" ] && rm -f conv_fast.o conv_igemm.o wgrad.o heads_fused.o
 echo $FLAVOUR > .build_flavour
 OBJS=""
 pids=""

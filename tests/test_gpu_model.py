@@ -545,7 +545,7 @@ def test_batched_heads_equal_one_by_one_launches(variant, monkeypatch):
 
     def one_step():
         m = make_model(dtype="bf16", dropout_p=0.2, variant=variant)
-        tr = Trainer(m, B, S, S, lr=0.0, use_graph=False)
+        tr = Trainer(m, B, S, S, lr=0.0, use_graph=False, fused_heads=False)   # (the fused pass has its own test below)
         tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
         tr.step()
         torch.cuda.synchronize()
@@ -570,6 +570,43 @@ def test_batched_heads_equal_one_by_one_launches(variant, monkeypatch):
             assert rel <= 1e-5, (name, rel)       # 1x1 convs and BN parameters of the heads: upstream of any bf16 re-rounding
         else:
             assert rel <= 1e-1, (name, rel)   # (worst seen: 2.4e-2 unet, 5.6e-2 unet2 -- the first block, ~60 bf16 roundings away)
+
+
+@pytest.mark.parametrize("variant", ["unet", "unet2"])
+def test_fused_heads_step_equals_unfused_step(variant):
+    """The Trainer's default bf16 step runs the heads' conv2 + loss + way back as ONE pass (csrc/heads_fused.hip).  Against
+    the same step on the separate kernels (fused_heads=False): logits bit for bit (same MFMA sequence), the loss to f64
+    summation order, conv2's gradients to the bf16 rounding of d(logits) (the separate kernels read them in f32), the rest
+    inside the bf16 gradient noise floor, as in the test above."""
+    from abcnet_amd.train import Trainer
+    B, S = 2, 128
+    x, tg = synthetic_images(B, S, seed=7), synthetic_targets(B, S // 4, seed=1)
+
+    def one_step(fused):
+        m = make_model(dtype="bf16", dropout_p=0.2, variant=variant)
+        tr = Trainer(m, B, S, S, lr=0.0, use_graph=False, fused_heads=fused)
+        assert (tr.eng.hf is not None) == fused
+        tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+        tr.step()
+        torch.cuda.synchronize()
+        return [t.clone() for t in tr.eng.logits], m._flat_grad.clone(), tr.loss_value(), dict(m._lay_p)
+
+    lg_f, g_f, loss_f, lay = one_step(True)
+    lg_u, g_u, loss_u, _ = one_step(False)
+    for a, b in zip(lg_f, lg_u):
+        assert torch.equal(a, b)
+    for k in loss_u:
+        assert abs(loss_f[k] - loss_u[k]) <= 1e-10 * abs(loss_u[k]) + 1e-14, k
+    for name, (off, n) in lay.items():
+        a, b = g_f[off:off + n].double(), g_u[off:off + n].double()
+        rel = (a - b).norm().item() / (b.norm().item() + 1e-30)
+        if name == "s":
+            assert rel <= 1e-6, (name, rel)
+        elif name.startswith("out_modules.") and "conv2" in name:
+            assert rel <= 1e-2, (name, rel)
+        else:
+            # (worst seen: 1.2e-1 on a CBAM MLP bias of unet2's first block -- the far end of the chain, a near-cancelling sum)
+            assert rel <= (1e-1 if variant == "unet" else 2e-1), (name, rel)
 
 
 @pytest.mark.parametrize("prefix", ["dconv2", "dconv1", "up1.conv", "inc2", "down2.maxpool_conv.1"])
