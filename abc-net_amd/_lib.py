@@ -161,6 +161,7 @@ SYMBOLS = {
     "abc_heads_batch": (C.c_int, [vp, i32, i32, vp]),
     "abc_heads_fused_pack_bytes": (i64, []),
     "abc_heads_fused_chunks": (C.c_int, [P(HeadsFusedDesc)]),
+    "abc_heads_fused_loss_blocks": (C.c_int, [P(HeadsFusedDesc)]),
     "abc_heads_fused_dl_elems": (i64, [P(HeadsFusedDesc)]),
     "abc_heads_fused_wgrad_floats": (i64, [P(HeadsFusedDesc)]),
     "abc_heads_fused_rows": (C.c_int, [i32]),

@@ -53,10 +53,19 @@ __device__ inline float abc_act(float x, float sc, float sh, float sl) {
 // Counter-based dropout keep-decision (K7).  idx = element index in the tensor the
 // mask applies to.  Mirrored bit-for-bit by abcnet_amd.dropout.keep_mask (torch int ops)
 // so that the oracle can be driven with the identical mask.
-__host__ __device__ inline bool abc_drop_keep(uint32_t idx, uint32_t seed, float p) {
+__host__ __device__ inline uint32_t abc_drop_hash24(uint32_t idx, uint32_t seed) {
     uint32_t h = idx * 0x9E3779B1u ^ seed;
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+    return h >> 8;
+}
+__host__ __device__ inline bool abc_drop_keep(uint32_t idx, uint32_t seed, float p) {
+    return (float)abc_drop_hash24(idx, seed) * (1.0f / 16777216.0f) >= p;
+}
+// the same decision as an integer compare: k * 2^-24 >= p  <=>  k >= ceil(p * 2^24)  (k < 2^24 and the scaling are exact)
+__host__ inline uint32_t abc_drop_threshold(float p) {
+    const double t = (double)p * 16777216.0;
+    const uint32_t f = (uint32_t)t;
+    return (double)f < t ? f + 1u : f;
 }
 
 // XCD-aware, bijective block remap: blocks with equal (bid % 8) share an XCD (and

@@ -48,31 +48,37 @@ struct HFK {
     bf16* g;
     int ld;
     float drop_p;
-    uint32_t drop_seed;
+    uint32_t drop_seed, drop_thr;   // drop_thr: keep <=> hash24 >= drop_thr (abc_drop_threshold)
     const uint32_t* drop_salt;
     const float *t_atom, *t_types, *t_charges, *t_hs, *t_bond, *t_btypes;
     const double *t_rho, *t_omega;
     float* bnpart;      // [nchunk][2][ld]
-    double* losspart;   // [2 nchunk][16]
+    double* losspart;   // [HF_GROUPS nchunk][16]
     int HW, nchunk, dbg;
     HFHead hd[HF_NH];
 };
 
-constexpr int OROW = 128 * 2 + 16;         // row of the g transpose tile: 128 feature channels bf16 + pad
-constexpr int TROW = 32 * 2 + 16;          // row of the d(logits) tile: 32 pixels bf16 + pad
-constexpr int WV_OT = 32 * OROW;           // 8704 (the d(logits) tile aliases it: 32 x 80)
-constexpr int WV_DN = 30 * 64 * 4;         // per-lane sum of the bond-type targets of each of its 30 omega bins
-constexpr int WV = WV_OT + WV_DN;
-constexpr int LDS_BSUM = 4 * WV;           // [2 buffers][4 waves][2][128] f32
-constexpr int LDS_LSUM = LDS_BSUM + 2 * 4 * 2 * 128 * 4;   // [4 waves][16] f64
+// Wave-private LDS (16 KB per wave):
+//   [0, 4608)      d(logits) tile [32 rows][32 pixels] bf16 (rows of 80 B) during the row-tile loop; in the epilogue the
+//                  transpose tile of half a slice, [32 pixels][64 channels] bf16 (rows of 144 B)
+//   [2560, 5120)   the head's packed bias (<= 480 f32 from 2560; dead once the row-tile loop is over)
+//   [5120, 7680)   the slice's per-channel coefficients [scale | shift | slope | mean | invstd][128] f32
+//   [8704, 16384)  group 0: per-lane sum of the bond-type targets of each of its 30 omega bins (bond types -> rho);
+//                  omega: the omega targets of the lane's 30 bins
+constexpr int TROW = 32 * 2 + 16;          // row of the d(logits) tile
+constexpr int HROW = 64 * 2 + 16;          // row of the epilogue's transpose tile
+constexpr int WV_BIAS = 2560, WV_CF = 5120, WV_DN = 8704;
+constexpr int WV = 16384;
+constexpr int LDS_BSUM = 4 * WV;           // the waves' BatchNorm sums: [4 waves][<= 2 slices][2][128] f32 = 8 KB
+constexpr int LDS_LSUM = LDS_BSUM + 4 * 2 * 2 * 128 * 4;   // [4 waves][16] f64
 constexpr int HF_LDS = LDS_LSUM + 4 * 16 * 8;
 
 struct Ctx {
-    int lane, r, h, wave, chunk, b, yx, parity;
+    int lane, r, h, wave, chunk, b, yx, nslice;
     uint32_t pix, pix0;
     char* ot;
     float* dnl;
-    float* bsum;
+    float* wsum;     // this wave's BatchNorm sums: [slice of the group][2][128]
     float dscale;
     uint32_t dseed;
 };
@@ -85,49 +91,71 @@ __device__ inline double wave_sum_d(double v) {
     return v;
 }
 
-// One head for the wave's 32 pixels.  num / den: this lane's share of the head's loss numerator / denominator.
+// One head for the wave's 32 pixels; its loss numerator / denominator (summed over the wave) go to lsum[HEAD] / lsum[8 + HEAD].
+//
+// The row-tile loop is software-pipelined by hand: on this hardware loads and stores retire through ONE in-order counter, so
+// a wait for a load also waits for every store issued before it.  Each iteration therefore issues everything the NEXT one
+// needs (its weight fragments, its targets, the data-gradient fragments of this tile) BEFORE its own stores, and the
+// data-gradient MFMAs of a tile run at the top of the following iteration.
 template <int HEAD>
-__device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) {
+__device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
+    double num = 0.0, den = 0.0;
     constexpr int CH = hf_ch(HEAD), NT = hf_tiles(HEAD), CPAD = NT * 32;
     const HFHead& hd = a.hd[HEAD];
     const int slice = 128 * HEAD;
     const int r = c.r, h = c.h, lane = c.lane;
-    const size_t HW = (size_t)a.HW;
-    // plane (b, ch) of a C-channel NCHW map at this lane's pixel
-    auto pl = [&](int C, int ch) -> size_t { return ((size_t)c.b * C + ch) * HW + c.yx; };
+    // NCHW planes: address = base + [uniform: plane chu of the head] + [this lane: image, the lane half's 30 bins, pixel].  The
+    // uniform part stays in scalar registers (one VGPR offset serves every plane access of the head; per-plane VGPR pointers,
+    // strength-reduced over the tile loop, cost 50 spilled registers)
+    const uint32_t lch = HEAD >= 5 ? 30u * h : 0u;
+    const uint32_t loff = ((uint32_t)(c.b * CH) + lch) * (uint32_t)a.HW + (uint32_t)c.yx;   // elements (32-bit: checked on the host)
+    auto at4 = [&](const float* base, int chu) -> const float* { return (const float*)((const char*)(base + (size_t)chu * a.HW) + 4u * loff); };
+    auto at4w = [&](float* base, int chu) -> float* { return (float*)((char*)(base + (size_t)chu * a.HW) + 4u * loff); };
+    auto at8 = [&](const double* base, int chu) -> const double* { return (const double*)((const char*)(base + (size_t)chu * a.HW) + 8u * loff); };
+    float* cf = (float*)(c.ot + WV_CF);
+    float* bl = (float*)(c.ot + WV_BIAS);
+    const uint32_t e0 = c.pix * (uint32_t)a.ld + slice + 8 * h;   // this lane's first feature element
 
-    // ---- features of the wave's pixels as B fragments: lane (pixel r, half h) holds channels 16 kk + 8 h .. + 8
-    bf16x8 fb[8];
+    // ---- issue: features, coefficients + bias (-> LDS), the first tile's weights and targets
+    u32x4 raw[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) raw[kk] = *(const u32x4*)(a.y1 + e0 + 16 * kk);
     {
-        const uint32_t e0 = c.pix * (uint32_t)a.ld + slice + 8 * h;
-        u32x4 raw[8];
+        const int ch = slice + 2 * lane;
+        const float2 v0 = *(const float2*)(a.sc + ch), v1 = *(const float2*)(a.sh + ch), v2 = *(const float2*)(a.sl + ch),
+                     v3 = *(const float2*)(a.mean + ch), v4 = *(const float2*)(a.invstd + ch);
+        *(float2*)(cf + 0 * 128 + 2 * lane) = v0; *(float2*)(cf + 1 * 128 + 2 * lane) = v1; *(float2*)(cf + 2 * 128 + 2 * lane) = v2;
+        *(float2*)(cf + 3 * 128 + 2 * lane) = v3; *(float2*)(cf + 4 * 128 + 2 * lane) = v4;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) raw[kk] = *(const u32x4*)(a.y1 + e0 + 16 * kk);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float v[8], sc[8], sh[8], sl[8];
-            const int cc = slice + 16 * kk + 8 * h;
-            LoadVec<float, 8>::ld(a.sc + cc, sc); LoadVec<float, 8>::ld(a.sh + cc, sh); LoadVec<float, 8>::ld(a.sl + cc, sl);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(raw[kk][j] << 16); v[2 * j + 1] = __uint_as_float(raw[kk][j] & 0xFFFF0000u); }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = abc_act(v[j], sc[j], sh[j], sl[j]);
-            if (a.drop_p > 0.f) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(e0 + 16 * kk + j, c.dseed, a.drop_p) ? v[j] * c.dscale : 0.f;
-            }
-            fb[kk] = pack_frag<bf16>(v);
-        }
+        for (int i = 0; i < (CPAD + 63) / 64; ++i)
+            if (lane + 64 * i < CPAD) bl[lane + 64 * i] = hd.biasp[lane + 64 * i];
     }
+    bf16x8 fa[8];
+    auto load_fa = [&](int mt) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            fa[kk] = *(const bf16x8*)((const char*)(hd.w2f + (size_t)((kk >> 1) * CPAD + 32 * mt) * 32 + 16 * (kk & 1)) + (uint32_t)(r * 64 + h * 16));
+    };
+    float tn[HEAD == 5 ? 12 : 1];
+    auto load_t5 = [&](int mt) {
+        if constexpr (HEAD == 5) {
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) tn[6 * gi + k] = *at4(a.t_btypes, k * 60 + 2 * mt + gi);
+        }
+    };
+    // (only the 15-tile head is worth the registers the prefetch holds across the loss code; the others load at the point of use)
+    constexpr bool PIPE = HEAD == 5;
+    if constexpr (PIPE) { load_fa(0); load_t5(0); }
 
     // omega: the per-pixel weight is the sum of the pixel's 60 omega targets (train.py:124): this lane's 30 + the other half's
-    // (the targets are parked in the wave's LDS slots the bond-type group uses for its sums: this group has no such sums)
     double wpix = 0.0;
     if constexpr (HEAD == 7) {
         double wp = 0.0;
 #pragma unroll 6
         for (int j = 0; j < 30; ++j) {
-            const double t = a.t_omega[pl(60, 30 * h + j)];
+            const double t = *at8(a.t_omega, j);
             wp += t;
             c.dnl[j * 64 + lane] = (float)t;
         }
@@ -135,51 +163,97 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
         den = (h == 0) ? wpix : 0.0;
     }
 
+    // ---- features as B fragments: lane (pixel r, half h) holds channels 16 kk + 8 h .. + 8, BN + LeakyReLU + dropout applied
+    lds_sync();
+    // (bit 8 (kk & 3) + j of word kk >> 2 = element j of fragment kk: kept by the dropout / BatchNorm output positive -- the
+    //  epilogue's LeakyReLU' and dropout mask without a second hash)
+    bf16x8 fb[8];
+    uint32_t kbits[2] = {0u, 0u}, pbits[2] = {0u, 0u};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        float v[8], sc[8], sh[8], sl[8];
+        const int cc = 16 * kk + 8 * h;
+        LoadVec<float, 8>::ld(cf + cc, sc); LoadVec<float, 8>::ld(cf + 128 + cc, sh); LoadVec<float, 8>::ld(cf + 256 + cc, sl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(raw[kk][j] << 16); v[2 * j + 1] = __uint_as_float(raw[kk][j] & 0xFFFF0000u); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = fmaf(v[j], sc[j], sh[j]);
+            const bool keep = a.drop_p > 0.f ? abc_drop_hash24(e0 + 16 * kk + j, c.dseed) >= a.drop_thr : true;
+            const int bit = 8 * (kk & 3) + j;
+            kbits[kk >> 2] |= (keep ? 1u : 0u) << bit;
+            pbits[kk >> 2] |= (y > 0.f ? 1u : 0u) << bit;
+            v[j] = keep ? fmaxf(y, sl[j] * y) * c.dscale : 0.f;
+        }
+        fb[kk] = pack_frag<bf16>(v);
+    }
+
     f32x16 accD[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int k = 0; k < 16; ++k) accD[mi][k] = 0.f;
+    bf16x8 wt[8], bqp[2];
+    auto dgrad_mfma = [&]() {
+        if (ABC_DBG(a.dbg) & 8) return;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) accD[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[4 * u + mi], bqp[u], accD[mi], 0, 0, 0);
+    };
 
 #pragma unroll 1
     for (int mt = 0; mt < NT; ++mt) {
-        // ---- logits of 32 packed rows x 32 pixels
-        bf16x8 fa[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-            fa[kk] = *(const bf16x8*)(hd.w2f + ((size_t)((kk >> 1) * CPAD + 32 * mt + r) * 32 + 16 * (kk & 1) + 8 * h));
-        f32x4 b4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = *(const f32x4*)(hd.biasp + 32 * mt + 8 * q + 4 * h);
+        // ---- data gradient of the previous tile: dA[ci][p] += W2^T x dL, K-step u = registers 8 u .. 8 u + 7 of both halves
+        if (PIPE && mt > 0) dgrad_mfma();
+        if constexpr (!PIPE) load_fa(mt);
+        // ---- logits of 32 packed rows x 32 pixels (the accumulators start from the bias)
         f32x16 acc;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *(const f32x4*)(bl + 32 * mt + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * q + j] = b4[j];
+        }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk], acc, 0, 0, 0);
         float v[16], dlv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { v[k] = acc[k] + b4[k >> 2][k & 3]; dlv[k] = 0.f; }
-
+        for (int k = 0; k < 16; ++k) { v[k] = acc[k]; dlv[k] = 0.f; }
         // ---- loss + d(logits): register k of lane half h = packed row 32 mt + (k & 3) + 8 (k >> 2) + 4 h (hf_chan_of_row)
         if constexpr (HEAD == 5) {
             // registers 8 gi .. 8 gi + 5 = the six bond types of omega bin 30 h + 2 mt + gi (train.py:101 view)
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi) {
-                const int o = 30 * h + 2 * mt + gi;
                 float z[6], t[6], dz[6], dn = 0.f;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    z[k] = v[8 * gi + k];
-                    const size_t at = pl(360, k * 60 + o);
-                    t[k] = a.t_btypes[at];
-                    if (!(ABC_DBG(a.dbg) & 2)) hd.logits[at] = z[k];
-                }
+                for (int k = 0; k < 6; ++k) { z[k] = v[8 * gi + k]; t[k] = tn[6 * gi + k]; }
                 if (ABC_DBG(a.dbg) & 1) { for (int k = 0; k < 6; ++k) dz[k] = z[k] * t[k]; dn = t[0]; } else
-                num += (double)class_focal<6>(z, t, nullptr, dz, &dn);
+                num += (double)class_focal<6, true>(z, t, nullptr, dz, &dn);
                 den += (double)dn;
                 c.dnl[(2 * mt + gi) * 64 + lane] = dn;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) dlv[8 * gi + k] = dz[k];
+            }
+            // ---- loads of the next iteration (weights, targets) and this tile's data-gradient fragments: after the loss
+            // arithmetic (its registers are free again), still AHEAD of this tile's stores
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler would hoist these loads over the loss arithmetic: 80 spilled registers)
+            {
+                const int mtn = mt + 1 < NT ? mt + 1 : mt;
+                load_fa(mtn);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        wt[4 * u + mi] = *(const bf16x8*)((const char*)(hd.w2t + (size_t)((2 * mt + u) * 128 + 32 * mi) * 16) + (uint32_t)(r * 32 + h * 16));
+                load_t5(mtn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABC_DBG(a.dbg) & 2)) {
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) *at4w(hd.logits, k * 60 + 2 * mt + gi) = v[8 * gi + k];
             }
         } else if constexpr (HEAD == 6) {
             // rho: |abs(pred) - rho| * sum_types(t)   (train.py:105,121), f64 like the reference
@@ -187,10 +261,9 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
             for (int k = 0; k < 16; ++k) {
                 const int j = 16 * mt + k;
                 if (j < 30) {
-                    const size_t at = pl(60, 30 * h + j);
                     const float zr = v[k];
-                    hd.logits[at] = zr;
-                    const double tr = a.t_rho[at];
+                    const double tr = *at8(a.t_rho, j);
+                    *at4w(hd.logits, j) = zr;
                     const float dn = c.dnl[j * 64 + lane];
                     const double diff = (double)fabsf(zr) - tr;
                     num += fabs(diff) * (double)dn;
@@ -198,6 +271,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
                     const float sz = (zr > 0.f) ? 1.f : ((zr < 0.f) ? -1.f : 0.f);
                     dlv[k] = sg * sz * dn;
                 }
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the 16 bins from being interleaved: registers)
             }
         } else if constexpr (HEAD == 7) {
             // omega: focal per bin weighted by the pixel's weight (train.py:124-125)
@@ -205,32 +279,32 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
             for (int k = 0; k < 16; ++k) {
                 const int j = 16 * mt + k;
                 if (j < 30) {
-                    hd.logits[pl(60, 30 * h + j)] = v[k];
+                    *at4w(hd.logits, j) = v[k];
                     float dz;
-                    num += (double)center_focal(v[k], c.dnl[j * 64 + lane], (float)wpix, &dz);
+                    num += (double)center_focal<true>(v[k], c.dnl[j * 64 + lane], (float)wpix, &dz);
                     dlv[k] = dz;
                 }
+                if ((k & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
         } else if (h == 0) {
             if constexpr (HEAD == 0 || HEAD == 4) {
-                const size_t at = pl(1, 0);
-                const float t = (HEAD == 0 ? a.t_atom : a.t_bond)[at];
-                hd.logits[at] = v[0];
+                const float t = *at4(HEAD == 0 ? a.t_atom : a.t_bond, 0);
+                *at4w(hd.logits, 0) = v[0];
                 float dz;
-                num += (double)center_focal(v[0], t, 1.f, &dz);
+                num += (double)center_focal<true>(v[0], t, 1.f, &dz);
                 den += (t == 1.f) ? 1.0 : 0.0;
                 dlv[0] = dz;
             } else {
                 const float* tg = HEAD == 1 ? a.t_types : (HEAD == 2 ? a.t_charges : a.t_hs);
                 float z[CH], t[CH], dz[CH], dn = 0.f;
 #pragma unroll
+                for (int k = 0; k < CH; ++k) t[k] = *at4(tg, k);
+#pragma unroll
                 for (int k = 0; k < CH; ++k) {
-                    const size_t at = pl(CH, k);
                     z[k] = v[k];
-                    t[k] = tg[at];
-                    hd.logits[at] = z[k];
+                    *at4w(hd.logits, k) = z[k];
                 }
-                num += (double)class_focal<CH>(z, t, HEAD == 1 ? c_type_w : nullptr, dz, &dn);
+                num += (double)class_focal<CH, true>(z, t, HEAD == 1 ? c_type_w : nullptr, dz, &dn);
                 den += (double)dn;
 #pragma unroll
                 for (int k = 0; k < CH; ++k) dlv[k] = dz[k];
@@ -238,96 +312,109 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double& num, double& den) 
         }
 
         // ---- d(logits) as bf16: [row][pixel] tile -> the blocked buffer of the weight gradient
-        bf16x8 bq[2];
-        bq[0] = pack_frag<bf16>(dlv);
-        bq[1] = pack_frag<bf16>(dlv + 8);
+        bqp[0] = pack_frag<bf16>(dlv);
+        bqp[1] = pack_frag<bf16>(dlv + 8);
         if (!(ABC_DBG(a.dbg) & 4)) {
             char* tl = c.ot;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) *(bf16*)(tl + ((k & 3) + 8 * (k >> 2) + 4 * h) * TROW + r * 2) = bq[k >> 3][k & 7];
+            for (int k = 0; k < 16; ++k) *(bf16*)(tl + ((k & 3) + 8 * (k >> 2) + 4 * h) * TROW + r * 2) = bqp[k >> 3][k & 7];
             lds_sync();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = lane + 64 * j, row = q >> 2, part = q & 3;
                 const u32x4 t = *(const u32x4*)(tl + row * TROW + part * 16);
-                *(u32x4*)(hd.dlb + ((size_t)c.chunk * CPAD + 32 * mt + row) * 128 + 32 * c.wave + part * 8) = t;
+                *(u32x4*)((char*)(hd.dlb + ((size_t)c.chunk * CPAD + 32 * mt) * 128) + (uint32_t)((row * 128 + 32 * c.wave + part * 8) * 2)) = t;
             }
             lds_sync();
         }
-        // ---- data gradient: dA[ci][p] += sum over the tile's 32 rows; K-step u = registers 8 u .. 8 u + 7 of both halves
-        if (!(ABC_DBG(a.dbg) & 8))
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const bf16x8 af = *(const bf16x8*)(hd.w2t + ((size_t)((2 * mt + u) * 128 + 32 * mi + r) * 2 + h) * 8);
-                accD[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[u], accD[mi], 0, 0, 0);
-            }
+                for (int mi = 0; mi < 4; ++mi)
+                    wt[4 * u + mi] = *(const bf16x8*)((const char*)(hd.w2t + (size_t)((2 * mt + u) * 128 + 32 * mi) * 16) + (uint32_t)(r * 32 + h * 16));
+            if (mt + 1 < NT) dgrad_mfma();
+        }
     }
+    // the raw features again (the epilogue's LeakyReLU' / dropout mask / xhat), issued ahead of the last tile's MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) raw[kk] = *(const u32x4*)(a.y1 + e0 + 16 * kk);
+    dgrad_mfma();
 
-    // ---- dA -> g: transpose through the wave's LDS tile ([32 pixels][128 channels]) so that a lane owns 8 consecutive
-    // channels of a pixel (16-byte loads of the raw feature, 16-byte stores of g); LeakyReLU' and the dropout mask from
-    // the raw feature; per-channel sums for BatchNorm's backward
+    // ---- dA -> g.  The packed W2^T puts feature channel 32 mi + 16 (k >> 3) + 8 h + (k & 7) in register k of accumulator mi:
+    // element (kk = 2 mi + (k >> 3), j = k & 7) of this lane's own feature fragments.  g and g * xhat are formed here, then go
+    // through the wave's LDS tile (half a slice at a time) so that a lane owns 8 consecutive channels of a pixel: 16-byte stores
+    // of g, and per-channel sums over the wave's pixels for BatchNorm's backward.
     if (!(ABC_DBG(a.dbg) & 16)) {
         char* ot = c.ot;
+        const int sg = lane & 7, pg = lane >> 3;
+        float* ws = c.wsum + c.nslice * 256;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int half = 0; half < 2; ++half) {
+            float gv[2][16], gx[2][16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bf16x4 o;
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const int mi = 2 * half + m2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (bf16)accD[mi][4 * q + j];
-                *(bf16x4*)(ot + r * OROW + (32 * mi + 8 * q + 4 * h) * 2) = o;
+                for (int k8 = 0; k8 < 2; ++k8) {
+                    const int kk = 2 * mi + k8, cc = 16 * kk + 8 * h;
+                    float sl[8], mu[8], is[8];
+                    LoadVec<float, 8>::ld(cf + 256 + cc, sl); LoadVec<float, 8>::ld(cf + 384 + cc, mu); LoadVec<float, 8>::ld(cf + 512 + cc, is);
+                    const uint32_t kb = kbits[kk >> 2] >> (8 * (kk & 3)), pb = pbits[kk >> 2] >> (8 * (kk & 3));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t w = raw[kk][j >> 1];
+                        const float x = __uint_as_float((j & 1) ? (w & 0xFFFF0000u) : (w << 16));
+                        const float m1 = ((pb >> j) & 1u) ? c.dscale : sl[j] * c.dscale;
+                        const float gg = ((kb >> j) & 1u) ? accD[mi][8 * k8 + j] * m1 : 0.f;
+                        gv[m2][8 * k8 + j] = gg;
+                        gx[m2][8 * k8 + j] = gg * ((x - mu[j]) * is[j]);
+                    }
+                }
             }
-        lds_sync();
-        const int sg = lane & 15, pg = lane >> 4;
-        const int cc = slice + sg * 8;
-        float sc[8], sh[8], sl[8], mu[8], is[8], a1[8], a2[8];
-        LoadVec<float, 8>::ld(a.sc + cc, sc); LoadVec<float, 8>::ld(a.sh + cc, sh); LoadVec<float, 8>::ld(a.sl + cc, sl);
-        LoadVec<float, 8>::ld(a.mean + cc, mu); LoadVec<float, 8>::ld(a.invstd + cc, is);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+            for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int px = it * 4 + pg;
-            const bf16x8 dav = *(const bf16x8*)(ot + px * OROW + sg * 16);
-            const uint32_t e = (c.pix0 + px) * (uint32_t)a.ld + cc;
-            const bf16x8 raw = *(const bf16x8*)(a.y1 + e);
-            float out[8];
+                for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = (float)raw[j];
-                const float y = fmaf(x, sc[j], sh[j]);
-                float gg = (float)dav[j] * (y > 0.f ? 1.f : sl[j]);
-                if (a.drop_p > 0.f) gg = abc_drop_keep(e + j, c.dseed, a.drop_p) ? gg * c.dscale : 0.f;
-                out[j] = gg;
-                a1[j] += gg;
-                a2[j] += gg * ((x - mu[j]) * is[j]);
-            }
-            *(bf16x8*)(a.g + e) = pack_frag<bf16>(out);
-        }
+                    for (int q = 0; q < 4; ++q) {
+                        bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            a1[j] += __shfl_xor(a1[j], 16); a1[j] += __shfl_xor(a1[j], 32);
-            a2[j] += __shfl_xor(a2[j], 16); a2[j] += __shfl_xor(a2[j], 32);
-        }
-        float* bs = c.bsum + c.parity * (4 * 2 * 128);
-        if (lane < 16) {
+                        for (int j = 0; j < 4; ++j) o[j] = (bf16)(pass ? gx[m2][4 * q + j] : gv[m2][4 * q + j]);
+                        *(bf16x4*)(ot + r * HROW + (32 * m2 + 16 * (q >> 1) + 8 * h + 4 * (q & 1)) * 2) = o;
+                    }
+                lds_sync();
+                float acc8[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bs[(c.wave * 2 + 0) * 128 + sg * 8 + j] = a1[j];
-                bs[(c.wave * 2 + 1) * 128 + sg * 8 + j] = a2[j];
+                for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int px = it * 8 + pg;
+                    const bf16x8 tv = *(const bf16x8*)(ot + px * HROW + sg * 16);
+                    if (pass == 0) *(bf16x8*)(a.g + (size_t)(c.pix0 + px) * a.ld + slice + 64 * half + sg * 8) = tv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc8[j] += (float)tv[j];
+                }
+                lds_sync();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc8[j] += __shfl_xor(acc8[j], 8); acc8[j] += __shfl_xor(acc8[j], 16); acc8[j] += __shfl_xor(acc8[j], 32);
+                }
+                if (lane < 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ws[pass * 128 + 64 * half + sg * 8 + j] = acc8[j];
+                }
             }
         }
-        __syncthreads();   // (every wave of the workgroup runs the same list of heads)
-        {
-            const int row = threadIdx.x >> 7, ch = threadIdx.x & 127;
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) s += bs[(w * 2 + row) * 128 + ch];
-            a.bnpart[((size_t)c.chunk * 2 + row) * a.ld + slice + ch] = s;
+    }
+    c.nslice += 1;
+    {
+        const double s1 = wave_sum_d(num), s2 = wave_sum_d(den);
+        if (lane == 0) {
+            lsum[HEAD] = s1;
+            if (HEAD != 6) lsum[8 + HEAD] = s2;
+            if (HEAD == 5) lsum[8 + 6] = s2;     // rho is normalised by the same sum of bond-type targets (train.py:121)
         }
-        c.parity ^= 1;
     }
 }
 
@@ -342,38 +429,42 @@ __global__ __launch_bounds__(256, 2) void heads_fused_kernel(const HFK a) {
     c.b = (int)(c.pix0 / (uint32_t)a.HW);
     c.yx = (int)(c.pix - (uint32_t)c.b * (uint32_t)a.HW);
     c.ot = smem + c.wave * WV;
-    c.dnl = (float*)(smem + c.wave * WV + WV_OT);
-    c.bsum = (float*)(smem + LDS_BSUM);
-    c.parity = 0;
+    c.dnl = (float*)(smem + c.wave * WV + WV_DN);
+    const int group = blockIdx.y;
+    c.wsum = (float*)(smem + LDS_BSUM) + c.wave * 512;
+    c.nslice = 0;
     c.dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     c.dseed = a.drop_seed + ((a.drop_p > 0.f && a.drop_salt) ? *a.drop_salt : 0u);
-    double num[8], den[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { num[i] = 0.0; den[i] = 0.0; }
-    const int group = blockIdx.y;
-    if (group == 0) {
-        run_head<5>(a, c, num[5], den[5]);
-        den[6] = den[5];                     // rho is normalised by the same sum of bond-type targets (train.py:121)
-        double unused = 0.0;
-        run_head<6>(a, c, num[6], unused);
-    } else {
-        run_head<7>(a, c, num[7], den[7]);
-        run_head<0>(a, c, num[0], den[0]);
-        run_head<1>(a, c, num[1], den[1]);
-        run_head<2>(a, c, num[2], den[2]);
-        run_head<3>(a, c, num[3], den[3]);
-        run_head<4>(a, c, num[4], den[4]);
-    }
     double* ls = (double*)(smem + LDS_LSUM);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const double s1 = wave_sum_d(num[i]), s2 = wave_sum_d(den[i]);
-        if (c.lane == 0) { ls[c.wave * 16 + i] = s1; ls[c.wave * 16 + 8 + i] = s2; }
+    double* lsum = ls + c.wave * 16;
+    if (c.lane < 16) lsum[c.lane] = 0.0;
+    lds_sync();
+    // (one workgroup = one of 7 work types: every path on its own keeps its registers; run back to back in one wave the
+    //  compiler's cross-head scheduling spilled 50 registers)
+    switch (group) {
+        case 0: run_head<5>(a, c, lsum); run_head<6>(a, c, lsum); break;
+        case 1: run_head<7>(a, c, lsum); break;
+        case 2: run_head<0>(a, c, lsum); break;
+        case 3: run_head<1>(a, c, lsum); break;
+        case 4: run_head<2>(a, c, lsum); break;
+        case 5: run_head<3>(a, c, lsum); break;
+        default: run_head<4>(a, c, lsum); break;
     }
     __syncthreads();
     if (threadIdx.x < 16)
         a.losspart[((size_t)group * a.nchunk + c.chunk) * 16 + threadIdx.x] =
             (ls[threadIdx.x] + ls[16 + threadIdx.x]) + (ls[32 + threadIdx.x] + ls[48 + threadIdx.x]);
+    // BatchNorm sums of the workgroup's 128 pixels: the four waves' rows, slice by slice in the order the heads ran
+    {
+        const int nsl = group == 0 ? 2 : 1;
+        const float* base = (const float*)(smem + LDS_BSUM);
+        for (int i = threadIdx.x; i < nsl * 256; i += 256) {
+            const int sl_i = i >> 8, row = (i >> 7) & 1, ch = i & 127;
+            const float s = (base[i] + base[512 + i]) + (base[1024 + i] + base[1536 + i]);
+            const int head = group == 0 ? 5 + sl_i : (group == 1 ? 7 : group - 2);
+            a.bnpart[((size_t)c.chunk * 2 + row) * a.ld + 128 * head + ch] = s;
+        }
+    }
 }
 
 // conv2 weights / biases of all heads into the two fragment layouts above (every step: the weights change)
@@ -399,7 +490,8 @@ __global__ __launch_bounds__(256) void heads_fused_pack_kernel(const HFPackK a) 
         w2f[idx] = (bf16)(ch >= 0 ? w[ch * 128 + chunk * 32 + within] : 0.f);
     }
     {   // data gradient: [K-step s][feature ci][half h][8]: slot j of half h = accumulator register 8 (s & 1) + j
-        const int j = idx & 7, h = (idx >> 3) & 1, ci = (idx >> 4) & 127, s = idx >> 11;
+        const int j = idx & 7, h = (idx >> 3) & 1, mrow = (idx >> 4) & 127, s = idx >> 11;
+        const int ci = (mrow & ~12) | ((mrow & 4) << 1) | ((mrow & 8) >> 1);   // accumulator row -> feature channel (see the epilogue)
         const int k = 8 * (s & 1) + j;
         const int m = 32 * (s >> 1) + (k & 3) + 8 * (k >> 2) + 4 * h;
         const int ch = hf_chan_of_row(head, m);
@@ -414,7 +506,8 @@ __global__ __launch_bounds__(256) void heads_fused_pack_kernel(const HFPackK a) 
 static int hf_check(const abc_heads_fused_desc* d) {
     if (d->B < 1 || d->h < 1 || d->w < 1 || (d->h * d->w) % 128) return abc_fail(ABC_EINVAL, "heads_fused: the map must hold whole 128-pixel chunks");
     if (d->ld < 128 * HF_NH || d->ld % 8) return abc_fail(ABC_EINVAL, "heads_fused: feature stride");
-    if ((int64_t)d->B * d->h * d->w * d->ld >= (int64_t(1) << 32)) return abc_fail(ABC_EUNSUPPORTED, "heads_fused: 32-bit element offsets");
+    if ((int64_t)d->B * d->h * d->w * d->ld >= (int64_t(1) << 32) || (int64_t)d->B * d->h * d->w * 360 >= (int64_t(1) << 31))
+        return abc_fail(ABC_EUNSUPPORTED, "heads_fused: 32-bit element offsets");
     return ABC_OK;
 }
 
@@ -422,6 +515,7 @@ static int hf_check(const abc_heads_fused_desc* d) {
 
 extern "C" int64_t abc_heads_fused_pack_bytes(void) { return hf_pack_off(HF_NH); }
 extern "C" int abc_heads_fused_chunks(const abc_heads_fused_desc* d) { return d->B * d->h * d->w / 128; }
+extern "C" int abc_heads_fused_loss_blocks(const abc_heads_fused_desc* d) { return HF_GROUPS * abc_heads_fused_chunks(d); }
 extern "C" int64_t abc_heads_fused_dl_elems(const abc_heads_fused_desc* d) { return (int64_t)abc_heads_fused_chunks(d) * hf_rows_total() * 128; }
 extern "C" int abc_heads_fused_rows(int32_t head) { return head >= 0 && head < HF_NH ? hf_tiles(head) * 32 : -1; }
 extern "C" int abc_heads_fused_chan_of_row(int32_t head, int32_t row) {
@@ -441,12 +535,12 @@ extern "C" int abc_heads_fused_fwd_bwd(const abc_heads_fused_desc* d, abc_stream
     HFK k;
     k.y1 = (const bf16*)d->feat; k.sc = d->scale; k.sh = d->shift; k.sl = d->slope; k.mean = d->mean; k.invstd = d->invstd;
     k.g = (bf16*)d->g; k.ld = d->ld;
-    k.drop_p = d->drop_p; k.drop_seed = d->drop_seed; k.drop_salt = d->drop_salt;
+    k.drop_p = d->drop_p; k.drop_seed = d->drop_seed; k.drop_salt = d->drop_salt; k.drop_thr = abc_drop_threshold(d->drop_p);
     k.t_atom = d->t_atom; k.t_types = d->t_types; k.t_charges = d->t_charges; k.t_hs = d->t_hs; k.t_bond = d->t_bond;
     k.t_btypes = d->t_btypes; k.t_rho = d->t_rho; k.t_omega = d->t_omega;
     k.bnpart = d->bn_partial; k.losspart = d->loss_partial;
     k.HW = d->h * d->w; k.nchunk = abc_heads_fused_chunks(d);
-    { const char* e = getenv("ABC_HF_DBG"); k.dbg = e ? atoi(e) : 0; }
+    { const char* e = ABC_DBG(getenv("ABC_HF_DBG")); k.dbg = e ? atoi(e) : 0; }   // (debug build only: phase ablations)
     size_t row0 = 0;
     for (int i = 0; i < HF_NH; ++i) {
         const int cpad = hf_tiles(i) * 32;
@@ -460,6 +554,6 @@ extern "C" int abc_heads_fused_fwd_bwd(const abc_heads_fused_desc* d, abc_stream
     }
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)heads_fused_kernel, HF_LDS, &lds_ok)) return rc;
-    hipLaunchKernelGGL(heads_fused_kernel, dim3(k.nchunk, 2), dim3(256), HF_LDS, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(heads_fused_kernel, dim3(k.nchunk, HF_GROUPS), dim3(256), HF_LDS, (hipStream_t)stream, k);
     return abc_check_launch("heads_fused_fwd_bwd");
 }

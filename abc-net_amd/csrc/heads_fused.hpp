@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 constexpr int HF_NH = 8;
+constexpr int HF_GROUPS = 7;   // work types of the fused kernel: {bond types, rho}, omega, and the five small heads one by one
 __host__ __device__ constexpr int hf_ch(int head) { return head == 0 ? 1 : head == 1 ? 14 : head == 2 ? 3 : head == 3 ? 2 : head == 4 ? 1 : head == 5 ? 360 : 60; }
 __host__ __device__ constexpr int hf_tiles(int head) { return head == 5 ? 15 : (head >= 6 ? 2 : 1); }
 // channel of packed row m of a head (-1: padding)

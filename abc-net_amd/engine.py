@@ -694,7 +694,8 @@ class Engine:
         self.hf_dl = self.new((lib.abc_heads_fused_dl_elems(C.byref(d)),), torch.bfloat16)
         self.hf_g = self.new((B, h, w, Ct))
         self.hf_bnpart = self.new((nchunk, 2, Ct), torch.float32)
-        self.hf_losspart = torch.zeros((2 * nchunk, 16), dtype=torch.float64, device=self.dev)
+        self.hf_lossblocks = lib.abc_heads_fused_loss_blocks(C.byref(d))
+        self.hf_losspart = torch.zeros((self.hf_lossblocks, 16), dtype=torch.float64, device=self.dev)
         self.chan_scale = self.new((sum(self.heads),), torch.float32, 0.0)
         self.hf_work = self.new((lib.abc_heads_fused_wgrad_floats(C.byref(d)),), torch.float32)
         d.w2_pack, d.dl, d.g = self.hf_pack.data_ptr(), self.hf_dl.data_ptr(), self.hf_g.data_ptr()
@@ -930,7 +931,7 @@ class Engine:
         npx = B * h * w
         writes = tuple(n for i in range(nh) for n in ("out_modules.%d.conv2.weight" % i, "out_modules.%d.conv2.bias" % i))
         ops.append((lambda _r, st: lib.abc_heads_fused_wgrad(C.byref(d), st), None, "wgrad out_modules.*.conv2", writes,
-                    {"kernel": "heads_fused_wgrad", "flops": 2.0 * npx * sum(self.heads) * 128,
+                    {"kernel": "heads_fused_wgrad", "side": "big", "flops": 2.0 * npx * sum(self.heads) * 128,
                      "bytes": float(npx * Ct * 2 + self.hf_dl.numel() * 2 + self.hf_work.numel() * 4)}))
         arr = (L.BnBwdDesc * nh)()
         merged, bwrites = [], []
@@ -1358,7 +1359,9 @@ class Engine:
         is joined before returning (so graph capture sees a closed fork/join and all-reduce buckets are complete)."""
         # measured on MI355X: the fork/join dependencies cost more than the overlap gains (1733 vs 1823 img/s inside the
         # hipGraph), so the second stream is opt-in (ABC_SIDE_STREAM=1) and the default is one stream
-        use_side = bool(os.environ.get("ABC_SIDE_STREAM")) and any(m.get("side") for _f, _r, _w, _x, m in ops)
+        mode = os.environ.get("ABC_SIDE_STREAM", "")
+        want = (lambda m: m.get("side") == "big") if mode == "2" else (lambda m: bool(m.get("side")))
+        use_side = bool(mode) and any(want(m) for _f, _r, _w, _x, m in ops)
         if use_side:
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream()
@@ -1366,14 +1369,14 @@ class Engine:
             side = self._side
         pending = {}
         for fn, ref, what, _w, m in ops:
-            if use_side and m.get("side"):
+            if use_side and want(m):
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
                 rc = fn(ref, side.cuda_stream)
                 done = torch.cuda.Event()
                 done.record(side)
-                pending[m["ws"]] = done
+                pending[m.get("ws", what)] = done
             else:
                 if use_side and m.get("ws") in pending:
                     main.wait_event(pending.pop(m["ws"]))   # the slabs of two layers ago have been consumed

@@ -74,7 +74,7 @@ class FusedHeadsLoss(FusedLoss):
         self._check_targets(eng, targets)
         d = eng.hf
         (d.t_atom, d.t_types, d.t_charges, d.t_hs, d.t_bond, d.t_btypes, d.t_rho, d.t_omega) = (t.data_ptr() for t in targets)
-        self.nblk = 2 * eng.hf_chunks
+        self.nblk = eng.hf_lossblocks
         self.partial = eng.hf_losspart
         self.out = torch.zeros(17, dtype=torch.float64, device=eng.logits[0].device)
         f = L.LossFinDesc()

@@ -316,7 +316,7 @@ int abc_heads_batch(const abc_conv_desc* descs, int32_t n, int32_t which, abc_st
  * backward of Dropout and LeakyReLU (unet.py:67-69) and BatchNorm-backward partial sums, for the eight heads
  * [1,14,3,2,1,360,60,60] (train.py:47).  Replaces abc_heads_batch(which = 0) + abc_loss_fwd_bwd + abc_heads_batch(which
  * = 1) + abc_act_bwd; abc_heads_fused_wgrad replaces abc_wgrad_heads_batch.  Order of a step:
- *   abc_heads_fused_pack (weights changed) -> abc_heads_fused_fwd_bwd -> abc_loss_finalize(loss_partial, 2 x chunks blocks)
+ *   abc_heads_fused_pack (weights changed) -> abc_heads_fused_fwd_bwd -> abc_loss_finalize(loss_partial, abc_heads_fused_loss_blocks())
  *   -> abc_heads_fused_wgrad, abc_bn_finalize_bwd(_batch) with in_scale = chan_scale + chan_off[i] and partial = bn_partial.
  * Everything the kernel writes is the gradient of each loss term's NUMERATOR (the normalisers are batch sums): g and the
  * BatchNorm sums lack the head's factor chan_scale[chan_off[i]], which the two consumers above apply. */
@@ -334,7 +334,7 @@ typedef struct abc_heads_fused_desc {
                                            per head [chunk][packed rows][128 pixels] (row order: abc_heads_fused_chan_of_row) */
     void* g;                            /* out: NHWC bf16 [B*h*w][ld]: gradient w.r.t. the BatchNorm outputs, without the head's factor */
     float* bn_partial;                  /* out: [abc_heads_fused_chunks()][2][ld]: sum g, sum g * xhat */
-    double* loss_partial;               /* out: [2 * abc_heads_fused_chunks()][16], the layout abc_loss_finalize reduces */
+    double* loss_partial;               /* out: [abc_heads_fused_loss_blocks()][16], the layout abc_loss_finalize reduces */
     int32_t B, h, w;                    /* h * w a multiple of 128 */
     /* abc_heads_fused_wgrad only: */
     const float* chan_scale; int32_t chan_off[8];   /* abc_loss_finalize's factors, first channel of head i */
@@ -343,6 +343,7 @@ typedef struct abc_heads_fused_desc {
 } abc_heads_fused_desc;
 int64_t abc_heads_fused_pack_bytes(void);
 int abc_heads_fused_chunks(const abc_heads_fused_desc* d);
+int abc_heads_fused_loss_blocks(const abc_heads_fused_desc* d);
 int64_t abc_heads_fused_dl_elems(const abc_heads_fused_desc* d);
 int64_t abc_heads_fused_wgrad_floats(const abc_heads_fused_desc* d);
 int abc_heads_fused_rows(int32_t head);                       /* packed rows of a head (multiple of 32) */

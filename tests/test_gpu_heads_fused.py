@@ -2,7 +2,7 @@
 through the C ABI:
 
   * logits against torch's 1x1 convolution of the same bf16-rounded operands (unet.py:70);
-  * d(logits) BIT-EXACT against the stand-alone loss kernel (abc_loss_fwd_bwd, itself held to the reference-exec golden)
+  * d(logits) against the stand-alone loss kernel to one bf16 ulp (same formulas; hardware exp / log here) (abc_loss_fwd_bwd, itself held to the reference-exec golden)
     run on the fused kernel's own logits, through the packed row order -- and the reduced loss against it and the oracle;
   * g (gradient w.r.t. the BatchNorm outputs), the BatchNorm-backward sums, conv2.weight.grad and conv2.bias.grad against
     torch autograd of the ORACLE's loss (oracle/loss_oracle.py, train.py:95-137) over the same graph in f32.
@@ -68,7 +68,8 @@ def _run(B, hw, drop_p, seed=3):
     dl = torch.zeros(lib.abc_heads_fused_dl_elems(C.byref(d)), dtype=torch.bfloat16, device=DEV)
     gbuf = torch.zeros((npix, ld), dtype=torch.bfloat16, device=DEV)
     bnp = torch.zeros((nchunk, 2, ld), device=DEV)
-    lp = torch.zeros((2 * nchunk, 16), dtype=torch.float64, device=DEV)
+    nlb = lib.abc_heads_fused_loss_blocks(C.byref(d))
+    lp = torch.zeros((nlb, 16), dtype=torch.float64, device=DEV)
     d.dl, d.g, d.bn_partial, d.loss_partial = dl.data_ptr(), gbuf.data_ptr(), bnp.data_ptr(), lp.data_ptr()
     st = torch.cuda.current_stream().cuda_stream
     L.check(lib.abc_heads_fused_pack(C.byref(d), st), "pack")
@@ -79,7 +80,7 @@ def _run(B, hw, drop_p, seed=3):
     out = torch.zeros(17, dtype=torch.float64, device=DEV)
     sdev, ds = dev(s), torch.zeros(10, device=DEV)
     f = L.LossFinDesc()
-    f.partial, f.nblk, f.s, f.ds, f.out = lp.data_ptr(), 2 * nchunk, sdev.data_ptr(), ds.data_ptr(), out.data_ptr()
+    f.partial, f.nblk, f.s, f.ds, f.out = lp.data_ptr(), nlb, sdev.data_ptr(), ds.data_ptr(), out.data_ptr()
     f.chan_scale, f.nchan, f.grad_scale = chan_scale.data_ptr(), chan_scale.numel(), 1.0
     for i in range(8):
         f.chan_off[i], f.head_c[i] = off[i], HEADS[i]
@@ -142,10 +143,11 @@ def test_fused_heads_pass(B, hw, drop_p):
         assert (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item()), ("logits", i)
     # 2. the loss: against the stand-alone kernel on the same logits, and the oracle
     o, oa = r["out"].cpu(), r["alone_out"].cpu()
-    assert torch.allclose(o, oa, rtol=1e-12, atol=1e-14), (o, oa)
-    assert torch.allclose(r["ds"].cpu(), r["alone_ds"].cpu(), rtol=1e-6, atol=1e-9)
-    assert torch.equal(r["chan_scale"].cpu(), r["alone"].chan_scale.cpu())
-    assert abs(o[0].item() - ref["total"]) <= 1e-5 * abs(ref["total"])
+    # (the fused kernel evaluates exp / log / 1/x with the hardware approximations, ~1e-6 relative: loss_math.hpp)
+    assert torch.allclose(o, oa, rtol=5e-6, atol=1e-12), (o, oa)
+    assert torch.allclose(r["ds"].cpu(), r["alone_ds"].cpu(), rtol=2e-5, atol=1e-8)
+    assert torch.allclose(r["chan_scale"].cpu(), r["alone"].chan_scale.cpu(), rtol=1e-6, atol=0)
+    assert abs(o[0].item() - ref["total"]) <= 2e-5 * abs(ref["total"])
     # 3. d(logits): the blocked bf16 buffer holds bf16(the stand-alone kernel's values), row by row
     nchunk, row0 = r["nchunk"], 0
     dl = r["dl"].cpu()
@@ -159,7 +161,11 @@ def test_fused_heads_pass(B, hw, drop_p):
             if ch < 0:
                 assert not blk[:, m, :].any(), ("padding row not zero", i, m)
             else:
-                assert torch.equal(blk[:, m, :], want[ch]), ("d(logits)", i, m, ch)
+                # equal up to the hardware exp / log (a few f32 ulps before the bf16 rounding: at most one bf16 ulp apart,
+                # and only where the f32 value sat on a rounding boundary)
+                a_, b_ = blk[:, m, :].float(), want[ch].float()
+                assert ((a_ - b_).abs() <= 2.0 ** -7 * b_.abs() + 1e-30).all(), ("d(logits)", i, m, ch)
+                assert (a_ != b_).float().mean().item() <= 0.02, ("d(logits) mismatches", i, m, ch, (a_ != b_).float().mean().item())
         row0 += rows
     # 4. g and the BatchNorm-backward sums: autograd's d(loss)/d(features) through LeakyReLU' and the dropout mask
     npix, ld = r["npix"], r["ld"]

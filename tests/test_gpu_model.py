@@ -575,8 +575,8 @@ def test_batched_heads_equal_one_by_one_launches(variant, monkeypatch):
 @pytest.mark.parametrize("variant", ["unet", "unet2"])
 def test_fused_heads_step_equals_unfused_step(variant):
     """The Trainer's default bf16 step runs the heads' conv2 + loss + way back as ONE pass (csrc/heads_fused.hip).  Against
-    the same step on the separate kernels (fused_heads=False): logits bit for bit (same MFMA sequence), the loss to f64
-    summation order, conv2's gradients to the bf16 rounding of d(logits) (the separate kernels read them in f32), the rest
+    the same step on the separate kernels (fused_heads=False): logits to f32 rounding order, the loss to the hardware
+    exp / log of the fused kernel, conv2's gradients to the bf16 rounding of d(logits) (the separate kernels read them in f32), the rest
     inside the bf16 gradient noise floor, as in the test above."""
     from abcnet_amd.train import Trainer
     B, S = 2, 128
@@ -593,10 +593,10 @@ def test_fused_heads_step_equals_unfused_step(variant):
 
     lg_f, g_f, loss_f, lay = one_step(True)
     lg_u, g_u, loss_u, _ = one_step(False)
-    for a, b in zip(lg_f, lg_u):
-        assert torch.equal(a, b)
-    for k in loss_u:
-        assert abs(loss_f[k] - loss_u[k]) <= 1e-10 * abs(loss_u[k]) + 1e-14, k
+    for a, b in zip(lg_f, lg_u):   # (same bf16 operands; the fused kernel's accumulators start from the bias: f32 rounding order)
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+    for k in loss_u:               # (hardware exp / log in the fused kernel: loss_math.hpp)
+        assert abs(loss_f[k] - loss_u[k]) <= 1e-5 * abs(loss_u[k]) + 1e-12, k
     for name, (off, n) in lay.items():
         a, b = g_f[off:off + n].double(), g_u[off:off + n].double()
         rel = (a - b).norm().item() / (b.norm().item() + 1e-30)
