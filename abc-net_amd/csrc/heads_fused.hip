@@ -53,6 +53,7 @@ struct HFK {
     const float *t_atom, *t_types, *t_charges, *t_hs, *t_bond, *t_btypes;
     const double *t_rho, *t_omega;
     float* bnpart;      // [nchunk][2][ld]
+    float* dwsmall;     // [nchunk][HF_SMALL_ROWS][128 + 1]: the small heads' conv2 weight / bias gradient partials (see run_head)
     double* losspart;   // [HF_GROUPS nchunk][16]
     int HW, nchunk, dbg;
     HFHead hd[HF_NH];
@@ -63,11 +64,13 @@ struct HFK {
 //                  transpose tile of half a slice, [32 pixels][64 channels] bf16 (rows of 144 B)
 //   [2560, 5120)   the head's packed bias (<= 480 f32 from 2560; dead once the row-tile loop is over)
 //   [5120, 7680)   the slice's per-channel coefficients [scale | shift | slope | mean | invstd][128] f32
+//   [7680, 16384)  the five small heads: the activated features of the wave's pixels (conv2's weight gradient, see run_head)
 //   [8704, 16384)  group 0: per-lane sum of the bond-type targets of each of its 30 omega bins (bond types -> rho);
 //                  omega: the omega targets of the lane's 30 bins
 constexpr int TROW = 32 * 2 + 16;          // row of the d(logits) tile
 constexpr int HROW = 64 * 2 + 16;          // row of the epilogue's transpose tile
 constexpr int WV_BIAS = 2560, WV_CF = 5120, WV_DN = 8704;
+constexpr int WV_AIMG = 7680, AROW = 128 * 2 + 16;   // small heads: the wave's activated features [32 pixels][128 channels] bf16 (rows of 272 B)
 constexpr int WV = 16384;
 constexpr int LDS_BSUM = 4 * WV;           // the waves' BatchNorm sums: [4 waves][<= 2 slices][2][128] f32 = 8 KB
 constexpr int LDS_LSUM = LDS_BSUM + 4 * 2 * 2 * 128 * 4;   // [4 waves][16] f64
@@ -82,6 +85,13 @@ struct Ctx {
     float dscale;
     uint32_t dseed;
 };
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_f;
+__device__ inline bf16x8 tr_read8f(const char* b0, const char* b1) {
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_f*)b0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_f*)b1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 __device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -341,6 +351,51 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
     for (int kk = 0; kk < 8; ++kk) raw[kk] = *(const u32x4*)(a.y1 + e0 + 16 * kk);
     dgrad_mfma();
 
+    // ---- the small heads (one row tile, <= 14 channels) also finish conv2's WEIGHT gradient here: dW2[c][ci] = sum_p dL[c][p] a[p][ci]
+    // over the workgroup's 128 pixels is 8 MFMAs per wave (wave w = feature tile w) from the four waves' d(logits) tiles and
+    // their activated features in LDS -- one 32 x 128 partial per workgroup instead of a pass of the blocked weight-gradient
+    // kernel over the head's features (5 of its 11 units of work went to these 21 channels).  A ones-fragment gives the row
+    // sums of dL (the bias gradient) on the way.
+    if constexpr (HEAD < 5) {
+        if (!(ABC_DBG(a.dbg) & 32)) {
+        char* img = c.ot + WV_AIMG;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) *(bf16x8*)(img + r * AROW + (16 * kk + 8 * h) * 2) = fb[kk];
+        __syncthreads();
+        const int trow = 8 * h + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        f32x16 aw, ab;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+        bf16x8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            const char* tw = c.ot + (w2 - c.wave) * WV;          // wave w2's region
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 fa2 = *(const bf16x8*)(tw + r * TROW + (16 * s2 + 8 * h) * 2);
+                const char* q0 = tw + WV_AIMG + (16 * s2 + trow) * AROW + (32 * c.wave + tcol) * 2;
+                const bf16x8 fb2 = tr_read8f(q0, q0 + 4 * AROW);
+                aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, fb2, aw, 0, 0, 0);
+                // (every wave: an MFMA under a lane-dependent branch -- `wave == 0` is a VGPR compare -- came out wrong,
+                //  the instruction ignores EXEC; only wave 0 stores the sums)
+                ab = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, ones, ab, 0, 0, 0);
+            }
+        }
+        if (h == 0) {
+            // register k of half 0 = packed row (k & 3) + 8 (k >> 2) = channel k (hf_chan_of_row)
+            float* dst = a.dwsmall + ((size_t)c.chunk * HF_SMALL_ROWS + hf_small_row0(HEAD)) * 129;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                dst[k * 129 + 32 * c.wave + r] = aw[k];
+                if (c.wave == 0 && r == 0) dst[k * 129 + 128] = ab[k];
+            }
+        }
+        __syncthreads();   // the tiles are read by the other waves: the epilogue below reuses their space
+        }
+    }
+
     // ---- dA -> g.  The packed W2^T puts feature channel 32 mi + 16 (k >> 3) + 8 h + (k & 7) in register k of accumulator mi:
     // element (kk = 2 mi + (k >> 3), j = k & 7) of this lane's own feature fragments.  g and g * xhat are formed here, then go
     // through the wave's LDS tile (half a slice at a time) so that a lane owns 8 consecutive channels of a pixel: 16-byte stores
@@ -538,7 +593,7 @@ extern "C" int abc_heads_fused_fwd_bwd(const abc_heads_fused_desc* d, abc_stream
     k.drop_p = d->drop_p; k.drop_seed = d->drop_seed; k.drop_salt = d->drop_salt; k.drop_thr = abc_drop_threshold(d->drop_p);
     k.t_atom = d->t_atom; k.t_types = d->t_types; k.t_charges = d->t_charges; k.t_hs = d->t_hs; k.t_bond = d->t_bond;
     k.t_btypes = d->t_btypes; k.t_rho = d->t_rho; k.t_omega = d->t_omega;
-    k.bnpart = d->bn_partial; k.losspart = d->loss_partial;
+    k.bnpart = d->bn_partial; k.losspart = d->loss_partial; k.dwsmall = d->wgrad_work;
     k.HW = d->h * d->w; k.nchunk = abc_heads_fused_chunks(d);
     { const char* e = ABC_DBG(getenv("ABC_HF_DBG")); k.dbg = e ? atoi(e) : 0; }   // (debug build only: phase ablations)
     size_t row0 = 0;

@@ -27,6 +27,9 @@ __host__ __device__ inline int hf_row_of_chan(int head, int ch) {
     else if (head >= 6) { const int j = ch % 30; h = ch / 30; mt = j >> 4; k = j & 15; }
     return 32 * mt + (k & 3) + 8 * (k >> 2) + 4 * h;
 }
+// the five small heads' conv2 gradients leave the fused kernel as per-chunk partial rows: head i's channels start at row
+constexpr int HF_SMALL_ROWS = 1 + 14 + 3 + 2 + 1;
+__host__ __device__ constexpr int hf_small_row0(int head) { return head == 0 ? 0 : head == 1 ? 1 : head == 2 ? 15 : head == 3 ? 18 : 20; }
 // byte offset of a head's block in the packed-weights workspace: [forward Cpad x 128 bf16][data-gradient Cpad x 128 bf16][bias Cpad f32]
 __host__ __device__ inline int64_t hf_pack_off(int head) {
     int64_t off = 0;

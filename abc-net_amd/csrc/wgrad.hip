@@ -634,32 +634,6 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_batch_kernel(const HeadWgBa
 // ... with d(logits) from the fused heads kernel's blocked bf16 buffer (abc_heads_fused_wgrad)
 __global__ __launch_bounds__(512, 2) void head_wgrad_blocked_kernel(const HeadWgBatch bt) { head_wgrad_body<true>(bt.k[blockIdx.z]); }
 
-// slabs of the blocked weight gradient -> conv2.weight.grad / conv2.bias.grad of every head: packed rows back to channels
-// (hf_row_of_chan), times the head's loss factor (abc_loss_finalize's chan_scale), slab order fixed
-struct HeadFusedRedK {
-    const float* partial[HF_NH]; const float* rowsum[HF_NH];
-    float* dw[HF_NH]; float* db[HF_NH];
-    const float* chan_scale;
-    int nsplit[HF_NH], chan_off[HF_NH];
-};
-__global__ __launch_bounds__(128) void head_fused_reduce_kernel(const HeadFusedRedK a) {
-    const int head = blockIdx.y, ch = blockIdx.x, ci = threadIdx.x;
-    if (ch >= hf_ch(head)) return;
-    const int cpad = hf_tiles(head) * 32, row = hf_row_of_chan(head, ch);
-    const float cs = a.chan_scale[a.chan_off[head] + ch];
-    const float* p = a.partial[head] + (size_t)row * 128 + ci;
-    float s0 = 0.f, s1 = 0.f;
-    int k = 0;
-    for (; k + 2 <= a.nsplit[head]; k += 2) { s0 += p[(size_t)k * cpad * 128]; s1 += p[(size_t)(k + 1) * cpad * 128]; }
-    if (k < a.nsplit[head]) s0 += p[(size_t)k * cpad * 128];
-    a.dw[head][ch * 128 + ci] = (s0 + s1) * cs;
-    if (ci == 0) {
-        float b = 0.f;
-        for (int q = 0; q < a.nsplit[head]; ++q) b += a.rowsum[head][(size_t)q * cpad + row];
-        a.db[head][ch] = b * cs;
-    }
-}
-
 static bool head_ok(const abc_wgrad_desc* d) {
     if (getenv("ABC_WGRAD_NOHEAD")) return false;
     if (!d->p.planar || d->dtype_p != ABC_F32 || d->dtype_q != ABC_BF16 || d->dtype_c != ABC_BF16) return false;
@@ -1044,17 +1018,19 @@ extern "C" int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc
     return abc_check_launch("wgrad_heads_batch");
 }
 
-// K-splits of the blocked weight gradient: ONE round of ~256 workgroups (the kernel holds 150 KB of LDS) shared out over the
-// heads by the cost of a 128-pixel chunk (the feature tile is staged and activated once per workgroup, the d(logits) rows on top)
+// K-splits of the blocked weight gradient (heads 5, 6, 7: the five small heads' gradients come out of the fused kernel
+// itself): ONE round of ~256 workgroups (the kernel holds 150 KB of LDS) shared out over the heads by the cost of a
+// 128-pixel chunk (the feature tile is staged and activated once per workgroup, the d(logits) rows on top)
 static void hf_splits(int nchunk, int* nsplit) {
     double cost[HF_NH], tot = 0;
     int units[HF_NH];
-    for (int i = 0; i < HF_NH; ++i) {
+    for (int i = 5; i < HF_NH; ++i) {
         units[i] = abc_cdiv(hf_tiles(i), 4);
         cost[i] = 4.0 + 1.5 * (double)hf_tiles(i) / units[i] / 4.0;
         tot += units[i] * cost[i];
     }
     for (int i = 0; i < HF_NH; ++i) {
+        if (i < 5) { nsplit[i] = 0; continue; }
         int n = (int)(256.0 * cost[i] / tot);
         n = n < 1 ? 1 : n;
         nsplit[i] = n > nchunk ? nchunk : n;
@@ -1063,13 +1039,67 @@ static void hf_splits(int nchunk, int* nsplit) {
 
 extern "C" int64_t abc_heads_fused_wgrad_floats(const abc_heads_fused_desc* d) {
     int ns[HF_NH];
-    hf_splits(d->B * d->h * d->w / 128, ns);
-    int64_t n = 0;
-    for (int i = 0; i < HF_NH; ++i) n += (int64_t)ns[i] * hf_tiles(i) * 32 * (128 + 1);
+    const int nchunk = d->B * d->h * d->w / 128;
+    hf_splits(nchunk, ns);
+    int64_t n = (int64_t)(nchunk + 16) * HF_SMALL_ROWS * 129;      // the fused kernel's partials of the small heads + their first reduction
+    for (int i = 5; i < HF_NH; ++i) n += (int64_t)ns[i] * hf_tiles(i) * 32 * (128 + 1);
     return n;
 }
 
-// conv2.weight.grad / conv2.bias.grad of all heads from the fused kernel's blocked d(logits) (unet.py:70 under autograd):
+// slabs -> conv2.weight.grad / conv2.bias.grad: packed rows back to channels (hf_row_of_chan), times the head's loss factor
+// (abc_loss_finalize's chan_scale), fixed summation order.  Heads 5-7: the K-split slabs of the blocked kernel; heads 0-4: the
+// per-chunk partial rows [chunk][21][128 weights | 1 bias] the fused kernel left.
+struct HeadFusedRedK {
+    const float* partial[HF_NH]; const float* rowsum[HF_NH];
+    float* dw[HF_NH]; float* db[HF_NH];
+    const float* chan_scale;
+    const float* small2;
+    int nsplit[HF_NH], chan_off[HF_NH];
+};
+// first stage for the small heads: [nchunk][21][129] -> 16 row slices [16][21][129] (grid = 21 x 16: enough loads in flight)
+__global__ __launch_bounds__(192) void head_fused_small_reduce_kernel(const float* part, int nchunk, float* out) {
+    const int row = blockIdx.x, sl = blockIdx.y, c2 = threadIdx.x;
+    if (c2 >= 129) return;
+    const float* p = part + (size_t)row * 129 + c2;
+    const size_t step = (size_t)HF_SMALL_ROWS * 129;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = sl;
+    for (; k + 48 < nchunk; k += 64) {
+        s0 += p[(size_t)k * step]; s1 += p[(size_t)(k + 16) * step]; s2 += p[(size_t)(k + 32) * step]; s3 += p[(size_t)(k + 48) * step];
+    }
+    for (; k < nchunk; k += 16) s0 += p[(size_t)k * step];
+    out[((size_t)sl * HF_SMALL_ROWS + row) * 129 + c2] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(128) void head_fused_reduce_kernel(const HeadFusedRedK a) {
+    const int head = blockIdx.y, ch = blockIdx.x, ci = threadIdx.x;
+    if (ch >= hf_ch(head)) return;
+    const float cs = a.chan_scale[a.chan_off[head] + ch];
+    if (head < 5) {
+        // 16 row slices of the per-chunk partials were summed by head_fused_small_reduce_kernel: [16][21][129]
+        const float* p = a.small2 + (size_t)(hf_small_row0(head) + ch) * 129;
+        for (int c2 = ci; c2 < 129; c2 += 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += p[(size_t)k * HF_SMALL_ROWS * 129 + c2];
+            if (c2 < 128) a.dw[head][ch * 128 + c2] = s * cs; else a.db[head][ch] = s * cs;
+        }
+        return;
+    }
+    const int cpad = hf_tiles(head) * 32, row = hf_row_of_chan(head, ch);
+    const float* p = a.partial[head] + (size_t)row * 128 + ci;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 2 <= a.nsplit[head]; k += 2) { s0 += p[(size_t)k * cpad * 128]; s1 += p[(size_t)(k + 1) * cpad * 128]; }
+    if (k < a.nsplit[head]) s0 += p[(size_t)k * cpad * 128];
+    a.dw[head][ch * 128 + ci] = (s0 + s1) * cs;
+    if (ci == 0) {
+        float b = 0.f;
+        for (int q = 0; q < a.nsplit[head]; ++q) b += a.rowsum[head][(size_t)q * cpad + row];
+        a.db[head][ch] = b * cs;
+    }
+}
+
+// conv2.weight.grad / conv2.bias.grad of all heads from the fused kernel's outputs (unet.py:70 under autograd):
 // dW2[c][ci] = factor_c * sum_p dL[c][p] * act(feat[p][ci]); run after abc_loss_finalize (chan_scale)
 extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t stream) {
     const int HW = d->h * d->w, nchunk = d->B * HW / 128;
@@ -1079,34 +1109,40 @@ extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t
     hf_splits(nchunk, ns);
     HeadWgBatch bt;
     HeadFusedRedK rk;
-    float* ws = d->wgrad_work;
+    float* ws = d->wgrad_work + (size_t)nchunk * HF_SMALL_ROWS * 129;
+    rk.small2 = ws; ws += 16 * HF_SMALL_ROWS * 129;
     size_t row0 = 0;
     int gx = 0, gy = 0;
     for (int i = 0; i < HF_NH; ++i) {
-        HeadK& k = bt.k[i];
         const int cpad = hf_tiles(i) * 32;
-        k.dl = (const float*)((const bf16*)d->dl + row0 * (size_t)nchunk * 128);
-        k.psc = k.psh = k.psl = nullptr;
-        k.q = d->feat; k.qsc = d->scale; k.qsh = d->shift; k.qsl = d->slope;
-        k.partial = ws; ws += (size_t)ns[i] * cpad * 128;
-        k.rowsum = ws; ws += (size_t)ns[i] * cpad;
-        k.HW = HW; k.hc = hf_ch(i); k.ldq = d->ld; k.cq_off = 128 * i; k.nchunks = nchunk; k.nsplit = ns[i];
-        k.mtiles = hf_tiles(i); k.Ca_pad = cpad;
-        k.drop_p = d->drop_p; k.drop_seed = d->drop_seed; k.drop_salt = d->drop_salt;
-        k.bytesP = (unsigned)((size_t)nchunk * cpad * 128 * 2); k.bytesQ = (unsigned)((int64_t)d->B * HW * d->ld * 2);
-        k.cpad_blk = cpad;
-        if ((size_t)nchunk * cpad * 128 * 2 >= (size_t(1) << 31)) return abc_fail(ABC_EUNSUPPORTED, "heads_fused_wgrad: d(logits) block above 2 GB");
-        gx = ns[i] > gx ? ns[i] : gx;
-        gy = abc_cdiv(k.mtiles, 4) > gy ? abc_cdiv(k.mtiles, 4) : gy;
-        rk.partial[i] = k.partial; rk.rowsum[i] = k.rowsum; rk.dw[i] = d->dw2[i]; rk.db[i] = d->db2[i];
-        rk.nsplit[i] = ns[i]; rk.chan_off[i] = d->chan_off[i];
+        rk.dw[i] = d->dw2[i]; rk.db[i] = d->db2[i]; rk.nsplit[i] = ns[i]; rk.chan_off[i] = d->chan_off[i];
+        rk.partial[i] = nullptr; rk.rowsum[i] = nullptr;
+        if (i >= 5) {
+            HeadK& k = bt.k[i - 5];
+            k.dl = (const float*)((const bf16*)d->dl + row0 * (size_t)nchunk * 128);
+            k.psc = k.psh = k.psl = nullptr;
+            k.q = d->feat; k.qsc = d->scale; k.qsh = d->shift; k.qsl = d->slope;
+            k.partial = ws; ws += (size_t)ns[i] * cpad * 128;
+            k.rowsum = ws; ws += (size_t)ns[i] * cpad;
+            k.HW = HW; k.hc = hf_ch(i); k.ldq = d->ld; k.cq_off = 128 * i; k.nchunks = nchunk; k.nsplit = ns[i];
+            k.mtiles = hf_tiles(i); k.Ca_pad = cpad;
+            k.drop_p = d->drop_p; k.drop_seed = d->drop_seed; k.drop_salt = d->drop_salt;
+            k.bytesP = (unsigned)((size_t)nchunk * cpad * 128 * 2); k.bytesQ = (unsigned)((int64_t)d->B * HW * d->ld * 2);
+            k.cpad_blk = cpad;
+            if ((size_t)nchunk * cpad * 128 * 2 >= (size_t(1) << 31)) return abc_fail(ABC_EUNSUPPORTED, "heads_fused_wgrad: d(logits) block above 2 GB");
+            gx = ns[i] > gx ? ns[i] : gx;
+            gy = abc_cdiv(k.mtiles, 4) > gy ? abc_cdiv(k.mtiles, 4) : gy;
+            rk.partial[i] = k.partial; rk.rowsum[i] = k.rowsum;
+        }
         row0 += cpad;
     }
+    for (int i = 3; i < 8; ++i) bt.k[i] = bt.k[0];
     rk.chan_scale = d->chan_scale;
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)head_wgrad_blocked_kernel, 160 * 1024, &lds_ok)) return rc;
-    hipLaunchKernelGGL(head_wgrad_blocked_kernel, dim3(gx, gy, HF_NH), dim3(512), HEAD_LDS, (hipStream_t)stream, bt);
+    hipLaunchKernelGGL(head_wgrad_blocked_kernel, dim3(gx, gy, 3), dim3(512), HEAD_LDS, (hipStream_t)stream, bt);
     if (int rc = abc_check_launch("heads_fused_wgrad")) return rc;
+    hipLaunchKernelGGL(head_fused_small_reduce_kernel, dim3(HF_SMALL_ROWS, 16), dim3(192), 0, (hipStream_t)stream, (const float*)d->wgrad_work, nchunk, (float*)rk.small2);
     hipLaunchKernelGGL(head_fused_reduce_kernel, dim3(360, HF_NH), dim3(128), 0, (hipStream_t)stream, rk);
     return abc_check_launch("heads_fused_wgrad_reduce");
 }

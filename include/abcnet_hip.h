@@ -336,10 +336,11 @@ typedef struct abc_heads_fused_desc {
     float* bn_partial;                  /* out: [abc_heads_fused_chunks()][2][ld]: sum g, sum g * xhat */
     double* loss_partial;               /* out: [abc_heads_fused_loss_blocks()][16], the layout abc_loss_finalize reduces */
     int32_t B, h, w;                    /* h * w a multiple of 128 */
-    /* abc_heads_fused_wgrad only: */
+    /* abc_heads_fused_wgrad (wgrad_work: both): */
     const float* chan_scale; int32_t chan_off[8];   /* abc_loss_finalize's factors, first channel of head i */
     float* dw2[8]; float* db2[8];       /* out: conv2.weight.grad [C_i][128], conv2.bias.grad [C_i] */
-    float* wgrad_work;                  /* abc_heads_fused_wgrad_floats() floats */
+    float* wgrad_work;                  /* abc_heads_fused_wgrad_floats() floats; ALSO written by abc_heads_fused_fwd_bwd (the five
+                                           small heads' weight-gradient partials), so set it for both calls */
 } abc_heads_fused_desc;
 int64_t abc_heads_fused_pack_bytes(void);
 int abc_heads_fused_chunks(const abc_heads_fused_desc* d);

@@ -71,6 +71,8 @@ def _run(B, hw, drop_p, seed=3):
     nlb = lib.abc_heads_fused_loss_blocks(C.byref(d))
     lp = torch.zeros((nlb, 16), dtype=torch.float64, device=DEV)
     d.dl, d.g, d.bn_partial, d.loss_partial = dl.data_ptr(), gbuf.data_ptr(), bnp.data_ptr(), lp.data_ptr()
+    work = torch.zeros(lib.abc_heads_fused_wgrad_floats(C.byref(d)), device=DEV)
+    d.wgrad_work = work.data_ptr()
     st = torch.cuda.current_stream().cuda_stream
     L.check(lib.abc_heads_fused_pack(C.byref(d), st), "pack")
     L.check(lib.abc_heads_fused_fwd_bwd(C.byref(d), st), "fwd_bwd")
@@ -89,10 +91,8 @@ def _run(B, hw, drop_p, seed=3):
     d.chan_scale = chan_scale.data_ptr()
     dw2 = [torch.zeros((c, 128), device=DEV) for c in HEADS]
     db2 = [torch.zeros((c,), device=DEV) for c in HEADS]
-    work = torch.zeros(lib.abc_heads_fused_wgrad_floats(C.byref(d)), device=DEV)
     for i in range(8):
         d.chan_off[i], d.dw2[i], d.db2[i] = off[i], dw2[i].data_ptr(), db2[i].data_ptr()
-    d.wgrad_work = work.data_ptr()
     L.check(lib.abc_heads_fused_wgrad(C.byref(d), st), "wgrad")
     torch.cuda.synchronize()
 
