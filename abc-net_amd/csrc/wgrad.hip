@@ -443,7 +443,8 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
     const int split = blockIdx.x, mg = blockIdx.y;
     if (split >= a.nsplit || mg * 4 >= a.mtiles) return;   // (batched launch: the grid is sized for the largest head)
     const int mt = mg * 4 + mi;
-    const bool active = mt < a.mtiles;
+    // (wave-uniform IN A SCALAR REGISTER: an MFMA under a lane-dependent branch is not safe, the instruction ignores EXEC)
+    const bool active = __builtin_amdgcn_readfirstlane(mt) < a.mtiles;
     const bool ptrans = a.psc != nullptr;
     const int c0 = (int)((long long)split * a.nchunks / a.nsplit), c1 = (int)((long long)(split + 1) * a.nchunks / a.nsplit);
 
