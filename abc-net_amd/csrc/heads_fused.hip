@@ -54,7 +54,7 @@ struct HFK {
     const double *t_rho, *t_omega;
     float* bnpart;      // [nchunk][2][ld]
     float* dwsmall;     // [nchunk][HF_SMALL_ROWS][128 + 1]: the small heads' conv2 weight / bias gradient partials (see run_head)
-    double* losspart;   // [HF_GROUPS nchunk][16]
+    double* losspart;   // [nchunk][16]
     int HW, nchunk, dbg;
     HFHead hd[HF_NH];
 };
@@ -506,9 +506,13 @@ __global__ __launch_bounds__(256, 2) void heads_fused_kernel(const HFK a) {
         default: run_head<4>(a, c, lsum); break;
     }
     __syncthreads();
-    if (threadIdx.x < 16)
-        a.losspart[((size_t)group * a.nchunk + c.chunk) * 16 + threadIdx.x] =
-            (ls[threadIdx.x] + ls[16 + threadIdx.x]) + (ls[32 + threadIdx.x] + ls[48 + threadIdx.x]);
+    // one row of 16 sums per 128-pixel chunk; a work type writes the columns of ITS heads (together they cover all 16)
+    if (threadIdx.x < 16) {
+        const int i = threadIdx.x & 7;   // head of this column (numerator i, denominator 8 + i)
+        const bool mine = group == 0 ? (i == 5 || i == 6) : (group == 1 ? i == 7 : i == group - 2);
+        if (mine)
+            a.losspart[(size_t)c.chunk * 16 + threadIdx.x] = (ls[threadIdx.x] + ls[16 + threadIdx.x]) + (ls[32 + threadIdx.x] + ls[48 + threadIdx.x]);
+    }
     // BatchNorm sums of the workgroup's 128 pixels: the four waves' rows, slice by slice in the order the heads ran
     {
         const int nsl = group == 0 ? 2 : 1;
@@ -570,7 +574,7 @@ static int hf_check(const abc_heads_fused_desc* d) {
 
 extern "C" int64_t abc_heads_fused_pack_bytes(void) { return hf_pack_off(HF_NH); }
 extern "C" int abc_heads_fused_chunks(const abc_heads_fused_desc* d) { return d->B * d->h * d->w / 128; }
-extern "C" int abc_heads_fused_loss_blocks(const abc_heads_fused_desc* d) { return HF_GROUPS * abc_heads_fused_chunks(d); }
+extern "C" int abc_heads_fused_loss_blocks(const abc_heads_fused_desc* d) { return abc_heads_fused_chunks(d); }
 extern "C" int64_t abc_heads_fused_dl_elems(const abc_heads_fused_desc* d) { return (int64_t)abc_heads_fused_chunks(d) * hf_rows_total() * 128; }
 extern "C" int abc_heads_fused_rows(int32_t head) { return head >= 0 && head < HF_NH ? hf_tiles(head) * 32 : -1; }
 extern "C" int abc_heads_fused_chan_of_row(int32_t head, int32_t row) {
