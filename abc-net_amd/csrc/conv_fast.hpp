@@ -11,6 +11,10 @@ struct abc_fast_geom {
 int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g);
 int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_stream_t stream);
 
+// plain-input 16 / 32-channel 3x3 convolution without statistics (conv_narrow.hip)
+int abc_conv_narrow_ok(const abc_conv_desc* d);
+int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream);
+
 // one-channel first convolution (stem.hip)
 int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks);
 int abc_conv_stem_launch(const abc_conv_desc* d, abc_stream_t stream);

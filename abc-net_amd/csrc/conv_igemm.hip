@@ -514,13 +514,14 @@ extern "C" int abc_conv_variant(const abc_conv_desc* d) {
     if (abc_conv_stem_ok(d, nullptr)) return 2;
     if (abc_head_fwd_ok(d)) return 3;
     if (abc_head_dgrad_ok(d)) return 4;
+    if (abc_conv_narrow_ok(d)) return 5;
     abc_fast_geom f;
     if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return 1;
     return 0;
 }
 
 extern "C" int abc_conv_weight_layout(const abc_conv_desc* d) {
-    if (abc_conv_stem_ok(d, nullptr) || abc_head_fwd_ok(d) || abc_head_dgrad_ok(d)) return 0;
+    if (abc_conv_stem_ok(d, nullptr) || abc_head_fwd_ok(d) || abc_head_dgrad_ok(d) || abc_conv_narrow_ok(d)) return 0;
     abc_fast_geom f;
     return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible && f.wd) ? 1 : 0;   // the weights-direct loop of conv_fast.hip
 }
@@ -578,6 +579,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     if (abc_conv_stem_ok(d, nullptr)) return abc_conv_stem_launch(d, stream);
     if (abc_head_fwd_ok(d)) return abc_head_fwd_launch(d, stream);
     if (abc_head_dgrad_ok(d)) return abc_head_dgrad_launch(d, stream);
+    if (abc_conv_narrow_ok(d)) return abc_conv_narrow_launch(d, stream);
     {
         abc_fast_geom f;
         if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return abc_conv_fast_launch(d, f, stream);

@@ -1,0 +1,224 @@
+// 3x3 convolution of a PLAIN bf16 NHWC tensor with 16 or 32 input channels into 16 / 32 output channels: the narrow
+// levels of the inference graph (BatchNorm folded, img2smiles2.py:42-49 over unet.py:12,15) and the data gradients of the
+// narrow levels in training (unet.py:12,15 under autograd).  These layers are HBM-bound (10 KB in, 8 KB out per 256
+// pixels) and the general lean kernel (conv_fast.hip) runs them at 2 TB/s: ~600 VALU instructions per wave and tile for
+// staging with the transform on load, weight fragments through LDS, an LDS-transposed epilogue, two workgroup barriers.
+// Nothing of that is needed when the input is a finished tensor:
+//
+//   * a WAVE owns an 8 x 16 pixel tile (four 32-pixel MFMA tiles) and walks a contiguous run of tiles: no workgroup
+//     barriers at all, only its own LDS queue to wait for;
+//   * the halo (10 x 18 pixels) goes global -> registers -> LDS untouched (6 / 12 16-byte loads per lane, issued one tile
+//     AHEAD: they land under the current tile's MFMAs and stores);
+//   * the weights live in REGISTERS for the whole kernel (9 taps x 1-2 K-steps = 36 / 72 VGPRs): the inner loop is one
+//     conflict-free ds_read_b128 + one MFMA per (tile, tap, K-step), tap offsets as immediates;
+//   * the MFMA runs "transposed" (A = weights, B = pixels), so a lane of the result holds ONE PIXEL and its registers
+//     channels; with the weight rows permuted (bits 2 and 3 swapped) register k of lane half h is channel
+//     (k & 7) + 8 h + 16 (k >> 3): bias, activation and 16-byte stores straight from the accumulators.
+//
+// ~250 instructions per wave and 128 pixels.  Served: stride 1, taps within +-1, unit output stride, no statistics.
+#include "common.hpp"
+#include "../../include/abcnet_hip.h"
+#include "capi_util.hpp"
+#include "conv_fast.hpp"
+#include <stdlib.h>
+
+namespace {
+
+struct NarrowK {
+    const bf16* x; const bf16* w; const float* bias; bf16* y;
+    int B, H, W, ldx, cin_off, ldy, cout_off, Cout;
+    int tiles_x, tiles_y, ntiles, tpw;         // tiles per wave (contiguous runs)
+    int out_act; float out_slope;
+    unsigned bytesX;
+    int8_t ty[9], tx[9];                       // tap offsets + 1 (0 .. 2)
+};
+
+template <int CK>
+__global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
+    constexpr int CKB = CK * 2;                // bytes of a pixel's channels
+    constexpr int PS = CKB + 16;               // padded pixel stride: 16 consecutive pixels = 16 distinct 16-byte bank slots
+    constexpr int RS = 18 * PS;
+    constexpr int SEGS = CKB / 16;             // 16-byte segments per pixel
+    constexpr int NSEG = 10 * 18 * SEGS;       // of the halo
+    constexpr int NL = (NSEG + 63) / 64;       // loads per lane
+    constexpr int KS = CK / 16;                // K-steps per tap
+    constexpr int LHB = CKB / 2;               // a lane half's bytes of a pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    char* halo = smem + wave * (10 * RS);
+
+    // ---- weights: A fragments, row = output channel with bits 2 and 3 of the lane swapped (see above).  16 input channels:
+    // 36 registers for the whole kernel; 32: 72 would not leave room for the prefetch -- they sit in LDS in fragment order
+    // ([tap][K-step][lane] x 16 bytes: one conflict-free ds_read_b128 per four MFMAs)
+    const int rw = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
+    constexpr bool WREG = CK == 16;
+    bf16x8 wf[WREG ? 9 : 1][WREG ? KS : 1];
+    char* swt = smem + 4 * 10 * RS + 128;
+    if constexpr (WREG) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                wf[t][ks] = *(const bf16x8*)(a.w + ((size_t)(t * 32 + rw) * CK + h * (LHB / 2) + 8 * ks));
+    } else {
+        for (int s2 = wave; s2 < 9 * KS; s2 += 4)
+            *(bf16x8*)(swt + (s2 * 64 + lane) * 16) = *(const bf16x8*)(a.w + ((size_t)((s2 / KS) * 32 + rw) * CK + h * (LHB / 2) + 8 * (s2 % KS)));
+    }
+    // bias -> LDS (read back per tile as the accumulators' initial value: register k <-> channel (k & 7) + 8 h + 16 (k >> 3))
+    float* sbias = (float*)(smem + 4 * 10 * RS);
+    if (threadIdx.x < 32) sbias[threadIdx.x] = (a.bias != nullptr && (int)threadIdx.x < a.Cout) ? a.bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX);
+
+    // segment i of this lane = 16-byte part sg of halo pixel p0 + (64 / SEGS) i (the same for every tile); row / column by a
+    // multiply (pixel < 192), recomputed where needed: as stored arrays they cost 18-36 registers the kernel does not have
+    const int sg16 = (lane % SEGS) * 16, p0 = lane / SEGS;
+    auto seg_rc = [&](int i, int& hr, int& hc) {
+        const int pix = p0 + (64 / SEGS) * i;
+        hr = (pix * 3641) >> 16;          // pix / 18 for pix < 1024
+        hc = pix - 18 * hr;
+    };
+    const int wid = blockIdx.x * 4 + wave;
+    const int t0 = wid * a.tpw, t1 = min(t0 + a.tpw, a.ntiles);
+    const int wldx2 = a.W * a.ldx * 2, ldx2 = a.ldx * 2;
+    u32x4 pre[NL];
+    auto issue = [&](int tile) {
+        int id = tile;
+        const int tx_i = id % a.tiles_x; id /= a.tiles_x;
+        const int ty_i = id % a.tiles_y;
+        const int b = id / a.tiles_y;
+        const int iy0 = ty_i * 8 - 1, ix0 = tx_i * 16 - 1;
+        const int tbase = (((b * a.H + iy0) * a.W + ix0) * a.ldx + a.cin_off) * 2 + sg16;   // (may point before the image: masked below)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int hr, hc;
+            seg_rc(i, hr, hc);
+            const int iy = iy0 + hr, ix = ix0 + hc;
+            const bool ok = tile < t1 && hr < 10 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (unsigned)(tbase + hr * wldx2 + hc * ldx2) : 0x80000000u, 0, 0);   // (out of range: zeros = the padding)
+        }
+    };
+    if (t0 < t1) issue(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        // ---- this tile's halo: registers -> LDS (the wave's previous reads are ahead of these writes in its LDS queue)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int hr, hc;
+            seg_rc(i, hr, hc);
+            if (hr < 10) *(u32x4*)(halo + hr * RS + hc * PS + sg16) = pre[i];
+        }
+        issue(tile + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int id = tile;
+        const int tx_i = id % a.tiles_x; id /= a.tiles_x;
+        const int ty_i = id % a.tiles_y;
+        const int b = id / a.tiles_y;
+        f32x16 acc[4];
+        {
+            const f32x4 b0 = *(const f32x4*)(sbias + 8 * h), b1 = *(const f32x4*)(sbias + 8 * h + 4),
+                        b2 = *(const f32x4*)(sbias + 16 + 8 * h), b3 = *(const f32x4*)(sbias + 16 + 8 * h + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { acc[i][k] = b0[k]; acc[i][4 + k] = b1[k]; acc[i][8 + k] = b2[k]; acc[i][12 + k] = b3[k]; }
+        }
+        const char* base = halo + (r >> 4) * RS + (r & 15) * PS + h * LHB;
+        // K-steps (tap, 16-channel slice) software-pipelined by one: the four fragment reads of step s + 1 are issued in front
+        // of the four MFMAs of step s (two named register sets; without the fences the scheduler hoists all 36-72 reads and spills)
+        constexpr int NS = 9 * KS;
+        auto frag_off = [&](int s2) { const int t = s2 / KS, ks = s2 % KS; return a.ty[t] * RS + a.tx[t] * PS + 16 * ks; };
+        bf16x8 pa[4], pb[4], wa, wb;
+        auto wfrag = [&](int s2) -> bf16x8 {
+            if constexpr (WREG) return wf[s2 / KS][s2 % KS];
+            else return *(const bf16x8*)(swt + (s2 * 64 + lane) * 16);
+        };
+        {
+            const int o = frag_off(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pa[i] = *(const bf16x8*)(base + o + 2 * i * RS);
+            wa = wfrag(0);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2 += 2) {
+            if (s2 + 1 < NS) {
+                const int o = frag_off(s2 + 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pb[i] = *(const bf16x8*)(base + o + 2 * i * RS);
+                wb = wfrag(s2 + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, pa[i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s2 + 1 < NS) {
+                if (s2 + 2 < NS) {
+                    const int o = frag_off(s2 + 2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pa[i] = *(const bf16x8*)(base + o + 2 * i * RS);
+                    wa = wfrag(s2 + 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, pb[i], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue: lane = pixel r of each 32-pixel tile, registers = channels
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gy = ty_i * 8 + 2 * i + (r >> 4), gx = tx_i * 16 + (r & 15);
+            if (gy < a.H && gx < a.W) {
+                bf16* dst = a.y + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldy + a.cout_off + 8 * h;
+#pragma unroll
+                for (int g8 = 0; g8 < 2; ++g8) {
+                    if (16 * g8 + 8 * h < a.Cout) {
+                        float vo[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float v = acc[i][8 * g8 + q];
+                            vo[q] = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                        }
+                        *(bf16x8*)(dst + 16 * g8) = pack_frag<bf16>(vo);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// plain bf16 NHWC in and out, 16 / 32 channels, nine taps within +-1, nothing on load, no statistics
+int abc_conv_narrow_ok(const abc_conv_desc* d) {
+    if (getenv("ABC_CONV_NONARROW")) return 0;
+    if (d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16) return 0;
+    if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->src.scale != nullptr || d->planar_out) return 0;
+    if (d->stats != nullptr || d->accumulate || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
+    if ((d->Cin != 16 && d->Cin != 32) || d->Cout_pad != 32 || d->Cout % 8 || d->ntaps != 9) return 0;
+    if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || d->src.Hx != d->Hin || d->src.Wx != d->Win) return 0;
+    if ((d->src.ldx | d->cin_off | d->ldy | d->cout_off) % 8) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return 0;
+    return (int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2 < (int64_t(1) << 31);
+}
+
+int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
+    NarrowK k;
+    k.x = (const bf16*)d->src.x; k.w = (const bf16*)d->w; k.bias = d->bias; k.y = (bf16*)d->y;
+    k.B = d->B; k.H = d->Hin; k.W = d->Win; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.ldy = d->ldy; k.cout_off = d->cout_off; k.Cout = d->Cout;
+    k.tiles_x = abc_cdiv(k.W, 16); k.tiles_y = abc_cdiv(k.H, 8); k.ntiles = k.tiles_x * k.tiles_y * k.B;
+    k.out_act = d->out_act; k.out_slope = d->out_slope;
+    k.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
+    for (int t = 0; t < 9; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] + 1); k.tx[t] = (int8_t)(d->tap_dx[t] + 1); }
+    const int wgs_per_cu = 2;
+    int nwg = 256 * wgs_per_cu;
+    if (nwg * 4 > k.ntiles) nwg = abc_cdiv(k.ntiles, 4);
+    k.tpw = abc_cdiv(k.ntiles, nwg * 4);
+    nwg = abc_cdiv(k.ntiles, k.tpw * 4);
+    const int lds = 4 * 10 * 18 * (d->Cin * 2 + 16) + 128 + (d->Cin == 32 ? 18 * 1024 : 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->Cin == 16) hipLaunchKernelGGL(conv_narrow_kernel<16>, dim3(nwg), dim3(256), lds, st, k);
+    else hipLaunchKernelGGL(conv_narrow_kernel<32>, dim3(nwg), dim3(256), lds, st, k);
+    return abc_check_launch("conv_narrow");
+}

@@ -250,7 +250,7 @@ class Engine:
         bn, mt, ck = bn_.value, mt_.value, ck_.value
         npx = self.B * gh * gw
         in_px = self.B * lh * lw * (4 if src.pool else 1)
-        kname = ("conv_igemm", "conv_fast", "stem_conv", "head_fwd", "head_dgrad")[self.lib.abc_conv_variant(C.byref(d))]
+        kname = ("conv_igemm", "conv_fast", "stem_conv", "head_fwd", "head_dgrad", "conv_narrow")[self.lib.abc_conv_variant(C.byref(d))]
         meta = {"kernel": "%s<%s,%s,%s,CK%d,BN%d,S%d,MT%d>" % (kname, self._dn(src.dt), self._dn(self.dt), self._dn(y_dt), ck, bn, stride, mt),
                 "flops": 2.0 * npx * Cout * len(taps) * d.Cin,
                 "bytes": float(in_px * d.Cin * self._esz(src.dt) + npx * Cout * self._esz(y_dt))}

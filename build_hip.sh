@@ -13,7 +13,7 @@ FLAVOUR=production
 echo $FLAVOUR > .build_flavour
 OBJS=""
 pids=""
-for f in conv_igemm conv_fast stem heads heads_fused wgrad bn_act loss misc cbam metrics extract raster; do
+for f in conv_igemm conv_fast conv_narrow stem heads heads_fused wgrad bn_act loss misc cbam metrics extract raster; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.hpp -nt $f.o ] || [ conv_fast.hpp -nt $f.o ] || [ loss_math.hpp -nt $f.o ] || [ capi_util.hpp -nt $f.o ] || [ ../../include/abcnet_hip.h -nt $f.o ]; then
     hipcc $FLAGS -c $f.hip -o $f.o &
     pids="$pids $!"

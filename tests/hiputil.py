@@ -48,7 +48,7 @@ def pack(lib, w, mode, dt, Cout, Cin, k, rows_pad, red_real, py=0, px=0):
 
 def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, Hout, Wout, ldy=None, cout_off=0, coef=None,
          pool=False, stride=1, grid=None, om=1, oy0=0, ox0=0, out=None, out_dt=None, stats=False, drop_p=0.0, drop_seed=0,
-         planar_in=0, planar_out=False):
+         planar_in=0, planar_out=False, out_slope=None):
     out_dt = dt if out_dt is None else out_dt
     ldy = Cout if ldy is None else ldy
     if out is None:
@@ -64,7 +64,10 @@ def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, 
     gh, gw = grid if grid else (Hout, Wout)
     d.Hg, d.Wg, d.Hout, d.Wout, d.ldy, d.cout_off, d.Cout, d.Cout_pad = gh, gw, Hout, Wout, ldy, cout_off, Cout, -(-Cout // 32) * 32
     d.stride, d.om, d.oy0, d.ox0 = stride, om, oy0, ox0
+    if out_slope is not None:
+        d.out_act, d.out_slope = 1, out_slope
     L.set_taps(d, taps)
+    conv.last_variant = lib.abc_conv_variant(C.byref(d))
     if lib.abc_conv_weight_layout(C.byref(d)) == 1:
         # the kernel serving this descriptor reads abc_pack_desc.layout 1: re-order the row-major packing here (an independent
         # statement of the permutation; abc_pack_conv_weights' own layout-1 path is held to it in test_gpu_kernels.py)

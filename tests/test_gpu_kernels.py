@@ -92,6 +92,48 @@ def test_conv_forward(lib, dt, case):
     np.testing.assert_allclose(s[1] / n, (ref.double() ** 2).mean((0, 2, 3)), rtol=U.tol(dt, 1e-4, 3e-2), atol=1e-4)
 
 
+@pytest.mark.parametrize("case", [
+    dict(Cin=16, Cout=16, H=64, W=96),
+    dict(Cin=32, Cout=32, H=40, W=48, slope=0.0),
+    dict(Cin=32, Cout=16, H=24, W=40, mirror=True),           # a data gradient: mirrored taps, no bias
+    dict(Cin=16, Cout=32, H=20, W=40, slope=0.01),            # ragged tiles: 20 = 2 x 8 + 4 rows, 40 = 2 x 16 + 8 columns
+    dict(Cin=16, Cout=16, H=72, W=88, ld=48, coff=16, ldy=40, ycoff=8),   # channel slices of wider tensors
+    dict(Cin=32, Cout=32, H=256, W=384, slope=0.0),           # every wave walks several tiles
+])
+def test_conv_narrow_plain_input(lib, case):
+    """3x3 over a FINISHED bf16 tensor with 16 / 32 channels (the folded inference graph's narrow levels, unet.py:12,15 in eval
+    mode; the narrow data gradients of training): csrc/conv_narrow.hip -- wave-private tiles, weights in registers, stores
+    straight from transposed accumulators -- against F.conv2d of the same bf16 operands"""
+    dt = L.BF16
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H, W = 2, case["Cin"], case["Cout"], case["H"], case["W"]
+    ld, coff = case.get("ld", Cin), case.get("coff", 0)
+    ldy, ycoff = case.get("ldy", Cout), case.get("ycoff", 0)
+    xfull = q(torch.randn((B, ld, H, W), generator=g), dt)
+    x = xfull[:, coff:coff + Cin]
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5
+    bias = None if case.get("mirror") else torch.randn(Cout, generator=g)
+    taps = taps_mirror(taps_square(3)) if case.get("mirror") else taps_square(3)
+    wref = q(w, dt).flip(2, 3) if case.get("mirror") else q(w, dt)
+    ref = F.conv2d(x, wref, bias, padding=1)
+    slope = case.get("slope")
+    if slope is not None:
+        ref = torch.maximum(ref, slope * ref)
+    xd = xfull.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(U.DEV)
+    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, 3, 32, Cin)
+    out = torch.full((B, H, W, ldy), 7.0, dtype=torch.bfloat16, device=U.DEV)
+    y, _ = U.conv(lib, xd, dt, dt, B, H, W, ld, coff, Cin, wp, None if bias is None else bias.to(U.DEV), Cout, taps, H, W, ldy=ldy,
+                  cout_off=ycoff, out=out, out_slope=slope)
+    torch.cuda.synchronize()
+    assert U.conv.last_variant == 5, "not served by conv_narrow"
+    got = y[..., ycoff:ycoff + Cout].float().permute(0, 3, 1, 2).cpu()
+    assert U.relerr(got, ref) < 1.5e-2, U.relerr(got, ref)
+    # the other channels of the output tensor are untouched
+    if ldy > Cout:
+        rest = torch.cat([y[..., :ycoff], y[..., ycoff + Cout:]], dim=-1)
+        assert (rest == 7.0).all()
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("Cout,W", [(14, 32), (60, 24), (1, 20), (360, 18)])
 def test_head_conv1x1_writes_nchw(lib, dt, Cout, W):
