@@ -14,6 +14,7 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
 // plain-input 16 / 32-channel 3x3 convolution without statistics (conv_narrow.hip)
 int abc_conv_narrow_ok(const abc_conv_desc* d);
 int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream);
+int abc_conv_narrow_stat_blocks(const abc_conv_desc* d);   // statistics rows it writes: one per workgroup
 
 // one-channel first convolution (stem.hip)
 int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks);

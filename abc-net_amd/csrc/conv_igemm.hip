@@ -528,6 +528,7 @@ extern "C" int abc_conv_weight_layout(const abc_conv_desc* d) {
 
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
     { int nb = 0; if (abc_conv_stem_ok(d, &nb)) return nb; }
+    if (abc_conv_narrow_ok(d)) return abc_conv_narrow_stat_blocks(d);
     abc_fast_geom f;
     if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return (f.b_static && d->stats_rows != 4) ? f.nwg : f.tiles_x * f.tiles_y * d->B;   // (resident weights: one row per workgroup)
     Geom g;

@@ -26,6 +26,8 @@ namespace {
 
 struct NarrowK {
     const bf16* x; const bf16* w; const float* bias; bf16* y;
+    const float *sc, *sh, *sl;                 // XF: previous layer's BatchNorm + activation applied on load (absolute channel index)
+    float* stats;                              // NST: [grid][2][Cout] sum, sum of squares of the f32 outputs (one row per workgroup)
     int B, H, W, ldx, cin_off, ldy, cout_off, Cout;
     int tiles_x, tiles_y, ntiles, tpw;         // tiles per wave (contiguous runs)
     int out_act; float out_slope;
@@ -33,7 +35,9 @@ struct NarrowK {
     int8_t ty[9], tx[9];                       // tap offsets + 1 (0 .. 2)
 };
 
-template <int CK>
+// XF: transform on load; NST: 0 = no statistics, 1 / 2 = BatchNorm partial sums for Cout <= 16 / <= 32 (per-lane running sums
+// over all tiles of the wave, reduced once at the end)
+template <int CK, bool XF, int NST>
 __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
     constexpr int CKB = CK * 2;                // bytes of a pixel's channels
     constexpr int PS = CKB + 16;               // padded pixel stride: 16 consecutive pixels = 16 distinct 16-byte bank slots
@@ -74,6 +78,15 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
     // segment i of this lane = 16-byte part sg of halo pixel p0 + (64 / SEGS) i (the same for every tile); row / column by a
     // multiply (pixel < 192), recomputed where needed: as stored arrays they cost 18-36 registers the kernel does not have
     const int sg16 = (lane % SEGS) * 16, p0 = lane / SEGS;
+    // (a lane always stages the SAME 8 channels: their coefficients stay in registers)
+    float csc[XF ? 8 : 1], csh[XF ? 8 : 1], csl[XF ? 8 : 1];
+    if constexpr (XF) {
+        const int c0 = a.cin_off + (sg16 >> 1);
+        LoadVec<float, 8>::ld(a.sc + c0, csc); LoadVec<float, 8>::ld(a.sh + c0, csh); LoadVec<float, 8>::ld(a.sl + c0, csl);
+    }
+    float st1[NST ? 8 * NST : 1], st2[NST ? 8 * NST : 1];
+#pragma unroll
+    for (int k = 0; k < (NST ? 8 * NST : 1); ++k) { st1[k] = 0.f; st2[k] = 0.f; }
     auto seg_rc = [&](int i, int& hr, int& hc) {
         const int pix = p0 + (64 / SEGS) * i;
         hr = (pix * 3641) >> 16;          // pix / 18 for pix < 1024
@@ -106,7 +119,22 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
         for (int i = 0; i < NL; ++i) {
             int hr, hc;
             seg_rc(i, hr, hc);
-            if (hr < 10) *(u32x4*)(halo + hr * RS + hc * PS + sg16) = pre[i];
+            if constexpr (XF) {
+                // BN + activation of the producer; the zero padding applies to the ACTIVATED tensor: out-of-image stays 0
+                int id2 = tile;
+                const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
+                const int ty2 = id2 % a.tiles_y;
+                const int iy = ty2 * 8 - 1 + hr, ix = tx2 * 16 - 1 + hc;
+                const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(pre[i][j] << 16); v[2 * j + 1] = __uint_as_float(pre[i][j] & 0xFFFF0000u); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = in ? abc_act(v[j], csc[j], csh[j], csl[j]) : 0.f;
+                if (hr < 10) *(bf16x8*)(halo + hr * RS + hc * PS + sg16) = pack_frag<bf16>(v);
+            } else {
+                if (hr < 10) *(u32x4*)(halo + hr * RS + hc * PS + sg16) = pre[i];
+            }
         }
         issue(tile + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -177,6 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             const float v = acc[i][8 * g8 + q];
+                            if constexpr (NST > 0) {
+                                if (g8 < NST) { st1[8 * (g8 < NST ? g8 : 0) + q] += v; st2[8 * (g8 < NST ? g8 : 0) + q] = fmaf(v, v, st2[8 * (g8 < NST ? g8 : 0) + q]); }
+                            }
                             vo[q] = a.out_act ? fmaxf(v, a.out_slope * v) : v;
                         }
                         *(bf16x8*)(dst + 16 * g8) = pack_frag<bf16>(vo);
@@ -185,40 +216,95 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
             }
         }
     }
+    if constexpr (NST > 0) {
+        // per-lane sums -> per-channel sums of the wave (lanes of one half hold the same channels, one pixel column each),
+        // then the four waves through LDS: ONE partial row per workgroup (abc_conv_stat_blocks = the grid)
+        __syncthreads();                       // (every wave is done with its halo: the sums reuse wave 0's)
+        float* red = (float*)smem;             // [4 waves][2][32]
+#pragma unroll
+        for (int k = 0; k < 8 * NST; ++k) {
+            float v1 = st1[k], v2 = st2[k];
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) { v1 += __shfl_xor(v1, m); v2 += __shfl_xor(v2, m); }
+            if (r == 0) {
+                const int n = (k & 7) + 8 * h + 16 * (k >> 3);
+                red[(wave * 2 + 0) * 32 + n] = v1;
+                red[(wave * 2 + 1) * 32 + n] = v2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64 && (int)(threadIdx.x & 31) < a.Cout) {
+            const int row = threadIdx.x >> 5, n = threadIdx.x & 31;
+            a.stats[((size_t)blockIdx.x * 2 + row) * a.Cout + n] = (red[(0 * 2 + row) * 32 + n] + red[(1 * 2 + row) * 32 + n]) + (red[(2 * 2 + row) * 32 + n] + red[(3 * 2 + row) * 32 + n]);
+        }
+    }
 }
 
 }  // namespace
 
-// plain bf16 NHWC in and out, 16 / 32 channels, nine taps within +-1, nothing on load, no statistics
+// geometry shared by the eligibility test, abc_conv_stat_blocks and the launch
+static void narrow_grid(const abc_conv_desc* d, int* nwg, int* tpw) {
+    const int ntiles = abc_cdiv(d->Win, 16) * abc_cdiv(d->Hin, 8) * d->B;
+    int n = 256 * 2;
+    if (n * 4 > ntiles) n = abc_cdiv(ntiles, 4);
+    *tpw = abc_cdiv(ntiles, n * 4);
+    *nwg = abc_cdiv(ntiles, *tpw * 4);
+}
+
+// bf16 NHWC in and out, 16 / 32 input channels, <= 32 output channels, nine taps within +-1, unit strides; optionally the
+// producer's BatchNorm + activation on load and BatchNorm partial sums of the outputs (2 rows).  (32 input channels with BOTH
+// the transform and the sums does not fit the registers: that one stays on conv_fast.)
 int abc_conv_narrow_ok(const abc_conv_desc* d) {
     if (getenv("ABC_CONV_NONARROW")) return 0;
     if (d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16) return 0;
-    if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->src.scale != nullptr || d->planar_out) return 0;
-    if (d->stats != nullptr || d->accumulate || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
+    if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->planar_out) return 0;
+    if (d->accumulate || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
     if ((d->Cin != 16 && d->Cin != 32) || d->Cout_pad != 32 || d->Cout % 8 || d->ntaps != 9) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || d->src.Hx != d->Hin || d->src.Wx != d->Win) return 0;
     if ((d->src.ldx | d->cin_off | d->ldy | d->cout_off) % 8) return 0;
+    // (must not depend on the statistics POINTER: abc_conv_stat_blocks is asked before that buffer exists)
+    if (d->stats_rows == 4) return 0;                                   // unet2's CBAM rows: per image, per tile
+    if (d->src.scale != nullptr && d->Cin == 32) return 0;             // transform + sums + 72 weight registers do not fit
+    if (d->src.scale != nullptr && getenv("ABC_CONV_NONARROW_XF")) return 0;
     for (int t = 0; t < 9; ++t)
         if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return 0;
     return (int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2 < (int64_t(1) << 31);
 }
 
+int abc_conv_narrow_stat_blocks(const abc_conv_desc* d) {
+    int nwg, tpw;
+    narrow_grid(d, &nwg, &tpw);
+    return nwg;
+}
+
 int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
     NarrowK k;
     k.x = (const bf16*)d->src.x; k.w = (const bf16*)d->w; k.bias = d->bias; k.y = (bf16*)d->y;
+    k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.stats = d->stats;
     k.B = d->B; k.H = d->Hin; k.W = d->Win; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.ldy = d->ldy; k.cout_off = d->cout_off; k.Cout = d->Cout;
     k.tiles_x = abc_cdiv(k.W, 16); k.tiles_y = abc_cdiv(k.H, 8); k.ntiles = k.tiles_x * k.tiles_y * k.B;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
     k.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
     for (int t = 0; t < 9; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] + 1); k.tx[t] = (int8_t)(d->tap_dx[t] + 1); }
-    const int wgs_per_cu = 2;
-    int nwg = 256 * wgs_per_cu;
-    if (nwg * 4 > k.ntiles) nwg = abc_cdiv(k.ntiles, 4);
-    k.tpw = abc_cdiv(k.ntiles, nwg * 4);
-    nwg = abc_cdiv(k.ntiles, k.tpw * 4);
+    int nwg;
+    narrow_grid(d, &nwg, &k.tpw);
     const int lds = 4 * 10 * 18 * (d->Cin * 2 + 16) + 128 + (d->Cin == 32 ? 18 * 1024 : 0);
     hipStream_t st = (hipStream_t)stream;
-    if (d->Cin == 16) hipLaunchKernelGGL(conv_narrow_kernel<16>, dim3(nwg), dim3(256), lds, st, k);
-    else hipLaunchKernelGGL(conv_narrow_kernel<32>, dim3(nwg), dim3(256), lds, st, k);
+    const bool xf = d->src.scale != nullptr;
+    const int nst = d->stats != nullptr ? (d->Cout <= 16 ? 1 : 2) : 0;
+#define NARROW_LAUNCH(CK, XF, NST) hipLaunchKernelGGL((conv_narrow_kernel<CK, XF, NST>), dim3(nwg), dim3(256), lds, st, k)
+    if (d->Cin == 16) {
+        if (!xf && nst == 0) NARROW_LAUNCH(16, false, 0);
+        else if (!xf && nst == 1) NARROW_LAUNCH(16, false, 1);
+        else if (!xf && nst == 2) NARROW_LAUNCH(16, false, 2);
+        else if (xf && nst == 0) NARROW_LAUNCH(16, true, 0);
+        else if (xf && nst == 1) NARROW_LAUNCH(16, true, 1);
+        else NARROW_LAUNCH(16, true, 2);
+    } else {
+        if (nst == 0) NARROW_LAUNCH(32, false, 0);
+        else if (nst == 1) NARROW_LAUNCH(32, false, 1);
+        else NARROW_LAUNCH(32, false, 2);
+    }
+#undef NARROW_LAUNCH
     return abc_check_launch("conv_narrow");
 }

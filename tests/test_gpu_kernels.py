@@ -99,6 +99,11 @@ def test_conv_forward(lib, dt, case):
     dict(Cin=16, Cout=32, H=20, W=40, slope=0.01),            # ragged tiles: 20 = 2 x 8 + 4 rows, 40 = 2 x 16 + 8 columns
     dict(Cin=16, Cout=16, H=72, W=88, ld=48, coff=16, ldy=40, ycoff=8),   # channel slices of wider tensors
     dict(Cin=32, Cout=32, H=256, W=384, slope=0.0),           # every wave walks several tiles
+    # training forward: the producer's BatchNorm + activation on load, BatchNorm partial sums of the outputs
+    dict(Cin=16, Cout=16, H=64, W=96, coef=True, stats=True),
+    dict(Cin=16, Cout=16, H=200, W=136, coef=True, stats=True),   # ragged tiles, several tiles per wave
+    dict(Cin=16, Cout=32, H=48, W=64, stats=True),                # a pooled (finished) input into a wider layer
+    dict(Cin=32, Cout=16, H=40, W=48, stats=True),
 ])
 def test_conv_narrow_plain_input(lib, case):
     """3x3 over a FINISHED bf16 tensor with 16 / 32 channels (the folded inference graph's narrow levels, unet.py:12,15 in eval
@@ -111,6 +116,13 @@ def test_conv_narrow_plain_input(lib, case):
     ldy, ycoff = case.get("ldy", Cout), case.get("ycoff", 0)
     xfull = q(torch.randn((B, ld, H, W), generator=g), dt)
     x = xfull[:, coff:coff + Cin]
+    coef = None
+    if case.get("coef"):
+        sc = torch.rand(ld, generator=g) * 2 - 0.6
+        sh = torch.randn(ld, generator=g) * 0.3
+        sl = torch.tensor([0.0, 0.01, 1.0])[torch.randint(0, 3, (ld,), generator=g)]
+        coef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
+        x = q(act(x, sc[coff:coff + Cin], sh[coff:coff + Cin], sl[coff:coff + Cin]), dt)
     w = torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5
     bias = None if case.get("mirror") else torch.randn(Cout, generator=g)
     taps = taps_mirror(taps_square(3)) if case.get("mirror") else taps_square(3)
@@ -122,12 +134,17 @@ def test_conv_narrow_plain_input(lib, case):
     xd = xfull.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(U.DEV)
     wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, 3, 32, Cin)
     out = torch.full((B, H, W, ldy), 7.0, dtype=torch.bfloat16, device=U.DEV)
-    y, _ = U.conv(lib, xd, dt, dt, B, H, W, ld, coff, Cin, wp, None if bias is None else bias.to(U.DEV), Cout, taps, H, W, ldy=ldy,
-                  cout_off=ycoff, out=out, out_slope=slope)
+    y, st = U.conv(lib, xd, dt, dt, B, H, W, ld, coff, Cin, wp, None if bias is None else bias.to(U.DEV), Cout, taps, H, W, ldy=ldy,
+                   cout_off=ycoff, out=out, out_slope=slope, coef=coef, stats=bool(case.get("stats")))
     torch.cuda.synchronize()
     assert U.conv.last_variant == 5, "not served by conv_narrow"
     got = y[..., ycoff:ycoff + Cout].float().permute(0, 3, 1, 2).cpu()
     assert U.relerr(got, ref) < 1.5e-2, U.relerr(got, ref)
+    if case.get("stats"):
+        ssum = st.double().sum(0).cpu()
+        n = B * H * W
+        np.testing.assert_allclose(ssum[0] / n, ref.double().mean((0, 2, 3)), atol=2e-2)
+        np.testing.assert_allclose(ssum[1] / n, (ref.double() ** 2).mean((0, 2, 3)), rtol=3e-2, atol=1e-4)
     # the other channels of the output tensor are untouched
     if ldy > Cout:
         rest = torch.cat([y[..., :ycoff], y[..., ycoff + Cout:]], dim=-1)
