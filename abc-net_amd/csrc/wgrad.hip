@@ -673,12 +673,14 @@ struct C1K {
     const float* x;      // image, [B][H][W] (one channel, f32)
     float* partial;      // [nsplit][ntaps][Ca]
     int B, H, W, ldp, cp_off, Ca, ntaps, nsplit, dy_min, dy_max, dx_min, dx_max;
+    // DUAL: P = ca * g + cb * y_raw + cc (the BatchNorm-backward correction, abc_wgrad_desc.p_dual), optionally written out
+    const void* p2; const float *ca, *cb, *cc; void* p_out; int ld_p2, cp2_off, ld_pout;
     int8_t ty[25], tx[25];
 };
 
 // NT = tap capacity (9: 3x3 stem of unet.py; 25: 5x5 stem of unet2.py:135), CPT = dY channels per thread (NT * CPT
 // accumulators live in registers)
-template <typename PT, int NT, int CPT>
+template <typename PT, int NT, int CPT, bool DUAL = false>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
     constexpr int NR = NT > 9 ? 5 : 4;
     __shared__ float sx[NR][512 + 8];    // the image rows a row of dY needs, W <= 512 columns, 4-column halo either side
@@ -695,6 +697,11 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < CPT; ++j) acc[t][j] = 0.f;
+    float ca[DUAL ? CPT : 1], cb[DUAL ? CPT : 1], cc[DUAL ? CPT : 1];
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { ca[j] = a.ca[a.cp_off + cg * CPT + j]; cb[j] = a.cb[a.cp_off + cg * CPT + j]; cc[j] = a.cc[a.cp_off + cg * CPT + j]; }
+    }
     for (int row = r0; row < r1; ++row) {
         const int b = row / a.H, y = row - b * a.H;
         __syncthreads();
@@ -708,6 +715,17 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
             float g[CPT];
             const PT* src = (const PT*)a.p + ((size_t)row * a.W + x0) * a.ldp + a.cp_off + cg * CPT;
             LoadVec<PT, CPT>::ld(src, g);
+            if constexpr (DUAL) {
+                float yv[CPT];
+                LoadVec<PT, CPT>::ld((const PT*)a.p2 + ((size_t)row * a.W + x0) * a.ld_p2 + a.cp2_off + cg * CPT, yv);
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) g[j] = fmaf(ca[j], g[j], fmaf(cb[j], yv[j], cc[j]));
+                if (a.p_out != nullptr) {
+                    PT* dst = (PT*)a.p_out + ((size_t)row * a.W + x0) * a.ld_pout + cg * CPT;
+                    if constexpr (sizeof(PT) == 2 && CPT == 8) *(bf16x8*)dst = pack_frag<bf16>(g);
+                    else { for (int j = 0; j < CPT; ++j) dst[j] = (PT)g[j]; }
+                }
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (t < a.ntaps) {
@@ -744,7 +762,9 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
 static bool c1_ok(const abc_wgrad_desc* d) {
     if (getenv("ABC_WGRAD_NOC1")) return false;
     if (d->Cb != 1 || d->cq_off != 0 || d->q.ldx != 1 || d->dtype_q != ABC_F32 || d->q.scale || d->q.pool || d->q.planar || d->q.drop_p > 0.f) return false;
-    if (d->p.scale || d->p.pool || d->p.planar || d->p.drop_p > 0.f || d->stride != 1 || d->ntaps > 25) return false;
+    // (a transform on P only as the BatchNorm-backward correction of abc_wgrad_desc.p_dual: bf16, the 3x3 form)
+    if (d->p.scale && !(d->p_dual && d->dtype_p == ABC_BF16 && d->ntaps <= 9 && d->p2 != nullptr && (d->ld_p2 % 8) == 0 && (d->cp2_off % 8) == 0)) return false;
+    if (d->p.pool || d->p.planar || d->p.drop_p > 0.f || d->stride != 1 || d->ntaps > 25) return false;
     if (d->Ca % 8 || d->Ca > 64 || (d->Ca & (d->Ca - 1)) || d->Wg > 512 || (d->p.ldx % 8) || (d->cp_off % 8)) return false;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
     for (int t = 0; t < d->ntaps; ++t) {
@@ -762,6 +782,12 @@ static int c1_launch(const abc_wgrad_desc* d, hipStream_t st) {
     for (int t = 0; t < d->ntaps; ++t) { dymin = d->tap_dy[t] < dymin ? d->tap_dy[t] : dymin; dymax = d->tap_dy[t] > dymax ? d->tap_dy[t] : dymax; }
     k.dy_min = dymin; k.dy_max = dymax; k.dx_min = 0; k.dx_max = 0;
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - dymin); k.tx[t] = (int8_t)d->tap_dx[t]; }
+    k.p2 = d->p2; k.ld_p2 = d->ld_p2; k.cp2_off = d->cp2_off; k.p_out = d->p_out; k.ld_pout = d->ld_pout;
+    k.ca = d->p.scale; k.cc = d->p.shift; k.cb = d->p.slope;     // (abc_act_src of a deferred BatchNorm backward: scale = ca, shift = cc, slope = cb)
+    if (d->p_dual && d->p.scale) {
+        hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 9, 8, true>), dim3(d->nsplit), dim3(256), 0, st, k);
+        return abc_check_launch("wgrad_c1");
+    }
     if (d->ntaps > 9) {
         if (d->dtype_p == ABC_BF16) hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 25, 4>), dim3(d->nsplit), dim3(256), 0, st, k);
         else hipLaunchKernelGGL((wgrad_c1_kernel<float, 25, 4>), dim3(d->nsplit), dim3(256), 0, st, k);
@@ -1149,7 +1175,8 @@ extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t
 }
 
 extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {
-    if (head_ok(d) || c1_ok(d)) return 0;
+    if (head_ok(d)) return 0;
+    if (c1_ok(d)) return (d->p_dual && d->p.scale) ? 1 : 0;     // the one-channel kernel applies the correction on load too
     WGeom g;
     if (wgeom(d, &g)) return 0;
     return dual_ok(d, g) ? 1 : 0;
