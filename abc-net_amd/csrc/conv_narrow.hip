@@ -32,33 +32,35 @@ struct NarrowK {
     int tiles_x, tiles_y, ntiles, tpw;         // tiles per wave (contiguous runs)
     int out_act; float out_slope;
     unsigned bytesX;
-    int8_t ty[9], tx[9];                       // tap offsets + 1 (0 .. 2)
+    int8_t ty[25], tx[25];                     // tap offsets + R (0 .. 2 R)
 };
 
 // XF: transform on load; NST: 0 = no statistics, 1 / 2 = BatchNorm partial sums for Cout <= 16 / <= 32 (per-lane running sums
 // over all tiles of the wave, reduced once at the end)
-template <int CK, bool XF, int NST>
-__global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
+// R: tap radius (1: 3x3, nine taps; 2: 5x5, 25 taps -- unet2.py's 32-channel levels: weights in LDS, one workgroup per CU)
+template <int CK, bool XF, int NST, int R = 1>
+__global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const NarrowK a) {
+    constexpr int NTAP = (2 * R + 1) * (2 * R + 1), HR = 8 + 2 * R, HC = 16 + 2 * R;
     constexpr int CKB = CK * 2;                // bytes of a pixel's channels
     constexpr int PS = CKB + 16;               // padded pixel stride: 16 consecutive pixels = 16 distinct 16-byte bank slots
-    constexpr int RS = 18 * PS;
+    constexpr int RS = HC * PS;
     constexpr int SEGS = CKB / 16;             // 16-byte segments per pixel
-    constexpr int NSEG = 10 * 18 * SEGS;       // of the halo
+    constexpr int NSEG = HR * HC * SEGS;       // of the halo
     constexpr int NL = (NSEG + 63) / 64;       // loads per lane
     constexpr int KS = CK / 16;                // K-steps per tap
     constexpr int LHB = CKB / 2;               // a lane half's bytes of a pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    char* halo = smem + wave * (10 * RS);
+    char* halo = smem + wave * (HR * RS);
 
     // ---- weights: A fragments, row = output channel with bits 2 and 3 of the lane swapped (see above).  16 input channels:
     // 36 registers for the whole kernel; 32: 72 would not leave room for the prefetch -- they sit in LDS in fragment order
     // ([tap][K-step][lane] x 16 bytes: one conflict-free ds_read_b128 per four MFMAs)
     const int rw = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
-    constexpr bool WREG = CK == 16;
+    constexpr bool WREG = CK == 16 && R == 1;
     bf16x8 wf[WREG ? 9 : 1][WREG ? KS : 1];
-    char* swt = smem + 4 * 10 * RS + 128;
+    char* swt = smem + 4 * HR * RS + 128;
     if constexpr (WREG) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -66,11 +68,11 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
             for (int ks = 0; ks < KS; ++ks)
                 wf[t][ks] = *(const bf16x8*)(a.w + ((size_t)(t * 32 + rw) * CK + h * (LHB / 2) + 8 * ks));
     } else {
-        for (int s2 = wave; s2 < 9 * KS; s2 += 4)
+        for (int s2 = wave; s2 < NTAP * KS; s2 += 4)
             *(bf16x8*)(swt + (s2 * 64 + lane) * 16) = *(const bf16x8*)(a.w + ((size_t)((s2 / KS) * 32 + rw) * CK + h * (LHB / 2) + 8 * (s2 % KS)));
     }
     // bias -> LDS (read back per tile as the accumulators' initial value: register k <-> channel (k & 7) + 8 h + 16 (k >> 3))
-    float* sbias = (float*)(smem + 4 * 10 * RS);
+    float* sbias = (float*)(smem + 4 * HR * RS);
     if (threadIdx.x < 32) sbias[threadIdx.x] = (a.bias != nullptr && (int)threadIdx.x < a.Cout) ? a.bias[threadIdx.x] : 0.f;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX);
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
     for (int k = 0; k < (NST ? 8 * NST : 1); ++k) { st1[k] = 0.f; st2[k] = 0.f; }
     auto seg_rc = [&](int i, int& hr, int& hc) {
         const int pix = p0 + (64 / SEGS) * i;
-        hr = (pix * 3641) >> 16;          // pix / 18 for pix < 1024
-        hc = pix - 18 * hr;
+        hr = (pix * (R == 1 ? 3641 : 3277)) >> 16;          // pix / HC (18 or 20) for pix < 1024
+        hc = pix - HC * hr;
     };
     const int wid = blockIdx.x * 4 + wave;
     const int t0 = wid * a.tpw, t1 = min(t0 + a.tpw, a.ntiles);
@@ -101,14 +103,14 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
         const int tx_i = id % a.tiles_x; id /= a.tiles_x;
         const int ty_i = id % a.tiles_y;
         const int b = id / a.tiles_y;
-        const int iy0 = ty_i * 8 - 1, ix0 = tx_i * 16 - 1;
+        const int iy0 = ty_i * 8 - R, ix0 = tx_i * 16 - R;
         const int tbase = (((b * a.H + iy0) * a.W + ix0) * a.ldx + a.cin_off) * 2 + sg16;   // (may point before the image: masked below)
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             int hr, hc;
             seg_rc(i, hr, hc);
             const int iy = iy0 + hr, ix = ix0 + hc;
-            const bool ok = tile < t1 && hr < 10 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const bool ok = tile < t1 && hr < HR && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (unsigned)(tbase + hr * wldx2 + hc * ldx2) : 0x80000000u, 0, 0);   // (out of range: zeros = the padding)
         }
     };
@@ -124,16 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
                 int id2 = tile;
                 const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
                 const int ty2 = id2 % a.tiles_y;
-                const int iy = ty2 * 8 - 1 + hr, ix = tx2 * 16 - 1 + hc;
+                const int iy = ty2 * 8 - R + hr, ix = tx2 * 16 - R + hc;
                 const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(pre[i][j] << 16); v[2 * j + 1] = __uint_as_float(pre[i][j] & 0xFFFF0000u); }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = in ? abc_act(v[j], csc[j], csh[j], csl[j]) : 0.f;
-                if (hr < 10) *(bf16x8*)(halo + hr * RS + hc * PS + sg16) = pack_frag<bf16>(v);
+                if (hr < HR) *(bf16x8*)(halo + hr * RS + hc * PS + sg16) = pack_frag<bf16>(v);
             } else {
-                if (hr < 10) *(u32x4*)(halo + hr * RS + hc * PS + sg16) = pre[i];
+                if (hr < HR) *(u32x4*)(halo + hr * RS + hc * PS + sg16) = pre[i];
             }
         }
         issue(tile + 1);
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
         const char* base = halo + (r >> 4) * RS + (r & 15) * PS + h * LHB;
         // K-steps (tap, 16-channel slice) software-pipelined by one: the four fragment reads of step s + 1 are issued in front
         // of the four MFMAs of step s (two named register sets; without the fences the scheduler hoists all 36-72 reads and spills)
-        constexpr int NS = 9 * KS;
+        constexpr int NS = NTAP * KS;
         auto frag_off = [&](int s2) { const int t = s2 / KS, ks = s2 % KS; return a.ty[t] * RS + a.tx[t] * PS + 16 * ks; };
         bf16x8 pa[4], pb[4], wa, wb;
         auto wfrag = [&](int s2) -> bf16x8 {
@@ -245,29 +247,32 @@ __global__ __launch_bounds__(256, 2) void conv_narrow_kernel(const NarrowK a) {
 // geometry shared by the eligibility test, abc_conv_stat_blocks and the launch
 static void narrow_grid(const abc_conv_desc* d, int* nwg, int* tpw) {
     const int ntiles = abc_cdiv(d->Win, 16) * abc_cdiv(d->Hin, 8) * d->B;
-    int n = 256 * 2;
+    int n = 256 * (d->ntaps == 9 ? 2 : 1);      // workgroups per CU: two (3x3), one (5x5: 128 KB of LDS)
     if (n * 4 > ntiles) n = abc_cdiv(ntiles, 4);
     *tpw = abc_cdiv(ntiles, n * 4);
     *nwg = abc_cdiv(ntiles, *tpw * 4);
 }
 
-// bf16 NHWC in and out, 16 / 32 input channels, <= 32 output channels, nine taps within +-1, unit strides; optionally the
-// producer's BatchNorm + activation on load and BatchNorm partial sums of the outputs (2 rows).  (32 input channels with BOTH
-// the transform and the sums does not fit the registers: that one stays on conv_fast.)
+// bf16 NHWC in and out, 16 / 32 input channels, <= 32 output channels, unit strides, the nine taps of a 3x3 (or, 32 input
+// channels, the 25 of a 5x5 over a finished tensor); optionally the producer's BatchNorm + activation on load (3x3) and
+// BatchNorm partial sums of the outputs (2 rows).  (32 input channels with BOTH the transform and the sums does not fit the
+// registers: that one stays on conv_fast.)
 int abc_conv_narrow_ok(const abc_conv_desc* d) {
     if (getenv("ABC_CONV_NONARROW")) return 0;
     if (d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16) return 0;
     if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->planar_out) return 0;
     if (d->accumulate || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
-    if ((d->Cin != 16 && d->Cin != 32) || d->Cout_pad != 32 || d->Cout % 8 || d->ntaps != 9) return 0;
+    if ((d->Cin != 16 && d->Cin != 32) || d->Cout_pad != 32 || d->Cout % 8 || (d->ntaps != 9 && d->ntaps != 25)) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || d->src.Hx != d->Hin || d->src.Wx != d->Win) return 0;
     if ((d->src.ldx | d->cin_off | d->ldy | d->cout_off) % 8) return 0;
     // (must not depend on the statistics POINTER: abc_conv_stat_blocks is asked before that buffer exists)
     if (d->stats_rows == 4) return 0;                                   // unet2's CBAM rows: per image, per tile
     if (d->src.scale != nullptr && d->Cin == 32) return 0;             // transform + sums + 72 weight registers do not fit
     if (d->src.scale != nullptr && getenv("ABC_CONV_NONARROW_XF")) return 0;
-    for (int t = 0; t < 9; ++t)
-        if (d->tap_dy[t] < -1 || d->tap_dy[t] > 1 || d->tap_dx[t] < -1 || d->tap_dx[t] > 1) return 0;
+    const int R = d->ntaps == 9 ? 1 : 2;
+    if (R == 2 && (d->Cin != 32 || d->src.scale != nullptr || getenv("ABC_CONV_NONARROW5"))) return 0;
+    for (int t = 0; t < d->ntaps; ++t)
+        if (d->tap_dy[t] < -R || d->tap_dy[t] > R || d->tap_dx[t] < -R || d->tap_dx[t] > R) return 0;
     return (int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2 < (int64_t(1) << 31);
 }
 
@@ -275,6 +280,17 @@ int abc_conv_narrow_stat_blocks(const abc_conv_desc* d) {
     int nwg, tpw;
     narrow_grid(d, &nwg, &tpw);
     return nwg;
+}
+
+template <int CK, bool XF, int NST, int R>
+static int narrow_launch_inst(const NarrowK& k, int nwg, int lds, hipStream_t st) {
+    auto fn = conv_narrow_kernel<CK, XF, NST, R>;
+    if (lds > 64 * 1024) {
+        static unsigned long long lds_ok = 0;
+        if (int rc = abc_allow_lds((const void*)fn, lds, &lds_ok)) return rc;
+    }
+    hipLaunchKernelGGL(fn, dim3(nwg), dim3(256), lds, st, k);
+    return abc_check_launch("conv_narrow");
 }
 
 int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
@@ -285,26 +301,29 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
     k.tiles_x = abc_cdiv(k.W, 16); k.tiles_y = abc_cdiv(k.H, 8); k.ntiles = k.tiles_x * k.tiles_y * k.B;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
     k.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
-    for (int t = 0; t < 9; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] + 1); k.tx[t] = (int8_t)(d->tap_dx[t] + 1); }
+    const int R = d->ntaps == 9 ? 1 : 2;
+    for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] + R); k.tx[t] = (int8_t)(d->tap_dx[t] + R); }
     int nwg;
     narrow_grid(d, &nwg, &k.tpw);
-    const int lds = 4 * 10 * 18 * (d->Cin * 2 + 16) + 128 + (d->Cin == 32 ? 18 * 1024 : 0);
+    const int wlds = (d->Cin == 32 || R == 2) ? d->ntaps * (d->Cin / 16) * 1024 : 0;
+    const int lds = 4 * (8 + 2 * R) * (16 + 2 * R) * (d->Cin * 2 + 16) + 128 + wlds;
     hipStream_t st = (hipStream_t)stream;
     const bool xf = d->src.scale != nullptr;
     const int nst = d->stats != nullptr ? (d->Cout <= 16 ? 1 : 2) : 0;
-#define NARROW_LAUNCH(CK, XF, NST) hipLaunchKernelGGL((conv_narrow_kernel<CK, XF, NST>), dim3(nwg), dim3(256), lds, st, k)
-    if (d->Cin == 16) {
-        if (!xf && nst == 0) NARROW_LAUNCH(16, false, 0);
-        else if (!xf && nst == 1) NARROW_LAUNCH(16, false, 1);
-        else if (!xf && nst == 2) NARROW_LAUNCH(16, false, 2);
-        else if (xf && nst == 0) NARROW_LAUNCH(16, true, 0);
-        else if (xf && nst == 1) NARROW_LAUNCH(16, true, 1);
-        else NARROW_LAUNCH(16, true, 2);
-    } else {
-        if (nst == 0) NARROW_LAUNCH(32, false, 0);
-        else if (nst == 1) NARROW_LAUNCH(32, false, 1);
-        else NARROW_LAUNCH(32, false, 2);
+    if (R == 2) {
+        if (nst == 0) return narrow_launch_inst<32, false, 0, 2>(k, nwg, lds, st);
+        if (nst == 1) return narrow_launch_inst<32, false, 1, 2>(k, nwg, lds, st);
+        return narrow_launch_inst<32, false, 2, 2>(k, nwg, lds, st);
     }
-#undef NARROW_LAUNCH
-    return abc_check_launch("conv_narrow");
+    if (d->Cin == 16) {
+        if (!xf && nst == 0) return narrow_launch_inst<16, false, 0, 1>(k, nwg, lds, st);
+        if (!xf && nst == 1) return narrow_launch_inst<16, false, 1, 1>(k, nwg, lds, st);
+        if (!xf && nst == 2) return narrow_launch_inst<16, false, 2, 1>(k, nwg, lds, st);
+        if (nst == 0) return narrow_launch_inst<16, true, 0, 1>(k, nwg, lds, st);
+        if (nst == 1) return narrow_launch_inst<16, true, 1, 1>(k, nwg, lds, st);
+        return narrow_launch_inst<16, true, 2, 1>(k, nwg, lds, st);
+    }
+    if (nst == 0) return narrow_launch_inst<32, false, 0, 1>(k, nwg, lds, st);
+    if (nst == 1) return narrow_launch_inst<32, false, 1, 1>(k, nwg, lds, st);
+    return narrow_launch_inst<32, false, 2, 1>(k, nwg, lds, st);
 }

@@ -104,6 +104,10 @@ def test_conv_forward(lib, dt, case):
     dict(Cin=16, Cout=16, H=200, W=136, coef=True, stats=True),   # ragged tiles, several tiles per wave
     dict(Cin=16, Cout=32, H=48, W=64, stats=True),                # a pooled (finished) input into a wider layer
     dict(Cin=32, Cout=16, H=40, W=48, stats=True),
+    # unet2's 5x5 32 -> 32 levels (unet2.py:49-74): data gradient (mirrored taps), block-first conv (sums), inference
+    dict(Cin=32, Cout=32, H=40, W=48, k=5, mirror=True),
+    dict(Cin=32, Cout=32, H=72, W=104, k=5, stats=True),
+    dict(Cin=32, Cout=32, H=128, W=192, k=5, slope=0.0),
 ])
 def test_conv_narrow_plain_input(lib, case):
     """3x3 over a FINISHED bf16 tensor with 16 / 32 channels (the folded inference graph's narrow levels, unet.py:12,15 in eval
@@ -111,7 +115,7 @@ def test_conv_narrow_plain_input(lib, case):
     straight from transposed accumulators -- against F.conv2d of the same bf16 operands"""
     dt = L.BF16
     g = torch.Generator().manual_seed(5)
-    B, Cin, Cout, H, W = 2, case["Cin"], case["Cout"], case["H"], case["W"]
+    B, Cin, Cout, H, W, k = 2, case["Cin"], case["Cout"], case["H"], case["W"], case.get("k", 3)
     ld, coff = case.get("ld", Cin), case.get("coff", 0)
     ldy, ycoff = case.get("ldy", Cout), case.get("ycoff", 0)
     xfull = q(torch.randn((B, ld, H, W), generator=g), dt)
@@ -123,16 +127,16 @@ def test_conv_narrow_plain_input(lib, case):
         sl = torch.tensor([0.0, 0.01, 1.0])[torch.randint(0, 3, (ld,), generator=g)]
         coef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
         x = q(act(x, sc[coff:coff + Cin], sh[coff:coff + Cin], sl[coff:coff + Cin]), dt)
-    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
     bias = None if case.get("mirror") else torch.randn(Cout, generator=g)
-    taps = taps_mirror(taps_square(3)) if case.get("mirror") else taps_square(3)
+    taps = taps_mirror(taps_square(k)) if case.get("mirror") else taps_square(k)
     wref = q(w, dt).flip(2, 3) if case.get("mirror") else q(w, dt)
-    ref = F.conv2d(x, wref, bias, padding=1)
+    ref = F.conv2d(x, wref, bias, padding=k // 2)
     slope = case.get("slope")
     if slope is not None:
         ref = torch.maximum(ref, slope * ref)
     xd = xfull.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(U.DEV)
-    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, 3, 32, Cin)
+    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, k, 32, Cin)
     out = torch.full((B, H, W, ldy), 7.0, dtype=torch.bfloat16, device=U.DEV)
     y, st = U.conv(lib, xd, dt, dt, B, H, W, ld, coff, Cin, wp, None if bias is None else bias.to(U.DEV), Cout, taps, H, W, ldy=ldy,
                    cout_off=ycoff, out=out, out_slope=slope, coef=coef, stats=bool(case.get("stats")))
