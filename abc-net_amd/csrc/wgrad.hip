@@ -723,6 +723,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
                 if (a.p_out != nullptr) {
                     PT* dst = (PT*)a.p_out + ((size_t)row * a.W + x0) * a.ld_pout + cg * CPT;
                     if constexpr (sizeof(PT) == 2 && CPT == 8) *(bf16x8*)dst = pack_frag<bf16>(g);
+                    else if constexpr (sizeof(PT) == 2 && CPT == 4) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16)g[j]; *(bf16x4*)dst = o; }
                     else { for (int j = 0; j < CPT; ++j) dst[j] = (PT)g[j]; }
                 }
             }
@@ -762,8 +763,8 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
 static bool c1_ok(const abc_wgrad_desc* d) {
     if (getenv("ABC_WGRAD_NOC1")) return false;
     if (d->Cb != 1 || d->cq_off != 0 || d->q.ldx != 1 || d->dtype_q != ABC_F32 || d->q.scale || d->q.pool || d->q.planar || d->q.drop_p > 0.f) return false;
-    // (a transform on P only as the BatchNorm-backward correction of abc_wgrad_desc.p_dual: bf16, the 3x3 form)
-    if (d->p.scale && !(d->p_dual && d->dtype_p == ABC_BF16 && d->ntaps <= 9 && d->p2 != nullptr && (d->ld_p2 % 8) == 0 && (d->cp2_off % 8) == 0)) return false;
+    // (a transform on P only as the BatchNorm-backward correction of abc_wgrad_desc.p_dual: bf16)
+    if (d->p.scale && !(d->p_dual && d->dtype_p == ABC_BF16 && d->p2 != nullptr && (d->ld_p2 % 8) == 0 && (d->cp2_off % 8) == 0)) return false;
     if (d->p.pool || d->p.planar || d->p.drop_p > 0.f || d->stride != 1 || d->ntaps > 25) return false;
     if (d->Ca % 8 || d->Ca > 64 || (d->Ca & (d->Ca - 1)) || d->Wg > 512 || (d->p.ldx % 8) || (d->cp_off % 8)) return false;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
@@ -785,7 +786,8 @@ static int c1_launch(const abc_wgrad_desc* d, hipStream_t st) {
     k.p2 = d->p2; k.ld_p2 = d->ld_p2; k.cp2_off = d->cp2_off; k.p_out = d->p_out; k.ld_pout = d->ld_pout;
     k.ca = d->p.scale; k.cc = d->p.shift; k.cb = d->p.slope;     // (abc_act_src of a deferred BatchNorm backward: scale = ca, shift = cc, slope = cb)
     if (d->p_dual && d->p.scale) {
-        hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 9, 8, true>), dim3(d->nsplit), dim3(256), 0, st, k);
+        if (d->ntaps > 9) hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 25, 4, true>), dim3(d->nsplit), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 9, 8, true>), dim3(d->nsplit), dim3(256), 0, st, k);
         return abc_check_launch("wgrad_c1");
     }
     if (d->ntaps > 9) {
