@@ -70,7 +70,7 @@ __device__ inline void stage_slow(char* dst, int RS, int PS, int HH, int HW, int
 template <typename PT, typename QT, typename CT, int AT, int BT, int STRIDE, bool FAST, int PM, bool K3, bool DUAL = false, bool TS = false, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
     constexpr int WTHR = NW * 64;
-    static_assert(!TS || (AT == 1 && BT == 1 && FAST && !K3 && !DUAL && sizeof(CT) == 2), "tap split: one bf16 tile pair on the prefetch path");
+    static_assert(!TS || (AT == 1 && BT == 1 && FAST && !K3 && sizeof(CT) == 2), "tap split: one bf16 tile pair on the prefetch path");
     constexpr int MAXT = TS ? 4 : (FAST ? MAXT_FAST : MAXT_SLOW);
     constexpr int RSPLIT = TS ? 1 : NW / (AT * BT);   // waves sharing one tile pair, splitting the patch rows
     constexpr int PROWS = 8 * PM;           // patch rows (x 16 columns)
@@ -912,12 +912,16 @@ static int wgeom_pm(const abc_wgrad_desc* d, WGeom* g, int pm) {
 
 // BN-backward correction on load of P: prefetch path for both operands, bf16 everywhere, full 3x3 square, stride 1
 static bool dual_ok(const abc_wgrad_desc* d, const WGeom& g) {
-    if (!(g.fast_p && g.fast_q) || d->stride != 1 || d->ntaps != 9 || g.ngroups != 1 || g.HW != 18) return false;
     if (d->dtype_p != ABC_BF16 || d->dtype_q != ABC_BF16 || d->dtype_c != ABC_BF16) return false;
     if (d->p.scale == nullptr || d->p2 == nullptr || (d->ld_p2 % 8) || (d->cp2_off % 8) || (d->p_out && (d->ld_pout % 8))) return false;
+    if ((int64_t)d->B * d->Hg * d->Wg * d->ld_p2 * 2 >= (int64_t(1) << 31)) return false;
+    // (the correction is applied where P is committed to LDS: independent of the taps, so the tap-split form of the 5x5
+    //  layers takes it as well as the static 3x3 K-step)
+    if (g.ts) return g.fast_p && g.fast_q && d->stride == 1;
+    if (!(g.fast_p && g.fast_q) || d->stride != 1 || d->ntaps != 9 || g.ngroups != 1 || g.HW != 18) return false;
     for (int t = 0; t < 9; ++t)
         if (d->tap_dy[t] - g.dy_min != t / 3 || d->tap_dx[t] - g.dx_min != t % 3) return false;
-    return (int64_t)d->B * d->Hg * d->Wg * d->ld_p2 * 2 < (int64_t(1) << 31);
+    return true;
 }
 
 static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
@@ -960,7 +964,7 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     // more than 9 taps on one tile pair (5x5): split the taps over the waves, one pass over the operands
     static const bool nots = getenv("ABC_WGRAD_NOTS") != nullptr;  // (experiment switch)
     if (!nots && g->AT == 1 && g->BT == 1 && d->stride == 1 && csz == 2 && d->ntaps > MAXT_FAST && d->ntaps <= 32 &&
-        d->dtype_p == ABC_BF16 && d->dtype_q == ABC_BF16 && d->p2 == nullptr) {
+        d->dtype_p == ABC_BF16 && d->dtype_q == ABC_BF16) {
         for (int pm = (d->Hg % 16 == 0) ? 2 : 1; pm >= 1; --pm) {
             int rc = wgeom_pm(d, g, pm);
             if (rc == ABC_OK && g->fast_p && g->fast_q) { g->ts = 1; g->ngroups = 1; g->tgw = d->ntaps; return ABC_OK; }
@@ -1012,6 +1016,10 @@ static int wdispatch(const WgK& k, const WGeom& g, int stride, int nsplit, hipSt
     if constexpr (sizeof(CT) == 2) {
         if (g.BT == 4) return wlaunch<PT, QT, CT, 1, 4, 1>(k, g, nsplit, st);
         if constexpr (sizeof(PT) == 2 && sizeof(QT) == 2) {
+            if (g.ts && k.p2 != nullptr) {
+                if (g.PM == 2) return wlaunch3<PT, QT, CT, 1, 1, 1, true, 2, false, true, true>(k, g, nsplit, st);
+                return wlaunch3<PT, QT, CT, 1, 1, 1, true, 1, false, true, true>(k, g, nsplit, st);
+            }
             if (g.ts && g.PM == 2) return wlaunch3<PT, QT, CT, 1, 1, 1, true, 2, false, false, true>(k, g, nsplit, st);
             if (g.ts) return wlaunch3<PT, QT, CT, 1, 1, 1, true, 1, false, false, true>(k, g, nsplit, st);
         }

@@ -296,13 +296,14 @@ def test_pool_act_materialised(lib, dt):
     assert U.relerr(U.to_nchw(out), q(ref, dt)) < (1e-6 if dt == L.F32 else 1e-2)
 
 
-@pytest.mark.parametrize("Cout,Cin", [(128, 128), (64, 32), (32, 64)])
-def test_wgrad_fused_bn_apply(lib, Cout, Cin):
+@pytest.mark.parametrize("Cout,Cin,k", [(128, 128, 3), (64, 32, 3), (32, 64, 3), (32, 32, 5)])
+def test_wgrad_fused_bn_apply(lib, Cout, Cin, k):
     """abc_wgrad with p_dual: P = ca*g + cb*y_raw + cc applied on load (the BatchNorm-backward correction), the corrected
     tensor written to p_out -- against the explicit formula followed by the plain weight gradient"""
     dt = L.BF16
     g_ = torch.Generator().manual_seed(51)
-    B, H, W, k, ldy, coff = 2, 24, 32, 3, Cout + 32, 16
+    # (k = 5: unet2's 32-channel 5x5 layers, the tap-split form of the kernel)
+    B, H, W, ldy, coff = 2, 32 if k == 5 else 24, 32, Cout + 32, 16
     gq = q(torch.randn((B, Cout, H, W), generator=g_), dt)
     yq = q(torch.randn((B, ldy, H, W), generator=g_), dt)
     ca, cb, cc = (torch.randn(Cout, generator=g_) * s_ for s_ in (1.0, 0.3, 0.05))
@@ -312,7 +313,7 @@ def test_wgrad_fused_bn_apply(lib, Cout, Cin):
     sl = torch.zeros(Cin)
     a = q(act(x, sc, sh, sl), dt)
     w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
-    F.conv2d(a, w, None, padding=1).backward(dy)
+    F.conv2d(a, w, None, padding=k // 2).backward(dy)
     gd, yd, xd = U.nhwc(gq, dt), U.nhwc(yq, dt), U.nhwc(x, dt)
     pcoef = tuple(t.to(U.DEV) for t in (ca, cc, cb))   # (scale, shift, slope) = (ca, cc, cb)
     qcoef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
@@ -327,12 +328,12 @@ def test_wgrad_fused_bn_apply(lib, Cout, Cin):
     assert lib.abc_wgrad_fuses_apply(C.byref(d)) == 1
     ca_, cb_ = L.i32(), L.i32()
     L.check(lib.abc_wgrad_pads(C.byref(d), C.byref(ca_), C.byref(cb_)), "pads")
-    part = torch.zeros(3 * 9 * ca_.value * cb_.value, dtype=torch.float32, device=U.DEV)
+    part = torch.zeros(3 * k * k * ca_.value * cb_.value, dtype=torch.float32, device=U.DEV)
     d.partial = part.data_ptr()
     L.check(lib.abc_wgrad(C.byref(d), U.stream()), "wgrad")
-    dw = torch.zeros((Cout, Cin, 9), dtype=torch.float32, device=U.DEV)
+    dw = torch.zeros((Cout, Cin, k * k), dtype=torch.float32, device=U.DEV)
     r = L.WgradReduceDesc()
-    r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), 3, 9, Cout, Cin, ca_.value, cb_.value, dw.data_ptr(), 0
+    r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), 3, k * k, Cout, Cin, ca_.value, cb_.value, dw.data_ptr(), 0
     L.check(lib.abc_wgrad_reduce(C.byref(r), U.stream()), "reduce")
     torch.cuda.synchronize()
     assert U.relerr(U.to_nchw(out), dy) < 1e-2           # bf16 rounding of the same f32 formula
