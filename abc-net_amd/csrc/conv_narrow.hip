@@ -27,6 +27,7 @@ namespace {
 struct NarrowK {
     const bf16* x; const bf16* w; const float* bias; bf16* y;
     const float *sc, *sh, *sl;                 // XF: previous layer's BatchNorm + activation applied on load (absolute channel index)
+    bf16* pool_y; int ld_pool;                 // optional: 2x2 max-pool of the stored tensor, [B][H/2][W/2][ld_pool]
     float* stats;                              // NST: [grid][2][Cout] sum, sum of squares of the f32 outputs (one row per workgroup)
     int B, H, W, ldx, cin_off, ldy, cout_off, Cout;
     int tiles_x, tiles_y, ntiles, tpw;         // tiles per wave (contiguous runs)
@@ -198,21 +199,32 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gy = ty_i * 8 + 2 * i + (r >> 4), gx = tx_i * 16 + (r & 15);
-            if (gy < a.H && gx < a.W) {
-                bf16* dst = a.y + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldy + a.cout_off + 8 * h;
+            const bool valid = gy < a.H && gx < a.W;
+            bf16* dst = a.y + ((size_t)(b * a.H + gy) * a.W + gx) * a.ldy + a.cout_off + 8 * h;
 #pragma unroll
-                for (int g8 = 0; g8 < 2; ++g8) {
-                    if (16 * g8 + 8 * h < a.Cout) {
-                        float vo[8];
+            for (int g8 = 0; g8 < 2; ++g8) {
+                if (16 * g8 < a.Cout) {        // (uniform: both lane halves run the shuffles below)
+                    float vo[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = acc[i][8 * g8 + q];
+                        if constexpr (NST > 0) {
+                            if (g8 < NST && valid) { st1[8 * (g8 < NST ? g8 : 0) + q] += v; st2[8 * (g8 < NST ? g8 : 0) + q] = fmaf(v, v, st2[8 * (g8 < NST ? g8 : 0) + q]); }
+                        }
+                        vo[q] = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                    }
+                    const bool chan = 16 * g8 + 8 * h < a.Cout;
+                    if (valid && chan) *(bf16x8*)(dst + 16 * g8) = pack_frag<bf16>(vo);
+                    if (a.pool_y != nullptr) {
+                        // the 2x2 window of this 32-pixel tile (rows 2 i, 2 i + 1): lanes r, r ^ 1, r ^ 16, r ^ 17
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
-                            const float v = acc[i][8 * g8 + q];
-                            if constexpr (NST > 0) {
-                                if (g8 < NST) { st1[8 * (g8 < NST ? g8 : 0) + q] += v; st2[8 * (g8 < NST ? g8 : 0) + q] = fmaf(v, v, st2[8 * (g8 < NST ? g8 : 0) + q]); }
-                            }
-                            vo[q] = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                            float m = fmaxf(vo[q], __shfl_xor(vo[q], 1));
+                            vo[q] = fmaxf(m, __shfl_xor(m, 16));
                         }
-                        *(bf16x8*)(dst + 16 * g8) = pack_frag<bf16>(vo);
+                        const int py = ty_i * 4 + i, px = tx_i * 8 + ((r & 15) >> 1);
+                        if ((r & 17) == 0 && chan && 2 * py + 1 < a.H && 2 * px + 1 < a.W)
+                            *(bf16x8*)(a.pool_y + ((size_t)(b * (a.H >> 1) + py) * (a.W >> 1) + px) * a.ld_pool + 16 * g8 + 8 * h) = pack_frag<bf16>(vo);
                     }
                 }
             }
@@ -296,7 +308,7 @@ static int narrow_launch_inst(const NarrowK& k, int nwg, int lds, hipStream_t st
 int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
     NarrowK k;
     k.x = (const bf16*)d->src.x; k.w = (const bf16*)d->w; k.bias = d->bias; k.y = (bf16*)d->y;
-    k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.stats = d->stats;
+    k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.stats = d->stats; k.pool_y = (bf16*)d->pool_y; k.ld_pool = d->ld_pool;
     k.B = d->B; k.H = d->Hin; k.W = d->Win; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.ldy = d->ldy; k.cout_off = d->cout_off; k.Cout = d->Cout;
     k.tiles_x = abc_cdiv(k.W, 16); k.tiles_y = abc_cdiv(k.H, 8); k.ntiles = k.tiles_x * k.tiles_y * k.B;
     k.out_act = d->out_act; k.out_slope = d->out_slope;

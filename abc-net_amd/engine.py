@@ -239,6 +239,7 @@ class Engine:
         d.planar_out, d.ctot_out = (1, Cout) if planar_out else (0, 0)
         d.stats_rows, d.accumulate = stats_rows, 1 if accumulate else 0
         L.set_taps(d, taps)
+        self._last_conv_desc = d
         nblk = self.lib.abc_conv_stat_blocks(C.byref(d))
         st = None
         if stats:
@@ -486,6 +487,7 @@ class Engine:
                            out_slope=slope)
         rec = Rec(kind="conv", cname=cname, bname=bname, src=src, cin=cin, cout=cout, k=k, taps=taps, y=yt, H=H, W=W, ld=ld,
                   coff=coff, coef=None, slope=slope)
+        rec.fold_desc = self._last_conv_desc if shared is None else None
         self.recs.append(rec)
         return rec, Src(yt, self.dt, H, W, ld, coff, cout, coef=None, producer=rec)
 
@@ -509,6 +511,15 @@ class Engine:
             return Src(s.t, s.dt, s.H, s.W, s.ld, s.coff, s.C, coef=s.coef, pool=True, producer=s.producer)
         Ho, Wo = s.H // 2, s.W // 2
         out = self.new((self.B, Ho, Wo, s.C))
+        # folded inference graph: a producer on the narrow-level kernel writes the pooled tensor as a second output
+        # (abc_conv_desc.pool_y) -- no separate pass over the full-resolution tensor
+        d = getattr(s.producer, "fold_desc", None) if self.fold else None
+        if d is not None and s.coef is None and s.C % 8 == 0 and not os.environ.get("ABC_NO_POOL_FUSE") \
+                and self.lib.abc_conv_variant(C.byref(d)) == 5 and d.y == s.t.data_ptr() and d.cout_off == s.coff and d.Cout == s.C:
+            d.pool_y, d.ld_pool = out.data_ptr(), s.C
+            r = Src(out, self.dt, Ho, Wo, s.C, 0, s.C, coef=None, pool=False, producer=s.producer)
+            r.via_pool = True
+            return r
         a = L.ActSrc()
         s.fill(a)
         lib = self.lib

@@ -92,6 +92,10 @@ typedef struct abc_conv_desc {
                             the weights / bias (eval mode: abc_pack_desc.row_scale, abc_bn_eval_fold) the output is the ACTIVATED
                             tensor and its consumers load it with the identity transform; the statistics stay those of v */
     float out_slope;     /* 0 = ReLU, 0.01 = LeakyReLU */
+    void* pool_y;        /* optional second output: nn.MaxPool2d(2) of the stored tensor (unet.py:30), NHWC [B][Hout/2][Wout/2][ld_pool],
+                            same dtype as y -- saves the separate abc_pool_act pass of the folded inference graph.  Only where
+                            abc_conv_variant() == 5 (the narrow-level kernel); abc_conv_fwd refuses it elsewhere */
+    int32_t ld_pool;
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */

@@ -108,6 +108,10 @@ def test_conv_forward(lib, dt, case):
     dict(Cin=32, Cout=32, H=40, W=48, k=5, mirror=True),
     dict(Cin=32, Cout=32, H=72, W=104, k=5, stats=True),
     dict(Cin=32, Cout=32, H=128, W=192, k=5, slope=0.0),
+    # second output: MaxPool2d(2) of the stored tensor (the folded inference graph's levels)
+    dict(Cin=16, Cout=16, H=64, W=96, slope=0.0, pool=True),
+    dict(Cin=32, Cout=32, H=40, W=48, slope=0.01, pool=True),
+    dict(Cin=16, Cout=32, H=22, W=42, slope=0.0, pool=True),      # ragged tiles and an odd pooled width (21)
 ])
 def test_conv_narrow_plain_input(lib, case):
     """3x3 over a FINISHED bf16 tensor with 16 / 32 channels (the folded inference graph's narrow levels, unet.py:12,15 in eval
@@ -138,12 +142,17 @@ def test_conv_narrow_plain_input(lib, case):
     xd = xfull.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(U.DEV)
     wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, k, 32, Cin)
     out = torch.full((B, H, W, ldy), 7.0, dtype=torch.bfloat16, device=U.DEV)
+    pooled = torch.full((B, H // 2, W // 2, Cout), 7.0, dtype=torch.bfloat16, device=U.DEV) if case.get("pool") else None
     y, st = U.conv(lib, xd, dt, dt, B, H, W, ld, coff, Cin, wp, None if bias is None else bias.to(U.DEV), Cout, taps, H, W, ldy=ldy,
-                   cout_off=ycoff, out=out, out_slope=slope, coef=coef, stats=bool(case.get("stats")))
+                   cout_off=ycoff, out=out, out_slope=slope, coef=coef, stats=bool(case.get("stats")), pool_out=pooled)
     torch.cuda.synchronize()
     assert U.conv.last_variant == 5, "not served by conv_narrow"
     got = y[..., ycoff:ycoff + Cout].float().permute(0, 3, 1, 2).cpu()
     assert U.relerr(got, ref) < 1.5e-2, U.relerr(got, ref)
+    if case.get("pool"):
+        # max-pool of the STORED (bf16) tensor: exact against the kernel's own full-resolution output
+        want = F.max_pool2d(got, 2)
+        assert torch.equal(pooled.float().permute(0, 3, 1, 2).cpu(), want)
     if case.get("stats"):
         ssum = st.double().sum(0).cpu()
         n = B * H * W
