@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("Hout", i32), ("Wout", i32), ("ldy", i32), ("cout_off", i32), ("Cout", i32), ("Cout_pad", i32),
                 ("stride", i32), ("om", i32), ("oy0", i32), ("ox0", i32), ("ntaps", i32),
                 ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("stats_rows", i32), ("accumulate", i32),
-                ("planar_out", i32), ("ctot_out", i32), ("out_act", i32), ("out_slope", f32), ("pool_y", vp), ("ld_pool", i32)]
+                ("planar_out", i32), ("ctot_out", i32), ("out_act", i32), ("out_slope", f32), ("pool_y", vp), ("ld_pool", i32),
+                ("stem_x", vp), ("stem_w", vp), ("stem_scale", vp), ("stem_bias", vp), ("stem_slope", f32)]
 
 
 class PackDesc(C.Structure):

@@ -27,6 +27,8 @@ namespace {
 struct NarrowK {
     const bf16* x; const bf16* w; const float* bias; bf16* y;
     const float *sc, *sh, *sl;                 // XF: previous layer's BatchNorm + activation applied on load (absolute channel index)
+    // STEM: the input tensor is never materialised -- it is relu-like(conv3x3(one-channel f32 image) * scale + bias), computed into the halo
+    const float *stem_x, *stem_w, *stem_scale, *stem_bias; float stem_slope;
     bf16* pool_y; int ld_pool;                 // optional: 2x2 max-pool of the stored tensor, [B][H/2][W/2][ld_pool]
     float* stats;                              // NST: [grid][2][Cout] sum, sum of squares of the f32 outputs (one row per workgroup)
     int B, H, W, ldx, cin_off, ldy, cout_off, Cout;
@@ -39,8 +41,12 @@ struct NarrowK {
 // XF: transform on load; NST: 0 = no statistics, 1 / 2 = BatchNorm partial sums for Cout <= 16 / <= 32 (per-lane running sums
 // over all tiles of the wave, reduced once at the end)
 // R: tap radius (1: 3x3, nine taps; 2: 5x5, 25 taps -- unet2.py's 32-channel levels: weights in LDS, one workgroup per CU)
-template <int CK, bool XF, int NST, int R = 1>
+// STEM (inference, 16 channels): the halo is not loaded but COMPUTED from the one-channel image -- the network's first
+// convolution + folded BatchNorm + ReLU (unet.py:12-14) fused in front of its second one: the 16-channel full-resolution
+// tensor between them (0.5 GB written + read at 512 x 512, batch 64) never exists
+template <int CK, bool XF, int NST, int R = 1, bool STEM = false>
 __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const NarrowK a) {
+    static_assert(!STEM || (CK == 16 && !XF && R == 1), "stem fusion: 16 channels, 3x3");
     constexpr int NTAP = (2 * R + 1) * (2 * R + 1), HR = 8 + 2 * R, HC = 16 + 2 * R;
     constexpr int CKB = CK * 2;                // bytes of a pixel's channels
     constexpr int PS = CKB + 16;               // padded pixel stride: 16 consecutive pixels = 16 distinct 16-byte bank slots
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     // 36 registers for the whole kernel; 32: 72 would not leave room for the prefetch -- they sit in LDS in fragment order
     // ([tap][K-step][lane] x 16 bytes: one conflict-free ds_read_b128 per four MFMAs)
     const int rw = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
-    constexpr bool WREG = CK == 16 && R == 1;
+    constexpr bool WREG = CK == 16 && R == 1 && !STEM;   // (STEM keeps the FIRST convolution's weights in registers instead)
     bf16x8 wf[WREG ? 9 : 1][WREG ? KS : 1];
     char* swt = smem + 4 * HR * RS + 128;
     if constexpr (WREG) {
@@ -75,8 +81,23 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     // bias -> LDS (read back per tile as the accumulators' initial value: register k <-> channel (k & 7) + 8 h + 16 (k >> 3))
     float* sbias = (float*)(smem + 4 * HR * RS);
     if (threadIdx.x < 32) sbias[threadIdx.x] = (a.bias != nullptr && (int)threadIdx.x < a.Cout) ? a.bias[threadIdx.x] : 0.f;
+    // STEM: folded first-layer weights [tap][16 channels] + bias [16] (f32), and a 12 x 20 image patch per wave
+    float* stw = (float*)(smem + 4 * HR * RS + 128 + (WREG ? 0 : NTAP * KS * 1024));
+    float* simg = stw + 160 + wave * 240;
+    if constexpr (STEM) {
+        if (threadIdx.x < 144) { const int t = threadIdx.x / 16, ch = threadIdx.x % 16; stw[t * 16 + ch] = a.stem_w[ch * 9 + t] * a.stem_scale[ch]; }
+        else if (threadIdx.x < 160) stw[threadIdx.x] = a.stem_bias[threadIdx.x - 144];
+    }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX);
+    // STEM: the first convolution's folded weights of this lane's 8 channels (a lane always stages the same channel group) and
+    // their bias, in registers: 80 VGPRs that turn the halo computation into 9 LDS reads + 72 FMAs per pixel segment
+    float sw[STEM ? 10 : 1][8];
+    if constexpr (STEM) {
+        const int c0 = ((lane % SEGS) * 16) >> 1;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) LoadVec<float, 8>::ld(stw + t * 16 + c0, sw[t]);
+    }
 
     // segment i of this lane = 16-byte part sg of halo pixel p0 + (64 / SEGS) i (the same for every tile); row / column by a
     // multiply (pixel < 192), recomputed where needed: as stored arrays they cost 18-36 registers the kernel does not have
@@ -98,8 +119,25 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     const int wid = blockIdx.x * 4 + wave;
     const int t0 = wid * a.tpw, t1 = min(t0 + a.tpw, a.ntiles);
     const int wldx2 = a.W * a.ldx * 2, ldx2 = a.ldx * 2;
-    u32x4 pre[NL];
+    u32x4 pre[STEM ? 1 : NL];
+    float pimg[STEM ? 4 : 1];
     auto issue = [&](int tile) {
+        if constexpr (STEM) {
+            // the 12 x 20 patch of the image under the halo (one pixel wider on every side), 240 values over 64 lanes
+            int id = tile;
+            const int tx_i = id % a.tiles_x; id /= a.tiles_x;
+            const int ty_i = id % a.tiles_y;
+            const int b = id / a.tiles_y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = lane + 64 * j;
+                const int pr = (v * 3277) >> 16, pc = v - 20 * pr;
+                const int iy = ty_i * 8 - 2 + pr, ix = tx_i * 16 - 2 + pc;
+                const bool ok = tile < t1 && v < 240 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                pimg[j] = ok ? a.stem_x[((size_t)b * a.H + iy) * a.W + ix] : 0.f;
+            }
+            return;
+        }
         int id = tile;
         const int tx_i = id % a.tiles_x; id /= a.tiles_x;
         const int ty_i = id % a.tiles_y;
@@ -117,9 +155,42 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     };
     if (t0 < t1) issue(t0);
     for (int tile = t0; tile < t1; ++tile) {
+        if constexpr (STEM) {
+            int id2 = tile;
+            const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
+            const int ty2 = id2 % a.tiles_y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane + 64 * j < 240) simg[lane + 64 * j] = pimg[j];
+            issue(tile + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // halo pixel (hr, hc), channels 8 sg .. 8 sg + 7 = first convolution at image position (iy, ix); zero outside the
+            // image (the SECOND convolution's padding)
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                int hr, hc;
+                seg_rc(i, hr, hc);
+                if (hr < HR) {
+                    const int iy = ty2 * 8 - 1 + hr, ix = tx2 * 16 - 1 + hc;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = sw[9][j];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float xv = simg[(hr + t / 3) * 20 + hc + t % 3];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaf(xv, sw[t][j], v[j]);
+                    }
+                    const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = in ? fmaxf(v[j], a.stem_slope * v[j]) : 0.f;
+                    *(bf16x8*)(halo + hr * RS + hc * PS + sg16) = pack_frag<bf16>(v);
+                }
+            }
+        }
         // ---- this tile's halo: registers -> LDS (the wave's previous reads are ahead of these writes in its LDS queue)
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
+        for (int i = 0; i < (STEM ? 0 : NL); ++i) {
             int hr, hc;
             seg_rc(i, hr, hc);
             if constexpr (XF) {
@@ -139,7 +210,7 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
                 if (hr < HR) *(u32x4*)(halo + hr * RS + hc * PS + sg16) = pre[i];
             }
         }
-        issue(tile + 1);
+        if constexpr (!STEM) issue(tile + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         int id = tile;
         const int tx_i = id % a.tiles_x; id /= a.tiles_x;
@@ -281,6 +352,7 @@ int abc_conv_narrow_ok(const abc_conv_desc* d) {
     if (d->stats_rows == 4) return 0;                                   // unet2's CBAM rows: per image, per tile
     if (d->src.scale != nullptr && d->Cin == 32) return 0;             // transform + sums + 72 weight registers do not fit
     if (d->src.scale != nullptr && getenv("ABC_CONV_NONARROW_XF")) return 0;
+    if (d->stem_x != nullptr && (d->Cin != 16 || d->ntaps != 9 || d->src.scale != nullptr || d->stats != nullptr || !d->stem_w || !d->stem_scale || !d->stem_bias)) return 0;
     const int R = d->ntaps == 9 ? 1 : 2;
     if (R == 2 && (d->Cin != 32 || d->src.scale != nullptr || getenv("ABC_CONV_NONARROW5"))) return 0;
     for (int t = 0; t < d->ntaps; ++t)
@@ -294,9 +366,9 @@ int abc_conv_narrow_stat_blocks(const abc_conv_desc* d) {
     return nwg;
 }
 
-template <int CK, bool XF, int NST, int R>
+template <int CK, bool XF, int NST, int R, bool STEM = false>
 static int narrow_launch_inst(const NarrowK& k, int nwg, int lds, hipStream_t st) {
-    auto fn = conv_narrow_kernel<CK, XF, NST, R>;
+    auto fn = conv_narrow_kernel<CK, XF, NST, R, STEM>;
     if (lds > 64 * 1024) {
         static unsigned long long lds_ok = 0;
         if (int rc = abc_allow_lds((const void*)fn, lds, &lds_ok)) return rc;
@@ -309,6 +381,7 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
     NarrowK k;
     k.x = (const bf16*)d->src.x; k.w = (const bf16*)d->w; k.bias = d->bias; k.y = (bf16*)d->y;
     k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.stats = d->stats; k.pool_y = (bf16*)d->pool_y; k.ld_pool = d->ld_pool;
+    k.stem_x = d->stem_x; k.stem_w = d->stem_w; k.stem_scale = d->stem_scale; k.stem_bias = d->stem_bias; k.stem_slope = d->stem_slope;
     k.B = d->B; k.H = d->Hin; k.W = d->Win; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.ldy = d->ldy; k.cout_off = d->cout_off; k.Cout = d->Cout;
     k.tiles_x = abc_cdiv(k.W, 16); k.tiles_y = abc_cdiv(k.H, 8); k.ntiles = k.tiles_x * k.tiles_y * k.B;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
@@ -317,8 +390,8 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] + R); k.tx[t] = (int8_t)(d->tap_dx[t] + R); }
     int nwg;
     narrow_grid(d, &nwg, &k.tpw);
-    const int wlds = (d->Cin == 32 || R == 2) ? d->ntaps * (d->Cin / 16) * 1024 : 0;
-    const int lds = 4 * (8 + 2 * R) * (16 + 2 * R) * (d->Cin * 2 + 16) + 128 + wlds;
+    const int wlds = (d->Cin == 32 || R == 2 || d->stem_x != nullptr) ? d->ntaps * (d->Cin / 16) * 1024 : 0;
+    const int lds = 4 * (8 + 2 * R) * (16 + 2 * R) * (d->Cin * 2 + 16) + 128 + wlds + (d->stem_x ? (160 + 4 * 240) * 4 : 0);
     hipStream_t st = (hipStream_t)stream;
     const bool xf = d->src.scale != nullptr;
     const int nst = d->stats != nullptr ? (d->Cout <= 16 ? 1 : 2) : 0;
@@ -327,6 +400,7 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         if (nst == 1) return narrow_launch_inst<32, false, 1, 2>(k, nwg, lds, st);
         return narrow_launch_inst<32, false, 2, 2>(k, nwg, lds, st);
     }
+    if (d->stem_x != nullptr) return narrow_launch_inst<16, false, 0, 1, true>(k, nwg, lds, st);
     if (d->Cin == 16) {
         if (!xf && nst == 0) return narrow_launch_inst<16, false, 0, 1>(k, nwg, lds, st);
         if (!xf && nst == 1) return narrow_launch_inst<16, false, 1, 1>(k, nwg, lds, st);

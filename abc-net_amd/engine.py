@@ -502,6 +502,24 @@ class Engine:
         _, b = self.conv_bn(p + ".3", p + ".4", a, cout, k, dst_b, 0.0)
         return b
 
+    def _stem_fused_double_conv(self, prefix, img: Src, cout):
+        """folded inference graph, one input channel: DoubleConv's first convolution (+ BatchNorm + ReLU, unet.py:12-14) is
+        computed inside the halo staging of its second one (abc_conv_desc.stem_*): the full-resolution 16-channel tensor
+        between them is never written"""
+        H, W = img.H, img.W
+        p = prefix + ".double_conv"
+        fs0, fb0 = self.new((cout,), torch.float32, 1.0), self.new((cout,), torch.float32)
+        self._fold_coeffs(p + ".0", p + ".1", cout, fs0, fb0)
+        tb, cb = self.act_buf(H, W, cout)
+        virt = Src(self.img, self.dt, H, W, cout, 0, cout, coef=None)      # (never read: the kernel computes it from the image)
+        rec, b = self._conv_bn_folded(p + ".3", p + ".4", virt, cout, 3, (tb, cb, H, W, cout, 0), 0.0, None)
+        d = rec.fold_desc
+        d.stem_x, d.stem_w = self.img.data_ptr(), self.P(p + ".0.weight")
+        d.stem_scale, d.stem_bias, d.stem_slope = fs0.data_ptr(), fb0.data_ptr(), 0.0
+        if self.lib.abc_conv_variant(C.byref(d)) != 5:
+            raise RuntimeError("stem fusion: the narrow-level kernel refused the descriptor")
+        return b
+
     def pooled(self, s: Src):
         """nn.MaxPool2d(2) (unet.py:30, unet2.py:83): materialised once by abc_pool_act, so that the level's first conv, its
         weight gradient (and, in unet2, the block's residual branch) read a plain tensor on their prefetch paths; the
@@ -589,7 +607,10 @@ class Engine:
             lib, sp = self.lib, self.drop_salt.data_ptr()
             self.fwd_ops.append((lambda _r, st: lib.abc_counter_add_u32(sp, DROP_STEP, st), None, "dropout step", (),
                                  {"kernel": "counter_add", "flops": 0, "bytes": 0}))
-        x = self.double_conv("inc1", img_src, 16, 3)
+        if self.fold and self.dt == L.BF16 and self.in_channels == 1 and not os.environ.get("ABC_NO_STEM_FUSE"):
+            x = self._stem_fused_double_conv("inc1", img_src, 16)
+        else:
+            x = self.double_conv("inc1", img_src, 16, 3)
         x1 = self.double_conv("inc2", x, 16, 3)
         x2 = self.double_conv("down1.maxpool_conv.1", self.pooled(x1), 32, 3)
         x = self.double_conv("down2.maxpool_conv.1", self.pooled(x2), 64, 3)

@@ -96,6 +96,11 @@ typedef struct abc_conv_desc {
                             same dtype as y -- saves the separate abc_pool_act pass of the folded inference graph.  Only where
                             abc_conv_variant() == 5 (the narrow-level kernel); abc_conv_fwd refuses it elsewhere */
     int32_t ld_pool;
+    /* optional (narrow-level kernel, 16 input channels, 3x3): the input tensor is not read but COMPUTED on the fly as the
+     * network's first convolution of the folded inference graph (unet.py:12-14, one input channel):
+     *   in[p][c] = lrelu(sum_t stem_x[p + d_t] * stem_w[c][t] * stem_scale[c] + stem_bias[c]; stem_slope)
+     * over the same 3x3 taps (zero padding), stem_x = the f32 image [B][Hin][Win]; src.x is ignored */
+    const float* stem_x; const float* stem_w; const float* stem_scale; const float* stem_bias; float stem_slope;
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */

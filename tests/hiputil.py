@@ -48,7 +48,7 @@ def pack(lib, w, mode, dt, Cout, Cin, k, rows_pad, red_real, py=0, px=0):
 
 def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, Hout, Wout, ldy=None, cout_off=0, coef=None,
          pool=False, stride=1, grid=None, om=1, oy0=0, ox0=0, out=None, out_dt=None, stats=False, drop_p=0.0, drop_seed=0,
-         planar_in=0, planar_out=False, out_slope=None, pool_out=None):
+         planar_in=0, planar_out=False, out_slope=None, pool_out=None, stem=None):
     out_dt = dt if out_dt is None else out_dt
     ldy = Cout if ldy is None else ldy
     if out is None:
@@ -68,6 +68,8 @@ def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, 
         d.out_act, d.out_slope = 1, out_slope
     if pool_out is not None:
         d.pool_y, d.ld_pool = pool_out.data_ptr(), pool_out.shape[-1]
+    if stem is not None:   # (image, first-layer weights, scale, bias, slope): device f32 tensors
+        d.stem_x, d.stem_w, d.stem_scale, d.stem_bias, d.stem_slope = stem[0].data_ptr(), stem[1].data_ptr(), stem[2].data_ptr(), stem[3].data_ptr(), stem[4]
     L.set_taps(d, taps)
     conv.last_variant = lib.abc_conv_variant(C.byref(d))
     if lib.abc_conv_weight_layout(C.byref(d)) == 1:

@@ -112,6 +112,9 @@ def test_conv_forward(lib, dt, case):
     dict(Cin=16, Cout=16, H=64, W=96, slope=0.0, pool=True),
     dict(Cin=32, Cout=32, H=40, W=48, slope=0.01, pool=True),
     dict(Cin=16, Cout=32, H=22, W=42, slope=0.0, pool=True),      # ragged tiles and an odd pooled width (21)
+    # the network's first convolution (one-channel image, folded BatchNorm, ReLU) computed inside the halo staging
+    dict(Cin=16, Cout=16, H=64, W=96, slope=0.0, stem=True),
+    dict(Cin=16, Cout=16, H=44, W=72, slope=0.0, stem=True, pool=True),
 ])
 def test_conv_narrow_plain_input(lib, case):
     """3x3 over a FINISHED bf16 tensor with 16 / 32 channels (the folded inference graph's narrow levels, unet.py:12,15 in eval
@@ -125,6 +128,15 @@ def test_conv_narrow_plain_input(lib, case):
     xfull = q(torch.randn((B, ld, H, W), generator=g), dt)
     x = xfull[:, coff:coff + Cin]
     coef = None
+    stem = None
+    if case.get("stem"):
+        img = torch.rand((B, 1, H, W), generator=g)
+        w0 = torch.randn((Cin, 1, 3, 3), generator=g) / 3
+        sc0, b0 = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+        y0 = F.conv2d(img, w0, None, padding=1) * sc0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1)
+        x = q(torch.relu(y0), dt)                 # what the fused kernel puts into its halo (bf16)
+        xfull = x
+        stem = (img.reshape(B, H, W).contiguous().to(U.DEV), w0.to(U.DEV).contiguous(), sc0.to(U.DEV), b0.to(U.DEV), 0.0)
     if case.get("coef"):
         sc = torch.rand(ld, generator=g) * 2 - 0.6
         sh = torch.randn(ld, generator=g) * 0.3
@@ -144,7 +156,7 @@ def test_conv_narrow_plain_input(lib, case):
     out = torch.full((B, H, W, ldy), 7.0, dtype=torch.bfloat16, device=U.DEV)
     pooled = torch.full((B, H // 2, W // 2, Cout), 7.0, dtype=torch.bfloat16, device=U.DEV) if case.get("pool") else None
     y, st = U.conv(lib, xd, dt, dt, B, H, W, ld, coff, Cin, wp, None if bias is None else bias.to(U.DEV), Cout, taps, H, W, ldy=ldy,
-                   cout_off=ycoff, out=out, out_slope=slope, coef=coef, stats=bool(case.get("stats")), pool_out=pooled)
+                   cout_off=ycoff, out=out, out_slope=slope, coef=coef, stats=bool(case.get("stats")), pool_out=pooled, stem=stem)
     torch.cuda.synchronize()
     assert U.conv.last_variant == 5, "not served by conv_narrow"
     got = y[..., ycoff:ycoff + Cout].float().permute(0, 3, 1, 2).cpu()
