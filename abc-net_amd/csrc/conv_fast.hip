@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                         int id2 = nt / a.nblocks_n;
                         const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
                         const int ty2 = id2 % a.tiles_y; id2 /= a.tiles_y;
-                        apre.setup(gA, a.RS, PS, id2, ty2 * (2 * MT) * STRIDE + a.dy_min, tx2 * 16 * STRIDE + a.dx_min, a.cin_off, tid);
+                        apre.setup(gA, a.RS, PS, id2, ty2 * (2 * MT) * STRIDE + a.dy_min, tx2 * 16 * STRIDE + a.dx_min, a.cin_off, abc_launder(tid));   // (laundered: hoisted out of the tile loop, the lane-constant part of the setup was SPILLED and its reload waited for the whole weight ring)
                         apre.issue(rsA, 0u);
                     }
                 }
