@@ -568,6 +568,65 @@ def test_bn_act_pool_backward(lib, dt, pooled, same):
     assert U.relerr(U.to_nchw(gbuf), y.grad) < t
 
 
+@pytest.mark.parametrize("Cc,nblk,batch", [(16, 2304, 0), (128, 768, 0), (32, 100, 0), (256, 2048, 0), (128, 1152, 3), (48, 4099, 0), (12, 300, 0)])
+def test_bn_finalisers_many_rows(lib, Cc, nblk, batch):
+    """BatchNorm finalisers over many partial rows against f64 sums, single and batched with a column stride"""
+    g = torch.Generator().manual_seed(5)
+    n = max(batch, 1)
+    Ct = Cc * n
+    part = (torch.randn((nblk, 2, Ct), generator=g) * 3 + 0.5)
+    part[:, 1] = part[:, 1].abs() * 4 + 30       # (a valid sum of squares)
+    pd = part.to(U.DEV)
+    count = float(nblk * 7)
+    f32 = lambda k, v=0.0: torch.full((k,), v, dtype=torch.float32, device=U.DEV)
+    gam, bet, mean_in, istd_in = ((torch.rand(Ct, generator=g) + 0.5).to(U.DEV), torch.randn(Ct, generator=g).to(U.DEV),
+                                  torch.randn(Ct, generator=g).to(U.DEV), (torch.rand(Ct, generator=g) + 0.5).to(U.DEV))
+    outs_f = [f32(Ct) for _ in range(4)] + [f32(Ct), f32(Ct, 1.0)]
+    outs_b = [f32(Ct) for _ in range(8)]
+    nbt = torch.zeros(n, dtype=torch.int64, device=U.DEV)
+    fa, ba = (L.BnFwdDesc * n)(), (L.BnBwdDesc * n)()
+    for i in range(n):
+        o = 4 * Cc * i
+        d = fa[i]
+        d.partial, d.nblk, d.C, d.count, d.rows = pd.data_ptr() + o, nblk, Cc, count, 2
+        d.gamma, d.beta = gam.data_ptr() + o, bet.data_ptr() + o
+        d.scale, d.shift, d.mean, d.invstd, d.running_mean, d.running_var = (t.data_ptr() + o for t in outs_f)
+        d.num_batches_tracked, d.eps, d.momentum = nbt.data_ptr() + 8 * i, 1e-5, 0.1
+        f = ba[i]
+        f.partial, f.nblk, f.C, f.count = pd.data_ptr() + o, nblk, Cc, count
+        f.gamma, f.invstd, f.mean = gam.data_ptr() + o, istd_in.data_ptr() + o, mean_in.data_ptr() + o
+        f.dgamma, f.dbeta, f.k1, f.k2, f.gscale, f.ca, f.cb, f.cc = (t.data_ptr() + o for t in outs_b)
+    if batch:
+        L.check(lib.abc_bn_finalize_fwd_batch(fa, n, Ct, U.stream()), "bn_fwd_batch")
+        L.check(lib.abc_bn_finalize_bwd_batch(ba, n, Ct, U.stream()), "bn_bwd_batch")
+    else:
+        L.check(lib.abc_bn_finalize_fwd(C.byref(fa[0]), U.stream()), "bn_fwd")
+        L.check(lib.abc_bn_finalize_bwd(C.byref(ba[0]), U.stream()), "bn_bwd")
+    torch.cuda.synchronize()
+    s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    mean = s1 / count
+    var = (s2 / count - mean * mean).clamp_min(0)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift, mean_d, invstd_d, rm, rv = (t.cpu() for t in outs_f)
+    np.testing.assert_allclose(mean_d, mean.float(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(invstd_d, invstd.float(), rtol=2e-6)
+    np.testing.assert_allclose(scale, (gam.cpu().double() * invstd).float(), rtol=2e-6)
+    np.testing.assert_allclose(shift, (bet.cpu().double() - mean * gam.cpu().double() * invstd).float(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rm, 0.1 * mean.float(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv, (0.9 + 0.1 * var * count / (count - 1)).float(), rtol=1e-5)
+    assert (nbt.cpu() == 1).all()
+    dgam, dbet, k1, k2, gs, ca, cb, cc = (t.cpu() for t in outs_b)
+    np.testing.assert_allclose(dgam, s2.float(), rtol=1e-6)
+    np.testing.assert_allclose(dbet, s1.float(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(k1, (s1 / count).float(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(k2, (s2 / count).float(), rtol=1e-6)
+    gsr = (gam.cpu() * istd_in.cpu())
+    np.testing.assert_allclose(gs, gsr, rtol=1e-6)
+    np.testing.assert_allclose(ca, gsr, rtol=1e-6)
+    np.testing.assert_allclose(cb, -gsr * k2 * istd_in.cpu(), rtol=1e-5)
+    np.testing.assert_allclose(cc, gsr * (mean_in.cpu() * istd_in.cpu() * k2 - k1), rtol=1e-4, atol=1e-4)
+
+
 def test_adam_matches_oracle(lib, golden_dir):
     from oracle import adam_oracle
     from abcnet_amd.ops import FusedAdam
