@@ -198,6 +198,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
         fb[kk] = pack_frag<bf16>(v);
     }
 
+    const bool st_logits = hd.logits != nullptr;   // (uniform: a kernel argument)
     f32x16 accD[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -259,7 +260,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
                 load_t5(mtn);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (!(ABC_DBG(a.dbg) & 2)) {
+            if (st_logits && !(ABC_DBG(a.dbg) & 2)) {
 #pragma unroll
                 for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
@@ -273,7 +274,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
                 if (j < 30) {
                     const float zr = v[k];
                     const double tr = *at8(a.t_rho, j);
-                    *at4w(hd.logits, j) = zr;
+                    if (st_logits) *at4w(hd.logits, j) = zr;
                     const float dn = c.dnl[j * 64 + lane];
                     const double diff = (double)fabsf(zr) - tr;
                     num += fabs(diff) * (double)dn;
@@ -289,7 +290,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
             for (int k = 0; k < 16; ++k) {
                 const int j = 16 * mt + k;
                 if (j < 30) {
-                    *at4w(hd.logits, j) = v[k];
+                    if (st_logits) *at4w(hd.logits, j) = v[k];
                     float dz;
                     num += (double)center_focal<true>(v[k], c.dnl[j * 64 + lane], (float)wpix, &dz);
                     dlv[k] = dz;
@@ -299,7 +300,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
         } else if (h == 0) {
             if constexpr (HEAD == 0 || HEAD == 4) {
                 const float t = *at4(HEAD == 0 ? a.t_atom : a.t_bond, 0);
-                *at4w(hd.logits, 0) = v[0];
+                if (st_logits) *at4w(hd.logits, 0) = v[0];
                 float dz;
                 num += (double)center_focal<true>(v[0], t, 1.f, &dz);
                 den += (t == 1.f) ? 1.0 : 0.0;
@@ -312,7 +313,7 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     z[k] = v[k];
-                    *at4w(hd.logits, k) = z[k];
+                    if (st_logits) *at4w(hd.logits, k) = z[k];
                 }
                 num += (double)class_focal<CH, true>(z, t, HEAD == 1 ? c_type_w : nullptr, dz, &dn);
                 den += (double)dn;

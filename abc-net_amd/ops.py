@@ -67,12 +67,16 @@ class FusedHeadsLoss(FusedLoss):
     d(logits) + the gradient back to the heads' BatchNorm outputs in one pass (abc_heads_fused_fwd_bwd), then the same
     finalisation as FusedLoss.  Same interface."""
 
-    def __init__(self, eng, targets, s_ptr, ds_ptr, grad_scale=1.0):
+    def __init__(self, eng, targets, s_ptr, ds_ptr, grad_scale=1.0, keep_logits=True):
+        """keep_logits=False: the logits never leave the kernel (eng.logits keep their old contents) -- for a training
+        loop without the meters of train.py:145-215, the only other reader of the outputs"""
         lib = eng.lib
         self.eng, self.lib = eng, lib
         self.targets = targets
         self._check_targets(eng, targets)
         d = eng.hf
+        for i in range(8):
+            d.logits[i] = eng.logits[i].data_ptr() if keep_logits else None
         (d.t_atom, d.t_types, d.t_charges, d.t_hs, d.t_bond, d.t_btypes, d.t_rho, d.t_omega) = (t.data_ptr() for t in targets)
         self.nblk = eng.hf_lossblocks
         self.partial = eng.hf_losspart

@@ -20,11 +20,13 @@ from .ops import FusedAdam, FusedHeadsLoss, FusedLoss, FusedMetrics
 
 class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
-                 process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True):
+                 process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True, keep_logits=True):
         """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
         mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
         as DDP does; "lazy" (default): right before they are read (state_dict(), sync_buffers()), which is observably the
-        same because train-mode arithmetic never reads them; False: never (each rank keeps its own shard's statistics)."""
+        same because train-mode arithmetic never reads them; False: never (each rank keeps its own shard's statistics).
+        keep_logits=False (fused heads only, ignored with metrics=True): the eight output maps are not stored by the step
+        (`eng.logits` is stale) -- the loss and every gradient are unchanged."""
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("Trainer needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
@@ -56,8 +58,9 @@ class Trainer:
         dts = [torch.float32] * 6 + [torch.float64] * 2
         self.targets = [torch.zeros(s, dtype=dt, device=dev) for s, dt in zip(shapes, dts)]
         off_s, _ = model._lay_p["s"]
+        extra = {"keep_logits": bool(keep_logits or metrics)} if eng.hf is not None else {}
         self.loss = (FusedHeadsLoss if eng.hf is not None else FusedLoss)(
-            eng, self.targets, model._flat.data.data_ptr() + 4 * off_s, model._flat_grad.data_ptr() + 4 * off_s, grad_scale=1.0 / self.world)
+            eng, self.targets, model._flat.data.data_ptr() + 4 * off_s, model._flat_grad.data_ptr() + 4 * off_s, grad_scale=1.0 / self.world, **extra)
         # train.py:145-215: the 17 meters, updated every step on the device (no host round trips); off by default
         self.metrics = FusedMetrics(eng.logits, self.targets) if metrics else None
         self.lr, self.wd = lr, weight_decay

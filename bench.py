@@ -145,6 +145,8 @@ def main():
                     "img2smiles2.py:113-191 on the device inside the step")
     ap.add_argument("--raster", action="store_true", help="rasterise the targets on the device every step from compact records "
                     "(utils.py:83-228 on the GPU) instead of keeping pre-rasterised maps resident")
+    ap.add_argument("--no-logits", action="store_true", help="(train) do not store the eight output maps: nothing reads them without "
+                    "--metrics (Trainer(keep_logits=False)); NOT the default -- the headline line stores them as the reference does")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -208,7 +210,7 @@ def main():
         tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract)
         tr.load_batch(imgs.to(dev))
     else:
-        tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics)
+        tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits)
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
         tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
         if a.raster:
@@ -264,7 +266,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),
-                   "device_rasteriser": bool(a.raster), "device_extraction": bool(a.extract), "env_knobs": knobs},
+                   "device_rasteriser": bool(a.raster), "device_extraction": bool(a.extract),
+                   "logits_stored": bool(a.mode != "train" or a.metrics or not a.no_logits), "env_knobs": knobs},
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 

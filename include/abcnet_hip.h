@@ -336,7 +336,8 @@ typedef struct abc_heads_fused_desc {
     float drop_p; uint32_t drop_seed; const uint32_t* drop_salt;   /* Dropout after the activation (abc_act_src) */
     const float* w2[8]; const float* b2[8];   /* conv2.weight [C_i][128], conv2.bias [C_i] (reference layout, f32) */
     void* w2_pack;                      /* abc_heads_fused_pack_bytes() bytes, written by abc_heads_fused_pack */
-    float* logits[8];                   /* out: NCHW f32 [B][C_i][h][w] (unet.py:119) */
+    float* logits[8];                   /* out: NCHW f32 [B][C_i][h][w] (unet.py:119); an entry may be NULL when nothing
+                                         * downstream reads that head's logits (they are then never stored: 0.3 GB less) */
     const float* t_atom; const float* t_types; const float* t_charges; const float* t_hs; const float* t_bond;
     const float* t_btypes; const double* t_rho; const double* t_omega;   /* targets, as abc_loss_desc */
     void* dl;                           /* out: d(numerator)/d(logits), bf16, abc_heads_fused_dl_elems() elements:

@@ -609,6 +609,33 @@ def test_fused_heads_step_equals_unfused_step(variant):
             assert rel <= (1e-1 if variant == "unet" else 2e-1), (name, rel)
 
 
+def test_fused_step_without_stored_logits_is_the_same_step():
+    """Trainer(keep_logits=False): the fused heads pass does not store the eight output maps (abc_heads_fused_desc.logits[i] =
+    NULL) -- loss and every gradient bit-equal to the step that stores them, eng.logits untouched; with metrics=True the
+    maps are kept whatever the flag says (the meters read them)"""
+    from abcnet_amd.train import Trainer
+    B, S = 2, 128
+    x, tg = synthetic_images(B, S, seed=7), synthetic_targets(B, S // 4, seed=1)
+
+    def one_step(**kw):
+        m = make_model(dtype="bf16", dropout_p=0.2)
+        tr = Trainer(m, B, S, S, lr=0.0, use_graph=False, **kw)
+        assert tr.eng.hf is not None
+        tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+        tr.step()
+        torch.cuda.synchronize()
+        return [t.clone() for t in tr.eng.logits], m._flat_grad.clone(), tr.loss_value()
+
+    lg_k, g_k, loss_k = one_step()
+    lg_n, g_n, loss_n = one_step(keep_logits=False)
+    lg_m, g_m, loss_m = one_step(keep_logits=False, metrics=True)
+    assert torch.equal(g_k, g_n) and torch.equal(g_k, g_m)
+    assert loss_k == loss_n == loss_m
+    assert all(float(t.abs().max()) == 0.0 for t in lg_n)       # (never written)
+    assert all(torch.equal(a, b) for a, b in zip(lg_k, lg_m))
+    assert any(float(t.abs().max()) > 0.0 for t in lg_k)
+
+
 @pytest.mark.parametrize("prefix", ["dconv2", "dconv1", "up1.conv", "inc2", "down2.maxpool_conv.1"])
 def test_unet2_block_is_exact_in_situ(prefix):
     """Flip-free parity of unet2's CBAM + residual block (unet2.py:6-74), every abc_cbam_* entry by its own output: one
