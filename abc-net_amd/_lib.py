@@ -144,7 +144,7 @@ class HeadsFusedDesc(C.Structure):
                 ("logits", vp * 8), ("t_atom", vp), ("t_types", vp), ("t_charges", vp), ("t_hs", vp), ("t_bond", vp),
                 ("t_btypes", vp), ("t_rho", vp), ("t_omega", vp), ("dl", vp), ("g", vp), ("bn_partial", vp), ("loss_partial", vp),
                 ("B", i32), ("h", i32), ("w", i32), ("chan_scale", vp), ("chan_off", i32 * 8), ("dw2", vp * 8), ("db2", vp * 8),
-                ("wgrad_work", vp)]
+                ("wgrad_work", vp), ("keep_mask", vp)]
 
 
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,

@@ -40,6 +40,7 @@ struct HFHead {
     const float* biasp;  // [Cpad]
     float* logits;       // [B][C][HW]
     bf16* dlb;           // [chunk][Cpad][128 pixels]
+    uint2* keep;         // [pixel][2 halves]: the dropout keep bits of the head's 128 features (heads 5-7, or null)
 };
 
 struct HFK {
@@ -196,6 +197,11 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
             v[j] = keep ? fmaxf(y, sl[j] * y) * c.dscale : 0.f;
         }
         fb[kk] = pack_frag<bf16>(v);
+    }
+    // the blocked conv2 weight gradient (wgrad.hip) re-reads these features: it takes the keep bits from here instead of
+    // hashing 128 elements per pixel again (byte kk of this lane half = channels 16 kk + 8 h .. + 7)
+    if constexpr (HEAD >= 5) {
+        if (hd.keep != nullptr) hd.keep[2u * c.pix + h] = make_uint2(kbits[0], kbits[1]);
     }
 
     const bool st_logits = hd.logits != nullptr;   // (uniform: a kernel argument)
@@ -610,6 +616,7 @@ extern "C" int abc_heads_fused_fwd_bwd(const abc_heads_fused_desc* d, abc_stream
         k.hd[i].biasp = (const float*)(base + (size_t)cpad * 512);
         k.hd[i].logits = d->logits[i];
         k.hd[i].dlb = (bf16*)d->dl + row0 * (size_t)k.nchunk * 128;
+        k.hd[i].keep = (i >= 5 && d->keep_mask != nullptr && d->drop_p > 0.f) ? (uint2*)d->keep_mask + (size_t)(i - 5) * 2 * d->B * d->h * d->w : nullptr;
         row0 += cpad;
     }
     static unsigned long long lds_ok = 0;

@@ -474,6 +474,7 @@ struct HeadK {
     const uint32_t* drop_salt;
     unsigned bytesP, bytesQ;
     int cpad_blk;    // BLK: dl = bf16 [chunk][cpad_blk rows][128 pixels], written by the fused heads kernel (heads_fused.hip)
+    const uint8_t* keep;   // BLK: the fused kernel's dropout keep bits, 16 bytes per pixel (byte kk + 8 h = channels 16 kk + 8 h ..), or null
 };
 
 constexpr int HQ_PSW = 320;  // pixel stride of the [pixel][128 channel] bf16 LDS image (wgrad Q layout)
@@ -525,6 +526,11 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
     // (~4 us for 96 KB per CU) plus the commit -- the 16 MFMAs per wave of a chunk hide nothing.  Loads are issued
     // unconditionally (past the last chunk with an out-of-range offset: zeros, no traffic) so that vmcnt stays exact.
     u32x4 qreg0[4], preg0[8], qreg1[4], preg1[8];
+    // (BLK with the fused kernel's keep bits: the four pixels' mask bytes of this thread's channel segment ride in preg[4],
+    //  which the blocked form does not use for d(logits))
+    const bool kmask = BLK && a.keep != nullptr && a.drop_p > 0.f;
+    const __amdgpu_buffer_rsrc_t rsK = abc_make_rsrc(kmask ? a.keep : (const uint8_t*)a.q, kmask ? (unsigned)a.nchunks * 2048u : 0u);
+    const unsigned kbyte = (unsigned)((part & 1) * 8 + (part >> 1));
     const int CPI = a.HW / 128;  // chunks per image
     auto issue = [&](int c, u32x4 (&qreg)[4], u32x4 (&preg)[8]) {
         const bool live = c < c1;
@@ -533,6 +539,11 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, live ? qoff + (unsigned)(i * 32 * a.ldq * 2) : qoff, 0, 0);
         if constexpr (BLK) {
+            if (kmask) {
+                const unsigned koff = live ? (unsigned)(c * 128 + pix0) * 16u + kbyte : 0x80000000u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) preg[4][i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsK, live ? koff + (unsigned)(i * 32 * 16) : koff, 0, 0);
+            }
             // the chunk's 128 rows are ONE contiguous 32 KB block: 16-byte piece q = tid + 512 i = (row q >> 4, pixels 8 (q & 15) ..)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -566,7 +577,11 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = abc_act(v[j], qsc[j], qsh[j], qsl[j]);
             }
-            if (a.drop_p > 0.f) {
+            if (BLK && kmask) {
+                const unsigned kb = preg[4][i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? v[j] * dscale : 0.f;
+            } else if (a.drop_p > 0.f) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = abc_drop_keep(eoff + j, dseed, a.drop_p) ? v[j] * dscale : 0.f;
             }
@@ -704,7 +719,7 @@ static void head_fill(HeadK& k, const abc_wgrad_desc* d) {
     k.nchunks = d->B * k.HW / 128; k.nsplit = d->nsplit; k.mtiles = abc_cdiv(d->Ca, 32); k.Ca_pad = k.mtiles * 32;
     k.drop_p = d->q.drop_p; k.drop_seed = d->q.drop_seed; k.drop_salt = d->q.drop_salt;
     k.bytesP = (unsigned)((int64_t)d->B * d->Ca * k.HW * 4); k.bytesQ = (unsigned)((int64_t)d->B * k.HW * d->q.ldx * 2);
-    k.cpad_blk = 0;
+    k.cpad_blk = 0; k.keep = nullptr;
 }
 
 static int head_launch(const abc_wgrad_desc* d, hipStream_t st) {
@@ -1219,6 +1234,7 @@ extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t
             k.drop_p = d->drop_p; k.drop_seed = d->drop_seed; k.drop_salt = d->drop_salt;
             k.bytesP = (unsigned)((size_t)nchunk * cpad * 128 * 2); k.bytesQ = (unsigned)((int64_t)d->B * HW * d->ld * 2);
             k.cpad_blk = cpad;
+            k.keep = d->keep_mask != nullptr ? (const uint8_t*)d->keep_mask + (size_t)(i - 5) * nchunk * 2048 : nullptr;
             if ((size_t)nchunk * cpad * 128 * 2 >= (size_t(1) << 31)) return abc_fail(ABC_EUNSUPPORTED, "heads_fused_wgrad: d(logits) block above 2 GB");
             gx = ns[i] > gx ? ns[i] : gx;
             gy = abc_cdiv(k.mtiles, 4) > gy ? abc_cdiv(k.mtiles, 4) : gy;

@@ -733,6 +733,10 @@ class Engine:
         d.w2_pack, d.dl, d.g = self.hf_pack.data_ptr(), self.hf_dl.data_ptr(), self.hf_g.data_ptr()
         d.bn_partial, d.loss_partial = self.hf_bnpart.data_ptr(), self.hf_losspart.data_ptr()
         d.chan_scale, d.wgrad_work = self.chan_scale.data_ptr(), self.hf_work.data_ptr()
+        if self.drop_p > 0 and not os.environ.get("ABC_HF_NO_KEEPMASK"):
+            # the dropout keep bits of the three wide heads' features, from the fused pass to its conv2 weight gradient
+            self.hf_keep = self.new((3 * B * h * w * 16,), torch.uint8, 0)
+            d.keep_mask = self.hf_keep.data_ptr()
         for i in range(nh):
             p = "out_modules.%d.conv2" % i
             d.w2[i], d.b2[i], d.logits[i] = self.P(p + ".weight"), self.P(p + ".bias"), self.logits[i].data_ptr()

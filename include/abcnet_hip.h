@@ -351,6 +351,9 @@ typedef struct abc_heads_fused_desc {
     float* dw2[8]; float* db2[8];       /* out: conv2.weight.grad [C_i][128], conv2.bias.grad [C_i] */
     float* wgrad_work;                  /* abc_heads_fused_wgrad_floats() floats; ALSO written by abc_heads_fused_fwd_bwd (the five
                                            small heads' weight-gradient partials), so set it for both calls */
+    void* keep_mask;                    /* optional, 3 * B*h*w * 16 bytes: abc_heads_fused_fwd_bwd leaves the dropout keep bits of the three
+                                           wide heads' features here and abc_heads_fused_wgrad reads them instead of hashing every
+                                           element again (set it for both calls, or for neither) */
 } abc_heads_fused_desc;
 int64_t abc_heads_fused_pack_bytes(void);
 int abc_heads_fused_chunks(const abc_heads_fused_desc* d);

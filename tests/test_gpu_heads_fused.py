@@ -32,7 +32,7 @@ def rel(a, b):
     return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
 
 
-def _run(B, hw, drop_p, seed=3):
+def _run(B, hw, drop_p, seed=3, keepmask=False):
     lib = L.load()
     g = torch.Generator().manual_seed(seed)
     npix, ld = B * hw * hw, 1024
@@ -73,6 +73,9 @@ def _run(B, hw, drop_p, seed=3):
     d.dl, d.g, d.bn_partial, d.loss_partial = dl.data_ptr(), gbuf.data_ptr(), bnp.data_ptr(), lp.data_ptr()
     work = torch.zeros(lib.abc_heads_fused_wgrad_floats(C.byref(d)), device=DEV)
     d.wgrad_work = work.data_ptr()
+    kmask = torch.zeros((3, npix, 2, 8), dtype=torch.uint8, device=DEV) if keepmask else None
+    if keepmask:
+        d.keep_mask = kmask.data_ptr()
     st = torch.cuda.current_stream().cuda_stream
     L.check(lib.abc_heads_fused_pack(C.byref(d), st), "pack")
     L.check(lib.abc_heads_fused_fwd_bwd(C.byref(d), st), "fwd_bwd")
@@ -130,12 +133,14 @@ def _run(B, hw, drop_p, seed=3):
     return dict(lib=lib, d=d, B=B, hw=hw, ld=ld, npix=npix, nchunk=nchunk, logits=logits, dl=dl, g=gbuf, bnp=bnp, out=out, ds=ds,
                 chan_scale=chan_scale, off=off, dw2=dw2, db2=db2, alone=e, alone_out=fl.out, alone_ds=ds2,
                 ref=dict(total=total.item(), preds=preds, leaves=leaves, ws=ws, bs=bs, y=y, km=km, x=x, mean=mean, invstd=invstd, sl=sl),
-                keep=(keep, w2d, b2d, pack, tgd, lp, work, sdev))
+                kmask=kmask, keep=(keep, w2d, b2d, pack, tgd, lp, work, sdev))
 
 
-@pytest.mark.parametrize("B,hw,drop_p", [(2, 32, 0.2), (1, 48, 0.0)])
-def test_fused_heads_pass(B, hw, drop_p):
-    r = _run(B, hw, drop_p)
+@pytest.mark.parametrize("B,hw,drop_p,keepmask", [(2, 32, 0.2, False), (1, 48, 0.0, False), (2, 32, 0.2, True)])
+def test_fused_heads_pass(B, hw, drop_p, keepmask):
+    """keepmask: abc_heads_fused_desc.keep_mask set -- the fused pass leaves the wide heads' dropout keep bits for its conv2
+    weight gradient (checked against the host mirror of the hash below, and through dW2 of heads 5-7 like the hashed form)"""
+    r = _run(B, hw, drop_p, keepmask=keepmask)
     lib, ref = r["lib"], r["ref"]
     # 1. logits
     for i, c in enumerate(HEADS):
@@ -188,3 +193,11 @@ def test_fused_heads_pass(B, hw, drop_p):
     for i, c in enumerate(HEADS):
         assert rel(r["dw2"][i].cpu(), ref["ws"][i].grad) <= 6e-3, ("dW2", i, rel(r["dw2"][i].cpu(), ref["ws"][i].grad))
         assert rel(r["db2"][i].cpu(), ref["bs"][i].grad) <= 6e-3, ("db2", i, rel(r["db2"][i].cpu(), ref["bs"][i].grad))
+    # 6. the keep bits: byte kk of half h of a pixel = channels 16 kk + 8 h .. + 7 of the head's 128 features
+    if keepmask:
+        km = (ref["km"] > 0).view(npix, 8, 128)                       # [pixel][head][channel]
+        bits = r["kmask"].cpu()                                        # [3][pixel][h][kk]
+        for i in (5, 6, 7):
+            want = km[:, i, :].view(npix, 8, 2, 8).permute(0, 2, 1, 3)   # [pixel][h][kk][j]
+            wbyte = (want.to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8)
+            assert torch.equal(bits[i - 5], wbyte), ("keep bits", i)
