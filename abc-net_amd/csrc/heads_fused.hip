@@ -352,12 +352,6 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) raw[kk] = *(const u32x4*)(a.y1 + e0 + 16 * kk);
     dgrad_mfma();
-    // the blocked conv2 weight gradient (wgrad.hip) re-reads these features: it takes the keep bits from here instead of
-    // hashing 128 elements per pixel again (byte kk of this lane half = channels 16 kk + 8 h .. + 7).  (Stored HERE, behind
-    // the row-tile loop: placed where the bits are made it cost the 15-tile head 166 spilled registers.)
-    if constexpr (HEAD >= 5) {
-        if (hd.keep != nullptr) hd.keep[2u * c.pix + h] = make_uint2(kbits[0], kbits[1]);
-    }
 
     // ---- the small heads (one row tile, <= 14 channels) also finish conv2's WEIGHT gradient here: dW2[c][ci] = sum_p dL[c][p] a[p][ci]
     // over the workgroup's 128 pixels is 8 MFMAs per wave (wave w = feature tile w) from the four waves' d(logits) tiles and
@@ -469,6 +463,12 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
                 }
             }
         }
+    }
+    // the blocked conv2 weight gradient (wgrad.hip) re-reads these features: it takes the keep bits from here instead of
+    // hashing 128 elements per pixel again (byte kk of this lane half = channels 16 kk + 8 h .. + 7).  (Stored HERE, at the
+    // end of the head: placed where the bits are made it cost the 15-tile head 166 spilled registers.)
+    if constexpr (HEAD >= 5) {
+        if (hd.keep != nullptr) hd.keep[2u * c.pix + h] = make_uint2(kbits[0], kbits[1]);
     }
     c.nslice += 1;
     {
