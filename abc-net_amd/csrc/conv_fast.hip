@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         // (WD workgroups are persistent too when there are more tiles than workgroup slots: the next tile's first halo chunk
         //  is issued during the last chunk of this tile, see the main loop)
         if (!(STATIC || WD != 0) || first_tile) {
-            apre.setup(gA, a.RS, PS, b, iy0, ix0, a.cin_off, tid);
+            apre.setup(gA, a.RS, PS, b, iy0, ix0, a.cin_off, abc_launder(tid));   // (laundered like the next-tile setup: its lane constants were spilled and came back as eight serialised scratch round trips in front of the first halo loads)
             apre.issue(rsA, 0u);
         }
         int ci = 0, gi = 0;  // (chunk, tap group) of the next stage to issue
