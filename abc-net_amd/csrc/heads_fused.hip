@@ -198,6 +198,9 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
         }
         fb[kk] = pack_frag<bf16>(v);
     }
+    // (pin the masks HERE: left alone the compiler sinks the sign-bit computation behind the row-tile loop, keeps the 64 BatchNorm
+    //  outputs in scratch across it and brings them back one by one, each behind a full `s_waitcnt vmcnt(0)`)
+    asm volatile("" : "+v"(kbits[0]), "+v"(kbits[1]), "+v"(pbits[0]), "+v"(pbits[1]));
 
     const bool st_logits = hd.logits != nullptr;   // (uniform: a kernel argument)
     f32x16 accD[4];
