@@ -77,7 +77,14 @@ def read_rows(d, pattern):
 
 
 def key(row):
-    return (row["Kernel_Name"], int(row.get("Grid_Size", row.get("Grid_Size_X", 0)) or 0))
+    # total work-items: the counter files carry `Grid_Size` (all dimensions), the kernel trace one column per dimension -- with the
+    # X dimension alone the rows of every kernel launched on a 2-D / 3-D grid (the fused heads pass, the batched heads kernels,
+    # CBAM) found no counters
+    if row.get("Grid_Size") not in (None, ""):
+        g = int(row["Grid_Size"])
+    else:
+        g = int(row.get("Grid_Size_X", 0) or 0) * max(int(row.get("Grid_Size_Y", 1) or 1), 1) * max(int(row.get("Grid_Size_Z", 1) or 1), 1)
+    return (row["Kernel_Name"], g)
 
 
 def steps_in(rows):
