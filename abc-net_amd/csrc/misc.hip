@@ -127,17 +127,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackItem* items, 
     __shared__ int s_lo, s_hi;
     const int64_t i0 = (int64_t)blockIdx.x * PACK_CHUNK;
     const int64_t i1 = (i0 + PACK_CHUNK < total) ? i0 + PACK_CHUNK : total;
-    // item of the block's first / last element = (number of items that start at or before it) - 1, counted by all threads at
-    // once: ONE round trip to the table.  (Thread 0's two binary searches were 14 dependent loads before any of the block's
-    // 2048 elements moved -- with five rounds of blocks on the chip that latency WAS the kernel: 77 us for 21 M elements.)
-    int lo = -1, hi = -1;
-    for (int b0 = 0; b0 < nitems; b0 += 256) {
-        const int b = b0 + threadIdx.x;
-        const int64_t f = b < nitems ? items[b].first : INT64_MAX;
-        lo += __syncthreads_count(f <= i0);
-        hi += __syncthreads_count(f <= i1 - 1);
-    }
-    (void)s_lo; (void)s_hi;
+    if (threadIdx.x == 0) { s_lo = pack_find(items, nitems, i0); s_hi = pack_find(items, nitems, i1 - 1); }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
     if (lo == hi) {
         const PackItem& it = items[lo];
         const unsigned base = (unsigned)(i0 - it.first);
