@@ -584,7 +584,7 @@ extern "C" int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld
     {
         const int N = dtype == ABC_BF16 ? 8 : 4;
         const int ncv = C / N;
-        if (C % N == 0 && ncv >= 1 && ncv <= 256 && 256 % ncv == 0 && ld % N == 0 && c_off % N == 0 && !getenv("ABC_COLSUM_SCALAR")) {
+        if (C % N == 0 && ncv >= 1 && ncv <= 256 && 256 % ncv == 0 && ld % N == 0 && c_off % N == 0 && !abc_knob("ABC_COLSUM_SCALAR")) {
             if (dtype == ABC_BF16)
                 hipLaunchKernelGGL(colsum_vec_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, npix, ld, c_off, C, chan_scale, work);
             else

@@ -20,6 +20,15 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define ABC_PROF(p) ((long long*)nullptr)
 #endif
 
+// Experiment switches (kernel / tile choices of measured A/B runs) are read from the environment by the DEBUG build only:
+// the production library never looks at the environment, its kernel choice is a function of the descriptor alone.
+#ifdef ABC_KERNEL_DEBUG
+#include <stdlib.h>
+inline const char* abc_knob(const char* name) { return getenv(name); }
+#else
+inline const char* abc_knob(const char*) { return nullptr; }
+#endif
+
 #define ABC_MAX_TAPS 49
 #define ABC_WAVE 64
 

@@ -626,7 +626,7 @@ extern "C" void abc_debug_conv_prof(void* p) { g_prof = (long long*)p; }
 // Geometry of the lean kernel for this descriptor, or eligible = 0 (-> the general kernel of conv_igemm.hip).
 int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->eligible = 0;
-    if (getenv("ABC_CONV_NOFAST")) return ABC_OK;
+    if (abc_knob("ABC_CONV_NOFAST")) return ABC_OK;
     if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->planar_out) return ABC_OK;
     const int csz = d->dtype_c == ABC_BF16 ? 2 : 4;
     g->CK = abc_conv_chunk(d->dtype_c, d->Cin);
@@ -652,8 +652,8 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     // prologue + epilogue; rounds = ceil(tiles / 512 slots).  Deep layers (12x12 .. 24x24 pixels, K loops of 80 .. 160
     // stages) thus get narrow tiles with few tap groups, wide layers the biggest tile that fits the registers.
     const int bn_nat = (d->Cout_pad % 128 == 0) ? 128 : (d->Cout_pad % 64 == 0 ? 64 : 32);
-    const char* force = getenv("ABC_CONV_MT");
-    const char* force_bn = getenv("ABC_CONV_BN");
+    const char* force = abc_knob("ABC_CONV_MT");
+    const char* force_bn = abc_knob("ABC_CONV_BN");
     int best = -1, best_bn = 0;
     double best_cost = 0;
     for (int bn = bn_nat; bn >= 32; bn >>= 1) {
@@ -705,7 +705,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     // stages amortise the per-stage control code; a second halo buffer hides the chunk turn-over.  Prefer the big
     // stage, then the second halo buffer, as the 80 KB allow.
     int sr = SR_MAX;
-    { const char* e = getenv("ABC_CONV_SR"); if (e) sr = atoi(e); }
+    { const char* e = abc_knob("ABC_CONV_SR"); if (e) sr = atoi(e); }
     int tg = 1, abufs = 1;
     for (;;) {
         tg = sr / g->BN; if (tg < 1) tg = 1;
@@ -719,12 +719,12 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     (void)abufs;
     // weights-direct main loop (3x3 over 64-byte bf16 chunks, tiles of >= 64 channels): no weights in LDS at all
     {
-        const char* e = getenv("ABC_CONV_NOWD");   // "1": never; "2": only the 192 x 128 tile (experiments)
+        const char* e = abc_knob("ABC_CONV_NOWD");   // "1": never; "2": only the 192 x 128 tile (experiments)
         const int lim = e ? atoi(e) : 0;
         g->wd = (csz == 2 && g->CK == 32 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 9 : 0;
         // (25-tap form for unet2's 5x5 32 -> 32 layers: measured SLOWER than the LDS-staged weights, 136 vs 121 us -- a
         //  32-channel tile has only 4 MFMAs per tap to cover the global-load latency of the ring; opt-in for experiments)
-        if (csz == 2 && g->CK == 32 && g->BN == 32 && g->MT == 8 && d->stride == 1 && d->ntaps == 25 && getenv("ABC_CONV_WD25")) g->wd = 25;
+        if (csz == 2 && g->CK == 32 && g->BN == 32 && g->MT == 8 && d->stride == 1 && d->ntaps == 25 && abc_knob("ABC_CONV_WD25")) g->wd = 25;
     }
     if (g->wd) g->sB_bytes = 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
@@ -755,7 +755,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->ntiles = g->nbn * g->tiles_x * g->tiles_y * d->B;
     // persistent workgroups: three per CU with resident weights; two per CU (512 slots) on the weights-direct loop when
     // there are more tiles than slots (measured on one box, same run: 6144 tiles 482 -> 463 us, 5632 tiles 473 -> 448 us)
-    g->nwg = g->b_static ? (g->ntiles < 768 ? g->ntiles : 768) : ((g->wd && g->ntiles > 512 && !getenv("ABC_CONV_NOPERSIST")) ? 512 : g->ntiles);
+    g->nwg = g->b_static ? (g->ntiles < 768 ? g->ntiles : 768) : ((g->wd && g->ntiles > 512 && !abc_knob("ABC_CONV_NOPERSIST")) ? 512 : g->ntiles);
     g->eligible = 1;
     return ABC_OK;
 }
@@ -775,9 +775,9 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     k.tap_off = g.tap_off; k.coef_off = g.coef_off; k.cstride = g.cstride; k.stats_rows = d->stats_rows;
     k.accumulate = d->accumulate; k.b_static = g.b_static; k.stg_off = g.stg_off; k.red_off = g.red_off;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
-    { const char* e = getenv("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
+    { const char* e = abc_knob("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     k.prof = g_prof;
-    { const char* e = getenv("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }
+    { const char* e = abc_knob("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }
     k.bytesA = (unsigned)((int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4));
     k.bytesW = (unsigned)((int64_t)d->ntaps * k.nchunks * d->Cout_pad * g.CK * (d->dtype_c == ABC_BF16 ? 2 : 4));
     for (int t = 0; t < d->ntaps; ++t) {

@@ -341,7 +341,7 @@ static void narrow_grid(const abc_conv_desc* d, int* nwg, int* tpw) {
 // BatchNorm partial sums of the outputs (2 rows).  (32 input channels with BOTH the transform and the sums does not fit the
 // registers: that one stays on conv_fast.)
 int abc_conv_narrow_ok(const abc_conv_desc* d) {
-    if (getenv("ABC_CONV_NONARROW")) return 0;
+    if (abc_knob("ABC_CONV_NONARROW")) return 0;
     if (d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16) return 0;
     if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->planar_out) return 0;
     if (d->accumulate || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
@@ -351,10 +351,10 @@ int abc_conv_narrow_ok(const abc_conv_desc* d) {
     // (must not depend on the statistics POINTER: abc_conv_stat_blocks is asked before that buffer exists)
     if (d->stats_rows == 4) return 0;                                   // unet2's CBAM rows: per image, per tile
     if (d->src.scale != nullptr && d->Cin == 32) return 0;             // transform + sums + 72 weight registers do not fit
-    if (d->src.scale != nullptr && getenv("ABC_CONV_NONARROW_XF")) return 0;
+    if (d->src.scale != nullptr && abc_knob("ABC_CONV_NONARROW_XF")) return 0;
     if (d->stem_x != nullptr && (d->Cin != 16 || d->ntaps != 9 || d->src.scale != nullptr || d->stats != nullptr || !d->stem_w || !d->stem_scale || !d->stem_bias)) return 0;
     const int R = d->ntaps == 9 ? 1 : 2;
-    if (R == 2 && (d->Cin != 32 || d->src.scale != nullptr || getenv("ABC_CONV_NONARROW5"))) return 0;
+    if (R == 2 && (d->Cin != 32 || d->src.scale != nullptr || abc_knob("ABC_CONV_NONARROW5"))) return 0;
     for (int t = 0; t < d->ntaps; ++t)
         if (d->tap_dy[t] < -R || d->tap_dy[t] > R || d->tap_dx[t] < -R || d->tap_dx[t] > R) return 0;
     return (int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2 < (int64_t(1) << 31);

@@ -252,7 +252,7 @@ static void fill_dg(HeadDgK& k, const abc_conv_desc* d) {
 }  // namespace
 
 int abc_head_fwd_ok(const abc_conv_desc* d) {
-    if (getenv("ABC_CONV_NOHEAD")) return 0;
+    if (abc_knob("ABC_CONV_NOHEAD")) return 0;
     if (!d->planar_out || d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
     if (d->Cin != 128 || d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_F32) return 0;
     if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr || d->out_act) return 0;
@@ -271,7 +271,7 @@ int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream) {
 }
 
 int abc_head_dgrad_ok(const abc_conv_desc* d) {
-    if (getenv("ABC_CONV_NOHEAD")) return 0;
+    if (abc_knob("ABC_CONV_NOHEAD")) return 0;
     if (!d->src.planar || d->dtype_in != ABC_F32 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16 || d->planar_out) return 0;
     if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
     if (d->Cout != 128 || d->Cout_pad != 128 || d->cin_off != 0 || d->src.ctot != d->Cin || d->bias != nullptr || d->stats != nullptr || d->accumulate || d->out_act) return 0;

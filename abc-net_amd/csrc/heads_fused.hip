@@ -610,7 +610,7 @@ extern "C" int abc_heads_fused_fwd_bwd(const abc_heads_fused_desc* d, abc_stream
     k.t_btypes = d->t_btypes; k.t_rho = d->t_rho; k.t_omega = d->t_omega;
     k.bnpart = d->bn_partial; k.losspart = d->loss_partial; k.dwsmall = d->wgrad_work;
     k.HW = d->h * d->w; k.nchunk = abc_heads_fused_chunks(d);
-    { const char* e = ABC_DBG(getenv("ABC_HF_DBG")); k.dbg = e ? atoi(e) : 0; }   // (debug build only: phase ablations)
+    { const char* e = abc_knob("ABC_HF_DBG"); k.dbg = e ? atoi(e) : 0; }   // (debug build only: phase ablations)
     size_t row0 = 0;
     for (int i = 0; i < HF_NH; ++i) {
         const int cpad = hf_tiles(i) * 32;

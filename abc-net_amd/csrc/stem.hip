@@ -133,7 +133,7 @@ constexpr int STEM_ROWS = 8;
 
 // 1 when the one-channel kernel takes this descriptor; *stat_blocks = statistics partials it writes
 int abc_conv_stem_ok(const abc_conv_desc* d, int* stat_blocks) {
-    if (getenv("ABC_CONV_NOSTEM")) return 0;
+    if (abc_knob("ABC_CONV_NOSTEM")) return 0;
     if (d->Cin != 1 || d->cin_off != 0 || d->src.ldx != 1 || d->dtype_in != ABC_F32 || d->src.scale || d->src.pool || d->src.planar ||
         d->src.drop_p > 0.f)
         return 0;

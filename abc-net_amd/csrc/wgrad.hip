@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void head_wgrad_batch_kernel(const HeadWgBa
 __global__ __launch_bounds__(512, 2) void head_wgrad_blocked_kernel(const HeadWgBatch bt) { head_wgrad_body<true>(bt.k[blockIdx.z]); }
 
 static bool head_ok(const abc_wgrad_desc* d) {
-    if (getenv("ABC_WGRAD_NOHEAD")) return false;
+    if (abc_knob("ABC_WGRAD_NOHEAD")) return false;
     if (!d->p.planar || d->dtype_p != ABC_F32 || d->dtype_q != ABC_BF16 || d->dtype_c != ABC_BF16) return false;
     if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->Cb != 128 || d->cp_off != 0) return false;
     if (d->q.pool || d->q.planar || d->p.pool || d->p.drop_p > 0.f || (d->Hg * d->Wg) % 128) return false;
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
 }
 
 static bool c1_ok(const abc_wgrad_desc* d) {
-    if (getenv("ABC_WGRAD_NOC1")) return false;
+    if (abc_knob("ABC_WGRAD_NOC1")) return false;
     if (d->Cb != 1 || d->cq_off != 0 || d->q.ldx != 1 || d->dtype_q != ABC_F32 || d->q.scale || d->q.pool || d->q.planar || d->q.drop_p > 0.f) return false;
     // (a transform on P only as the BatchNorm-backward correction of abc_wgrad_desc.p_dual: bf16)
     // (9 taps only: the 25-tap form measured 332 us fused against 157 + 113 us with the separate apply pass)
@@ -1000,7 +1000,7 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     const int ta = abc_cdiv(d->Ca, 32), tb = abc_cdiv(d->Cb, 32);
     // 32x32 tile pairs per workgroup (one pair per wave, the remaining waves split the patch rows).  Ragged channel
     // tails are fine (zero-filled): wide tiles are what keeps the operands from being re-staged per pair.
-    static const bool no42 = getenv("ABC_WGRAD_NO42") != nullptr;  // (experiment switch)
+    static const bool no42 = abc_knob("ABC_WGRAD_NO42") != nullptr;  // (experiment switch)
     if (!no42 && d->stride == 1 && csz == 2 && ta >= 3 && tb >= 2) { g->AT = 4; g->BT = 2; }
     else if (d->stride == 1 && ta >= 2 && tb >= 2) { g->AT = 2; g->BT = 2; }
     else if (d->stride == 1 && csz == 2 && ta == 1 && tb >= 4) { g->AT = 1; g->BT = 4; }
@@ -1009,7 +1009,7 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     // 4 K-steps per wave between barriers instead of 1
     g->ts = 0; g->nw = 8;
     // (experiment, ABC_WGRAD_NW4=1) wide bf16 3x3 layers as 4-wave workgroups on 2 x 2 tile pairs, two per CU
-    static const bool nw4 = getenv("ABC_WGRAD_NW4") != nullptr;
+    static const bool nw4 = abc_knob("ABC_WGRAD_NW4") != nullptr;
     if (nw4 && g->AT == 4 && g->BT == 2 && d->ntaps == 9 && d->dtype_p == ABC_BF16 && d->dtype_q == ABC_BF16) {
         g->AT = 2; g->BT = 2;
         int rc = wgeom_pm(d, g, 1);
@@ -1030,7 +1030,7 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
         if (rc == ABC_OK && g->fast_p && g->fast_q) return ABC_OK;
     }
     // more than 9 taps on one tile pair (5x5): split the taps over the waves, one pass over the operands
-    static const bool nots = getenv("ABC_WGRAD_NOTS") != nullptr;  // (experiment switch)
+    static const bool nots = abc_knob("ABC_WGRAD_NOTS") != nullptr;  // (experiment switch)
     if (!nots && g->AT == 1 && g->BT == 1 && d->stride == 1 && csz == 2 && d->ntaps > MAXT_FAST && d->ntaps <= 32 &&
         d->dtype_p == ABC_BF16 && d->dtype_q == ABC_BF16) {
         for (int pm = (d->Hg % 16 == 0) ? 2 : 1; pm >= 1; --pm) {
@@ -1332,7 +1332,7 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
         if (d->tap_dy[t] - g.dy_min != t / 3 || d->tap_dx[t] - g.dx_min != t % 3) k.k3 = 0;
     k.bytesP = (unsigned)((int64_t)d->B * d->p.Hx * d->p.Wx * d->p.ldx * (d->dtype_p == ABC_BF16 ? 2 : 4));
     k.bytesQ = (unsigned)((int64_t)d->B * d->q.Hx * d->q.Wx * d->q.ldx * (d->dtype_q == ABC_BF16 ? 2 : 4));
-    { const char* e = getenv("ABC_WGRAD_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
+    { const char* e = abc_knob("ABC_WGRAD_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min); k.tx[t] = (int8_t)(d->tap_dx[t] - g.dx_min); }
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype_c == ABC_F32) {
@@ -1366,7 +1366,7 @@ extern "C" int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t str
         hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((int)n), dim3(64), 0, (hipStream_t)stream, *d);
         return abc_check_launch("wgrad_reduce");
     }
-    static const bool scalar_only = getenv("ABC_WGRAD_REDUCE_SCALAR") != nullptr;   // (A/B runs)
+    static const bool scalar_only = abc_knob("ABC_WGRAD_REDUCE_SCALAR") != nullptr;   // (A/B runs)
     if (!scalar_only && d->Cb % 4 == 0 && d->Cb_pad % 4 == 0 && ((uintptr_t)d->partial & 15) == 0 && d->nsplit >= 16 && n >= 16384) {
         hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((int)((n / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, *d);
         return abc_check_launch("wgrad_reduce");

@@ -151,13 +151,48 @@ def plan_buckets(ready, sizes, bucket_elems):
     return buckets
 
 
-class GradReducer:
-    """bucketed all-reduce(SUM) of a flat gradient tensor; the 1/world factor is folded into the loss
-    (abc_loss_finalize grad_scale), so no separate scaling pass over the gradients is needed."""
+def align_buckets(buckets, sizes, ready, align, padded_total):
+    """Move the bucket boundaries of plan_buckets() up to multiples of `align` elements (the last one to `padded_total`, the
+    size of the padded gradient store), so that every bucket splits evenly over the ranks of a reduce-scatter.  A boundary
+    need not coincide with a tensor boundary: a bucket is complete once every tensor it OVERLAPS is (ready = their max)."""
+    n = len(sizes)
+    offs = [0] * (n + 1)
+    for i, s in enumerate(sizes):
+        offs[i + 1] = offs[i] + s
+    cuts = sorted(set(-(-lo // align) * align for lo, _hi, _r in buckets if lo > 0))
+    cuts = [0] + [c for c in cuts if 0 < c < padded_total] + [padded_total]
+    out = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        rd = [ready[i] for i in range(n) if offs[i] < hi and offs[i + 1] > lo]
+        out.append((lo, hi, max(rd) if rd else -1))
+    out.sort(key=lambda b: b[2])
+    return out
 
-    def __init__(self, flat_grad, buckets, group=None):
+
+class GradReducer:
+    """Bucketed SUM over the ranks of a flat gradient tensor; the 1/world factor is folded into the loss (abc_loss_finalize
+    grad_scale), so no separate scaling pass touches the gradients.  Exchange of one bucket, `mode`:
+
+      "rs_ag"      reduce_scatter_tensor + all_gather_into_tensor, both in place on the arena (every rank reduces 1/world
+                   of the bucket).  Buckets must split evenly: align_buckets().
+      "direct"     all_to_all_single (rank r receives everybody's r-th shard: world-1 concurrent point-to-point transfers,
+                   one per xGMI link) + a local fixed-order sum + all_gather_into_tensor -- no ring at all
+      "all_reduce" one all_reduce per bucket (RCCL picks the algorithm) -- the plain alternative and the fallback
+
+    Whatever the mode, every rank ends with bit-identical sums (each shard is reduced by ONE rank, then copied).  The chosen
+    mode is self-checked once against all_reduce on a small tensor at construction (a collective: all ranks construct the
+    reducer together, as they construct the Trainer); a mode the backend does not serve falls back to "all_reduce"."""
+
+    MODES = ("rs_ag", "direct", "all_reduce")
+
+    def __init__(self, flat_grad, buckets, group=None, mode="rs_ag", force=False):
+        """force: run the exchange although the group has ONE rank (a sum over one rank: the identity) -- the RCCL launch
+        mechanics between the hipGraph segments on a one-GPU box (tests/rccl_world1_worker.py)"""
+        if mode not in self.MODES:
+            raise ValueError("GradReducer mode %r" % (mode,))
         self.g, self.buckets, self.group = flat_grad, buckets, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.cuda = flat_grad.is_cuda
         self.dev = flat_grad.device
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
@@ -165,9 +200,54 @@ class GradReducer:
         self.by_ready = {}
         for b in buckets:
             self.by_ready.setdefault(b[2], []).append(b)
+        self.mode = "all_reduce"
+        self.fallback_reason = None
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
+        if self.active and mode != "all_reduce":
+            if any((hi - lo) % self.world for lo, hi, _ in buckets):
+                self.fallback_reason = "bucket sizes do not divide by the world size"
+            else:
+                self._stage = None
+                if mode == "direct":
+                    self._stage = torch.empty(max(hi - lo for lo, hi, _ in buckets), dtype=flat_grad.dtype, device=self.dev)
+                self.mode = mode
+                self.fallback_reason = self._self_check()
+                if self.fallback_reason is not None:
+                    self.mode = "all_reduce"
+
+    # -- one bucket, synchronous on the current (communication) stream / thread
+    def _exchange(self, view, mode, stage=None):
+        w, r = self.world, self.rank
+        if mode == "all_reduce":
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        n = view.numel() // w
+        shard = view[r * n:(r + 1) * n]
+        if mode == "rs_ag":
+            dist.reduce_scatter_tensor(shard, view, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            recv = stage[:w * n]
+            dist.all_to_all_single(recv, view, group=self.group)
+            torch.sum(recv.view(w, n), dim=0, out=shard)       # rows in rank order on every rank: a fixed summation order
+        dist.all_gather_into_tensor(view, shard, group=self.group)
+
+    def _self_check(self):
+        """the chosen mode against all_reduce on 64 x world elements; returns None or the reason for falling back"""
+        w = self.world
+        try:
+            t = (torch.arange(64 * w, dtype=self.g.dtype, device=self.dev) % 7 + 1) * (self.rank + 1)
+            want = t.clone()
+            dist.all_reduce(want, op=dist.ReduceOp.SUM, group=self.group)
+            stage = torch.empty_like(t) if self.mode == "direct" else None
+            self._exchange(t, self.mode, stage)
+            ok = torch.tensor([1.0 if torch.equal(t, want) else 0.0], dtype=torch.float32, device=self.dev)
+        except (RuntimeError, NotImplementedError, ValueError) as e:  # the backend does not serve it: all ranks fail alike
+            return "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:120])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        return None if ok.item() == 1.0 else "self-check against all_reduce failed"
 
     def bucket_ready(self, lo, hi):
-        if self.world == 1:
+        if not self.active:
             return
         view = self.g[lo:hi]
         if self.cuda:
@@ -175,16 +255,18 @@ class GradReducer:
             ev.record(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-        else:
+                self._exchange(view, self.mode, self._stage if self.mode == "direct" else None)
+        elif self.mode == "all_reduce":
             self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._exchange(view, self.mode, self._stage if self.mode == "direct" else None)
 
     def after_op(self, op_index):
         for lo, hi, _ in self.by_ready.get(op_index, ()):
             self.bucket_ready(lo, hi)
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         if self.cuda:
             torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)

@@ -14,7 +14,6 @@ PyTorch is used here only to own device memory and the stream.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
@@ -107,7 +106,9 @@ class Rec:
 
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
-                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False):
+                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True):
+        """batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
+        batched one is tested against, tests/test_gpu_model.py::test_batched_heads_equal_one_by_one_launches)"""
         if variant not in ("unet", "unet2"):
             raise NotImplementedError("variant %r" % variant)
         if H < 32 or W < 32:
@@ -131,9 +132,10 @@ class Engine:
         # the fused train step's heads (csrc/heads_fused.hip): conv2 forward + loss + the way back to the BatchNorm outputs as
         # one pass.  Needs the loss in the plan (so: the Trainer asks for it; a module-style forward() cannot use it), bf16,
         # the reference's eight heads and whole 128-pixel chunks; settled in _build_heads
-        self.want_fused_heads = bool(fused_heads) and train and dtype == "bf16" and not os.environ.get("ABC_NO_HEADS_FUSED") \
-            and not os.environ.get("ABC_NO_HEADS_BATCH") and not os.environ.get("ABC_NO_HEAD_FUSE")
+        self.batched_heads = bool(batched_heads)
+        self.want_fused_heads = bool(fused_heads) and train and dtype == "bf16" and self.batched_heads
         self.hf = None
+        self.side_mode = ""
         self.dev = device
         self.params, self.grads, self.buffers, self.counters = params, grads, buffers, counters
         self.lay_p, self.lay_b, self.lay_c = layout
@@ -265,8 +267,7 @@ class Engine:
         """the heads' 1x1 convolutions collected by emit_conv(collect=...) as ONE launch (abc_heads_batch) when every one of
         them is served by the dedicated heads kernel (which = 0 forward / 1 data gradient), else one launch each"""
         want = 3 if which == 0 else 4
-        ok = 1 <= len(items) <= 8 and all(self.lib.abc_conv_variant(C.byref(d)) == want for d, _w, _m in items) \
-            and not os.environ.get("ABC_NO_HEADS_BATCH")
+        ok = 1 <= len(items) <= 8 and all(self.lib.abc_conv_variant(C.byref(d)) == want for d, _w, _m in items) and self.batched_heads
         if not ok:
             for d, w, m in items:
                 self._emit(ops, self.lib.abc_conv_fwd, d, w, meta=m)
@@ -367,7 +368,7 @@ class Engine:
             at_, bt_ = L.i32(), L.i32()
             L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
             return at_.value, bt_.value
-        ok = 1 <= len(items) <= 8 and all(tile(it["d"]) == (0, 0) for it in items) and not os.environ.get("ABC_NO_HEADS_BATCH")
+        ok = 1 <= len(items) <= 8 and all(tile(it["d"]) == (0, 0) for it in items) and self.batched_heads
         if ok:
             arr = (L.WgradDesc * len(items))()
             for i, it in enumerate(items):
@@ -505,9 +506,11 @@ class Engine:
     def _stem_fused_double_conv(self, prefix, img: Src, cout):
         """folded inference graph, one input channel: DoubleConv's first convolution (+ BatchNorm + ReLU, unet.py:12-14) is
         computed inside the halo staging of its second one (abc_conv_desc.stem_*): the full-resolution 16-channel tensor
-        between them is never written"""
+        between them is never written.  Returns None (and leaves the plan untouched) when the narrow-level kernel does not
+        serve the descriptor (e.g. B*H*W*16*2 bytes >= 2^31): the caller then emits the ordinary folded DoubleConv"""
         H, W = img.H, img.W
         p = prefix + ".double_conv"
+        undo = [(lst, len(lst)) for lst in (self.pack_ops, self._pack_descs, self.fwd_ops, self.recs)]
         fs0, fb0 = self.new((cout,), torch.float32, 1.0), self.new((cout,), torch.float32)
         self._fold_coeffs(p + ".0", p + ".1", cout, fs0, fb0)
         tb, cb = self.act_buf(H, W, cout)
@@ -517,7 +520,9 @@ class Engine:
         d.stem_x, d.stem_w = self.img.data_ptr(), self.P(p + ".0.weight")
         d.stem_scale, d.stem_bias, d.stem_slope = fs0.data_ptr(), fb0.data_ptr(), 0.0
         if self.lib.abc_conv_variant(C.byref(d)) != 5:
-            raise RuntimeError("stem fusion: the narrow-level kernel refused the descriptor")
+            for lst, n in undo:
+                del lst[n:]
+            return None
         return b
 
     def pooled(self, s: Src):
@@ -525,14 +530,12 @@ class Engine:
         weight gradient (and, in unet2, the block's residual branch) read a plain tensor on their prefetch paths; the
         gradient still routes to the producer as a pooled one (via_pool).  (unet2 pooled on load at first: its first
         conv of every level and that conv's weight gradient then ran on the general loaders -- 0.37 ms for down1 alone.)"""
-        if os.environ.get("ABC_UNET2_POOL_ON_LOAD") and self.variant != "unet":
-            return Src(s.t, s.dt, s.H, s.W, s.ld, s.coff, s.C, coef=s.coef, pool=True, producer=s.producer)
         Ho, Wo = s.H // 2, s.W // 2
         out = self.new((self.B, Ho, Wo, s.C))
         # folded inference graph: a producer on the narrow-level kernel writes the pooled tensor as a second output
         # (abc_conv_desc.pool_y) -- no separate pass over the full-resolution tensor
         d = getattr(s.producer, "fold_desc", None) if self.fold else None
-        if d is not None and s.coef is None and s.C % 8 == 0 and not os.environ.get("ABC_NO_POOL_FUSE") \
+        if d is not None and s.coef is None and s.C % 8 == 0 \
                 and self.lib.abc_conv_variant(C.byref(d)) == 5 and d.y == s.t.data_ptr() and d.cout_off == s.coff and d.Cout == s.C:
             d.pool_y, d.ld_pool = out.data_ptr(), s.C
             r = Src(out, self.dt, Ho, Wo, s.C, 0, s.C, coef=None, pool=False, producer=s.producer)
@@ -607,9 +610,10 @@ class Engine:
             lib, sp = self.lib, self.drop_salt.data_ptr()
             self.fwd_ops.append((lambda _r, st: lib.abc_counter_add_u32(sp, DROP_STEP, st), None, "dropout step", (),
                                  {"kernel": "counter_add", "flops": 0, "bytes": 0}))
-        if self.fold and self.dt == L.BF16 and self.in_channels == 1 and not os.environ.get("ABC_NO_STEM_FUSE"):
+        x = None
+        if self.fold and self.dt == L.BF16 and self.in_channels == 1:
             x = self._stem_fused_double_conv("inc1", img_src, 16)
-        else:
+        if x is None:
             x = self.double_conv("inc1", img_src, 16, 3)
         x1 = self.double_conv("inc2", x, 16, 3)
         x2 = self.double_conv("down1.maxpool_conv.1", self.pooled(x1), 32, 3)
@@ -668,12 +672,12 @@ class Engine:
         head_convs, head_fins = [], []
         # batch statistics of the eight heads' BatchNorms side by side (one act_bwd pass over all 8 x 128 channels)
         self.hmean, self.hinvstd = self.new((128 * nh,), torch.float32), self.new((128 * nh,), torch.float32, 1.0)
-        batch_fin = nh <= 8 and not os.environ.get("ABC_NO_HEADS_BATCH")
+        batch_fin = nh <= 8 and self.batched_heads
         # the eight conv1's (unet.py:66,116-118: the same 128-channel trunk into 8 x 128 channels) as ONE 128 -> 8 x 128
         # convolution: the input halo tile is shared by the 8 n-blocks of a pixel tile (same XCD, its L2), and 8 x 768 tiles
         # fill the 512 workgroup slots 12.0 times instead of 8 x 1.5
         shared = None
-        if batch_fin and self.dt == L.BF16 and trunk.C == 128 and not os.environ.get("ABC_NO_HEADS_CONV1_MERGE"):
+        if batch_fin and self.dt == L.BF16 and trunk.C == 128:
             shared = self._heads_conv1_merged(trunk, h, w)
         fused = self.want_fused_heads and shared is not None and self.heads == [1, 14, 3, 2, 1, 360, 60, 60] and (h * w) % 128 == 0 \
             and self.B * h * w * 128 * nh < (1 << 30)
@@ -733,7 +737,7 @@ class Engine:
         d.w2_pack, d.dl, d.g = self.hf_pack.data_ptr(), self.hf_dl.data_ptr(), self.hf_g.data_ptr()
         d.bn_partial, d.loss_partial = self.hf_bnpart.data_ptr(), self.hf_losspart.data_ptr()
         d.chan_scale, d.wgrad_work = self.chan_scale.data_ptr(), self.hf_work.data_ptr()
-        if self.drop_p > 0 and not os.environ.get("ABC_HF_NO_KEEPMASK"):
+        if self.drop_p > 0:
             # the dropout keep bits of the three wide heads' features, from the fused pass to its conv2 weight gradient
             self.hf_keep = self.new((3 * B * h * w * 16,), torch.uint8, 0)
             d.keep_mask = self.hf_keep.data_ptr()
@@ -903,7 +907,7 @@ class Engine:
         units = [-(-(-(-hc // 32)) // 4) for hc in self.heads]
         cost = [4.0 + 5.2 * (hc / u) / 128.0 for hc, u in zip(self.heads, units)]
         tot = sum(u * c for u, c in zip(units, cost))
-        head_splits = [max(1, int(256 * c / tot)) for c in cost] if not os.environ.get("ABC_NO_HEADS_BATCH") else [None] * nh
+        head_splits = [max(1, int(256 * c / tot)) for c in cost] if self.batched_heads else [None] * nh
         for r2 in self.head2:
             i, hc = r2.idx, r2.cout
             cs = self.chan_scale[self.head_off[i]:self.head_off[i] + hc]
@@ -927,10 +931,9 @@ class Engine:
         dyh = self.new((B, h, w, 128 * nh))
         wd_all = self.packed(9, 128 * nh, 128)
         merged = None
-        if self.dt == L.BF16 and not os.environ.get("ABC_NO_HEAD_FUSE") and not os.environ.get("ABC_NO_HEADS_BATCH") and nh <= 8:
+        if self.dt == L.BF16 and self.batched_heads and nh <= 8:
             merged = self._heads_act_bwd_merged(ops, dfeat)
-        one_wgrad = merged is not None and not os.environ.get("ABC_NO_HEADS_WGRAD_MERGE") and \
-            self._heads_conv1_wgrad_merged(ops, merged, dyh, taps)
+        one_wgrad = merged is not None and self._heads_conv1_wgrad_merged(ops, merged, dyh, taps)
         for i, rec in enumerate(self.head_recs):
             drop = (self.drop_p, self.drop_seed) if self.drop_p > 0 else None
             if one_wgrad:
@@ -940,7 +943,7 @@ class Engine:
                                      dual=(rec.y, rec.ld, rec.coff, dyh.data_ptr() + 128 * i * dyh.element_size(), 128 * nh))
                 if not ok:
                     raise RuntimeError("fused BN-backward apply was refused for " + rec.cname)
-            elif self.dt == L.BF16 and not os.environ.get("ABC_NO_HEAD_FUSE"):
+            elif self.dt == L.BF16:
                 # bf16: the weight-gradient kernel applies the BN-backward correction on load and writes dY into this
                 # head's channel slice of dyh (no separate apply pass)
                 gsrc, _apply = self._bn_backward(ops, rec, (dfeat, 128 * nh, 128 * i), None, drop=drop, defer=True)
@@ -1320,7 +1323,7 @@ class Engine:
             rec2, rec1 = blk.rec2, blk.rec1
             # (the BN-backward apply fused into the weight gradient's load, as unet does: neutral in round 1 -- bn_apply -0.27 ms,
             #  dual weight gradients +0.33 ms -- +0.9 % since the weight-gradient kernel's prefetch got cheaper: 1231 -> 1242 img/s)
-            defer2 = not os.environ.get("ABC_UNET2_NO_DEFER")
+            defer2 = True
             dY2 = self._bn_finish(ops, rec2, part3, nb3, dz, defer=defer2)
             dA1 = self._conv_backward(ops, rec2, dY2)
             rec1.grad_same = (dA1, rec1.cout, 0)
@@ -1394,8 +1397,8 @@ class Engine:
         overlap with the following layers' kernels; the two slab workspaces are fenced with events, and everything
         is joined before returning (so graph capture sees a closed fork/join and all-reduce buckets are complete)."""
         # measured on MI355X: the fork/join dependencies cost more than the overlap gains (1733 vs 1823 img/s inside the
-        # hipGraph), so the second stream is opt-in (ABC_SIDE_STREAM=1) and the default is one stream
-        mode = os.environ.get("ABC_SIDE_STREAM", "")
+        # hipGraph), so the second stream is off (Engine.side_mode = "" -- "1": every op marked side, "2": the big ones)
+        mode = self.side_mode
         want = (lambda m: m.get("side") == "big") if mode == "2" else (lambda m: bool(m.get("side")))
         use_side = bool(mode) and any(want(m) for _f, _r, _w, _x, m in ops)
         if use_side:

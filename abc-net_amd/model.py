@@ -36,6 +36,9 @@ from . import arch
 from .engine import Engine
 
 
+GRAD_STORE_ALIGN = 840 * 128   # lcm(1..8) x 128 elements
+
+
 def _kaiming_uniform_(t, fan_in, gen=None):
     b = 1.0 / (fan_in ** 0.5)  # kaiming_uniform(a=sqrt(5)) bound == 1/sqrt(fan_in), torch default for conv/linear
     with torch.no_grad():
@@ -78,6 +81,24 @@ class _UNetFn(torch.autograd.Function):
         return (None, None) + tuple(g[off:off + cnt].view(shape) for off, cnt, shape in model._param_slices)
 
 
+def _rebuild_unet(cls, in_channels, heads, dtype, dropout_p, flat, buf, counters, device, training, seed_base, req_grad):
+    """unpickle / deep-copy: a fresh module tree over fresh arenas (the named tensors must stay views of ONE arena; a
+    tensor-by-tensor copy, which is what nn.Module's default pickling and nn.Parameter.__deepcopy__ do, would detach them
+    from the arena the engines, Adam and the all-reduce work on)"""
+    m = cls(in_channels, list(heads), dtype=dtype, dropout_p=dropout_p)
+    with torch.no_grad():
+        m._flat.copy_(flat)
+        m._flat_buf.copy_(buf)
+        m._counters.copy_(counters)
+    m.dropout_seed_base = m.dropout_seed = seed_base
+    for p, r in zip(m.parameters(), req_grad):
+        p.requires_grad_(r)
+    if torch.device(device).type != "cpu":
+        m = m.to(device)
+    m.train(training)
+    return m
+
+
 class _Node(nn.Module):
     """a container of the reference's module tree (DoubleConv, Sequential, Conv2d, BatchNorm2d, ... by position): it only
     holds the reference-named parameters and buffers, which are views into the model's flat arenas"""
@@ -104,6 +125,7 @@ class UNetBase(nn.Module):
         self._flat_buf = torch.zeros(self._nb)
         self._counters = torch.zeros(len(self._lay_c), dtype=torch.int64)
         self._flat_grad = None
+        self._grad_store = None
         self._engines = {}
         self._leaves = []          # (name, holder module, attribute, role)
         self._param_slices = []    # (offset, numel, shape) in parameters() order
@@ -125,6 +147,21 @@ class UNetBase(nn.Module):
                 mod.register_buffer(attr, v)
             self._leaves.append((name, mod, attr, role))
         self.reset_parameters()
+
+    # ------------------------------------------------------------------ copies
+    def __reduce__(self):
+        """torch.save(model) / pickle / copy.deepcopy: the three arenas + the constructor arguments (engines, graphs and
+        the gradient arena are rebuilt on demand)"""
+        return (_rebuild_unet, (type(self), self.n_channels, list(self.heads), self.compute_dtype, self.dropout_p,
+                                self._flat.detach().cpu().clone(), self._flat_buf.detach().cpu().clone(), self._counters.cpu().clone(),
+                                str(self._flat.device), self.training, self.dropout_seed_base,
+                                [p.requires_grad for p in self.parameters()]))
+
+    def __deepcopy__(self, memo):
+        fn, args = self.__reduce__()
+        new = fn(*args)
+        memo[id(self)] = new
+        return new
 
     # ------------------------------------------------------------------ parameters
     def _shape_role(self, name):
@@ -230,7 +267,7 @@ class UNetBase(nn.Module):
         return super().load_state_dict(state_dict, strict=strict)
 
     # ------------------------------------------------------------------ engines
-    def _engine_for(self, x, train, fold_bn=False, fused_heads=False):
+    def _engine_for(self, x, train, fold_bn=False, fused_heads=False, batched_heads=True):
         if not x.is_cuda:
             raise L.AbcNetHipError("abcnet_amd runs on an MI355X only (got a %s tensor); there is no CPU fallback" % x.device)
         if x.device != self._flat.device:
@@ -241,16 +278,20 @@ class UNetBase(nn.Module):
         B, Cc, H, W = x.shape
         if Cc != self.n_channels:
             raise ValueError("expected %d input channels, got %d" % (self.n_channels, Cc))
-        key = (B, H, W, bool(train), self.compute_dtype, self.dropout_seed, bool(fold_bn), bool(fused_heads))
+        key = (B, H, W, bool(train), self.compute_dtype, self.dropout_seed, bool(fold_bn), bool(fused_heads), bool(batched_heads))
         eng = self._engines.get(key)
         if eng is None or eng.params.data_ptr() != self._flat.data_ptr():
             if self._flat_grad is None or self._flat_grad.device != x.device:
-                self._flat_grad = torch.zeros_like(self._flat)
+                # the gradient arena sits in a store padded to a multiple of 840 x 128 elements, so that a data-parallel
+                # reduce-scatter can cut it into buckets that split evenly over any world size up to 8 (distributed.py)
+                pad = -(-self._np // GRAD_STORE_ALIGN) * GRAD_STORE_ALIGN
+                self._grad_store = torch.zeros(pad, dtype=torch.float32, device=x.device)
+                self._flat_grad = self._grad_store[:self._np]
             with torch.cuda.device(x.device):
                 eng = Engine(self.VARIANT, self.n_channels, self.heads, self._flat, self._flat_grad, self._flat_buf,
                              self._counters, (self._lay_p, self._lay_b, self._lay_c), B, H, W, self.compute_dtype, train,
                              dropout_p=self.dropout_p, device=x.device, drop_seed=self.dropout_seed, fold_bn=fold_bn,
-                             fused_heads=fused_heads)
+                             fused_heads=fused_heads, batched_heads=batched_heads)
             self._engines[key] = eng
         return eng
 

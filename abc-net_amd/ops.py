@@ -52,6 +52,10 @@ class FusedLoss:
         L.check(self.lib.abc_loss_fwd_bwd(C.byref(self.d), stream), "loss_fwd_bwd")
         L.check(self.lib.abc_loss_finalize(C.byref(self.f), stream), "loss_finalize")
 
+    def total_device(self):
+        """the total loss of the last step as a 0-d f64 DEVICE tensor (a view of the finaliser's output: no host sync)"""
+        return self.out[0]
+
     def result(self):
         """dict: total + weighted terms + raw terms (device sync)"""
         o = self.out.cpu()

@@ -20,13 +20,19 @@ from .ops import FusedAdam, FusedHeadsLoss, FusedLoss, FusedMetrics
 
 class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
-                 process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True, keep_logits=True):
+                 process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True, keep_logits=True,
+                 batched_heads=True, exchange="rs_ag", force_exchange=False):
         """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
         mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
         as DDP does; "lazy" (default): right before they are read (state_dict(), sync_buffers()), which is observably the
         same because train-mode arithmetic never reads them; False: never (each rank keeps its own shard's statistics).
         keep_logits=False (fused heads only, ignored with metrics=True): the eight output maps are not stored by the step
-        (`eng.logits` is stale) -- the loss and every gradient are unchanged."""
+        (`eng.logits` is stale) -- the loss and every gradient are unchanged.
+        batched_heads=False: one launch per head (the plain form the batched / merged heads launches are tested against).
+        exchange: how a gradient bucket is summed over the ranks -- "rs_ag" (reduce-scatter + all-gather in place on the
+        arena), "direct" (all-to-all + local sum + all-gather), "all_reduce"; see distributed.GradReducer.
+        force_exchange: segment the plan and run the bucket exchanges although the group has one rank (testing RCCL's launch
+        mechanics between graph segments on a one-GPU box)."""
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("Trainer needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
@@ -50,7 +56,7 @@ class Trainer:
         with torch.cuda.device(dev):
             x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
             # (fused_heads: the heads' 1x1 convolutions, the loss and the way back as one pass where the engine can -- bf16)
-            self.eng = model._engine_for(x0, True, fused_heads=fused_heads)
+            self.eng = model._engine_for(x0, True, fused_heads=fused_heads, batched_heads=batched_heads)
         eng = self.eng
         h, w = eng.h, eng.w
         B = batch
@@ -72,12 +78,26 @@ class Trainer:
         for j, (_fn, _ref, _what, writes, _meta) in enumerate(eng.bwd_ops):
             for n in writes:
                 ready[n] = max(ready[n], j)
-        self.buckets = D.plan_buckets([ready[n] for n in names], sizes, int(bucket_mb * (1 << 20) / 4))
-        self.reducer = D.GradReducer(model._flat_grad, self.buckets, process_group)
+        rd = [ready[n] for n in names]
+        self.buckets = D.plan_buckets(rd, sizes, int(bucket_mb * (1 << 20) / 4))
+        store = getattr(model, "_grad_store", None)
+        align = 128 * self.world
+        self.exchange_on = self.world > 1 or (bool(force_exchange) and dist_on)
+        if self.exchange_on and exchange != "all_reduce" and store is not None and store.numel() % align == 0 \
+                and store.data_ptr() == model._flat_grad.data_ptr():
+            # bucket boundaries on multiples of 128 x world elements of the padded store: every bucket splits evenly
+            self.buckets = D.align_buckets(self.buckets, sizes, rd, align, store.numel())
+            self.reducer = D.GradReducer(store, self.buckets, process_group, mode=exchange, force=force_exchange)
+        else:
+            self.reducer = D.GradReducer(model._flat_grad, self.buckets, process_group, mode="all_reduce", force=force_exchange)
         self.use_graph = use_graph
         self._graphs = None
         self._segments = self._plan_segments()
         self.steps = 0
+        self._buffers_synced_at = 0   # value of self.steps when sync_buffers() last ran (lazy broadcast_buffers)
+        # running mean of the loss over ranks and steps WITHOUT a per-step host sync (multi_gpu_train.py:114-116 calls
+        # barrier() + reduce_mean(loss) + .item() every step): the device accumulates, read_loss_mean() reads every N steps
+        self._loss_acc = torch.zeros(2, dtype=torch.float64, device=dev)   # [sum of totals, count]
 
     # ------------------------------------------------------------------ data
     def load_batch(self, imgs, targets):
@@ -100,7 +120,7 @@ class Trainer:
         pre = [eng.run_pack, eng.run_forward, self.loss.run]
         if self.metrics is not None:
             pre.append(self.metrics.run)
-        cut = sorted(set(b[2] for b in self.buckets)) if self.world > 1 else []
+        cut = sorted(set(b[2] for b in self.buckets)) if self.exchange_on else []
         segs, seg_b = [], []
         cur = list(pre)
         start = 0
@@ -144,10 +164,28 @@ class Trainer:
 
     # ------------------------------------------------------------------ step
     def sync_buffers(self):
-        """rank 0's BatchNorm running statistics / num_batches_tracked to every rank (DDP broadcast_buffers)"""
+        """rank 0's BatchNorm running statistics / num_batches_tracked to every rank (DDP broadcast_buffers).
+        A COLLECTIVE: every rank of the group has to call it."""
         if self.world > 1:
             with torch.cuda.device(self.dev):
                 D.broadcast_buffers(self.model._flat_buf, self.model._counters, group=self.group)
+        self._buffers_synced_at = self.steps
+
+    def accumulate_loss(self):
+        """add this step's total loss to the device-side running sum (one tiny kernel, no host sync, graph-safe)"""
+        self._loss_acc[0] += self.loss.total_device()
+        self._loss_acc[1] += 1
+
+    def read_loss_mean(self, reset=True):
+        """mean of the accumulated step losses over steps AND ranks (multi_gpu_train.py:116's reduce_mean, taken every N
+        steps instead of every step).  A COLLECTIVE when world > 1; one host sync."""
+        acc = self._loss_acc.clone()
+        if self.world > 1:
+            torch.distributed.all_reduce(acc, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        s, n = acc.tolist()
+        if reset:
+            self._loss_acc.zero_()
+        return s / max(n, 1.0)
 
     def step(self):
         """one optimisation step on the batch currently in the static buffers"""
@@ -187,8 +225,13 @@ class Trainer:
         """everything a bit-exact resume needs: the model in the REFERENCE's state_dict layout (loads into
         /root/reference/src/unet.py as is, train.py:435), plus what the reference does not save -- the Adam moments and
         step counter, the learning rate, the dropout step counter and the running meters"""
-        if self.broadcast_buffers:
-            self.sync_buffers()   # every rank's checkpoint holds rank 0's BatchNorm buffers, as under DDP
+        # NO collective in here: the reference saves on one rank only (`if rank == 0: torch.save(...)`,
+        # multi_gpu_train.py:318-319), and rank 0's BatchNorm buffers ARE the ones DDP's broadcast_buffers would have
+        # handed to everybody.  Any other rank holds its own shard's statistics until sync_buffers() -- a collective, to be
+        # called on ALL ranks -- has run since the last step; its checkpoint would silently differ from DDP's, so it raises.
+        if self.broadcast_buffers and self.rank != 0 and self._buffers_synced_at != self.steps:
+            raise RuntimeError("Trainer.state_dict() on rank %d: this rank's BatchNorm buffers are its own shard's (DDP would have "
+                               "broadcast rank 0's).  Save from rank 0 only, or call sync_buffers() on ALL ranks first." % self.rank)
         sd = {"model": {k: v.clone() for k, v in self.model.state_dict().items()},
               "adam_m": self.opt.m.clone(), "adam_v": self.opt.v.clone(), "adam_step": self.opt.step_t.clone(),
               "lr": self.lr, "weight_decay": self.wd, "steps": self.steps, "drop_salt": self.eng.drop_salt.clone(),

@@ -246,13 +246,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
     loss = tr.loss_value()["total"] if a.mode == "train" else float(tr.atom_mask.sum().item())
-    if a.mode == "train" and world > 1:
-        # replicas must hold identical parameters after the averaged updates (cheap: one 8-byte all-gather after the clock stopped)
-        chk = model._flat.double().sum().reshape(1)
-        both = [torch.zeros_like(chk) for _ in range(world)]
-        dist.all_gather(both, chk)
-        if not all(b.item() == both[0].item() for b in both):
-            raise SystemExit("replicas diverged: parameter checksums %s" % [b.item() for b in both])
+    # what makes a multi-GPU line checkable from the line alone: who joined, on which device, over which backend and
+    # exchange, and that the replicas hold identical parameters after the averaged updates (after the clock stopped)
+    chk = model._flat.double().sum().item()
+    me = {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(), "param_checksum": chk}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        if a.mode == "train" and not all(r["param_checksum"] == ranks[0]["param_checksum"] for r in ranks):
+            raise SystemExit("replicas diverged: parameter checksums %s" % [r["param_checksum"] for r in ranks])
+        if backend == "nccl" and len(set(r["device"] for r in ranks)) != world:
+            raise SystemExit("ranks share a GPU: devices %s" % [r["device"] for r in ranks])
 
     if a.mode == "train":
         metric = "training images/sec (%dx%d, b%d/GPU)" % (a.size, a.size, a.batch)
@@ -262,7 +267,10 @@ def main():
         workload = "img2smiles2.py heat-map path on %s.py (eval forward + peak NMS), %dx%d, batch %d/GPU" % (a.variant, a.size, a.size, a.batch)
     out = {
         "metric": metric, "value": round(world * a.batch * a.steps / el, 2), "unit": "images/sec",
-        "n_gpus": world, "ranks_joined": dist.get_world_size() if world > 1 else 1, "backend": backend, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
+        "n_gpus": world, "ranks_joined": dist.get_world_size() if world > 1 else 1, "backend": backend,
+        "rank_devices": [r["device"] for r in ranks], "replica_checksum": ranks[0]["param_checksum"],
+        "exchange": (tr.reducer.mode if (a.mode == "train" and world > 1) else None),
+        "exchange_fallback": (tr.reducer.fallback_reason if (a.mode == "train" and world > 1) else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),

@@ -45,20 +45,38 @@ def main():
     tg = synthetic_targets(batch, size // 4, seed=1 + rank)
     tr.load_batch(x.to(dev), [t.to(dev) for t in tg])
     res = {"rank": rank, "world": world, "backend": dist.get_backend(), "p0": p0.cpu(), "n_buckets": len(tr.buckets),
-           "n_segments": len(tr._segments), "drop_seed": tr.eng.drop_seed}
+           "n_segments": len(tr._segments), "drop_seed": tr.eng.drop_seed,
+           "exchange": tr.reducer.mode, "exchange_fallback": tr.reducer.fallback_reason}
     tr.step()                                        # eager
     torch.cuda.synchronize()
     res["grad_step1"] = model._flat_grad.cpu().clone()      # mean over ranks of the per-rank gradients
     res["loss_step1"] = tr.loss_value()["total"]
     lm = D.reduce_mean(torch.tensor([res["loss_step1"]], dtype=torch.float64, device=dev), world)   # multi_gpu_train.py:116
     res["loss_mean_step1"] = lm.item()
+    # checkpointing the way the reference does it (multi_gpu_train.py:318-319): `if rank == 0: save`, between two steps.
+    # state_dict() must not be a collective (rank 0 alone would hang or mis-pair with the next all-reduce) ...
+    if rank == 0:
+        ck0 = tr.state_dict()
+        res["buffers_ckpt_rank0_alone"] = torch.cat([ck0["model"][k].reshape(-1).float().cpu() for k in ck0["model"] if "running_" in k])
+    else:
+        # ... and on another rank it refuses to hand out that rank's own statistics as if they were DDP's
+        try:
+            tr.state_dict()
+            res["other_rank_refused"] = False
+        except RuntimeError:
+            res["other_rank_refused"] = True
+    tr.accumulate_loss()
     for _ in range(steps - 1):                       # captured: one hipGraph per segment between two all-reduce launches
         tr.step()
+        tr.accumulate_loss()                         # device-side running sum: no host sync per step
     torch.cuda.synchronize()
+    res["loss_mean_async"] = tr.read_loss_mean()     # ONE collective + host sync for all steps (multi_gpu_train.py:114-116)
+    res["loss_last"] = tr.loss_value()["total"]
     res["graphs"] = tr._graphs is not None
     res["params"] = model._flat.cpu().clone()
     res["buffers_own"] = model._flat_buf.cpu().clone()      # this rank's own running statistics (its shard's)
-    ck = tr.state_dict()                             # "lazy": rank 0's buffers arrive here
+    tr.sync_buffers()                                # "lazy": a collective on ALL ranks -- rank 0's buffers arrive here
+    ck = tr.state_dict()
     res["buffers_ckpt"] = torch.cat([ck["model"][k].reshape(-1).float().cpu() for k in ck["model"] if "running_" in k])
     res["nbt_ckpt"] = int(ck["model"]["inc1.double_conv.1.num_batches_tracked"])
     res["adam_m"] = tr.opt.m.cpu().clone()

@@ -173,12 +173,31 @@ def _ddp_worker(rank, world, port, q):
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     want = sum(gathered)
+    # the other exchanges on buckets aligned for an even split over the ranks (the padded gradient store of the model):
+    # reduce-scatter + all-gather in place, all-to-all + local sum + all-gather; each is self-checked against all_reduce at
+    # construction and falls back to it (with the reason) when the backend does not serve it
+    modes = {}
+    tot = sum(sizes)
+    align = 128 * world
+    pad = -(-tot // align) * align
+    ab = D.align_buckets(buckets, sizes, ready, align, pad)
+    for mode in D.GradReducer.MODES:
+        store = torch.zeros(pad)
+        store[:tot] = mine
+        red = D.GradReducer(store, ab, mode=mode)
+        for j in range(0, 80):
+            red.after_op(j)
+        for lo, hi, r in ab:
+            if r < 0:
+                red.bucket_ready(lo, hi)
+        red.finish()
+        modes[mode] = (red.mode, red.fallback_reason, torch.equal(store[:tot], g), bool((store[tot:] == 0).all()))
     # parameters: rank 0 wins (DDP constructor semantics)
     p = torch.full((17,), float(rank))
     D.broadcast_parameters(p)
     # scalar loss for logging (multi_gpu_train.py:116)
     lm = D.reduce_mean(torch.tensor([float(rank + 1)]), world)
-    q.put((rank, torch.allclose(g, want, atol=1e-6), p.sum().item(), lm.item()))
+    q.put((rank, torch.allclose(g, want, atol=1e-6), p.sum().item(), lm.item(), modes, ab, pad))
     dist.destroy_process_group()
 
 
@@ -197,6 +216,58 @@ def test_gloo_world2_bucketed_allreduce_and_broadcast():
     assert all(r[1] for r in res), "bucketed all-reduce != sum over ranks"
     assert all(r[2] == 0.0 for r in res), "rank 0 parameters must win the broadcast"
     assert all(abs(r[3] - 1.5) < 1e-6 for r in res)
+    for r in res:
+        modes, ab, pad = r[4], r[5], r[6]
+        # aligned buckets tile the padded store exactly once, each splits evenly over the ranks, ready order kept
+        cov = sorted((lo, hi) for lo, hi, _ in ab)
+        assert cov[0][0] == 0 and cov[-1][1] == pad and all(cov[i][1] == cov[i + 1][0] for i in range(len(cov) - 1))
+        assert all((hi - lo) % (128 * 2) == 0 for lo, hi, _ in ab) and [x[2] for x in ab] == sorted(x[2] for x in ab)
+        for mode, (used, why, same_as_allreduce, tail_zero) in modes.items():
+            # bit-identical to the all_reduce result (two summands: one rounding whatever the order), padding untouched
+            assert same_as_allreduce and tail_zero, (mode, used, why)
+            assert used == mode or why is not None, (mode, used, why)
+        assert modes["all_reduce"][0] == "all_reduce"
+    print("exchange modes used over gloo:", {m: v[:2] for m, v in res[0][4].items()})
+
+
+def test_align_buckets_ready_is_max_over_overlapped_tensors():
+    sizes = [10, 400, 5, 300, 300, 7, 1000, 50]
+    ready = [-1, 70, 70, 40, 30, 30, 10, 5]
+    b = D.plan_buckets(ready, sizes, 500)
+    ab = D.align_buckets(b, sizes, ready, 256, 2304)
+    offs = [0]
+    for s_ in sizes:
+        offs.append(offs[-1] + s_)
+    for lo, hi, r in ab:
+        assert lo % 256 == 0 and hi % 256 == 0
+        over = [ready[i] for i in range(len(sizes)) if offs[i] < hi and offs[i + 1] > lo]
+        assert r == (max(over) if over else -1)
+
+
+def test_model_deepcopy_and_pickle_keep_the_named_tensors_inside_one_arena():
+    """copy.deepcopy(model) / torch.save(model): nn.Parameter.__deepcopy__ clones tensor by tensor, which would detach the
+    159 named parameters from the arena the engines, Adam and the all-reduce use"""
+    import copy
+    import io
+    from abcnet_amd.unet import UNet
+    m = UNet(1, HEADS)
+    next(iter(m.parameters())).requires_grad_(False)
+    for clone in (copy.deepcopy(m), torch.load(io.BytesIO(_saved(m)), weights_only=False)):
+        assert clone._flat.data_ptr() != m._flat.data_ptr() and torch.equal(clone._flat, m._flat)
+        assert torch.equal(clone._flat_buf, m._flat_buf) and clone.training == m.training
+        for (n, p), (n0, p0) in zip(clone.named_parameters(), m.named_parameters()):
+            off, cnt = clone._lay_p[n]
+            assert n == n0 and p.data_ptr() == clone._flat.data_ptr() + 4 * off and p.requires_grad == p0.requires_grad
+        with torch.no_grad():
+            dict(clone.named_parameters())["inc1.double_conv.0.weight"].add_(1.0)
+        assert not torch.equal(clone._flat, m._flat)        # the named tensor IS the arena
+
+
+def _saved(m):
+    import io
+    b = io.BytesIO()
+    torch.save(m, b)
+    return b.getvalue()
 
 
 _RANK_SCRIPT = """

@@ -69,7 +69,29 @@ def rank_runs(tmp_path_factory):
                                WORLD, timeout=900, env=env, rank0_stdout=sys.stderr)
         assert codes == [0] * WORLD, "%s %s: rank exit codes %s" % (variant, dtype, codes)
         runs[(variant, dtype)] = [torch.load(os.path.join(out, "rank%d.pt" % i), weights_only=False) for i in range(WORLD)]
+    # RCCL itself on this box: ONE rank, backend nccl, the exchange forced on (tests/rccl_world1_worker.py)
+    out = str(tmp_path_factory.mktemp("rccl1") / "res.json")
+    codes = D.launch_ranks([os.path.join(HERE, "rccl_world1_worker.py"), out, "128", "4", "4"], 1, timeout=900, env=dict(os.environ),
+                           rank0_stdout=sys.stderr)
+    assert codes == [0], "rccl world-1 worker: exit codes %s" % codes
+    import json
+    runs["rccl1"] = json.load(open(out))
     return runs, ndev
+
+
+def test_rccl_exchanges_between_graph_segments_are_the_identity_at_world_1(rank_runs):
+    """backend nccl (RCCL), one rank, Trainer(force_exchange=True): every gradient bucket goes through RCCL on the
+    communication stream between hipGraph segments of the backward plan -- as reduce-scatter + all-gather, as all-to-all +
+    sum + all-gather and as all-reduce -- and the parameters after 4 steps equal the plain Trainer's bit for bit"""
+    r = rank_runs[0]["rccl1"]
+    assert r["backend"] == "nccl" and r["plain"]["segments"] == 1
+    for mode in D.GradReducer.MODES:
+        m = r[mode]
+        assert m["segments"] >= 3 and m["buckets"] >= 3 and m["graphs"], (mode, m)
+        assert m["identical_to_plain"], (mode, m)
+        assert m["used"] == mode or m["fallback"] is not None, (mode, m)
+    print("RCCL world-1 exchange modes:", {k: (v.get("used"), v.get("fallback"), round(v["ms_per_step"], 3)) for k, v in r.items() if k != "backend"},
+          file=sys.stderr)
 
 
 @pytest.mark.parametrize("variant,dtype", CASES)
@@ -77,6 +99,8 @@ def test_two_ranks_average_gradients_and_stay_identical(variant, dtype, rank_run
     runs, ndev = rank_runs
     world, size, batch, steps = WORLD, SIZE, BATCH, STEPS
     r = runs[(variant, dtype)]
+    # the default exchange is reduce-scatter + all-gather on the padded arena (or its stated fallback)
+    assert all(x["exchange"] == "rs_ag" or x["exchange_fallback"] for x in r), [(x["exchange"], x["exchange_fallback"]) for x in r]
     assert [x["world"] for x in r] == [world] * world
     assert all(x["backend"] == ("nccl" if ndev >= world else "gloo") for x in r)
     assert r[0]["n_buckets"] >= 3 and r[0]["n_segments"] >= 3 and all(x["graphs"] for x in r)   # several all-reduces inside backward
@@ -107,3 +131,10 @@ def test_two_ranks_average_gradients_and_stay_identical(variant, dtype, rank_run
     assert not torch.equal(r[0]["buffers_own"], r[1]["buffers_own"])
     assert torch.equal(r[0]["buffers_ckpt"], r[1]["buffers_ckpt"])
     assert r[0]["nbt_ckpt"] == r[1]["nbt_ckpt"] == steps
+    # rank 0 saved ALONE between two steps (the reference's `if rank == 0: torch.save`): no collective inside state_dict()
+    # (the run would have hung or mis-paired with the next all-reduce), and the other rank refused to pass its own shard's
+    # statistics off as DDP's before sync_buffers()
+    assert r[0]["buffers_ckpt_rank0_alone"].numel() == r[0]["buffers_ckpt"].numel()
+    assert r[1]["other_rank_refused"] is True
+    # the loss mean over ranks and steps, accumulated on the device and read once: both ranks see the same number
+    assert r[0]["loss_mean_async"] == r[1]["loss_mean_async"] and r[0]["loss_mean_async"] > 0

@@ -534,27 +534,26 @@ def test_dropout_mask_changes_every_step_also_inside_a_graph():
 
 
 @pytest.mark.parametrize("variant", ["unet", "unet2"])
-def test_batched_heads_equal_one_by_one_launches(variant, monkeypatch):
+def test_batched_heads_equal_one_by_one_launches(variant):
     """bf16 throughput mode launches everything of the 8 heads batched (1x1 forward / data gradient / weight gradient,
     the BN -> LeakyReLU -> Dropout backward as one pass over 8 x 128 channels, batched finalisers and slab reductions).
-    The same step with one launch per head (ABC_NO_HEADS_BATCH) must give the same logits bit for bit and the same
+    The same step with one launch per head (Trainer(batched_heads=False)) must give the same logits bit for bit and the same
     gradients up to the f32 summation order of the BatchNorm partial sums."""
     from abcnet_amd.train import Trainer
     B, S = 2, 64
     x, tg = synthetic_images(B, S, seed=7), synthetic_targets(B, S // 4, seed=1)
 
-    def one_step():
+    def one_step(batched):
         m = make_model(dtype="bf16", dropout_p=0.2, variant=variant)
-        tr = Trainer(m, B, S, S, lr=0.0, use_graph=False, fused_heads=False)   # (the fused pass has its own test below)
+        tr = Trainer(m, B, S, S, lr=0.0, use_graph=False, fused_heads=False, batched_heads=batched)   # (the fused pass has its own test below)
         tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
         tr.step()
         torch.cuda.synchronize()
         kinds = set(op[4]["kernel"] for op in tr.eng.fwd_ops + tr.eng.bwd_ops)
         return [t.clone() for t in tr.eng.logits], m._flat_grad.clone(), tr.loss_value()["total"], kinds, dict(m._lay_p)
 
-    lg_b, g_b, loss_b, kinds_b, lay = one_step()
-    monkeypatch.setenv("ABC_NO_HEADS_BATCH", "1")
-    lg_s, g_s, loss_s, kinds_s, _ = one_step()
+    lg_b, g_b, loss_b, kinds_b, lay = one_step(True)
+    lg_s, g_s, loss_s, kinds_s, _ = one_step(False)
     assert "heads_fwd_batch" in kinds_b and "heads_wgrad_batch" in kinds_b and "heads_fwd_batch" not in kinds_s
     for a, b in zip(lg_b, lg_s):
         assert torch.equal(a, b)
