@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libabcnet_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 MAX_TAPS = 49
 
 vp, i32, u32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_float, C.c_double
@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("stride", i32), ("om", i32), ("oy0", i32), ("ox0", i32), ("ntaps", i32),
                 ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("stats_rows", i32), ("accumulate", i32),
                 ("planar_out", i32), ("ctot_out", i32), ("out_act", i32), ("out_slope", f32), ("pool_y", vp), ("ld_pool", i32),
-                ("stem_x", vp), ("stem_w", vp), ("stem_scale", vp), ("stem_bias", vp), ("stem_slope", f32)]
+                ("stem_x", vp), ("stem_w", vp), ("stem_scale", vp), ("stem_bias", vp), ("stem_slope", f32),
+                ("out_scale", vp), ("out_quant", vp)]
 
 
 class PackDesc(C.Structure):
@@ -103,7 +104,7 @@ class CbamChannelDesc(C.Structure):
     _fields_ = [("partial", vp), ("tiles_per_img", i32), ("B", i32), ("C", i32), ("mid", i32), ("HW", f64), ("scale", vp),
                 ("shift", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("ca", vp), ("avgz", vp), ("maxz", vp),
                 ("hid_avg", vp), ("hid_max", vp), ("dw1", vp), ("db1", vp), ("dw2", vp), ("db2", vp), ("d_avgz", vp),
-                ("d_maxz", vp), ("work", vp)]
+                ("d_maxz", vp), ("work", vp), ("ext", vp), ("first", vp)]
 
 
 class CbamPixDesc(C.Structure):
@@ -112,7 +113,7 @@ class CbamPixDesc(C.Structure):
                 ("dst", vp), ("res", vp), ("ld_res", i32), ("cres_off", i32), ("res_pool", i32), ("out", vp), ("ld_out", i32),
                 ("cout_off", i32), ("d_same", vp), ("ld_same", i32), ("csame_off", i32), ("d_pool", vp), ("ld_pool", i32),
                 ("cpool_off", i32), ("g", vp), ("ld_g", i32), ("dz", vp), ("ld_dz", i32), ("partial", vp), ("dtype", i32),
-                ("B", i32), ("H", i32), ("W", i32), ("C", i32)]
+                ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ext", vp), ("first", vp)]
 
 
 class CbamConv7Desc(C.Structure):
@@ -224,6 +225,9 @@ SYMBOLS = {
     "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),
+    "abc_absmax": (C.c_int, [vp, i32, i64, vp, vp]),
+    "abc_fp8_act_scale": (C.c_int, [vp, f32, vp, vp, vp]),
+    "abc_fp8_weight_scales": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp]),
     "abc_concat_f32": (C.c_int, [vp, vp, i32, vp, vp]),
     "abc_counter_add_u32": (C.c_int, [vp, u32, vp]),
     "abc_pool_act": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),

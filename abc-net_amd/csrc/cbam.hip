@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const abc_cbam_c
         const float sc = d.scale[c], sh = d.shift[c];
         d.avgz[(size_t)n * d.C + c] = sc * (float)(s / d.HW) + sh;
         d.maxz[(size_t)n * d.C + c] = (sc >= 0.f ? sc * vmax : sc * vmin) + sh;
+        d.ext[(size_t)n * d.C + c] = sc >= 0.f ? vmax : vmin;
+        d.first[(size_t)n * d.C + c] = 0x7FFFFFFF;
     }
 }
 
@@ -117,13 +119,13 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const abc_cbam_
     const int ppb = 256 / cpp;            // pixels per workgroup pass
     const int sub = threadIdx.x % cpp, pl = threadIdx.x / cpp;
     const T* y = (const T*)d.y;
-    float sc[NVL][N], sh[NVL][N], ca[NVL][N];
+    float sc[NVL][N], sh[NVL][N], ca[NVL][N], ex[NVL][N];
 #pragma unroll
     for (int u = 0; u < NVL; ++u)
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const int c = (sub + u * cpp) * N + j;
-            sc[u][j] = d.scale[c]; sh[u][j] = d.shift[c]; ca[u][j] = d.ca[(size_t)n * d.C + c];
+            sc[u][j] = d.scale[c]; sh[u][j] = d.shift[c]; ca[u][j] = d.ca[(size_t)n * d.C + c]; ex[u][j] = d.ext[(size_t)n * d.C + c];
         }
     for (int q = blockIdx.x * ppb + pl; q < hw; q += gridDim.x * ppb) {
         const int64_t p = (int64_t)n * hw + q;
@@ -139,6 +141,8 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const abc_cbam_
                 const float o1 = ca[u][j] * fmaf(v[j], sc[u][j], sh[u][j]);
                 s += o1;
                 if (o1 > m) { m = o1; am = vi * N + j; }
+                // the global max-pool's arg-max: FIRST pixel holding the extreme value (an integer min: order-independent)
+                if (v[j] == ex[u][j]) atomicMin(d.first + (size_t)n * d.C + vi * N + j, q);
             }
         }
         for (int o = 1; o < cpp; o <<= 1) {
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_ch
 }
 
 // ------------------------------------------------------------------ backward pass 3
-// d_z = d_o1*ca + d_avgz/HW + [z == maxz]*d_maxz ; BN partials (sum d_z, sum d_z*xhat) per workgroup; in place
+// d_z = d_o1*ca + d_avgz/HW + [pixel == arg-max of z]*d_maxz ; BN partials (sum d_z, sum d_z*xhat) per workgroup; in place
 template <typename T>
 __global__ __launch_bounds__(256) void cbam_bwd3_kernel(const abc_cbam_pix_desc d) {
     constexpr int N = V8<T>::N;
@@ -527,13 +531,14 @@ __global__ __launch_bounds__(256) void cbam_bwd3_kernel(const abc_cbam_pix_desc 
     const int ppass = gridDim.x * (256 / ncv);
     const T* y = (const T*)d.y;
     T* dz = (T*)d.dz;
-    float a1[N], a2[N], sc[N], sh[N], mu[N], is[N], ca[N], dav[N], mz[N], dmz[N];
+    float a1[N], a2[N], mu[N], is[N], ca[N], dav[N], dmz[N];
+    int fi[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const size_t nc = (size_t)n * d.C + c + j;
         a1[j] = 0.f; a2[j] = 0.f;
-        sc[j] = d.scale[c + j]; sh[j] = d.shift[c + j]; mu[j] = d.mean[c + j]; is[j] = d.invstd[c + j];
-        ca[j] = d.ca[nc]; dav[j] = d.d_avgz[nc] / (float)hw; mz[j] = d.maxz[nc]; dmz[j] = d.d_maxz[nc];
+        mu[j] = d.mean[c + j]; is[j] = d.invstd[c + j];
+        ca[j] = d.ca[nc]; dav[j] = d.d_avgz[nc] / (float)hw; fi[j] = d.first[nc]; dmz[j] = d.d_maxz[nc];
     }
     for (int q = gt / ncv; q < hw; q += ppass) {
         const int64_t p = (int64_t)n * hw + q;
@@ -542,9 +547,8 @@ __global__ __launch_bounds__(256) void cbam_bwd3_kernel(const abc_cbam_pix_desc 
         ld8<T, N>(y + p * d.ld_y + d.cy_off + c, v);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const float z = fmaf(v[j], sc[j], sh[j]);
             float gz = t[j] * ca[j] + dav[j];
-            if (z == mz[j]) gz += dmz[j];
+            if (q == fi[j]) gz += dmz[j];      // AdaptiveMaxPool2d(1) backward: the first pixel holding the maximum (torch's choice)
             o[j] = gz;
             a1[j] += gz;
             a2[j] += gz * ((v[j] - mu[j]) * is[j]);
@@ -606,6 +610,7 @@ static int check_channel(const abc_cbam_channel_desc* d) {
 extern "C" int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t stream) {
     int rc = check_channel(d);
     if (rc) return rc;
+    if (d->ext == nullptr || d->first == nullptr) return abc_fail(ABC_EINVAL, "cbam_channel_fwd: ext / first (arg-max of the global max-pool) required");
     const size_t sh = (size_t)(2 * d->C + 2 * d->mid) * sizeof(float);
     hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(abc_cdiv(d->C, 64), d->B), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_fwd_kernel, dim3(d->B), dim3(256), sh, (hipStream_t)stream, *d);
@@ -683,6 +688,7 @@ static int group_blocks(const abc_cbam_pix_desc* d) {
 }
 
 extern "C" int abc_cbam_spatial_stats(const abc_cbam_pix_desc* d, abc_stream_t stream) {
+    if (d->ext == nullptr || d->first == nullptr) return abc_fail(ABC_EINVAL, "cbam_spatial_stats: ext / first required");
     ABC_PIXGROUP_LAUNCH(cbam_spatial_stats_kernel, dim3(group_blocks(d), d->B));
     return abc_check_launch("cbam_spatial_stats");
 }
@@ -704,6 +710,7 @@ extern "C" int abc_cbam_bwd2(const abc_cbam_pix_desc* d, abc_stream_t stream) {
 }
 
 extern "C" int abc_cbam_bwd3(const abc_cbam_pix_desc* d, abc_stream_t stream) {
+    if (d->first == nullptr) return abc_fail(ABC_EINVAL, "cbam_bwd3: first (arg-max of the global max-pool) required");
     ABC_PIX_LAUNCH(cbam_bwd3_kernel, dim3(abc_cbam_bwd3_blocks(d) / d->B, d->B));
     return abc_check_launch("cbam_bwd3");
 }

@@ -9,6 +9,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// OCP e4m3fn (gfx950's fp8; max 448, no infinities): the 8-bit activations / weights of the fp8 inference graph
+// (img2smiles2.py:42-59 with BatchNorm folded).  Conversions saturate at +-448.
+struct f8 {
+    uint8_t v;
+    f8() = default;
+    __device__ inline explicit f8(float x) {
+        x = fminf(fmaxf(x, -448.f), 448.f);
+        v = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xFF);
+    }
+    __device__ inline explicit operator float() const { return __builtin_amdgcn_cvt_f32_fp8((int)v, 0); }
+};
 
 // Timing ablations (ABC_*_DBG bit masks that skip phases of a kernel: results invalid) and in-kernel phase timestamps exist
 // only in a debug build (ABC_KERNEL_DEBUG=1 ./build_hip.sh); the production library compiles them out.
@@ -40,6 +54,7 @@ __host__ __device__ inline int abc_cdiv(int a, int b) { return (a + b - 1) / b; 
 template <typename CT> struct Frag;
 template <> struct Frag<float> { typedef f32x4 type; static constexpr int NV = 4; };
 template <> struct Frag<bf16>  { typedef bf16x8 type; static constexpr int NV = 8; };
+template <> struct Frag<f8>    { typedef u32x4 type;  static constexpr int NV = 16; };
 
 // One 16-byte K-slice of a 32x32 MFMA tile: lane-half h of the wave holds the same
 // K-slice of A and of B, so any fixed channel permutation inside a chunk is legal.
@@ -49,6 +64,15 @@ __device__ inline void mma16B(f32x16& acc, f32x4 a, f32x4 b) {
 }
 __device__ inline void mma16B(f32x16& acc, bf16x8 a, bf16x8 b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+// fp8: ONE 32x32x64 MFMA takes a lane's whole 32 bytes of a 64-byte chunk (the two 16-byte halves a0 | a1, b0 | b1: lane half h
+// owns the same 32 k-indices of A and of B).  The block-scaled form with unit scales (E8M0 127 = 2^0): it runs at twice the
+// bf16 rate per clock, the unscaled 32x32x16 fp8 form only at the bf16 rate (MI355X_MICROARCH.md, matrix cores).
+__device__ inline void mma32B_f8(f32x16& acc, u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1) {
+    i32x8 A, B;
+    A[0] = (int)a0[0]; A[1] = (int)a0[1]; A[2] = (int)a0[2]; A[3] = (int)a0[3]; A[4] = (int)a1[0]; A[5] = (int)a1[1]; A[6] = (int)a1[2]; A[7] = (int)a1[3];
+    B[0] = (int)b0[0]; B[1] = (int)b0[1]; B[2] = (int)b0[2]; B[3] = (int)b0[3]; B[4] = (int)b1[0]; B[5] = (int)b1[1]; B[6] = (int)b1[2]; B[7] = (int)b1[3];
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
 // ---------------------------------------------------------------------------
@@ -137,6 +161,16 @@ template <> __device__ inline bf16x8 pack_frag<bf16>(const float* v) {
     bf16x8 r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = (bf16)v[j];
+    return r;
+}
+template <> __device__ inline u32x4 pack_frag<f8>(const float* v) {
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * j], -448.f), 448.f), fminf(fmaxf(v[4 * j + 1], -448.f), 448.f), 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * j + 2], -448.f), 448.f), fminf(fmaxf(v[4 * j + 3], -448.f), 448.f), w, true);
+        r[j] = (unsigned)w;
+    }
     return r;
 }
 
@@ -334,8 +368,6 @@ struct HaloPrefetch {
 //    loop invariants are hoisted instead, they spill, and a scratch reload between two loads waits on vmcnt(0)
 //    -> every load becomes a serial round trip (measured: 44 of 119 us on the 128x128 3x3 weight gradient).
 // Requires: tensor bytes < 2^31 (checked on the host), NHWC, no pool / dropout, whole 16-byte segments.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 __device__ inline __amdgpu_buffer_rsrc_t abc_make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
 }
@@ -349,6 +381,18 @@ template <> struct RawBuf<bf16, 8> {
     __device__ inline void get(float* o) const {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(v[j] << 16); o[2 * j + 1] = __uint_as_float(v[j] & 0xFFFF0000u); }
+    }
+};
+template <> struct RawBuf<f8, 16> {
+    u32x4 v;
+    __device__ inline void ld(__amdgpu_buffer_rsrc_t r, unsigned off) { v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+    __device__ inline void ld2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) { v = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0); }
+    __device__ inline void get(float* o) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[4 * j] = __builtin_amdgcn_cvt_f32_fp8((int)v[j], 0); o[4 * j + 1] = __builtin_amdgcn_cvt_f32_fp8((int)v[j], 1);
+            o[4 * j + 2] = __builtin_amdgcn_cvt_f32_fp8((int)v[j], 2); o[4 * j + 3] = __builtin_amdgcn_cvt_f32_fp8((int)v[j], 3);
+        }
     }
 };
 template <> struct RawBuf<float, 4> {

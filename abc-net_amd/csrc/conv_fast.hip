@@ -479,7 +479,12 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) { const float v = acc[i][j][k] + bv[j]; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
+                        for (int k = 0; k < 16; ++k) {
+                            // (max / min of the values AS STORED, i.e. after the rounding to OutT: CBAM's global max-pool and its backward,
+                            //  unet2.py:10,20, see the tensor -- taken before the rounding, the backward's "is this pixel the maximum"
+                            //  never found it in bf16 and the max branch's gradient was lost)
+                            const float v = (float)(OutT)(acc[i][j][k] + bv[j]); smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v);
+                        }
             }
             // channels past Cout (padding lanes of the last n-block) carry bias-free zeros: keep them out of the sums
 #pragma unroll
@@ -495,7 +500,10 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
                     const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
                     const float v = acc[i][j][k] + bv[j];
-                    if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
+                    if (nval[j] && gy < a.Hg && gx < a.Wg) {
+                        const float vr = (float)(OutT)v;
+                        s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], vr); smn[j] = fminf(smn[j], vr);
+                    }
                     *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)(a.out_act ? fmaxf(v, a.out_slope * v) : v);
                 }
             }

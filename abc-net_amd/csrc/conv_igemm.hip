@@ -278,7 +278,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvK a) {
                     const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
                     const int gy = cur_gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = cur_gx0 + (rit & 15);
                     const float v = acc[i][j][k] + bv[j];
-                    if (nval[j] && gy < a.Hg && gx < a.Wg) { s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v); }
+                    if (nval[j] && gy < a.Hg && gx < a.Wg) {
+                        // (max / min of the values AS STORED: CBAM's global max-pool and its backward -- unet2.py:10,20 -- see the tensor)
+                        const float vr = (float)(OutT)v;
+                        s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], vr); smn[j] = fminf(smn[j], vr);
+                    }
                     *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)(a.out_act ? fmaxf(v, a.out_slope * v) : v);
                 }
             }

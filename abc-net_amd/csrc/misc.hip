@@ -39,9 +39,10 @@ namespace {
 // ------------------------------------------------------------------ weight packing
 // element offset of (slice = tap * chunks + chunk, row, k) in a packed weight of `rows` rows per slice
 __host__ __device__ inline size_t abc_pack_offset(size_t slice, int rows, int row, int CK, int k, int layout) {
-    if (layout == 1) {   // bf16, CK = 32: [row / 32][kk][h][row % 32][8 elements] inside the slice (see abc_pack_desc.layout)
-        const int h = k >> 4, kk = (k >> 3) & 1, e = k & 7;
-        return (slice * rows + (size_t)(row & ~31)) * CK + (size_t)(((kk * 2 + h) * 32 + (row & 31)) * 8 + e);
+    if (layout == 1) {   // 64-byte chunk rows (bf16 CK = 32, fp8 CK = 64): [row / 32][kk][h][row % 32][16 bytes] inside the slice (see abc_pack_desc.layout)
+        const int E = CK >> 2;                    // elements per 16 bytes: 8 (bf16) or 16 (fp8)
+        const int h = k / (2 * E), kk = (k / E) & 1, e = k % E;
+        return (slice * rows + (size_t)(row & ~31)) * CK + (size_t)(((kk * 2 + h) * 32 + (row & 31)) * E + e);
     }
     return (slice * rows + row) * CK + k;
 }
@@ -76,12 +77,12 @@ __global__ void pack_kernel(const abc_pack_desc d, int CK, int ntaps, int nchunk
         }
         if (d.row_scale != nullptr && (d.mode == 0 || d.mode == 2) && n < d.Cout) v *= d.row_scale[n];
         const int rtot = d.rows_total > 0 ? d.rows_total : d.rows_pad;
-        dst[abc_pack_offset((size_t)t * nch_total + ch_off + c, rtot, d.rows_off + n, CK, k, d.layout)] = (CT)v;
+        dst[abc_pack_offset((size_t)t * nch_total + ch_off + c, rtot, d.rows_off + n, CK, k, d.layout)] = CT(v);
     }
 }
 
 // batched form: one launch over a device-resident table of descriptors (the plan packs ~100 small weights per step)
-struct PackItem { abc_pack_desc d; int32_t CK, ntaps, nchunks, is_bf16; int64_t first; };
+struct PackItem { abc_pack_desc d; int32_t CK, ntaps, nchunks, dtype; int64_t first; };
 __device__ inline void pack_one(const PackItem& it, unsigned r) {
     const abc_pack_desc& d = it.d;
     const unsigned CK = it.CK, ntaps = it.ntaps, nchunks = it.nchunks, rows = d.rows_pad;
@@ -108,7 +109,7 @@ __device__ inline void pack_one(const PackItem& it, unsigned r) {
     const unsigned nch_total = (d.red_total + CK - 1) / CK, ch_off = d.red_off / CK;
     const unsigned rtot = d.rows_total > 0 ? (unsigned)d.rows_total : rows;
     const size_t o = abc_pack_offset((size_t)t * nch_total + ch_off + c, (int)rtot, (int)((unsigned)d.rows_off + n), (int)CK, (int)k, d.layout);
-    if (it.is_bf16) ((bf16*)d.dst)[o] = (bf16)v; else ((float*)d.dst)[o] = v;
+    if (it.dtype == ABC_BF16) ((bf16*)d.dst)[o] = (bf16)v; else if (it.dtype == ABC_FP8) ((f8*)d.dst)[o] = f8(v); else ((float*)d.dst)[o] = v;
 }
 
 // A block owns 2048 consecutive destination elements of the concatenated items.  The item lookup (binary search over
@@ -237,7 +238,60 @@ __global__ void plane_sum_reduce_kernel(const float* work, int C, const float* c
     out[c] = (float)(s * (double)(cs ? cs[c] : 1.f));
 }
 
+// ------------------------------------------------------------------ fp8 inference graph: calibration + weight scales
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T* x, int64_t n, float* out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf((float)x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // non-negative floats order like their bit patterns: an integer atomic max is exact and order-independent
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)out, __float_as_uint(m));
+}
+__global__ void fp8_act_scale_kernel(const float* amax, float margin, float* s_out, float* inv_s_out) {
+    const float s = fmaxf(*amax, 1e-12f) * margin / 448.f;
+    *s_out = s; *inv_s_out = 1.f / s;
+}
+// one 64-lane wave per output row
+__global__ __launch_bounds__(256) void fp8_weight_scales_kernel(const float* w, int rows, int K, const float* fold, const float* s_in,
+                                                               float* qmul, float* deq) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= rows) return;
+    float m = 0.f;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(w[(size_t)n * K + k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) {
+        const float f = fold ? fold[n] : 1.f;
+        const float amax = m * fabsf(f);
+        const float sw = amax > 0.f ? amax / 448.f : 1.f;
+        qmul[n] = f / sw;
+        deq[n] = sw * *s_in;
+    }
+}
+
 }  // namespace
+
+extern "C" int abc_absmax(const void* x, int32_t dtype, int64_t n, float* out, abc_stream_t stream) {
+    if (n < 1) return abc_fail(ABC_EINVAL, "absmax: empty");
+    int64_t nb = (n + 2047) / 2048;
+    if (nb > 2048) nb = 2048;
+    if (dtype == ABC_BF16) hipLaunchKernelGGL(absmax_kernel<bf16>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n, out);
+    else if (dtype == ABC_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, out);
+    else return abc_fail(ABC_EUNSUPPORTED, "absmax: f32 or bf16");
+    return abc_check_launch("absmax");
+}
+extern "C" int abc_fp8_act_scale(const float* amax, float margin, float* s_out, float* inv_s_out, abc_stream_t stream) {
+    if (!(margin > 0.f)) return abc_fail(ABC_EINVAL, "fp8_act_scale: margin");
+    hipLaunchKernelGGL(fp8_act_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax, margin, s_out, inv_s_out);
+    return abc_check_launch("fp8_act_scale");
+}
+extern "C" int abc_fp8_weight_scales(const float* w, int32_t rows, int32_t K, const float* fold, const float* s_in, float* qmul, float* deq,
+                                     abc_stream_t stream) {
+    if (rows < 1 || K < 1) return abc_fail(ABC_EINVAL, "fp8_weight_scales: shape");
+    hipLaunchKernelGGL(fp8_weight_scales_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, rows, K, fold, s_in, qmul, deq);
+    return abc_check_launch("fp8_weight_scales");
+}
 
 extern "C" int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream) {
     int ntaps, red;
@@ -250,8 +304,8 @@ extern "C" int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream
     }
     const int CK = d->ck;
     if (CK != abc_conv_chunk(d->dtype_c, d->red_total)) return abc_fail(ABC_EINVAL, "pack: ck does not match red_total");
-    if (d->layout != 0 && (d->layout != 1 || d->dtype_c != ABC_BF16 || CK != 32 || (d->rows_total > 0 ? d->rows_total : d->rows_pad) % 32 || d->rows_off % 32))
-        return abc_fail(ABC_EINVAL, "pack: layout 1 needs bf16, CK = 32, whole 32-row blocks");
+    if (d->layout != 0 && (d->layout != 1 || CK * abc_dsize(d->dtype_c) != 64 || (d->rows_total > 0 ? d->rows_total : d->rows_pad) % 32 || d->rows_off % 32))
+        return abc_fail(ABC_EINVAL, "pack: layout 1 needs 64-byte chunks (bf16 CK = 32 / fp8 CK = 64), whole 32-row blocks");
     if (d->red_pad % CK || d->red_pad < red || d->red_off % CK || d->red_off + d->red_pad > abc_roundup(d->red_total, CK))
         return abc_fail(ABC_EINVAL, "pack: red_pad/red_off");
     const int nchunks = d->red_pad / CK;
@@ -259,6 +313,7 @@ extern "C" int abc_pack_conv_weights(const abc_pack_desc* d, abc_stream_t stream
     int nb = (int)((total + 255) / 256);
     if (nb > 4096) nb = 4096;
     if (d->dtype_c == ABC_BF16) hipLaunchKernelGGL(pack_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, CK, ntaps, nchunks);
+    else if (d->dtype_c == ABC_FP8) hipLaunchKernelGGL(pack_kernel<f8>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, CK, ntaps, nchunks);
     else hipLaunchKernelGGL(pack_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, CK, ntaps, nchunks);
     return abc_check_launch("pack_conv_weights");
 }
@@ -283,11 +338,11 @@ extern "C" int64_t abc_pack_item_fill(void* item, const abc_pack_desc* d, int64_
     const int CK = d->ck;
     if (CK != abc_conv_chunk(d->dtype_c, d->red_total) || d->red_pad % CK || d->red_pad < red || d->red_off % CK ||
         d->red_off + d->red_pad > abc_roundup(d->red_total, CK)) { abc_fail(ABC_EINVAL, "pack: red_pad/red_off/ck"); return -1; }
-    if (d->layout != 0 && (d->layout != 1 || d->dtype_c != ABC_BF16 || CK != 32 || (d->rows_total > 0 ? d->rows_total : d->rows_pad) % 32 || d->rows_off % 32)) {
-        abc_fail(ABC_EINVAL, "pack: layout 1 needs bf16, CK = 32, whole 32-row blocks"); return -1;
+    if (d->layout != 0 && (d->layout != 1 || CK * abc_dsize(d->dtype_c) != 64 || (d->rows_total > 0 ? d->rows_total : d->rows_pad) % 32 || d->rows_off % 32)) {
+        abc_fail(ABC_EINVAL, "pack: layout 1 needs 64-byte chunks (bf16 CK = 32 / fp8 CK = 64), whole 32-row blocks"); return -1;
     }
     PackItem* it = (PackItem*)item;
-    it->d = *d; it->CK = CK; it->ntaps = ntaps; it->nchunks = d->red_pad / CK; it->is_bf16 = d->dtype_c == ABC_BF16; it->first = first;
+    it->d = *d; it->CK = CK; it->ntaps = ntaps; it->nchunks = d->red_pad / CK; it->dtype = d->dtype_c; it->first = first;
     return (int64_t)ntaps * it->nchunks * d->rows_pad * CK;
 }
 

@@ -786,6 +786,7 @@ class Engine:
         the plain Src -- the caller picks one"""
         C_ = rec.cout
         g = self.new((self.B, rec.H, rec.W, C_))
+        rec.g = g      # (handle for the in-situ parity tests)
         d = L.ActBwdDesc()
         d.y_raw, d.ld_y = rec.y.data_ptr(), rec.ld
         if same is not None:
@@ -854,6 +855,7 @@ class Engine:
         wd = self.packed(len(rec.taps), rec.cout, rows_pad)
         self.emit_pack(rec.cname + ".weight", wd, 1, rec.cout, rec.cin, rec.k, rows_pad, rec.cout)
         dsrc = self.new((self.B, lh, lw, rec.cin))
+        rec.dsrc = dsrc
         self.emit_conv(ops, dY, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, taps_mirror(rec.taps), what="dgrad " + rec.cname)
         return dsrc
 
@@ -998,6 +1000,7 @@ class Engine:
         for i, rec in enumerate(self.head_recs):
             self.emit_pack(rec.cname + ".weight", wd_all, 1, 128, 128, 3, 128, 128, red_total=Ct, red_off=128 * i)
         dtrunk = self.new((B, h, w, 128))
+        self.dyh, self.dtrunk = dyh, dtrunk
         dy_all = Src(dyh, self.dt, h, w, Ct, 0, Ct)
         self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
         self.trunk.producer.grad_same = (dtrunk, 128, 0)
@@ -1118,6 +1121,7 @@ class Engine:
         wd = self.packed(9, rec.cout, rows_pad)
         self.emit_pack(rec.cname + ".weight", wd, 3, rec.cout, rec.cin, 3, rows_pad, rec.cout)
         dsrc = self.new((B, lh, lw, rec.cin))
+        rec.dsrc = dsrc
         self.emit_conv(ops, dOut, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, rec.taps_bwd, stride=2,
                        what="dgrad " + rec.cname)
         rec.src.producer.grad_same = (dsrc, rec.cin, 0)
@@ -1176,6 +1180,8 @@ class Engine:
         m = p + ".5.channel_attention.shared_MLP"
         blk = Rec(kind="blk2", prefix=prefix, rec1=rec1, rec2=rec2, xin=xin, cin=cin, cout=cout, k=k, H=H, W=W, mid=mid)
         blk.ca, blk.avgz, blk.maxz = self.f32buf(B, cout), self.f32buf(B, cout), self.f32buf(B, cout)
+        # arg-max of AdaptiveMaxPool2d(1) (unet2.py:10,20): the extreme raw value per (image, channel) and the first pixel holding it
+        blk.ext, blk.first = self.f32buf(B, cout), self.new((B, cout), torch.int32, 0x7FFFFFFF)
         blk.hid_a, blk.hid_m = self.f32buf(B, mid), self.f32buf(B, mid)
         ch = L.CbamChannelDesc()
         ch.partial, ch.tiles_per_img, ch.B, ch.C, ch.mid, ch.HW = rec2.stats.data_ptr(), rec2.nblk // B, B, cout, mid, float(H * W)
@@ -1183,6 +1189,7 @@ class Engine:
         ch.w1, ch.b1, ch.w2, ch.b2 = self.P(m + ".0.weight"), self.P(m + ".0.bias"), self.P(m + ".2.weight"), self.P(m + ".2.bias")
         ch.ca, ch.avgz, ch.maxz = blk.ca.data_ptr(), blk.avgz.data_ptr(), blk.maxz.data_ptr()
         ch.hid_avg, ch.hid_max = blk.hid_a.data_ptr(), blk.hid_m.data_ptr()
+        ch.ext, ch.first = blk.ext.data_ptr(), blk.first.data_ptr()
         self._emit(self.fwd_ops, lib.abc_cbam_channel_fwd, ch, "cbam_channel " + prefix)
         blk.st, blk.amax, blk.sa = self.f32buf(B, H, W, 2), self.new((B, H, W), torch.int32), self.f32buf(B, H, W)
         # residual branch (unet2.py:62-65,72)
@@ -1207,6 +1214,7 @@ class Engine:
             d.y, d.ld_y, d.cy_off = t2.data_ptr(), cout, 0
             d.scale, d.shift, d.mean, d.invstd = rec2.scale.data_ptr(), rec2.shift.data_ptr(), rec2.mean.data_ptr(), rec2.invstd.data_ptr()
             d.ca, d.maxz, d.sa, d.st, d.amax = blk.ca.data_ptr(), blk.maxz.data_ptr(), blk.sa.data_ptr(), blk.st.data_ptr(), blk.amax.data_ptr()
+            d.ext, d.first = blk.ext.data_ptr(), blk.first.data_ptr()
             d.res, d.ld_res, d.cres_off, d.res_pool = res[0].data_ptr(), res[1], res[2], res[3]
             d.out, d.ld_out, d.cout_off = to.data_ptr(), ld_o, coff_o
             d.dtype, d.B, d.H, d.W, d.C = self.dt, B, H, W, cout

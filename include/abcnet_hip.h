@@ -29,7 +29,7 @@ extern "C" {
 typedef void* abc_stream_t; /* hipStream_t */
 
 enum abc_status { ABC_OK = 0, ABC_EINVAL = -1, ABC_EUNSUPPORTED = -2, ABC_ELAUNCH = -3 };
-enum abc_dtype { ABC_F32 = 0, ABC_BF16 = 1 };
+enum abc_dtype { ABC_F32 = 0, ABC_BF16 = 1, ABC_FP8 = 2 /* OCP e4m3fn: the fp8 inference graph only (abc_conv_desc.out_scale) */ };
 #define ABC_MAX_TAPS_C 49
 
 /* A raw (pre-BatchNorm) activation tensor consumed through its BN affine +
@@ -101,6 +101,16 @@ typedef struct abc_conv_desc {
      *   in[p][c] = lrelu(sum_t stem_x[p + d_t] * stem_w[c][t] * stem_scale[c] + stem_bias[c]; stem_slope)
      * over the same 3x3 taps (zero padding), stem_x = the f32 image [B][Hin][Win]; src.x is ignored */
     const float* stem_x; const float* stem_w; const float* stem_scale; const float* stem_bias; float stem_slope;
+    /* fp8 (e4m3) inference graph -- the 128-channel 3x3 convolutions of the BatchNorm-folded eval graph (img2smiles2.py:42-59;
+     * SURVEY.md section 8f.4) on the block-scaled MFMA with unit scales (2 x the bf16 rate):
+     *   dtype_c = ABC_FP8 (then dtype_in = ABC_FP8 too): x and the packed weights are e4m3, x = real value / s_in (per tensor),
+     *   w = real (BatchNorm-folded) weight / s_w[n] (per output row); out_scale[n] = s_in * s_w[n] turns the f32 accumulator back:
+     *   v = acc * out_scale[n] + bias[n], then the activation (out_act).
+     *   dtype_out = ABC_FP8 (with bf16 or fp8 compute): the stored value is v * (*out_quant) rounded to e4m3 (saturating at 448),
+     *   *out_quant = 1 / s_out, a DEVICE scalar (calibrated per tensor: abc_fp8_act_scale), read by the kernel.
+     * Served by the weights-direct loop of the lean kernel only (3x3, stride 1, Cout a multiple of 128, Cin a multiple of 64). */
+    const float* out_scale;
+    const float* out_quant;
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
@@ -151,6 +161,18 @@ int abc_conv_weight_layout(const abc_conv_desc* d);
 int abc_pack_item_bytes(void);
 int64_t abc_pack_item_fill(void* item, const abc_pack_desc* d, int64_t first);
 int abc_pack_batch(const void* items_dev, int32_t nitems, int64_t total, abc_stream_t stream);
+
+/* fp8 inference graph, calibration and weight scales (all results stay on the device: no host sync, graph-safe).
+ *   abc_absmax:            *out = max(*out, max |x[i]|) over n elements of dtype (f32 / bf16); zero *out first (abc_fill_f32)
+ *   abc_fp8_act_scale:     s = max(*amax, 1e-12) * margin / 448, *s_out = s, *inv_s_out = 1 / s   (per-tensor activation scale)
+ *   abc_fp8_weight_scales: per output row n of a Conv2d weight [rows][K] (K = Cin * kh * kw) whose BatchNorm fold factor is
+ *                          fold[n] (NULL = 1):  s_w = max_k |w[n][k] * fold[n]| / 448 (1 when the row is zero),
+ *                          qmul[n] = fold[n] / s_w  (abc_pack_desc.row_scale of the fp8 packing),
+ *                          deq[n] = s_w * (*s_in)   (abc_conv_desc.out_scale) */
+int abc_absmax(const void* x, int32_t dtype, int64_t n, float* out, abc_stream_t stream);
+int abc_fp8_act_scale(const float* amax, float margin, float* s_out, float* inv_s_out, abc_stream_t stream);
+int abc_fp8_weight_scales(const float* w, int32_t rows, int32_t K, const float* fold, const float* s_in, float* qmul, float* deq,
+                          abc_stream_t stream);
 
 /* BatchNorm2d, training mode (unet.py:13,16,67): reduce the conv's stat partials
  * in f64, write the on-load coefficients (scale, shift) for consumers, keep
@@ -441,6 +463,10 @@ typedef struct abc_cbam_channel_desc { /* ChannelAttentionModule (unet2.py:6-22)
     float* ca; float* avgz; float* maxz; float* hid_avg; float* hid_max; /* [B][C], [B][C], [B][C], [B][mid] x2 */
     float* dw1; float* db1; float* dw2; float* db2; float* d_avgz; float* d_maxz; /* backward outputs */
     float* work;           /* backward scratch, B * (C + 2 mid) floats */
+    /* forward outputs for the backward of AdaptiveMaxPool2d(1) (unet2.py:10,20): ext[n][c] = the extreme RAW value of y2 whose BN image is
+     * max(z) (max of y2 for a positive BN scale, min for a negative one); first[n][c] is reset to INT32_MAX here and lowered by
+     * abc_cbam_spatial_stats to the first pixel (row-major) holding that value -- the one torch routes the gradient to */
+    float* ext; int32_t* first;
 } abc_cbam_channel_desc;
 int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
 int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
@@ -458,6 +484,7 @@ typedef struct abc_cbam_pix_desc { /* per-pixel passes of SpatialAttentionModule
     void* dz; int32_t ld_dz;                           /* d_o1, then d_z in place */
     float* partial;
     int32_t dtype, B, H, W, C;
+    const float* ext; int32_t* first;  /* see abc_cbam_channel_desc: spatial_stats lowers first[n][c], bwd3 adds d_maxz at that pixel only */
 } abc_cbam_pix_desc;
 int abc_cbam_spatial_stats(const abc_cbam_pix_desc* d, abc_stream_t stream); /* y,ca -> st[B,H,W,2], amax */
 int abc_cbam_apply_fwd(const abc_cbam_pix_desc* d, abc_stream_t stream);     /* -> out */

@@ -1,0 +1,409 @@
+"""Flip-free backward parity AT THE BENCHMARKED SIZE AND DTYPE (BASELINE.json configs 1-3; train.py:94-141).
+
+tests/test_gpu_fullsize.py holds one bf16 step at batch 16, 384x384 to the fp32 oracle end to end -- but at fresh weights
+thousands of ReLU decisions flip under bf16, the measured per-tensor gradient deviation is O(1) for the reference arithmetic
+too, and an end-to-end bound that loose cannot see a broken weight gradient.  The launch shapes that exist ONLY at full size
+(the 6144-tile merged heads convolution, persistent tiles with a balanced last round, XCD remaps, the 1024-row merged weight
+gradient with 16 K-splits, the fused heads pass at 2 M threads) are therefore held here link by link:
+
+  * test_backward_links_in_situ_bf16_b16_384 (unet.py, bf16, fused heads, no graph): every sampled data gradient, weight
+    gradient, bias gradient, BatchNorm backward (dgamma, dbeta, dY) and the fused heads pass (logits, g, conv2 gradients)
+    against torch ops / autograd applied ON THE GPU to the engine's OWN bf16 tensors, with every decision (ReLU sign,
+    dropout keep) taken from the engine's tensors -- no flip can enter, so the bounds are those of one bf16 rounding:
+    relative L2 4e-3 ... 1e-2 and 3e-2 of the largest element (what tests/test_gpu_kernels.py uses per kernel).
+    CAN detect: a wrong tile / split / remap / tap / channel offset in any sampled launch (a missing tile of 768 moves the
+    relative L2 by 3.6e-2), a wrong normaliser, a dropped K-split.  CANNOT detect: an error in an UNSAMPLED layer (the end-to-end
+    test still bounds those), nor a deviation below bf16 rounding.
+  * test_fp32_train_step_at_config1_workload: the fp32 (exact-f32 MFMA) step at 4 x 1 x 384 x 384 -- config 1's workload on
+    the HIP path -- against the oracle: loss 2e-4, every gradient under tests/test_gpu_model.py::_check_grads.
+  * test_unet2_links_in_situ_bf16_b16_384: the same link-by-link statement for unet2.py's CBAM blocks and convolutions.
+    (Its first run FOUND a bf16-only defect the end-to-end bound had absorbed: the conv epilogue took CBAM's global max before the
+    rounding to bf16, the backward looked for a pixel of the stored tensor equal to it, found none, and dropped the max-pool
+    branch's gradient -- d(y2) off by 6-10 %, dgamma2 by 9-21 %.  Now: max / min of the values as stored, and the gradient goes
+    to the FIRST maximal pixel, torch's rule, found by an integer atomic min in the forward's per-pixel pass.)
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import abcnet_amd  # noqa: E402,F401
+from abcnet_amd.dropout import head_keep_masks  # noqa: E402
+from abcnet_amd.synthetic import synthetic_images, synthetic_targets  # noqa: E402
+from oracle import loss_oracle  # noqa: E402
+from oracle import unet_oracle as uo  # noqa: E402
+
+HEADS = uo.HEADS
+DEV = "cuda"
+# the torch references run on the GPU through the native im2col + GEMM convolutions (no MIOpen kernel search / JIT on a fresh box)
+torch.backends.cudnn.enabled = False
+
+
+def _model(variant, dtype, dropout_p):
+    if variant == "unet2":
+        from abcnet_amd.unet2 import UNet
+    else:
+        from abcnet_amd.unet import UNet
+    m = UNet(1, HEADS, dtype=dtype, dropout_p=dropout_p)
+    m.load_state_dict(uo.filled_state(variant, 1, HEADS, seed=0))
+    return m.to(DEV)
+
+
+def _r(t):
+    """what an MFMA operand of the bf16 kernels holds: the f32 value rounded to bf16"""
+    return t.to(torch.bfloat16).float()
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2).contiguous()
+
+
+class Report:
+    """collects (what, relative L2, largest deviation / largest element) and asserts at the end, so that ONE run shows all"""
+
+    def __init__(self):
+        self.rows, self.bad = [], []
+
+    def close(self, what, got, ref, l2, linf=3e-2):
+        got, ref = got.double(), ref.double()
+        e2 = (got - ref).norm().item() / (ref.norm().item() + 1e-30)
+        ei = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        self.rows.append((what, e2, ei))
+        if not (e2 <= l2 and ei <= linf):
+            self.bad.append((what, e2, l2, ei, linf))
+
+    def finish(self):
+        for what, e2, ei in self.rows:
+            print("in-situ %-58s rel-L2 %.2e   max/max %.2e" % (what, e2, ei), file=sys.stderr)
+        assert not self.bad, self.bad
+
+
+def _activated(src):
+    """the tensor a consumer's loader makes of `src` (engine.Src: raw NHWC tensor + BatchNorm affine + leaky slope on load),
+    f32 NCHW -- decisions from the engine's own raw tensor and coefficients"""
+    x = src.t.float()[..., src.coff:src.coff + src.C]
+    if src.coef is not None:
+        sc, sh, sl = (c[src.coff:src.coff + src.C] for c in src.coef)
+        a = x * sc + sh
+        x = torch.where(a > 0, a, a * sl)
+    assert not src.pool and src.drop_p == 0.0
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def _bn_backward_ref(rec, m, rep, tag):
+    """closed form of BatchNorm backward from the engine's own g (= dA * act'), y_raw and batch statistics; returns dY (f32 NCHW)"""
+    G = rec.g.float()
+    y = rec.y.float()[..., rec.coff:rec.coff + rec.cout]
+    n = G.shape[0] * G.shape[1] * G.shape[2]
+    xh = (y - rec.mean) * rec.invstd
+    dbeta, dgamma = G.sum((0, 1, 2)), (G * xh).sum((0, 1, 2))
+    # a layer with TWO gradient routes (skip connection + max-pool: inc3, down3, down4) rounds g = bf16(dA_same + dA_pool) once
+    # more AFTER the kernel took its f32 sums; these sums cancel heavily (both signs), so the rounding noise of 147456 addends
+    # shows at ~3e-3 of the sum (measured: 3.0e-3 / 2.6e-3 on inc3.double_conv.3; 1e-7 where g = dA * act' is exact in bf16)
+    tol = 1e-2 if (rec.grad_pool is not None and rec.grad_same is not None) else 2e-3
+    rep.close(tag + " dbeta", m.grad_of(rec.bname + ".bias"), dbeta, tol)
+    rep.close(tag + " dgamma", m.grad_of(rec.bname + ".weight"), dgamma, tol)
+    gamma = m.state_dict()[rec.bname + ".weight"]
+    dY = gamma * rec.invstd * (G - dbeta / n - xh * dgamma / n)
+    if getattr(rec, "dY", None) is not None:
+        rep.close(tag + " dY (stored)", rec.dY.float(), dY, 1e-2)
+    return dY.permute(0, 3, 1, 2).contiguous()
+
+
+def _conv_links(rec, m, rep, sd):
+    """g -> BatchNorm backward -> dY; then conv2d's adjoints by torch autograd on (activated input, bf16 weights, dY)"""
+    tag = rec.cname
+    dY = _bn_backward_ref(rec, m, rep, tag)
+    X = _r(_activated(rec.src)).requires_grad_(True)
+    W = _r(sd[rec.cname + ".weight"]).requires_grad_(True)
+    k = W.shape[-1]
+    F.conv2d(X, W, padding=(k - 1) // 2).backward(_r(dY))
+    rep.close(tag + " wgrad", m.grad_of(rec.cname + ".weight"), W.grad, 5e-3)
+    if getattr(rec, "dsrc", None) is not None:
+        rep.close(tag + " dgrad", nchw(rec.dsrc), X.grad, 5e-3)
+    # the g of this layer itself: dA * act'(bn(y)) from the engine's own dA (same + pooled routes)
+    if rec.grad_pool is None and rec.grad_same is not None:
+        t, ld, co = rec.grad_same
+        dA = t.float()[..., co:co + rec.cout]
+        y = rec.y.float()[..., rec.coff:rec.coff + rec.cout]
+        a = y * rec.scale + rec.shift
+        rep.close(tag + " g = dA * act'", rec.g.float(), dA * torch.where(a > 0, torch.ones_like(a), rec.slopes.expand_as(a)), 4e-3)
+
+
+def _convT_links(rec, m, rep, sd):
+    """ConvTranspose2d(k3, s2) + the reference's crop of the first row / column (unet.py:51-56), by autograd"""
+    tag = rec.cname
+    dcat, ld, coff = rec.grad_out
+    dOut = nchw(dcat[..., coff:coff + rec.cout])
+    X = _r(_activated(rec.src)).requires_grad_(True)
+    W = _r(sd[rec.cname + ".weight"]).requires_grad_(True)
+    b = sd[rec.cname + ".bias"].clone().requires_grad_(True)
+    y = F.conv_transpose2d(X, W, b, stride=2)
+    y = y[:, :, y.shape[2] - rec.H:, y.shape[3] - rec.W:]
+    y.backward(dOut)
+    rep.close(tag + " wgrad", m.grad_of(rec.cname + ".weight"), W.grad, 5e-3)
+    rep.close(tag + " dbias", m.grad_of(rec.cname + ".bias"), b.grad, 2e-3)
+    rep.close(tag + " dgrad", nchw(rec.dsrc), X.grad, 5e-3)
+
+
+def _heads_links(eng, m, rep, sd, tg, B, h, w):
+    """the fused heads pass (conv2 + loss + way back) and the merged conv1 launches behind it, in situ"""
+    nh = len(HEADS)
+    Ct = 128 * nh
+    sc, sh, sl = eng.hcoef
+    y = eng.hfeat.float()
+    a = y * sc + sh
+    act = torch.where(a > 0, a, a * sl)
+    dact = torch.where(a > 0, torch.ones_like(a), sl.expand_as(a))
+    if eng.drop_p > 0:
+        masks = head_keep_masks(B, h, w, nh, eng.dropout_seed(1), eng.drop_p)        # 0 / 1, [B,128,h,w] per head
+        keep = torch.cat([mk.permute(0, 2, 3, 1) for mk in masks], dim=3).to(DEV) / (1.0 - eng.drop_p)
+    else:
+        keep = torch.ones_like(act)
+    feat = _r(act * keep)                                                              # conv2's input as the MFMA sees it
+    logits, leaves = [], []
+    for i, hc in enumerate(HEADS):
+        p = "out_modules.%d.conv2" % i
+        W2 = _r(sd[p + ".weight"]).requires_grad_(True)
+        b2 = sd[p + ".bias"].clone().requires_grad_(True)
+        fi = nchw(feat[..., 128 * i:128 * (i + 1)]).requires_grad_(True)
+        lg = F.conv2d(fi, W2, b2)
+        rep.close("heads_fused logits[%d]" % i, eng.logits[i], lg.detach(), 2e-4, 1e-3)
+        # the loss is evaluated on the ENGINE's logits (a leaf), so that the comparison of the gradients starts from identical values
+        leaf = eng.logits[i].detach().clone().requires_grad_(True)
+        logits.append(leaf)
+        leaves.append((lg, fi, W2, b2))
+    s = sd["s"].clone().to(DEV)
+    total = loss_oracle.abc_loss(logits, [t.to(DEV) for t in tg], s)[0]
+    total.backward()
+    for i, (lg, fi, W2, b2) in enumerate(leaves):
+        p = "out_modules.%d.conv2" % i
+        lg.backward(logits[i].grad.float())
+        rep.close("heads_fused " + p + ".weight", m.grad_of(p + ".weight"), W2.grad, 1.5e-2)
+        rep.close("heads_fused " + p + ".bias", m.grad_of(p + ".bias"), b2.grad, 1.5e-2)
+        # g of the head's BatchNorm output: d(feat) * keep * act'; the pass writes the gradient of the loss NUMERATORS, the
+        # head's normaliser arrives as chan_scale
+        g_ref = fi.grad.permute(0, 2, 3, 1) * (keep * dact)[..., 128 * i:128 * (i + 1)]
+        cs = eng.chan_scale[eng.head_off[i]]
+        rep.close("heads_fused g[%d]" % i, eng.hf_g.float()[..., 128 * i:128 * (i + 1)] * cs, g_ref, 1.5e-2)
+    # ---- BatchNorm backward of the eight heads from the engine's own g, then the merged conv1 launches
+    G = eng.hf_g.float() * torch.cat([eng.chan_scale[eng.head_off[i]].expand(128) for i in range(nh)])
+    n = B * h * w
+    xh = (y - eng.hmean) * eng.hinvstd
+    dbeta, dgamma = G.sum((0, 1, 2)), (G * xh).sum((0, 1, 2))
+    gam = torch.cat([sd["out_modules.%d.bn.weight" % i] for i in range(nh)])
+    for i in range(nh):
+        rep.close("heads bn[%d] dbeta" % i, m.grad_of("out_modules.%d.bn.bias" % i), dbeta[128 * i:128 * (i + 1)], 3e-3)
+        rep.close("heads bn[%d] dgamma" % i, m.grad_of("out_modules.%d.bn.weight" % i), dgamma[128 * i:128 * (i + 1)], 3e-3)
+    dY = gam * eng.hinvstd * (G - dbeta / n - xh * dgamma / n)
+    rep.close("heads conv1 dY (stored, 8 x 128 channels)", eng.dyh.float(), dY, 1e-2)
+    X = _r(_activated(eng.trunk)).requires_grad_(True)
+    Wall = _r(torch.cat([sd["out_modules.%d.conv1.weight" % i] for i in range(nh)], 0)).requires_grad_(True)
+    F.conv2d(X, Wall, padding=1).backward(_r(nchw(dY)))
+    for i in range(nh):
+        rep.close("heads conv1[%d] wgrad (1024-row merged launch)" % i, m.grad_of("out_modules.%d.conv1.weight" % i),
+                  Wall.grad[128 * i:128 * (i + 1)], 5e-3)
+    rep.close("heads conv1 dgrad (8 x 128 -> 128)", nchw(eng.dtrunk), X.grad, 5e-3)
+
+
+UNET_SAMPLE = ("dconv2.double_conv.3", "dconv2.double_conv.0", "up3.conv.double_conv.0", "inc3.double_conv.3",
+               "down2.maxpool_conv.1.double_conv.0", "down1.maxpool_conv.1.double_conv.3", "inc2.double_conv.3", "inc1.double_conv.3",
+               "down4.maxpool_conv.1.double_conv.0", "down5.maxpool_conv.1.double_conv.3", "up1.conv.double_conv.0")
+
+
+def test_backward_links_in_situ_bf16_b16_384():
+    from abcnet_amd.train import Trainer
+    B, S = 16, 384
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    m = _model("unet", "bf16", 0.2)
+    tr = Trainer(m, B, S, S, lr=0.0, use_graph=False)
+    eng = tr.eng
+    assert eng.hf is not None, "the benchmark's step runs the fused heads pass"
+    tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    rep = Report()
+    with torch.enable_grad():
+        _heads_links(eng, m, rep, sd, tg, B, S // 4, S // 4)
+        recs = {r.cname: r for r in eng.recs if r.kind == "conv"}
+        for cn in UNET_SAMPLE:
+            _conv_links(recs[cn], m, rep, sd)
+            torch.cuda.empty_cache()
+        for r in eng.recs:
+            if r.kind == "convT" and r.cname in ("up1.up", "up3.up"):
+                _convT_links(r, m, rep, sd)
+    rep.finish()
+
+
+def test_fp32_train_step_at_config1_workload():
+    """BASELINE.json config 1's workload (unet.py forward + backward on 4 x 1 x 384 x 384, fp32) on the HIP path"""
+    from test_gpu_model import _check_grads, _oracle_grads
+    from abcnet_amd.train import Trainer
+    B, S = 4, 384
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    m = _model("unet", "fp32", 0.2)
+    tr = Trainer(m, B, S, S, lr=0.0, use_graph=False)
+    masks = head_keep_masks(B, S // 4, S // 4, 8, tr.eng.dropout_seed(1), 0.2)
+    sd, total, weighted, _ = _oracle_grads(x, tg, dropout_masks=masks)
+    sd64 = _oracle_grads(x, tg, dropout_masks=masks, dtype=torch.float64)[0]
+    tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    res = tr.loss_value()
+    assert abs(res["total"] - total.item()) < 2e-4 * abs(total.item()), (res["total"], total.item())
+    for k in ("atom_t", "bond_t", "atom_types", "atom_charges", "bond_types", "bond_rhos", "bond_omega", "atom_hs"):
+        assert abs(res[k] - weighted[k].item()) < 5e-4 * abs(weighted[k].item()) + 1e-6, k
+    _check_grads(lambda n: m.grad_of(n), sd, sd64)
+
+
+UNET2_CONVS = ("dconv2.double_conv.3", "dconv2.double_conv.0", "inc2.double_conv.3", "inc2.double_conv.0", "down1.maxpool_conv.1.double_conv.0",
+               "down5.maxpool_conv.1.double_conv.3", "up3.conv.double_conv.0")
+UNET2_BLOCKS = ("dconv2", "inc2", "down2.maxpool_conv.1", "up1.conv")
+
+
+def _conv2_links(eng, rec, m, rep, sd):
+    """unet2: a convolution's weight and data gradient from the dY the engine's BatchNorm backward produced (the first conv of a
+    block has the plain chain of unet.py; the second one's g comes out of CBAM's backward: its dY is checked from the stored
+    dz in _cbam_links)"""
+    tag = "unet2 " + rec.cname
+    if getattr(rec, "g", None) is not None:
+        dY = _bn_backward_ref(rec, m, rep, tag)
+    elif getattr(rec, "dY", None) is not None:
+        dY = nchw(rec.dY)
+    else:
+        return
+    X = _r(_activated(rec.src)).requires_grad_(True)
+    W = _r(sd[rec.cname + ".weight"]).requires_grad_(True)
+    k = W.shape[-1]
+    F.conv2d(X, W, padding=(k - 1) // 2).backward(_r(dY))
+    rep.close(tag + " wgrad", m.grad_of(rec.cname + ".weight"), W.grad, 5e-3)
+    if getattr(rec, "dsrc", None) is None:
+        return
+    blk = [u for kd, u in eng.units2 if kd == "blk" and u.rec1 is rec]
+    if blk:
+        # the block's FIRST convolution: its data-gradient buffer also receives the residual branch's gradient (unet2.py:62-65,72):
+        # d_x = conv^T(dY1) + g for the identity, + res_conv^T(g) for the 1x1 convolution
+        blk = blk[0]
+        g = nchw(blk.bw["g"])
+        if blk.cin == blk.cout:
+            ref = X.grad + g
+        else:
+            Wr = _r(sd[blk.prefix + ".res_conv.weight"]).requires_grad_(True)
+            F.conv2d(X, Wr).backward(_r(g))
+            ref = X.grad
+            rep.close(tag[:-len("double_conv.0")] + "res_conv wgrad", m.grad_of(blk.prefix + ".res_conv.weight"), Wr.grad, 5e-3)
+        rep.close(tag + " dgrad + residual", nchw(rec.dsrc), ref, 8e-3)
+    else:
+        rep.close(tag + " dgrad", nchw(rec.dsrc), X.grad, 5e-3)
+
+
+def _cbam_links(eng, blk, m, rep, sd):
+    """unet2.py:6-74 forward + backward of one block on the engine's own tensors (as tests/test_gpu_model.py::
+    test_unet2_block_is_exact_in_situ, at the bf16 bounds)"""
+    prefix = blk.prefix
+    tag = "unet2 " + prefix
+    rec2 = blk.rec2
+    p = prefix + ".double_conv"
+    mlp = p + ".5.channel_attention.shared_MLP"
+    c7 = p + ".5.spatial_attention.conv2d"
+    C_ = blk.cout
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    y2 = leaf(nchw(rec2.y[..., rec2.coff:rec2.coff + C_]))
+    w1, b1, w2, b2 = (leaf(sd[mlp + k]) for k in (".0.weight", ".0.bias", ".2.weight", ".2.bias"))
+    w7, b7 = leaf(sd[c7 + ".weight"]), leaf(sd[c7 + ".bias"])
+    rt, ld_r, c_r, pooled_r = blk.res
+    r_full = nchw(rt[..., c_r:c_r + C_])
+    if pooled_r:
+        r_full = F.max_pool2d(r_full, 2)
+    r = leaf(r_full)
+    # BatchNorm with the ENGINE's batch statistics (its sums come from the f32 accumulators, before y2 was rounded to bf16)
+    gamma, beta = leaf(sd[rec2.bname + ".weight"]), leaf(sd[rec2.bname + ".bias"])
+    mean, invstd = rec2.mean.view(1, -1, 1, 1), rec2.invstd.view(1, -1, 1, 1)
+    z = (y2 - mean) * invstd * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+
+    def mlp_f(v):
+        return F.linear(F.relu(F.linear(v, w1, b1)), w2, b2)
+
+    # AdaptiveMaxPool2d(1) with torch's arg-max rule spelled out (the FIRST maximal pixel gets the gradient; in bf16 several
+    # pixels tie); max over channels at the ENGINE's arg-max channel (a decision: taken from the engine)
+    zf = z.flatten(2)
+    first = zf.detach().argmax(dim=2, keepdim=True)
+    ca = torch.sigmoid(mlp_f(F.adaptive_avg_pool2d(z, 1).flatten(1)) + mlp_f(zf.gather(2, first).squeeze(2)))
+    o1 = ca[:, :, None, None] * z
+    st = torch.cat([torch.mean(o1, dim=1, keepdim=True), o1.gather(1, blk.amax[:, None].long())], 1)
+    rep.close(tag + " arg-max of the global max-pool", blk.first.float(), first.squeeze(2).float(), 0.0, 0.0)
+    sa = torch.sigmoid(F.conv2d(st, w7, b7, padding=3))
+    out = F.relu(sa * o1 + r)
+    rep.close(tag + " ca", blk.ca, ca.detach(), 5e-3)
+    rep.close(tag + " [mean, max] over channels", blk.st.permute(0, 3, 1, 2), st.detach(), 5e-3)
+    rep.close(tag + " sa", blk.sa.unsqueeze(1), sa.detach(), 5e-3)
+    got_out = nchw(blk.out[..., blk.coff_out:blk.coff_out + C_])
+    rep.close(tag + " out", got_out, out.detach(), 5e-3)
+    dOut = torch.zeros_like(out)
+    if blk.grad_same is not None:
+        t, ld, co = blk.grad_same
+        dOut = dOut + nchw(t[..., co:co + C_])
+    if blk.grad_pool is not None:
+        t, ld, co = blk.grad_pool
+        oo = got_out.detach().clone().requires_grad_(True)
+        F.max_pool2d(oo, 2).backward(nchw(t[..., co:co + C_]))
+        dOut = dOut + oo.grad
+    mask = (got_out > 0).float()
+    (sa * o1 + r).backward(dOut * mask)
+    bw = blk.bw
+    rep.close(tag + " g = dOut * [out > 0]", nchw(bw["g"]), dOut * mask, 5e-3)
+    # d(y2): through CBAM (both attention branches, the global and per-pixel max routes) and BatchNorm's batch statistics
+    n = y2.shape[0] * y2.shape[2] * y2.shape[3]
+    xh = ((y2 - mean) * invstd).detach()
+    # autograd above treated mean / invstd as constants: finish BatchNorm's backward in closed form
+    dzz = y2.grad / (invstd * gamma.detach().view(1, -1, 1, 1))          # = d(loss)/d(z)
+    dbeta, dgamma = dzz.sum((0, 2, 3)), (dzz * xh).sum((0, 2, 3))
+    dy2 = gamma.detach().view(1, -1, 1, 1) * invstd * (dzz - dbeta.view(1, -1, 1, 1) / n - xh * dgamma.view(1, -1, 1, 1) / n)
+    rep.close(tag + " dgamma2", m.grad_of(rec2.bname + ".weight"), dgamma, 1e-2)
+    rep.close(tag + " dbeta2", m.grad_of(rec2.bname + ".bias"), dbeta, 1e-2)
+    if getattr(rec2, "dY", None) is not None:
+        rep.close(tag + " d(y2) (stored)", nchw(rec2.dY), dy2, 1e-2)       # (measured 2.9e-3: two bf16 roundings, dz and dY)
+    rep.close(tag + " dw7", m.grad_of(c7 + ".weight"), w7.grad, 2e-3)
+    rep.close(tag + " db7", m.grad_of(c7 + ".bias"), b7.grad, 2e-3)
+    for k, t in ((".0.weight", w1), (".0.bias", b1), (".2.weight", w2), (".2.bias", b2)):
+        rep.close(tag + " mlp" + k, m.grad_of(mlp + k), t.grad, 2e-3)          # (measured <= 1.5e-4)
+
+
+def test_unet2_links_in_situ_bf16_b16_384():
+    from abcnet_amd.train import Trainer
+    B, S = 16, 384
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    m = _model("unet2", "bf16", 0.0)
+    tr = Trainer(m, B, S, S, lr=0.0, use_graph=False)
+    eng = tr.eng
+    tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+    tr.step()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    rep = Report()
+    with torch.enable_grad():
+        if eng.hf is not None:
+            _heads_links(eng, m, rep, sd, tg, B, S // 4, S // 4)
+        recs = {r.cname: r for r in eng.recs if r.kind == "conv"}
+        for cn in UNET2_CONVS:
+            _conv2_links(eng, recs[cn], m, rep, sd)
+            torch.cuda.empty_cache()
+        blks = {u.prefix: u for k, u in eng.units2 if k == "blk"}
+        for pf in UNET2_BLOCKS:
+            _cbam_links(eng, blks[pf], m, rep, sd)
+            torch.cuda.empty_cache()
+        for k, u in eng.units2:
+            if k == "convT" and u.cname == "up3.up":
+                _convT_links(u, m, rep, sd)
+    rep.finish()
