@@ -68,11 +68,14 @@ __device__ inline void mma16B(f32x16& acc, bf16x8 a, bf16x8 b) {
 // fp8: ONE 32x32x64 MFMA takes a lane's whole 32 bytes of a 64-byte chunk (the two 16-byte halves a0 | a1, b0 | b1: lane half h
 // owns the same 32 k-indices of A and of B).  The block-scaled form with unit scales (E8M0 127 = 2^0): it runs at twice the
 // bf16 rate per clock, the unscaled 32x32x16 fp8 form only at the bf16 rate (MI355X_MICROARCH.md, matrix cores).
-__device__ inline void mma32B_f8(f32x16& acc, u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1) {
-    i32x8 A, B;
-    A[0] = (int)a0[0]; A[1] = (int)a0[1]; A[2] = (int)a0[2]; A[3] = (int)a0[3]; A[4] = (int)a1[0]; A[5] = (int)a1[1]; A[6] = (int)a1[2]; A[7] = (int)a1[3];
-    B[0] = (int)b0[0]; B[1] = (int)b0[1]; B[2] = (int)b0[2]; B[3] = (int)b0[3]; B[4] = (int)b1[0]; B[5] = (int)b1[1]; B[6] = (int)b1[2]; B[7] = (int)b1[3];
+__device__ inline void mma32B_f8(f32x16& acc, i32x8 A, i32x8 B) {
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+// a lane's 32 operand bytes as the instruction wants them: eight consecutive registers, filled by two 16-byte loads
+__device__ inline i32x8 abc_join32B(u32x4 lo, u32x4 hi) {
+    i32x8 r;
+    r[0] = (int)lo[0]; r[1] = (int)lo[1]; r[2] = (int)lo[2]; r[3] = (int)lo[3]; r[4] = (int)hi[0]; r[5] = (int)hi[1]; r[6] = (int)hi[2]; r[7] = (int)hi[3];
+    return r;
 }
 
 // ---------------------------------------------------------------------------

@@ -48,6 +48,8 @@ struct FastK {
     int tiles_x, tiles_y, nblocks_n, ntiles;
     int sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, stats_rows, accumulate, b_static, stg_off, red_off, dbg, stagger;
     int out_act; float out_slope;   // epilogue activation (BatchNorm folded into the weights: eval mode)
+    const float* oscale;            // fp8 compute: per output channel, accumulator -> real value (s_in * s_w[n])
+    const float* oquant;            // fp8 output: device scalar 1 / s_out applied before the rounding to e4m3
     unsigned bytesA, bytesW;
     long long* prof;  // debugging: per-workgroup phase timestamps (null in production)
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
@@ -74,6 +76,9 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     static_assert(TM >= 1 && TM * WM == MT && TN >= 1 && TN * WN == NT, "tile/wave layout");
     constexpr int NB = (SR_MAX * SEGS + FT - 1) / FT;  // weight segments per thread per stage (a stage = <= SR_MAX weight rows)
     typedef typename Frag<CT>::type frag_t;
+    constexpr bool F8C = sizeof(CT) == 1;    // e4m3 operands: one 32x32x64 MFMA per lane-half of a 64-byte chunk (weights-direct loop only)
+    constexpr bool F8O = sizeof(OutT) == 1;  // e4m3 output: v * (1 / s_out), saturating
+    static_assert(!F8C || WD == 9, "fp8 compute is served by the 9-tap weights-direct loop");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -178,13 +183,16 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         w_n0 = (unsigned)(n0 * CK) * (unsigned)sizeof(CT);
         const int iy0 = gy0 * STRIDE + a.dy_min, ix0 = gx0 * STRIDE + a.dx_min;
         float bv[TN];   // bias of this lane's output channels: loaded here, used in the epilogue (latency under the main loop)
+        float osc[TN];  // fp8 compute: the lane's dequantisation factors
         bool nval[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn * TN + j) * 32 + r;
             nval[j] = n < a.Cout;
             bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
+            osc[j] = (F8C && nval[j]) ? a.oscale[n] : 1.f;
         }
+        const float oq = F8O ? *a.oquant : 1.f;
 
         // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile).
         // Persistent (resident-weight) workgroups prefetched this tile's halo during the previous tile.
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         constexpr int WNT = WD ? WD : 1;              // taps (static: the loop is fully unrolled)
         constexpr int RING = WD == 25 ? 5 : 3;        // taps in flight; divides the tap count
         static_assert(WNT % RING == 0 || !WD, "ring must divide the tap count");
-        u32x4 bq[WD ? RING : 1][TN][2];
+        u32x4 bq[(WD && !F8C) ? RING : 1][TN][2];
+        i32x8 bq8[F8C ? RING : 1][TN];     // e4m3: a tile's B operand is one 8-register tuple (both 16-byte halves)
         const unsigned chunk_stride = (unsigned)(a.Cout_pad * CK) * (unsigned)sizeof(CT);
         // (the wave's n-offset sits in the VGPR part: everything in the scalar offset must be provably wave-uniform, or
         //  the compiler wraps every load in a readfirstlane loop)
@@ -228,10 +237,16 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         auto bq_load = [&](int slot, int c, int t) {
             const unsigned soff = w_n0 + (unsigned)t * tap_stride + (unsigned)c * chunk_stride;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (F8C) {
+                    bq8[slot][j] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB), soff, 0),
+                                               __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + 1024), soff, 0));
+                } else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 1024), soff, 0);
+                    for (int kk = 0; kk < 2; ++kk)
+                        bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 1024), soff, 0);
+                }
+            }
         };
         if constexpr (WD != 0) {
 #pragma unroll
@@ -285,6 +300,38 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                         apre.issue(rsA, 0u);
                     }
                 }
+                if constexpr (F8C) {
+                    // e4m3: a tap of a 64-byte chunk is ONE MFMA per tile pair (both 16-byte halves of the lane's 32 bytes at once);
+                    // the fragments of tap t + 1 are read while the MFMAs of tap t run (two register sets, static after unrolling)
+                    // (one A set: the CU's other waves -- two per SIMD, two workgroups -- cover the LDS latency; a second set of 24
+                    //  registers spilled)
+#pragma unroll
+                    for (int t = 0; t < WNT; ++t) {
+                        const int slot = t % RING;
+                        const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
+                        i32x8 fq[TM];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            fq[i] = abc_join32B(*(const u32x4*)(sAc + aBase[i] + aoff), *(const u32x4*)(sAc + aBase[i] + aoff + 16));
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) mma32B_f8(acc[i][j], fq[i], bq8[slot][j]);
+                        // hipcc treats the scaled MFMA as freely sinkable: without a use here it moved all 54 of a chunk behind the
+                        // halo commit at the end of the chunk, with the nine taps' fragments (216 registers) spilled to scratch on
+                        // the way.  An empty asm that READS the accumulators pins each tap's MFMAs to its place (no instruction, no stall).
+                        // (device pass only: on the host pass a 64-byte "v" operand is not a valid x86 constraint, and clang then drops
+                        //  the whole kernel stub without a diagnostic)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                        bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
+                    }
+                } else {
                 frag_t fa0[TM], fa1[TM];
                 // (tap offsets from the kernel arguments: scalar registers, no LDS round trip in front of the fragment reads)
                 {
@@ -318,6 +365,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     // the slot is free: tap t + RING (of this chunk or the next; past the last chunk the offsets run off
                     // the buffer and the loads return zeros -- unconditional, so that vmcnt stays exact)
                     bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
+                }
                 }
                 if (more) {
                     if (a.a_bufs == 2) {
@@ -455,9 +503,10 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
-                        const float v = acc[i][j][k] + bv[j];
+                        const float v = F8C ? fmaf(acc[i][j][k], osc[j], bv[j]) : acc[i][j][k] + bv[j];
                         s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
-                        const float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                        float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                        if constexpr (F8O) vo *= oq;
                         *(OutT*)(wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT)) = (OutT)vo;
                     }
                 }
@@ -499,12 +548,14 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                 for (int k = 0; k < 16; ++k) {
                     const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
                     const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
-                    const float v = acc[i][j][k] + bv[j];
+                    const float v = F8C ? fmaf(acc[i][j][k], osc[j], bv[j]) : acc[i][j][k] + bv[j];
                     if (nval[j] && gy < a.Hg && gx < a.Wg) {
                         const float vr = (float)(OutT)v;
                         s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], vr); smn[j] = fminf(smn[j], vr);
                     }
-                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)(a.out_act ? fmaxf(v, a.out_slope * v) : v);
+                    float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                    if constexpr (F8O) vo *= oq;
+                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)vo;
                 }
             }
             lds_wave_sync();
@@ -636,10 +687,14 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->eligible = 0;
     if (abc_knob("ABC_CONV_NOFAST")) return ABC_OK;
     if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->planar_out) return ABC_OK;
-    const int csz = d->dtype_c == ABC_BF16 ? 2 : 4;
+    const int csz = abc_dsize(d->dtype_c);
+    const bool f8 = d->dtype_c == ABC_FP8 || d->dtype_out == ABC_FP8 || d->dtype_in == ABC_FP8;
+    // e4m3 (the fp8 inference graph): 3x3 / stride 1 / 128-channel tiles on the weights-direct loop, nothing else
+    if (f8 && (d->stride != 1 || d->ntaps != 9 || d->Cout_pad % 128 || d->Cout != d->Cout_pad || d->src.scale != nullptr || d->accumulate || d->stats != nullptr ||
+               (d->dtype_c == ABC_FP8) != (d->dtype_in == ABC_FP8) || d->dtype_c == ABC_F32 || d->dtype_out == ABC_F32)) return ABC_OK;
     g->CK = abc_conv_chunk(d->dtype_c, d->Cin);
     if (g->CK <= 0 || d->Cin % g->CK) return ABC_OK;
-    const int64_t bytes_a = (int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4);
+    const int64_t bytes_a = (int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * abc_dsize(d->dtype_in);
     if (bytes_a >= (int64_t(1) << 31)) return ABC_OK;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
     for (int t = 0; t < d->ntaps; ++t) {
@@ -652,7 +707,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     const int segs = CKB / 16;
     g->cstride = abc_roundup(d->Cin, 4);
     const int coef_bytes = abc_roundup(3 * g->cstride * 4, 256);
-    const int osz = d->dtype_out == ABC_BF16 ? 2 : 4;
+    const int osz = abc_dsize(d->dtype_out);
 
     // tile shape (BN output channels x MT*32 pixels) by a small time model calibrated on the round-1 profiles
     // (DESIGN.md section 3): a workgroup walks nchunks x ngroups stages; a stage costs max(0.47 us of staging /
@@ -672,6 +727,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
             const int mt = cand_all[ci];
             if (force && atoi(force) != mt) continue;
             if (mt == 6 && (bn != 128 || d->stride != 1)) continue;
+            if (f8 && (mt != 6 || bn != 128)) continue;
             if (mt == 8 && bn == 128) continue;  // 4 x 2 tiles per wave + staging registers exceed 256 VGPRs
             if (mt == 2 && bn == 32) continue;   // 4 x 1 wave layout needs 4 m-tiles
             if (d->stride == 2 && mt != 4) continue;
@@ -729,7 +785,8 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     {
         const char* e = abc_knob("ABC_CONV_NOWD");   // "1": never; "2": only the 192 x 128 tile (experiments)
         const int lim = e ? atoi(e) : 0;
-        g->wd = (csz == 2 && g->CK == 32 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 9 : 0;
+        g->wd = (csz <= 2 && CKB == 64 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 9 : 0;
+        if (f8 && (g->wd != 9 || g->BN != 128 || g->MT != 6)) return ABC_OK;
         // (25-tap form for unet2's 5x5 32 -> 32 layers: measured SLOWER than the LDS-staged weights, 136 vs 121 us -- a
         //  32-channel tile has only 4 MFMAs per tap to cover the global-load latency of the ring; opt-in for experiments)
         if (csz == 2 && g->CK == 32 && g->BN == 32 && g->MT == 8 && d->stride == 1 && d->ntaps == 25 && abc_knob("ABC_CONV_WD25")) g->wd = 25;
@@ -783,17 +840,31 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     k.tap_off = g.tap_off; k.coef_off = g.coef_off; k.cstride = g.cstride; k.stats_rows = d->stats_rows;
     k.accumulate = d->accumulate; k.b_static = g.b_static; k.stg_off = g.stg_off; k.red_off = g.red_off;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
+    k.oscale = d->out_scale; k.oquant = d->out_quant;
     { const char* e = abc_knob("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     k.prof = g_prof;
     { const char* e = abc_knob("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }
-    k.bytesA = (unsigned)((int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * (d->dtype_in == ABC_BF16 ? 2 : 4));
-    k.bytesW = (unsigned)((int64_t)d->ntaps * k.nchunks * d->Cout_pad * g.CK * (d->dtype_c == ABC_BF16 ? 2 : 4));
+    k.bytesA = (unsigned)((int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * abc_dsize(d->dtype_in));
+    k.bytesW = (unsigned)((int64_t)d->ntaps * k.nchunks * d->Cout_pad * g.CK * abc_dsize(d->dtype_c));
     for (int t = 0; t < d->ntaps; ++t) {
         k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);
         k.tx[t] = (int8_t)(d->tap_dx[t] - g.dx_min);
     }
     hipStream_t st = (hipStream_t)stream;
     const int di = d->dtype_in, dc = d->dtype_c, dout = d->dtype_out;
+    if (dc == ABC_FP8 || dout == ABC_FP8 || di == ABC_FP8) {
+        // the fp8 inference graph (abc_conv_desc.out_scale / out_quant): the 192-pixel x 128-channel weights-direct tile only
+        if (!(g.BN == 128 && g.MT == 6 && g.wd == 9 && d->stride == 1)) return abc_fail(ABC_EUNSUPPORTED, "conv: fp8 needs the 3x3 weights-direct tile");
+        if (dout == ABC_FP8 && d->out_quant == nullptr) return abc_fail(ABC_EINVAL, "conv: fp8 output needs out_quant");
+        if (dc == ABC_FP8) {
+            if (di != ABC_FP8 || d->out_scale == nullptr) return abc_fail(ABC_EINVAL, "conv: fp8 compute needs an fp8 input and out_scale");
+            if (dout == ABC_FP8) return launch_st<f8, f8, f8, 64, 128, 1, 6, false, 9>(k, g, st);
+            if (dout == ABC_BF16) return launch_st<f8, f8, bf16, 64, 128, 1, 6, false, 9>(k, g, st);
+        } else if (dc == ABC_BF16 && di == ABC_BF16 && dout == ABC_FP8 && g.CK == 32) {
+            return launch_st<bf16, bf16, f8, 32, 128, 1, 6, false, 9>(k, g, st);
+        }
+        return abc_fail(ABC_EUNSUPPORTED, "conv: fp8 dtype combination");
+    }
     if (dc == ABC_F32) {
         if (di != ABC_F32 || dout != ABC_F32) return abc_fail(ABC_EUNSUPPORTED, "conv: f32 compute needs f32 in/out");
         return launch_bn<float, float, float, 16>(k, g, d->stride, st);

@@ -382,6 +382,7 @@ struct Geom {
 static int conv_geom(const abc_conv_desc* d, Geom* g) {
     if (d->ntaps < 1 || d->ntaps > ABC_MAX_TAPS) return abc_fail(ABC_EINVAL, "conv: ntaps out of range");
     if (d->stride != 1 && d->stride != 2) return abc_fail(ABC_EUNSUPPORTED, "conv: stride must be 1 or 2");
+    if (d->dtype_c == ABC_FP8 || d->dtype_in == ABC_FP8 || d->dtype_out == ABC_FP8) return abc_fail(ABC_EUNSUPPORTED, "conv: the general kernel has no fp8 form");
     const int csz = d->dtype_c == ABC_BF16 ? 2 : 4;
     g->CK = abc_conv_chunk(d->dtype_c, d->Cin);
     if (g->CK <= 0) return abc_fail(ABC_EINVAL, "conv: Cin must be positive");
@@ -501,6 +502,7 @@ extern "C" int abc_conv_chunk(int dtype_c, int Cin) {
     if (Cin <= 0) return -1;
     const int cp = abc_roundup(Cin, 16);
     if (dtype_c == ABC_BF16) return (cp % 32 == 0) ? 32 : 16;
+    if (dtype_c == ABC_FP8) return (Cin % 64 == 0) ? 64 : -1;   // 64-byte chunks only (the lean kernel's weights-direct loop)
     return 16;
 }
 
@@ -541,6 +543,17 @@ extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
 }
 
 extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
+    if (d->dtype_c == ABC_FP8 || d->dtype_out == ABC_FP8 || d->dtype_in == ABC_FP8) {
+        // the fp8 inference graph: served by the lean kernel's weights-direct tile or not at all
+        if (d->src.pool || d->src.planar || d->planar_out || d->src.Hx != d->Hin || d->src.Wx != d->Win || d->stem_x != nullptr || d->pool_y != nullptr)
+            return abc_fail(ABC_EUNSUPPORTED, "conv: fp8 needs a plain NHWC input and output");
+        if ((d->src.ldx * abc_dsize(d->dtype_in)) % 16 || (d->cin_off * abc_dsize(d->dtype_in)) % 16 || (d->ldy * abc_dsize(d->dtype_out)) % 16 || (d->cout_off * abc_dsize(d->dtype_out)) % 16)
+            return abc_fail(ABC_EINVAL, "conv: fp8 tensors must keep 16-byte alignment");
+        if ((d->Hg - 1) * d->om + d->oy0 >= d->Hout || (d->Wg - 1) * d->om + d->ox0 >= d->Wout) return abc_fail(ABC_EINVAL, "conv: output grid exceeds output tensor");
+        abc_fast_geom f;
+        if (abc_conv_fast_geom(d, &f) != ABC_OK || !f.eligible) return abc_fail(ABC_EUNSUPPORTED, "conv: fp8 is served for 3x3, stride 1, Cin % 64 == 0, Cout % 128 == 0 only");
+        return abc_conv_fast_launch(d, f, stream);
+    }
     Geom g;
     int rc = conv_geom(d, &g);  // (also validates the descriptor)
     if (rc) return rc;

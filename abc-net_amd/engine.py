@@ -79,6 +79,7 @@ class Src:
         self.coef, self.pool, self.drop_p, self.drop_seed, self.producer = coef, pool, drop_p, drop_seed, producer
         self.drop_salt = None  # device uint32 scalar added to drop_seed (the engine's per-step counter)
         self.planar = planar  # NCHW f32 [B][C][H][W] (head maps / their gradients)
+        self.q = None         # fp8 tensors: (amax, s, 1 / s) device scalars of the per-tensor scale
 
     def lh(self):  # logical dims
         return (self.H // 2, self.W // 2) if self.pool else (self.H, self.W)
@@ -106,7 +107,7 @@ class Rec:
 
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
-                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True):
+                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False):
         """batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
         batched one is tested against, tests/test_gpu_model.py::test_batched_heads_equal_one_by_one_launches)"""
         if variant not in ("unet", "unet2"):
@@ -127,6 +128,15 @@ class Engine:
         self.fold = bool(fold_bn)
         if self.fold and (train or variant != "unet"):
             raise ValueError("fold_bn is the eval-mode graph of unet.py")
+        # fp8 (e4m3) form of that graph (BASELINE config 5): the 128-channel 3x3 convolutions at the output
+        # resolution -- up3.conv's second convolution, dconv1, dconv2 and the eight heads' conv1, 13 of the graph's 15 "128 -> 128"
+        # units -- run on the block-scaled MFMA (2 x the bf16 rate) over e4m3 activations (one calibrated scale per tensor) and
+        # e4m3 weights (one scale per output row); everything else stays bf16.  calibrate_fp8() sets the activation scales.
+        self.fp8 = bool(fp8)
+        if self.fp8 and not (self.fold and dtype == "bf16"):
+            raise ValueError("fp8 is a form of the BatchNorm-folded bf16 inference graph (fold_bn=True, dtype='bf16')")
+        self.fp8_recs = []
+        self.fp8_calibrated = False
         self.dt = L.BF16 if dtype == "bf16" else L.F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         # the fused train step's heads (csrc/heads_fused.hip): conv2 forward + loss + the way back to the BatchNorm outputs as
@@ -183,8 +193,8 @@ class Engine:
         self.keep.append(t)
         return t
 
-    def act_buf(self, H, W, C):
-        t = self.new((self.B, H, W, C))
+    def act_buf(self, H, W, C, dt=None):
+        t = self.new((self.B, H, W, C), self._tdt(dt)) if dt is not None else self.new((self.B, H, W, C))
         coef = (self.new((C,), torch.float32, 1.0), self.new((C,), torch.float32, 0.0), self.new((C,), torch.float32, 1.0))
         return t, coef
 
@@ -197,40 +207,58 @@ class Engine:
         ops.append((fn, ref, what, tuple(writes), meta or {"kernel": what.split(" ")[0], "flops": 0, "bytes": 0}))
 
     def _dn(self, dt):
-        return "bf16" if dt == L.BF16 else "f32"
+        return {L.BF16: "bf16", L.F32: "f32", L.FP8: "fp8"}[dt]
 
     def _esz(self, dt):
-        return 2 if dt == L.BF16 else 4
+        return {L.BF16: 2, L.F32: 4, L.FP8: 1}[dt]
+
+    def _tdt(self, dt):
+        return {L.BF16: torch.bfloat16, L.F32: torch.float32, L.FP8: torch.float8_e4m3fn}[dt]
+
+    # fp8 inference graph: which convolutions write e4m3 (their consumers then compute in e4m3)
+    FP8_OUT = ("up3.conv.double_conv.0", "up3.conv.double_conv.3", "dconv1.double_conv.0", "dconv1.double_conv.3",
+               "dconv2.double_conv.0", "dconv2.double_conv.3")
+
+    def _out_dt(self, cname):
+        return L.FP8 if (self.fp8 and cname in self.FP8_OUT) else self.dt
 
     def emit_pack(self, wname, dst, mode, Cout, Cin, k, rows_pad, red_real, red_total=None, red_off=0, py=0, px=0, rows_total=0,
-                  rows_off=0, row_scale=None):
+                  rows_off=0, row_scale=None, cdt=None):
+        cdt = self.dt if cdt is None else cdt
         d = L.PackDesc()
         d.rows_total, d.rows_off = rows_total, rows_off
         d.row_scale = row_scale
-        d.w, d.dst, d.mode, d.dtype_c = self.P(wname), dst.data_ptr(), mode, self.dt
+        d.w, d.dst, d.mode, d.dtype_c = self.P(wname), dst.data_ptr(), mode, cdt
         d.Cout, d.Cin, d.kh, d.kw, d.py, d.px = Cout, Cin, k, k, py, px
         total = red_real if red_total is None else red_total
-        ck = self.lib.abc_conv_chunk(self.dt, total)
+        ck = self.lib.abc_conv_chunk(cdt, total)
         d.rows_pad, d.red_pad, d.red_total, d.red_off, d.ck = rows_pad, -(-red_real // ck) * ck, total, red_off, ck
         self.keep.append(d)
         self._pack_descs.append(d)
 
-    def packed(self, ntaps, red, rows_pad):
-        ck = self.lib.abc_conv_chunk(self.dt, red)
-        return self.new((ntaps * (-(-red // ck)) * rows_pad * ck,))
+    def packed(self, ntaps, red, rows_pad, cdt=None):
+        cdt = self.dt if cdt is None else cdt
+        ck = self.lib.abc_conv_chunk(cdt, red)
+        if ck <= 0:
+            raise ValueError("no K-chunk for %d reduction channels in %s" % (red, self._dn(cdt)))
+        return self.new((ntaps * (-(-red // ck)) * rows_pad * ck,), self._tdt(cdt))
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
                   grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
-                  accumulate=False, collect=None, out_slope=None):
+                  accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None):
         """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch;
-        out_slope: not None -> the epilogue stores max(v, out_slope * v) (folded-BatchNorm eval graph)"""
+        out_slope: not None -> the epilogue stores max(v, out_slope * v) (folded-BatchNorm eval graph);
+        cdt / out_scale / out_quant: fp8 inference graph (abc_conv_desc.out_scale, .out_quant)"""
+        cdt = self.dt if cdt is None else cdt
         d = L.ConvDesc()
         if out_slope is not None:
             d.out_act, d.out_slope = 1, out_slope
         src.fill(d.src)
         d.w, d.bias, d.y = w.data_ptr(), bias, y.data_ptr()
         d.stats = None
-        d.dtype_in, d.dtype_c, d.dtype_out = src.dt, self.dt, y_dt
+        d.out_scale = None if out_scale is None else out_scale.data_ptr()
+        d.out_quant = None if out_quant is None else out_quant.data_ptr()
+        d.dtype_in, d.dtype_c, d.dtype_out = src.dt, cdt, y_dt
         lh, lw = src.lh()
         d.B, d.Hin, d.Win = self.B, lh, lw
         d.cin_off = src.coff if cin_off is None else cin_off
@@ -254,7 +282,7 @@ class Engine:
         npx = self.B * gh * gw
         in_px = self.B * lh * lw * (4 if src.pool else 1)
         kname = ("conv_igemm", "conv_fast", "stem_conv", "head_fwd", "head_dgrad", "conv_narrow")[self.lib.abc_conv_variant(C.byref(d))]
-        meta = {"kernel": "%s<%s,%s,%s,CK%d,BN%d,S%d,MT%d>" % (kname, self._dn(src.dt), self._dn(self.dt), self._dn(y_dt), ck, bn, stride, mt),
+        meta = {"kernel": "%s<%s,%s,%s,CK%d,BN%d,S%d,MT%d>" % (kname, self._dn(src.dt), self._dn(cdt), self._dn(y_dt), ck, bn, stride, mt),
                 "flops": 2.0 * npx * Cout * len(taps) * d.Cin,
                 "bytes": float(in_px * d.Cin * self._esz(src.dt) + npx * Cout * self._esz(y_dt))}
         if collect is not None:
@@ -479,26 +507,74 @@ class Engine:
         cin = src.C
         taps = taps_square(k)
         rows_pad = -(-cout // 32) * 32
+        y_dt = self._out_dt(cname) if shared is None else self.dt
+        q_out = None
         if shared is None:
             fs, fb = self.new((cout,), torch.float32, 1.0), self.new((cout,), torch.float32)
             self._fold_coeffs(cname, bname, cout, fs, fb)
-            wf = self.packed(len(taps), cin, rows_pad)
-            self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin, row_scale=fs.data_ptr())
-            self.emit_conv(self.fwd_ops, src, wf, fb.data_ptr(), yt, self.dt, H, W, ld, coff, cout, taps, what="fwd " + cname,
-                           out_slope=slope)
+            in_f8 = src.dt == L.FP8
+            if y_dt == L.FP8:
+                # per-tensor scale of this convolution's e4m3 output: (amax, s, 1 / s) on the device, set by calibrate_fp8()
+                q_out = (self.new((1,), torch.float32, 0.0), self.new((1,), torch.float32, 1.0), self.new((1,), torch.float32, 1.0))
+            if in_f8:
+                qmul, deq = self._fp8_weight_scales(cname + ".weight", cout, cin * k * k, fs, src.q[1], self.new((cout,), torch.float32, 1.0),
+                                                    self.new((cout,), torch.float32, 1.0))
+                wf = self.packed(len(taps), cin, rows_pad, cdt=L.FP8)
+                self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin, row_scale=qmul.data_ptr(), cdt=L.FP8)
+                self.emit_conv(self.fwd_ops, src, wf, fb.data_ptr(), yt, y_dt, H, W, ld, coff, cout, taps, what="fwd " + cname,
+                               out_slope=slope, cdt=L.FP8, out_scale=deq, out_quant=None if q_out is None else q_out[2])
+            else:
+                wf = self.packed(len(taps), cin, rows_pad)
+                self.emit_pack(cname + ".weight", wf, 0, cout, cin, k, rows_pad, cin, row_scale=fs.data_ptr())
+                self.emit_conv(self.fwd_ops, src, wf, fb.data_ptr(), yt, y_dt, H, W, ld, coff, cout, taps, what="fwd " + cname,
+                               out_slope=slope, out_quant=None if q_out is None else q_out[2])
         rec = Rec(kind="conv", cname=cname, bname=bname, src=src, cin=cin, cout=cout, k=k, taps=taps, y=yt, H=H, W=W, ld=ld,
                   coff=coff, coef=None, slope=slope)
         rec.fold_desc = self._last_conv_desc if shared is None else None
+        rec.q = q_out
+        if q_out is not None:
+            self.fp8_recs.append(rec)
         self.recs.append(rec)
-        return rec, Src(yt, self.dt, H, W, ld, coff, cout, coef=None, producer=rec)
+        out = Src(yt, y_dt, H, W, ld, coff, cout, coef=None, producer=rec)
+        out.q = q_out
+        return rec, out
+
+    def _fp8_weight_scales(self, wname, rows, K, fold, s_in, qmul, deq):
+        """pack-time op (before the weight packing): per output row the e4m3 scale of the BatchNorm-folded weight --
+        qmul = fold / s_w (what the packing multiplies the master weight with), deq = s_w * s_in (the convolution's out_scale)"""
+        lib = self.lib
+        a = (self.P(wname), rows, K, fold.data_ptr(), s_in.data_ptr(), qmul.data_ptr(), deq.data_ptr())
+        self.keep += [fold, s_in, qmul, deq]
+        self.pack_ops.append((lambda _r, st, a=a: lib.abc_fp8_weight_scales(*a, st), None, "fp8 scales " + wname, (),
+                              {"kernel": "fp8_weight_scales", "flops": 0, "bytes": 0}))
+        return qmul, deq
+
+    def calibrate_fp8(self, ref, stream, margin=1.0):
+        """per-tensor activation scales of the e4m3 tensors from the bf16 folded graph `ref` (same model, same batch, forward
+        already run on `stream`): s = max|x| * margin / 448.  All on the device; call run_pack() afterwards (the weight
+        scales fold s_in in)."""
+        lib = self.lib
+        mine = {r.cname: r for r in self.fp8_recs}
+        theirs = {r.cname: r for r in ref.recs if r.kind == "conv" and r.cname in mine}
+        if set(mine) != set(theirs):
+            raise ValueError("calibrate_fp8: the reference graph lacks %s" % sorted(set(mine) - set(theirs)))
+        for cname, r in mine.items():
+            t = theirs[cname]
+            if t.y.dtype != torch.bfloat16 or (t.ld, t.coff) != (t.cout, 0):
+                raise ValueError("calibrate_fp8: %s of the reference graph is not a plain bf16 tensor" % cname)
+            amax, s, inv_s = r.q
+            L.check(lib.abc_fill_f32(amax.data_ptr(), 0.0, 1, stream), "fill")
+            L.check(lib.abc_absmax(t.y.data_ptr(), L.BF16, t.y.numel(), amax.data_ptr(), stream), "absmax")
+            L.check(lib.abc_fp8_act_scale(amax.data_ptr(), margin, s.data_ptr(), inv_s.data_ptr(), stream), "fp8_act_scale")
+        self.fp8_calibrated = True
 
     def double_conv(self, prefix, src, cout, k, dst_b=None):
         H, W = src.lh()
-        ta, ca = self.act_buf(H, W, cout)
         p = prefix + ".double_conv"
+        ta, ca = self.act_buf(H, W, cout, self._out_dt(p + ".0") if self.fold else None)
         _, a = self.conv_bn(p + ".0", p + ".1", src, cout, k, (ta, ca, H, W, cout, 0), 0.0)
         if dst_b is None:
-            tb, cb = self.act_buf(H, W, cout)
+            tb, cb = self.act_buf(H, W, cout, self._out_dt(p + ".3") if self.fold else None)
             dst_b = (tb, cb, H, W, cout, 0)
         _, b = self.conv_bn(p + ".3", p + ".4", a, cout, k, dst_b, 0.0)
         return b
@@ -759,13 +835,23 @@ class Engine:
         bias_all = self.new((Ct,), torch.float32)
         if self.fold:
             scale_all = self.new((Ct,), torch.float32, 1.0)
+            f8 = trunk.dt == L.FP8      # fp8 graph: e4m3 trunk and weights, bf16 features for the heads' 1x1 convolutions
+            if f8:
+                wf = self.packed(len(taps), 128, Ct, cdt=L.FP8)
+                qmul_all, deq_all = self.new((Ct,), torch.float32, 1.0), self.new((Ct,), torch.float32, 1.0)
             for i in range(nh):
                 p = "out_modules.%d" % i
-                self._fold_coeffs(p + ".conv1", p + ".bn", 128, scale_all[128 * i:128 * (i + 1)], bias_all[128 * i:128 * (i + 1)])
-                self.emit_pack(p + ".conv1.weight", wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i,
-                               row_scale=scale_all[128 * i:128 * (i + 1)].data_ptr())
+                sl = slice(128 * i, 128 * (i + 1))
+                self._fold_coeffs(p + ".conv1", p + ".bn", 128, scale_all[sl], bias_all[sl])
+                if f8:
+                    self._fp8_weight_scales(p + ".conv1.weight", 128, 128 * 9, scale_all[sl], trunk.q[1], qmul_all[sl], deq_all[sl])
+                    self.emit_pack(p + ".conv1.weight", wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i,
+                                   row_scale=qmul_all[sl].data_ptr(), cdt=L.FP8)
+                else:
+                    self.emit_pack(p + ".conv1.weight", wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i,
+                                   row_scale=scale_all[sl].data_ptr())
             self.emit_conv(self.fwd_ops, trunk, wf, bias_all.data_ptr(), self.hfeat, self.dt, h, w, Ct, 0, Ct, taps,
-                           what="fwd out_modules.*.conv1", out_slope=0.01)
+                           what="fwd out_modules.*.conv1", out_slope=0.01, cdt=L.FP8 if f8 else None, out_scale=deq_all if f8 else None)
             return None, 0
         for i in range(nh):
             self.emit_pack("out_modules.%d.conv1.weight" % i, wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i)

@@ -20,8 +20,11 @@ from . import _lib as L
 
 class InferenceRunner:
     def __init__(self, model, batch, height, width, use_graph=True, device=None, extract=False, cap_atoms=512, cap_bonds=16384,
-                 fold_bn=None):
-        """fold_bn: run the eval graph with every BatchNorm folded into the convolution in front of it and the activation in
+                 fold_bn=None, fp8=False, fp8_margin=1.0):
+        """fp8: the e4m3 form of the BatchNorm-folded graph (unet.py, bf16 model): the 128-channel 3x3 convolutions at the output
+        resolution on the block-scaled MFMA over e4m3 activations and weights (Engine(fp8=True)); the per-tensor activation scales
+        are calibrated on the FIRST batch loaded (calibrate(); again on demand) by running the bf16 folded graph on it.
+        fold_bn: run the eval graph with every BatchNorm folded into the convolution in front of it and the activation in
         that convolution's epilogue (weights re-packed times gamma / sqrt(running_var + eps) by refresh()); default: on for
         unet.py, off for unet2.py (whose CBAM reads the un-activated BatchNorm output)"""
         if not torch.cuda.is_available():
@@ -39,7 +42,12 @@ class InferenceRunner:
             if fold_bn is None:
                 fold_bn = model.VARIANT == "unet"
             self.fold_bn = bool(fold_bn)
-            self.eng = eng = model._engine_for(x0, False, fold_bn=self.fold_bn)
+            self.fp8 = bool(fp8)
+            self.fp8_margin = float(fp8_margin)
+            if self.fp8 and not (self.fold_bn and model.VARIANT == "unet" and model.compute_dtype == "bf16"):
+                raise L.AbcNetHipError("fp8 inference is a form of the BatchNorm-folded bf16 graph of unet.py")
+            self.eng = eng = model._engine_for(x0, False, fold_bn=self.fold_bn, fp8=self.fp8)
+            self._ref = model._engine_for(x0, False, fold_bn=True) if self.fp8 else None   # bf16 graph, calibration only
         lg = eng.logits
         self.atom_mask, self.bond_mask = torch.empty_like(lg[0]), torch.empty_like(lg[4])
         self.rho_abs, self.omega_mask = torch.empty_like(lg[6]), torch.empty_like(lg[7])
@@ -67,6 +75,23 @@ class InferenceRunner:
 
     def load_batch(self, imgs):
         self.eng.img.copy_(imgs.reshape(self.eng.img.shape), non_blocking=True)
+        if self.fp8 and not self.eng.fp8_calibrated:
+            self.calibrate()
+
+    def calibrate(self):
+        """fp8: set the per-tensor e4m3 scales from the batch in the image buffer (the bf16 folded graph runs once on it), then
+        re-pack the weights (their scales fold the input scale in).  No host sync; call again when the data distribution moves."""
+        if not self.fp8:
+            return
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream().cuda_stream
+            ref = self._ref
+            ref.img.copy_(self.eng.img)
+            ref.run_pack(st)
+            ref.run_forward(st)
+            self.eng.calibrate_fp8(ref, st, self.fp8_margin)
+            self.eng.run_pack(st)
+            self._graph = None
 
     def _run(self, st):
         self.eng.run_forward(st)

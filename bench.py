@@ -26,7 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
-MFMA_PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md
+MFMA_PEAK = {"bf16": 2500.0, "fp32": 157.3, "fp8": 5000.0}  # dense TFLOP/s, MI355X_MICROARCH.md (fp8: the block-scaled MFMA)
 HBM_PEAK = 8000.0  # GB/s
 # SURVEY.md section 8(d) / BASELINE.md section 3: per-layer roofline rate R = 1 / sum_l max(bytes_l / 8 TB/s, flops_l / 2.5 PF) in
 # images/s per GPU (bf16, every conv reads its input and writes its output once, train = 3 x forward + loss + Adam bytes),
@@ -138,7 +138,9 @@ def main():
                     help="train = the headline metric (configs 2-4); infer = config 5, img2smiles2.py heat-map path (eval forward + NMS)")
     ap.add_argument("--size", type=int, default=None, help="default 384 (train) / 512 (infer)")
     ap.add_argument("--batch", type=int, default=None, help="per GPU; default 16 (train) / 64 (infer)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="fp8 (--mode infer only): the e4m3 form of the BatchNorm-folded graph -- the 128-channel 3x3 convolutions at the output "
+                         "resolution on the block-scaled MFMA, the rest bf16 (InferenceRunner(fp8=True)); calibrated on the benchmark batch")
     ap.add_argument("--variant", default="unet", choices=["unet", "unet2"], help="unet.py (headline) or unet2.py (config 3)")
     ap.add_argument("--metrics", action="store_true", help="also update the 17 training meters of train.py:145-215 on the device every step")
     ap.add_argument("--extract", action="store_true", help="(--mode infer) also build the atom / bond candidate lists of "
@@ -198,7 +200,9 @@ def main():
         if dist.get_world_size() != a.gpus:
             raise SystemExit("--gpus %d but %d ranks joined" % (a.gpus, dist.get_world_size()))
 
-    model = UNet(1, HEADS, dtype=a.dtype)
+    if a.dtype == "fp8" and (a.mode != "infer" or a.variant != "unet"):
+        raise SystemExit("--dtype fp8 is the inference graph of unet.py (--mode infer)")
+    model = UNet(1, HEADS, dtype="bf16" if a.dtype == "fp8" else a.dtype)
     model.reset_parameters(seed=1234)  # identical random init on every rank (and re-broadcast below)
     model = model.to(dev)
     if world > 1:
@@ -207,7 +211,7 @@ def main():
     imgs = synthetic_images(a.batch, a.size, seed=7 + rank)
     if a.mode == "infer":
         from abcnet_amd.infer import InferenceRunner
-        tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract)
+        tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract, fp8=(a.dtype == "fp8"))
         tr.load_batch(imgs.to(dev))
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits)
@@ -280,7 +284,7 @@ def main():
     }
 
     sr = SURVEY_ROOFLINE.get((a.mode, a.variant, a.size))
-    if sr is not None and a.dtype == "bf16":
+    if sr is not None and a.dtype in ("bf16", "fp8"):
         per_gpu = out["value"] / world
         out["survey_roofline"] = {"R_img_s_per_gpu": sr["R_img_s"], "frac": round(per_gpu / sr["R_img_s"], 4),
                                   "hbm_frac": round(per_gpu * sr["mb_per_img"] * 1e6 / (HBM_PEAK * 1e9), 4),
@@ -295,8 +299,10 @@ def main():
             dom = max((k for k in prof if prof[k]["flops"] > 0), key=lambda k: prof[k]["ms"])
             r = prof[dom]
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK[a.dtype], "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_PEAK[a.dtype], 4), "traffic": pmc_traffic(dom, a.mode, a.variant),
+            # (a mixed graph: the dominant kernel is priced against the peak of ITS operand type)
+            peak = MFMA_PEAK["fp8" if "<fp8,fp8," in dom else ("bf16" if a.dtype == "fp8" else a.dtype)]
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom, a.mode, a.variant),
                                "algorithmic_mb_per_launch": round(r["bytes"] / r["calls"] / 1e6, 2),
                                "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
                                "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
@@ -311,7 +317,7 @@ def main():
             flops_step = sum(v["flops"] for v in prof.values())
             bytes_step = sum(v["bytes"] for v in prof.values())
             out["whole_step"] = {"algorithmic_tflop": round(flops_step / 1e12, 3), "algorithmic_gb": round(bytes_step / 1e9, 3),
-                                 "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK[a.dtype], 4),
+                                 "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK["bf16" if a.dtype == "fp8" else a.dtype], 4),
                                  "hbm_frac": round(bytes_step / (el / a.steps) / 1e9 / HBM_PEAK, 4)}
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline if a.mode == "train" else cpu_baseline_infer)(a.size, variant=a.variant)

@@ -109,14 +109,14 @@ def measure_train(variant, with_autocast=False):
 SAMPLE = (0, 21, 42, 63)
 
 
-def measure_infer(fold_bn=True):
-    """config 5: eval forward + NMS at 512x512, batch 64, bf16 (the BatchNorm-folded graph the benchmark runs); a sample of
-    the batch against the oracle"""
+def measure_infer(fold_bn=True, fp8=False):
+    """config 5: eval forward + NMS at 512x512, batch 64, bf16 (the BatchNorm-folded graph the benchmark runs) or its fp8 (e4m3)
+    form; a sample of the batch against the oracle"""
     from abcnet_amd.infer import InferenceRunner
     B, S = 64, 512
     x = synthetic_images(B, S, seed=7)
     m = _model("unet", "bf16", 0.2)
-    run = InferenceRunner(m, B, S, S, use_graph=True, fold_bn=fold_bn)
+    run = InferenceRunner(m, B, S, S, use_graph=True, fold_bn=fold_bn, fp8=fp8)
     run.load_batch(x.to(DEV))
     run.step()
     run.step()      # the second step is the captured graph
@@ -133,7 +133,7 @@ def measure_infer(fold_bn=True):
     exact = (torch.equal(run.atom_mask[idx.to(DEV)].cpu(), da) and torch.equal(run.bond_mask[idx.to(DEV)].cpu(), db)
              and torch.equal(run.omega_mask[idx.to(DEV)].cpu(), do) and torch.equal(run.rho_abs[idx.to(DEV)].cpu(), dr))
     n_pix = len(SAMPLE) * (S // 4) ** 2
-    return {"fold_bn": bool(fold_bn), "logits_linf": linf, "atom_mask_flips": flips(run.atom_mask, ra), "bond_mask_flips": flips(run.bond_mask, rb),
+    return {"fold_bn": bool(fold_bn), "fp8": bool(fp8), "logits_linf": linf, "atom_mask_flips": flips(run.atom_mask, ra), "bond_mask_flips": flips(run.bond_mask, rb),
             "omega_mask_flips": flips(run.omega_mask, ro), "pixels": n_pix, "omega_entries": 60 * n_pix,
             "atom_peaks_oracle": int(ra.sum().item()), "omega_peaks_oracle": int(ro.sum().item()),
             "nms_on_device_logits_exact": bool(exact)}
@@ -158,9 +158,11 @@ def test_bf16_train_step_at_benchmark_config(variant):
     assert got["grad_rel_l2_whole_model"] <= max(ac["grad_rel_l2_whole_model"], 1.5 * b["grad_rel_l2_whole_model"])
 
 
-def test_bf16_inference_at_benchmark_config():
-    b = _bounds()["infer_unet"]
-    got = measure_infer()
+@pytest.mark.parametrize("key", ["infer_unet", "infer_unet_fp8"])
+def test_inference_at_benchmark_config(key):
+    """bf16 folded graph / its fp8 (e4m3) form at 512 x 512, batch 64 (`bench.py --mode infer [--dtype fp8]`)"""
+    b = _bounds()[key]
+    got = measure_infer(fp8=key.endswith("fp8"))
     assert got["nms_on_device_logits_exact"], "device NMS != oracle NMS on the device's own logits"
     assert got["logits_linf"] <= 1.5 * b["logits_linf"], (got["logits_linf"], b["logits_linf"])
     for k in ("atom_mask_flips", "bond_mask_flips", "omega_mask_flips"):
@@ -174,7 +176,8 @@ if __name__ == "__main__":
         res = {"how": "python tests/test_gpu_fullsize.py --measure on an MI355X (bf16, the shapes of BASELINE.json configs 2, 3, 5); "
                       "deviations are against the fp32 oracle on the same inputs; oracle_autocast = the oracle itself under "
                       "torch.autocast('cpu', bfloat16) against its own fp32 run; host threads: %d" % torch.get_num_threads()}
-        for key, fn in (("infer_unet", measure_infer), ("infer_unet_unfolded", lambda: measure_infer(False)), ("train_unet", lambda: measure_train("unet", True)),
+        for key, fn in (("infer_unet", measure_infer), ("infer_unet_fp8", lambda: measure_infer(fp8=True)),
+                        ("infer_unet_unfolded", lambda: measure_infer(False)), ("train_unet", lambda: measure_train("unet", True)),
                         ("train_unet2", lambda: measure_train("unet2", True))):
             t0 = time.time()
             res[key] = fn()
