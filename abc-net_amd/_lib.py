@@ -62,7 +62,7 @@ class BnBwdDesc(C.Structure):
 
 class BnApplyDesc(C.Structure):
     _fields_ = [("g", vp), ("ld_g", i32), ("y_raw", vp), ("ld_y", i32), ("cy_off", i32), ("mean", vp), ("invstd", vp),
-                ("k1", vp), ("k2", vp), ("gscale", vp), ("dtype", i32), ("C", i32), ("npix", i64)]
+                ("k1", vp), ("k2", vp), ("gscale", vp), ("dtype", i32), ("C", i32), ("npix", i64), ("out", vp), ("ld_out", i32)]
 
 
 class WgradDesc(C.Structure):

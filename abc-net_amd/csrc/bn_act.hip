@@ -337,6 +337,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const abc_bn_apply_desc d
     const int64_t nitems = d.npix * ncv;
     const int64_t stride = (int64_t)gridDim.x * 256;
     T* g = (T*)d.g;
+    T* o = d.out ? (T*)d.out : g;
+    const int ld_o = d.out ? d.ld_out : d.ld_g;
     const T* yr = (const T*)d.y_raw;
     for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < nitems; it += stride) {
         const int64_t p = it / ncv;
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const abc_bn_apply_desc d
             const float xh = (x[j] - d.mean[c + j]) * d.invstd[c + j];
             out[j] = d.gscale[c + j] * (gv[j] - d.k1[c + j] - xh * d.k2[c + j]);
         }
-        stv<N>(g + p * d.ld_g + c, out);
+        stv<N>(o + p * ld_o + c, out);
     }
 }
 
@@ -564,7 +566,7 @@ extern "C" int abc_act_bwd(const abc_act_bwd_desc* d, abc_stream_t stream) {
 
 extern "C" int abc_bn_apply_bwd(const abc_bn_apply_desc* d, abc_stream_t stream) {
     const int N = d->dtype == ABC_BF16 ? 8 : 4;
-    if (d->C % N || (d->ld_g | d->ld_y | d->cy_off) % N) return abc_fail(ABC_EINVAL, "bn_apply: alignment");
+    if (d->C % N || (d->ld_g | d->ld_y | d->cy_off) % N || (d->out && d->ld_out % N)) return abc_fail(ABC_EINVAL, "bn_apply: alignment");
     const int nb = ew_blocks(d->npix * (d->C / N));
     if (d->dtype == ABC_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);
     else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d);

@@ -145,7 +145,6 @@ class Engine:
         self.batched_heads = bool(batched_heads)
         self.want_fused_heads = bool(fused_heads) and train and dtype == "bf16" and self.batched_heads
         self.hf = None
-        self.side_mode = ""
         self.dev = device
         self.params, self.grads, self.buffers, self.counters = params, grads, buffers, counters
         self.lay_p, self.lay_b, self.lay_c = layout
@@ -351,9 +350,8 @@ class Engine:
         d.nsplit = nsplit
         need = nsplit * len(taps) * ca_pad * cb_pad
         self._ws_need = max(self._ws_need, need)
-        # split-K slabs alternate between two workspaces so that the reduction of one layer can run on the side stream
-        # under the next layer's kernels (see _run)
-        wsk = self._ws_k = 1 - getattr(self, "_ws_k", 1)
+        # (one workspace for the split-K slabs: a layer's reduction runs before the next layer's weight gradient, in stream order)
+        wsk = 0
         r = L.WgradReduceDesc()
         r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = nsplit, len(taps), Ca, Cb, ca_pad, cb_pad, dw_ptr, 0
         if collect is not None:
@@ -378,7 +376,7 @@ class Engine:
             r2.partial, r2.nsplit, r2.ntaps, r2.Ca, r2.Cb, r2.Ca_pad, r2.Cb_pad, r2.dw, r2.accumulate = rs.data_ptr(), nsplit, 1, Ca, 1, ca_pad, 1, self.G(rowsum_to), 0
             fused_rowsum = True
         post.append((r, what + " reduce", (wname,) if wname else (),
-                     {"ws": wsk, "side": True, "kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)}))
+                     {"ws": wsk, "kernel": "wgrad_reduce", "flops": 0, "bytes": float(need * 4 + Ca * Cb * len(taps) * 4)}))
         if fused_rowsum:
             post.append((r2, "dbias " + what[6:] + " reduce", (rowsum_to,),
                          {"kernel": "wgrad_reduce", "flops": 0, "bytes": float(nsplit * ca_pad * 4)}))
@@ -730,7 +728,7 @@ class Engine:
         self.pack_ops.append((lambda _r, st, a=a: lib.abc_pack_batch(a[0], a[1], a[2], st), None, "pack weights", (),
                               {"kernel": "pack_batch", "flops": 0, "bytes": float(first * (2 if self.dt == L.BF16 else 4) + first * 4)}))
         # shared workspaces
-        self.ws = [self.new((max(self._ws_need, 4),), torch.float32) for _ in range(2)]
+        self.ws = [self.new((max(self._ws_need, 4),), torch.float32)]
         for d, k in self._ws_users:
             d.partial = self.ws[k].data_ptr()
         self.cs_ws = self.new((max(self._colsum_need, 4),), torch.float32)
@@ -907,10 +905,12 @@ class Engine:
         a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
 
         def emit_apply():
+            dy = self.new((self.B, rec.H, rec.W, C_))      # (g is kept: the in-situ parity tests read it)
+            a.out, a.ld_out = dy.data_ptr(), C_
             self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
                        meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
-            rec.dY = g
-            return Src(g, self.dt, rec.H, rec.W, C_, 0, C_)
+            rec.dY = dy
+            return Src(dy, self.dt, rec.H, rec.W, C_, 0, C_)
 
         if defer:
             return Src(g, self.dt, rec.H, rec.W, C_, 0, C_, coef=(ca, cc, cb)), emit_apply
@@ -1058,7 +1058,7 @@ class Engine:
         npx = B * h * w
         writes = tuple(n for i in range(nh) for n in ("out_modules.%d.conv2.weight" % i, "out_modules.%d.conv2.bias" % i))
         ops.append((lambda _r, st: lib.abc_heads_fused_wgrad(C.byref(d), st), None, "wgrad out_modules.*.conv2", writes,
-                    {"kernel": "heads_fused_wgrad", "side": "big", "flops": 2.0 * npx * sum(self.heads) * 128,
+                    {"kernel": "heads_fused_wgrad", "flops": 2.0 * npx * sum(self.heads) * 128,
                      "bytes": float(npx * Ct * 2 + self.hf_dl.numel() * 2 + self.hf_work.numel() * 4)}))
         arr = (L.BnBwdDesc * nh)()
         merged, bwrites = [], []
@@ -1486,38 +1486,16 @@ class Engine:
 
     # ------------------------------------------------------------------ execution
     def _run(self, ops, stream):
-        """launch ops in order on `stream` (the current stream's handle).  Ops marked side (the split-K reductions: they
-        only produce final parameter gradients, nothing before the optimiser reads them) go to a second stream and
-        overlap with the following layers' kernels; the two slab workspaces are fenced with events, and everything
-        is joined before returning (so graph capture sees a closed fork/join and all-reduce buckets are complete)."""
-        # measured on MI355X: the fork/join dependencies cost more than the overlap gains (1733 vs 1823 img/s inside the
-        # hipGraph), so the second stream is off (Engine.side_mode = "" -- "1": every op marked side, "2": the big ones)
-        mode = self.side_mode
-        want = (lambda m: m.get("side") == "big") if mode == "2" else (lambda m: bool(m.get("side")))
-        use_side = bool(mode) and any(want(m) for _f, _r, _w, _x, m in ops)
-        if use_side:
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream()
-            main = torch.cuda.current_stream(self.dev)
-            side = self._side
-        pending = {}
+        """launch ops in order on `stream` (the current stream's handle).  ONE stream: a second stream for work that is off the
+        data-gradient chain was measured twice and lost both times inside the hipGraph -- the slab reductions (round 1:
+        1733 vs 1823 img/s) and, with the BatchNorm-backward apply as its own pass so that nothing chains them in front of the
+        data gradient, the weight gradients of the 12 x 12 .. 48 x 48 levels and the transposed convolutions (round 3,
+        profiles/tools/ab_side.py history: 6.68 ms -> 6.93 ms with 16 launches forked, 6.99 ms with 46): every fork / join
+        edge of the graph costs more than the 20-70 workgroup kernels it lets overlap."""
         for fn, ref, what, _w, m in ops:
-            if use_side and want(m):
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                rc = fn(ref, side.cuda_stream)
-                done = torch.cuda.Event()
-                done.record(side)
-                pending[m.get("ws", what)] = done
-            else:
-                if use_side and m.get("ws") in pending:
-                    main.wait_event(pending.pop(m["ws"]))   # the slabs of two layers ago have been consumed
-                rc = fn(ref, stream)
+            rc = fn(ref, stream)
             if rc != 0:
                 L.check(rc, what)
-        for done in pending.values():
-            main.wait_event(done)
 
     def run_pack(self, stream):
         self._run(self.pack_ops, stream)

@@ -239,6 +239,7 @@ typedef struct abc_bn_apply_desc {
     void* g; int32_t ld_g; const void* y_raw; int32_t ld_y; int32_t cy_off;
     const float* mean; const float* invstd; const float* k1; const float* k2; const float* gscale;
     int32_t dtype, C; int64_t npix;
+    void* out; int32_t ld_out;   /* NULL: dY replaces g in place; else dY goes to out[pixel * ld_out + c] and g is kept */
 } abc_bn_apply_desc;
 int abc_bn_apply_bwd(const abc_bn_apply_desc* d, abc_stream_t stream);
 
