@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) void cbam_bwd1_kernel(const abc_cbam_pix_desc 
 #pragma unroll
                 for (int j = 0; j < N; ++j) gv[j] += t[j];
             }
-            if (dp != nullptr) {
+            // (odd H / W: nn.MaxPool2d(2) floors -- the last row / column lies in no window and receives nothing, unet2.py:83)
+            if (dp != nullptr && (yy >> 1) < d.H / 2 && (x >> 1) < d.W / 2) {
                 // this pixel receives the pooled gradient iff it is the FIRST maximum of its 2x2 window of `out`
                 float t[N], w[N];
                 const int wy = yy >> 1, wx = x >> 1, me = (yy & 1) * 2 + (x & 1);
@@ -699,7 +700,6 @@ extern "C" int abc_cbam_apply_fwd(const abc_cbam_pix_desc* d, abc_stream_t strea
 }
 
 extern "C" int abc_cbam_bwd1(const abc_cbam_pix_desc* d, abc_stream_t stream) {
-    if (d->d_pool && ((d->H | d->W) & 1)) return abc_fail(ABC_EUNSUPPORTED, "cbam: pooled dims must be even");
     ABC_PIXGROUP_LAUNCH(cbam_bwd1_kernel, dim3(group_blocks(d), d->B));
     return abc_check_launch("cbam_bwd1");
 }

@@ -114,8 +114,6 @@ class Engine:
             raise NotImplementedError("variant %r" % variant)
         if H < 32 or W < 32:
             raise ValueError("H and W must be at least 32 (five 2x2 poolings; got %dx%d)" % (H, W))
-        if (H % 32 or W % 32) and variant != "unet":
-            raise ValueError("unet2: H and W must be multiples of 32 (got %dx%d)" % (H, W))
         if in_channels < 1:
             raise ValueError("in_channels must be positive")
         self.in_channels = in_channels

@@ -158,13 +158,22 @@ def main():
             passes[c] = by_ordinal(sel, lambda r: float(r["Counter_Value"]))
             if c == "GRBM_GUI_ACTIVE":
                 passes["_sq_us"] = by_ordinal(sel, dur_us)
-    total_us = sum(s for o in trace.values() for n, s in o.values())
+    # SETUP launches are not step work: torch's fills / copies of the engine's buffer allocations, the one-off weight packing
+    # of an inference run, calibration.  They are listed (role = "setup", launches counted per PASS) but kept out of the shares.
+    def is_setup(name, nlaunch, nsteps):
+        return name.startswith(("at::native::", "__amd_rocclr_", "void at::native::")) or "FillFunctor" in name or nlaunch % max(nsteps, 1) != 0
+
+    nsteps = steps_in(read_rows(opt["trace"], "*kernel_trace.csv"))
+    setup_keys = set(k for k, o in trace.items() if is_setup(short(k[0]), sum(n for n, _s in o.values()), nsteps))
+    total_us = sum(s for k, o in trace.items() if k not in setup_keys for n, s in o.values())
     rows = []
     for k, ords in trace.items():
         for cl in shape_clusters(ords):
             n = sum(ords[o][0] for o in cl)
             us = sum(ords[o][1] for o in cl) / n
-            r = {"kernel": short(k[0]), "grid": k[1], "launches": n, "launches_per_step": len(cl), "us": round(us, 2), "share": round(n * us / total_us, 4)}
+            setup = k in setup_keys
+            r = {"kernel": short(k[0]), "grid": k[1], "role": "setup" if setup else "step", "launches": n,
+                 "launches_per_step": (None if setup else len(cl)), "us": round(us, 2), "share": (None if setup else round(n * us / total_us, 4))}
 
             def mean(counter):
                 p = passes.get(counter, {}).get(k)
@@ -192,14 +201,14 @@ def main():
                         if v is not None:
                             r[name] = round(v / wc, 3)
             rows.append(r)
-    rows.sort(key=lambda r: -r["share"])
+    rows.sort(key=lambda r: (r["role"] == "setup", -(r["share"] or 0.0)))
     with open(prefix + ".json", "w") as f:
         json.dump({"total_us_per_pass": round(total_us, 1), "rows": rows,
                    "columns": "see profiles/kernel_table.py; a row = the launches of one kernel instantiation and grid whose durations lie "
                               "within 15 % (one launch SHAPE); mfma_util is against the nominal 2.4 GHz x 1024 SIMD matrix-pipe cycles "
                               "(= fraction of the 2.5 PFLOP/s dense bf16 peak for bf16 MFMAs), hbm_frac against 8 TB/s"}, f, indent=1)
     top = int(opt.get("top", 48))
-    cols = ["kernel", "grid", "launches_per_step", "us", "share", "hbm_mb", "hbm_gbs", "hbm_frac", "mfma_util", "clk_ghz", "wait", "stall", "active"]
+    cols = ["kernel", "grid", "role", "launches_per_step", "us", "share", "hbm_mb", "hbm_gbs", "hbm_frac", "mfma_util", "clk_ghz", "wait", "stall", "active"]
     with open(prefix + ".md", "w") as f:
         f.write("| " + " | ".join(cols) + " |\n|" + "---|" * len(cols) + "\n")
         for r in rows[:top]:

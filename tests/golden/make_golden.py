@@ -155,16 +155,19 @@ def shape_goldens():
     unet.py:51-56 then crops on some levels and not on others) and in_channels = 3 (unet.py:122-134's own self-check).
     Stored: strided samples + statistics of the eight head maps in eval and train mode, and (train mode) the gradient
     norms / leading samples of a few parameters under the surrogate loss sum_i mean(head_i ** 2)."""
-    mod = ref_module("unet")
     res = {}
-    for tag, cin, H, W in (("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40)):
-        sd = uo.filled_state("unet", cin, HEADS, seed=0)
+    # (unet2.py's general pad path, unet2.py:104-109, at a size that is not a multiple of 32: shapes_unet2.npz)
+    for tag, cin, H, W in (("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40), ("odd2", 1, 72, 88), ("odd2b", 1, 104, 40)):
+        variant = "unet2" if tag.startswith("odd2") else "unet"
+        mod = ref_module(variant)
+        sd = uo.filled_state(variant, cin, HEADS, seed=0)
         x = synthetic_images(2, max(H, W), seed=7, in_channels=cin)[:, :, :H, :W].contiguous()
         for mode in ("eval", "train"):
             m = mod.UNet(cin, HEADS)
             m.load_state_dict(sd, strict=True)
             for om in m.out_modules:
-                om.drop.p = 0.0
+                if hasattr(om, "drop"):
+                    om.drop.p = 0.0
             m.train(mode == "train")
             ys = m(x)
             for i, y in enumerate(ys):
@@ -179,11 +182,14 @@ def shape_goldens():
                 named = dict(m.named_parameters())
                 for k in ("inc1.double_conv.0.weight", "down3.maxpool_conv.1.double_conv.3.weight", "up1.up.weight", "up2.up.weight",
                           "up3.up.weight", "up2.up.bias", "up2.conv.double_conv.0.weight", "dconv2.double_conv.4.weight",
-                          "out_modules.5.conv2.weight"):
+                          "out_modules.5.conv2.weight") + (("down2.maxpool_conv.1.double_conv.5.channel_attention.shared_MLP.0.weight",
+                                                            "up1.conv.res_conv.weight", "inc2.double_conv.5.spatial_attention.conv2d.weight")
+                                                           if variant == "unet2" else ()):
                     g = named[k].grad
                     res["%s_gnorm/%s" % (tag, k)] = np.array(g.double().norm().item())
                     res["%s_ghead/%s" % (tag, k)] = g.reshape(-1)[:64].double().numpy()
-    np.savez(os.path.join(HERE, "shapes_unet.npz"), **res)
+    np.savez(os.path.join(HERE, "shapes_unet.npz"), **{k: v for k, v in res.items() if not k.startswith("odd2")})
+    np.savez(os.path.join(HERE, "shapes_unet2.npz"), **{k: v for k, v in res.items() if k.startswith("odd2")})
     print("wrote shapes")
 
 

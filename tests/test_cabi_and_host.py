@@ -85,7 +85,7 @@ def test_engine_plan_builds_without_gpu():
 
 def test_sizes_that_are_not_multiples_of_32_build_for_unet_only():
     """unet.py:51-56: the transposed convs meet skip tensors of 2n or 2n+1 rows; the plan lowers both (per axis: crop the first
-    row, or not).  unet2's CBAM passes keep the multiple-of-32 restriction; below 32 pixels five poolings leave nothing."""
+    row, or not).  unet2.py's plan builds at such sizes too (unet2.py:104-109); below 32 pixels five poolings leave nothing."""
     from abcnet_amd.engine import Engine, convT_phase_taps, convT_pack_parity
     from abcnet_amd.unet import UNet
     from abcnet_amd.unet2 import UNet as UNet2
@@ -103,8 +103,11 @@ def test_sizes_that_are_not_multiples_of_32_build_for_unet_only():
         Engine("unet", 1, HEADS, m._flat, m._flat_grad, m._flat_buf, m._counters, lay, 1, 31, 96, "fp32", False, device="cpu")
     m2 = UNet2(1, HEADS)
     m2._flat_grad = torch.zeros_like(m2._flat)
+    e2 = Engine("unet2", 1, HEADS, m2._flat, m2._flat_grad, m2._flat_buf, m2._counters, (m2._lay_p, m2._lay_b, m2._lay_c), 1, 72, 88,
+                "fp32", True, device="cpu")
+    assert (e2.h, e2.w) == (18, 22)
     with pytest.raises(ValueError):
-        Engine("unet2", 1, HEADS, m2._flat, m2._flat_grad, m2._flat_buf, m2._counters, (m2._lay_p, m2._lay_b, m2._lay_c), 1, 100, 96,
+        Engine("unet2", 1, HEADS, m2._flat, m2._flat_grad, m2._flat_buf, m2._counters, (m2._lay_p, m2._lay_b, m2._lay_c), 1, 96, 24,
                "fp32", False, device="cpu")
 
 

@@ -773,16 +773,18 @@ def test_folded_inference_graph_matches_oracle(dtype, size, tol):
     assert max((y.cpu() - r).abs().max().item() for y, r in zip(run.logits, ref2)) < tol
 
 
-@pytest.mark.parametrize("tag,cin,H,W", [("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40)])
+@pytest.mark.parametrize("tag,cin,H,W", [("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40), ("odd2", 1, 72, 88), ("odd2b", 1, 104, 40)])
 def test_general_shapes_match_reference_golden_and_oracle(tag, cin, H, W, golden_dir):
     """the reference's general code paths on the HIP kernels: input sizes that are not multiples of 32 (unet.py:51-56: per level
     and axis the transposed conv's first row is cropped, or nothing is; MaxPool2d floors) and in_channels = 3
     (unet.py:122-134).  fp32 logits within the 1e-3 gate of the reference-generated golden and of the oracle, eval and train;
     gradients of the reference loop body (loss.backward() through the module) against the oracle's autograd"""
-    gold = np.load(os.path.join(golden_dir, "shapes_unet.npz"))
+    # (tags odd2*: unet2.py's general pad path, unet2.py:104-109 -- CBAM blocks, residuals and pooled gradients on odd-sized levels)
+    variant = "unet2" if tag.startswith("odd2") else "unet"
+    gold = np.load(os.path.join(golden_dir, "shapes_%s.npz" % variant))
     x = synthetic_images(2, max(H, W), seed=7, in_channels=cin)[:, :, :H, :W].contiguous()
-    sd0 = uo.filled_state("unet", cin, HEADS, seed=0)
-    m = UNet(cin, HEADS, dtype="fp32", dropout_p=0.0)
+    sd0 = uo.filled_state(variant, cin, HEADS, seed=0)
+    m = (UNet2 if variant == "unet2" else UNet)(cin, HEADS, dtype="fp32", dropout_p=0.0)
     m.load_state_dict(sd0)
     m = m.to(DEV)
     for mode in ("eval", "train"):
@@ -790,7 +792,7 @@ def test_general_shapes_match_reference_golden_and_oracle(tag, cin, H, W, golden
         m.train(mode == "train")
         with torch.no_grad():
             ys = m(x.to(DEV))
-            ref = uo.forward("unet", uo.clone_state(sd0), x, train=(mode == "train"))
+            ref = uo.forward(variant, uo.clone_state(sd0), x, train=(mode == "train"))
         for i, (y, r) in enumerate(zip(ys, ref)):
             assert tuple(y.shape) == tuple(r.shape) == tuple(gold["%s_%s_head%d_shape" % (tag, mode, i)])
             assert (y.cpu() - r).abs().max().item() < 1e-3, (tag, mode, i)
@@ -805,10 +807,12 @@ def test_general_shapes_match_reference_golden_and_oracle(tag, cin, H, W, golden
     loss.backward()
     assert abs(loss.item() - gold["%s_loss" % tag].item()) <= 1e-4 * abs(gold["%s_loss" % tag].item())
     sd = uo.clone_state(sd0, requires_grad=True)
-    sum((y ** 2).mean() for y in uo.forward("unet", sd, x, train=True)).backward()
+    sum((y ** 2).mean() for y in uo.forward(variant, sd, x, train=True)).backward()
     named = dict(m.named_parameters())
+    extra = ("down2.maxpool_conv.1.double_conv.5.channel_attention.shared_MLP.0.weight", "up1.conv.res_conv.weight",
+                "inc2.double_conv.5.spatial_attention.conv2d.weight") if variant == "unet2" else ()
     for k in ("inc1.double_conv.0.weight", "down3.maxpool_conv.1.double_conv.3.weight", "up1.up.weight", "up2.up.weight", "up3.up.weight",
-              "up2.up.bias", "up2.conv.double_conv.0.weight", "dconv2.double_conv.4.weight", "out_modules.5.conv2.weight"):
+              "up2.up.bias", "up2.conv.double_conv.0.weight", "dconv2.double_conv.4.weight", "out_modules.5.conv2.weight") + extra:
         g, r = named[k].grad.cpu().double(), sd[k].grad.double()
         assert (g - r).norm().item() <= 2e-2 * r.norm().item() + 1e-12, (tag, k, (g - r).norm().item(), r.norm().item())
         assert abs(g.norm().item() - gold["%s_gnorm/%s" % (tag, k)].item()) <= 2e-2 * gold["%s_gnorm/%s" % (tag, k)].item() + 1e-12

@@ -209,7 +209,9 @@ def test_raster_oracle_matches_reference(golden_dir):
         assert all(bt[x, y] in (1.0, np.float32(0.8)) for x, y in bonds[:, :2])
 
 
-SHAPE_CASES = (("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40))
+SHAPE_CASES = (("odd", 1, 72, 88), ("rgb", 3, 64, 64), ("odd_rgb", 3, 104, 40), ("odd2", 1, 72, 88), ("odd2b", 1, 104, 40))
+SHAPE_GRADS2 = ("down2.maxpool_conv.1.double_conv.5.channel_attention.shared_MLP.0.weight", "up1.conv.res_conv.weight",
+                "inc2.double_conv.5.spatial_attention.conv2d.weight")
 SHAPE_GRADS = ("inc1.double_conv.0.weight", "down3.maxpool_conv.1.double_conv.3.weight", "up1.up.weight", "up2.up.weight", "up3.up.weight",
                "up2.up.bias", "up2.conv.double_conv.0.weight", "dconv2.double_conv.4.weight", "out_modules.5.conv2.weight")
 
@@ -221,12 +223,14 @@ def shape_case_input(cin, H, W):
 @pytest.mark.parametrize("tag,cin,H,W", SHAPE_CASES)
 def test_general_shapes_match_reference(tag, cin, H, W, golden_dir):
     """unet.py:51-56 (pad / crop of the transposed conv against a skip tensor of 2n or 2n+1 rows) and in_channels = 3
-    (unet.py:122-134): the oracle against the reference's own outputs on inputs that are not multiples of 32"""
-    gold = np.load(os.path.join(golden_dir, "shapes_unet.npz"))
+    (unet.py:122-134): the oracle against the reference's own outputs on inputs that are not multiples of 32; tags odd2*:
+    unet2.py's general pad path (unet2.py:104-109) with its CBAM blocks on odd-sized levels"""
+    variant = "unet2" if tag.startswith("odd2") else "unet"
+    gold = np.load(os.path.join(golden_dir, "shapes_%s.npz" % variant))
     x = shape_case_input(cin, H, W)
     for mode in ("eval", "train"):
-        sd = uo.clone_state(uo.filled_state("unet", cin, HEADS, seed=0), requires_grad=(mode == "train"))
-        ys = uo.forward("unet", sd, x, train=(mode == "train"))
+        sd = uo.clone_state(uo.filled_state(variant, cin, HEADS, seed=0), requires_grad=(mode == "train"))
+        ys = uo.forward(variant, sd, x, train=(mode == "train"))
         for i, y in enumerate(ys):
             assert list(y.shape) == list(gold["%s_%s_head%d_shape" % (tag, mode, i)])
             np.testing.assert_allclose(_sample(y), gold["%s_%s_head%d_sample" % (tag, mode, i)], atol=2e-5, rtol=1e-5)
@@ -234,7 +238,7 @@ def test_general_shapes_match_reference(tag, cin, H, W, golden_dir):
             loss = sum((y ** 2).mean() for y in ys)
             loss.backward()
             assert abs(loss.item() - gold["%s_loss" % tag].item()) <= 1e-6 * abs(gold["%s_loss" % tag].item())
-            for k in SHAPE_GRADS:
+            for k in SHAPE_GRADS + (SHAPE_GRADS2 if variant == "unet2" else ()):
                 g = sd[k].grad
                 ref_n = gold["%s_gnorm/%s" % (tag, k)].item()
                 assert abs(g.double().norm().item() - ref_n) <= 1e-4 * ref_n + 1e-9, k
