@@ -107,7 +107,8 @@ class Rec:
 
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
-                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False):
+                 dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
+                 guards=False):
         """batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
         batched one is tested against, tests/test_gpu_model.py::test_batched_heads_equal_one_by_one_launches)"""
         if variant not in ("unet", "unet2"):
@@ -135,6 +136,8 @@ class Engine:
             raise ValueError("fp8 is a form of the BatchNorm-folded bf16 inference graph (fold_bn=True, dtype='bf16')")
         self.fp8_recs = []
         self.fp8_calibrated = False
+        self.guards = bool(guards)
+        self._guarded = []
         self.dt = L.BF16 if dtype == "bf16" else L.F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         # the fused train step's heads (csrc/heads_fused.hip): conv2 forward + loss + the way back to the BatchNorm outputs as
@@ -185,10 +188,44 @@ class Engine:
     def Cn(self, name):
         return self.counters.data_ptr() + 8 * self.lay_c[name]
 
+    GUARD_BYTES = 4096
+
     def new(self, shape, dtype=None, fill=0.0):
-        t = torch.full(shape, fill, dtype=dtype or self.tdt, device=self.dev)
+        """a device buffer of the plan.  Debug plans (Engine(guards=True), the bounds-check build of SURVEY section 5): the buffer
+        sits between two 4 KB guard bands of 0xA5 bytes that check_guards() inspects -- the kernels take raw pointers, loads
+        are range-checked by the buffer descriptors, stores are not"""
+        dtype = dtype or self.tdt
+        if not self.guards:
+            t = torch.full(shape, fill, dtype=dtype, device=self.dev)
+            self.keep.append(t)
+            return t
+        n = 1
+        for s_ in shape:
+            n *= s_
+        esz = torch.empty((), dtype=dtype).element_size()
+        body = -(-n * esz // 256) * 256                   # (keeps every buffer 256-byte aligned, as the caching allocator does)
+        raw = torch.full((body + 2 * self.GUARD_BYTES,), 0xA5, dtype=torch.uint8, device=self.dev)
+        t = raw[self.GUARD_BYTES:self.GUARD_BYTES + n * esz].view(dtype).view(shape)
+        t.fill_(fill)
         self.keep.append(t)
+        self._guarded.append((raw, n * esz, tuple(shape), str(dtype)))
         return t
+
+    def check_guards(self):
+        """debug plans: every guard band (and the alignment slack behind each buffer) still holds its pattern; returns the number
+        of buffers checked, raises with the offenders otherwise (host sync)"""
+        if not self.guards:
+            raise RuntimeError("this plan was built without guards (Engine(guards=True) / Trainer(guards=True))")
+        bad = []
+        for i, (raw, nbytes, shape, dt) in enumerate(self._guarded):
+            G = self.GUARD_BYTES
+            lo_ok = bool((raw[:G] == 0xA5).all())
+            hi_ok = bool((raw[G + nbytes:] == 0xA5).all())
+            if not (lo_ok and hi_ok):
+                bad.append((i, shape, dt, "below" if not lo_ok else "above"))
+        if bad:
+            raise RuntimeError("out-of-bounds stores next to %d of %d plan buffers: %s" % (len(bad), len(self._guarded), bad[:8]))
+        return len(self._guarded)
 
     def act_buf(self, H, W, C, dt=None):
         t = self.new((self.B, H, W, C), self._tdt(dt)) if dt is not None else self.new((self.B, H, W, C))
