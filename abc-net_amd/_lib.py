@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("stats_rows", i32), ("accumulate", i32),
                 ("planar_out", i32), ("ctot_out", i32), ("out_act", i32), ("out_slope", f32), ("pool_y", vp), ("ld_pool", i32),
                 ("stem_x", vp), ("stem_w", vp), ("stem_scale", vp), ("stem_bias", vp), ("stem_slope", f32),
-                ("out_scale", vp), ("out_quant", vp)]
+                ("out_scale", vp), ("out_quant", vp), ("out_quant_stride", i32)]
 
 
 class PackDesc(C.Structure):
@@ -226,6 +226,7 @@ SYMBOLS = {
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     "abc_fill_f32": (C.c_int, [vp, f32, i64, vp]),
     "abc_absmax": (C.c_int, [vp, i32, i64, vp, vp]),
+    "abc_absmax_cols": (C.c_int, [vp, i32, i64, i32, i32, i32, vp, vp]),
     "abc_fp8_act_scale": (C.c_int, [vp, f32, vp, vp, vp]),
     "abc_fp8_weight_scales": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp]),
     "abc_concat_f32": (C.c_int, [vp, vp, i32, vp, vp]),

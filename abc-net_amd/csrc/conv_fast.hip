@@ -49,7 +49,8 @@ struct FastK {
     int sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, stats_rows, accumulate, b_static, stg_off, red_off, dbg, stagger;
     int out_act; float out_slope;   // epilogue activation (BatchNorm folded into the weights: eval mode)
     const float* oscale;            // fp8 compute: per output channel, accumulator -> real value (s_in * s_w[n])
-    const float* oquant;            // fp8 output: device scalar 1 / s_out applied before the rounding to e4m3
+    const float* oquant;            // fp8 output: 1 / s_out (device), applied before the rounding to e4m3
+    int oq_stride;                  // 0: a scalar; 1: one per n-block (128 output channels)
     unsigned bytesA, bytesW;
     long long* prof;  // debugging: per-workgroup phase timestamps (null in production)
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
             bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
             osc[j] = (F8C && nval[j]) ? a.oscale[n] : 1.f;
         }
-        const float oq = F8O ? *a.oquant : 1.f;
+        const float oq = F8O ? a.oquant[nb * a.oq_stride] : 1.f;
 
         // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile).
         // Persistent (resident-weight) workgroups prefetched this tile's halo during the previous tile.
@@ -840,7 +841,7 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     k.tap_off = g.tap_off; k.coef_off = g.coef_off; k.cstride = g.cstride; k.stats_rows = d->stats_rows;
     k.accumulate = d->accumulate; k.b_static = g.b_static; k.stg_off = g.stg_off; k.red_off = g.red_off;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
-    k.oscale = d->out_scale; k.oquant = d->out_quant;
+    k.oscale = d->out_scale; k.oquant = d->out_quant; k.oq_stride = d->out_quant_stride ? 1 : 0;
     { const char* e = abc_knob("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     k.prof = g_prof;
     { const char* e = abc_knob("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }

@@ -507,6 +507,7 @@ extern "C" int abc_conv_chunk(int dtype_c, int Cin) {
 }
 
 extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, int32_t* ck) {
+    if (abc_head_fwd_ok(d)) { *bn = 32; *mt = 2; *ck = abc_conv_chunk(d->dtype_c, d->Cin); return ABC_OK; }   // (a wave: 32 rows x 64 pixels)
     abc_fast_geom f;
     if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) { *bn = f.BN; *mt = f.MT; *ck = f.CK; return ABC_OK; }
     Geom g;
@@ -544,7 +545,8 @@ extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
 
 extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     if (d->dtype_c == ABC_FP8 || d->dtype_out == ABC_FP8 || d->dtype_in == ABC_FP8) {
-        // the fp8 inference graph: served by the lean kernel's weights-direct tile or not at all
+        // the fp8 inference graph: the heads' 1x1 convolution into NCHW f32 (heads.hip), else the lean kernel's weights-direct tile
+        if (abc_head_fwd_ok(d)) return abc_head_fwd_launch(d, stream);
         if (d->src.pool || d->src.planar || d->planar_out || d->src.Hx != d->Hin || d->src.Wx != d->Win || d->stem_x != nullptr || d->pool_y != nullptr)
             return abc_fail(ABC_EUNSUPPORTED, "conv: fp8 needs a plain NHWC input and output");
         if ((d->src.ldx * abc_dsize(d->dtype_in)) % 16 || (d->cin_off * abc_dsize(d->dtype_in)) % 16 || (d->ldy * abc_dsize(d->dtype_out)) % 16 || (d->cout_off * abc_dsize(d->dtype_out)) % 16)

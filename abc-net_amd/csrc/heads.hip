@@ -25,9 +25,63 @@ struct HeadFwdK {
     uint32_t drop_seed;
     const uint32_t* drop_salt;
     unsigned bytesX, bytesW;
+    int f8;                // e4m3 features and weights (the fp8 inference graph): oscale[co] = s_x * s_w[co]
+    const float* oscale;
 };
 
+// e4m3 form (fp8 inference graph: finished features, no transform on load): a pixel's 128 channels are 128 bytes = two K = 64
+// steps of the block-scaled MFMA (unit scales); packed weights [1 tap][2 chunks][Cout_pad][64]; logits = acc * oscale[co] + b[co]
+__device__ inline void head_fwd_f8_body(const HeadFwdK& a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.npairs) return;
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX), rsW = abc_make_rsrc(a.w, a.bytesW);
+    i32x8 fb[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t pix = (uint32_t)pair * 64u + t * 32 + r;
+        const uint32_t e0 = pix * (uint32_t)a.ldx + (uint32_t)a.cin_off + 32 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            fb[t][s] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsX, e0 + 64 * s, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsX, e0 + 64 * s + 16, 0, 0));
+    }
+    const int b = (pair * 64) / a.HW, pp = pair * 64 - b * a.HW;
+    const int mtiles = a.Cout_pad / 32;
+    for (int mt = 0; mt < mtiles; ++mt) {
+        i32x8 fa[2];
+        const int co = mt * 32 + r;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned off = (unsigned)((s * a.Cout_pad + co) * 64 + 32 * h);
+            fa[s] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsW, off + 16, 0, 0));
+        }
+        float bvv[16], osc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+            const bool ok = oc < a.Cout;
+            bvv[k] = (a.bias && ok) ? a.bias[oc] : 0.f;
+            osc[k] = ok ? a.oscale[oc] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mma32B_f8(acc, fa[s], fb[t][s]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                if (oc < a.Cout) a.y[((size_t)(b * a.ctot + a.cout_off + oc)) * a.HW + pp + t * 32 + r] = fmaf(acc[k], osc[k], bvv[k]);
+            }
+        }
+    }
+}
+
 __device__ inline void head_fwd_body(const HeadFwdK& a) {
+    if (a.f8) { head_fwd_f8_body(a); return; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int pair = blockIdx.x * 4 + wave;   // 64 consecutive pixels (never straddling an image: HW % 64 == 0)
@@ -237,8 +291,9 @@ static void fill_fwd(HeadFwdK& k, const abc_conv_desc* d) {
     k.HW = d->Hg * d->Wg; k.ldx = d->src.ldx; k.cin_off = d->cin_off; k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;
     k.ctot = d->ctot_out; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
     k.drop_p = d->src.drop_p; k.drop_seed = d->src.drop_seed; k.drop_salt = d->src.drop_salt;
-    k.bytesX = (unsigned)((int64_t)d->B * k.HW * d->src.ldx * 2);
-    k.bytesW = (unsigned)((int64_t)4 * d->Cout_pad * 32 * 2);
+    k.f8 = d->dtype_c == ABC_FP8 ? 1 : 0; k.oscale = d->out_scale;
+    k.bytesX = (unsigned)((int64_t)d->B * k.HW * d->src.ldx * (k.f8 ? 1 : 2));
+    k.bytesW = (unsigned)((int64_t)128 * d->Cout_pad * (k.f8 ? 1 : 2));
 }
 
 static void fill_dg(HeadDgK& k, const abc_conv_desc* d) {
@@ -254,12 +309,15 @@ static void fill_dg(HeadDgK& k, const abc_conv_desc* d) {
 int abc_head_fwd_ok(const abc_conv_desc* d) {
     if (abc_knob("ABC_CONV_NOHEAD")) return 0;
     if (!d->planar_out || d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
-    if (d->Cin != 128 || d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_F32) return 0;
+    const bool f8 = d->dtype_in == ABC_FP8 && d->dtype_c == ABC_FP8;
+    // (e4m3: finished features only -- no transform, no dropout -- with the dequantisation factors in out_scale)
+    if (f8 && (d->out_scale == nullptr || d->src.scale != nullptr || d->src.drop_p > 0.f || (d->src.ldx % 16) || (d->cin_off % 16))) return 0;
+    if (d->Cin != 128 || !(f8 || (d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16)) || d->dtype_out != ABC_F32) return 0;
     if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr || d->out_act) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
     if ((d->src.ldx % 8) || (d->cin_off % 8) || d->Cout_pad % 32) return 0;
     // (all offsets in the kernel are unsigned 32-bit bytes: a batch-64 512x512 feature buffer of 8 x 128 channels is 2^31)
-    const int64_t bx = (int64_t)d->B * d->Hg * d->Wg * d->src.ldx * 2;
+    const int64_t bx = (int64_t)d->B * d->Hg * d->Wg * d->src.ldx * (f8 ? 1 : 2);
     return bx < (int64_t(1) << 32) - 4096;
 }
 

@@ -248,6 +248,23 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* x, int64_t n, floa
     // non-negative floats order like their bit patterns: an integer atomic max is exact and order-independent
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)out, __float_as_uint(m));
 }
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_cols_kernel(const T* x, int64_t npix, int ld, int c_off, int C, float* out) {
+    const int ncv = C / 8;
+    const int64_t nitems = npix * ncv;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nitems; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i / ncv;
+        const int c = (int)(i % ncv) * 8;
+        float v[8];
+        LoadVec<T, 8>::ld(x + p * ld + c_off + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned*)out, __float_as_uint(m));
+}
 __global__ void fp8_act_scale_kernel(const float* amax, float margin, float* s_out, float* inv_s_out) {
     const float s = fmaxf(*amax, 1e-12f) * margin / 448.f;
     *s_out = s; *inv_s_out = 1.f / s;
@@ -280,6 +297,15 @@ extern "C" int abc_absmax(const void* x, int32_t dtype, int64_t n, float* out, a
     else if (dtype == ABC_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, out);
     else return abc_fail(ABC_EUNSUPPORTED, "absmax: f32 or bf16");
     return abc_check_launch("absmax");
+}
+extern "C" int abc_absmax_cols(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C, float* out, abc_stream_t stream) {
+    if (npix < 1 || C < 8 || (C % 8) || (ld % 8) || (c_off % 8)) return abc_fail(ABC_EINVAL, "absmax_cols: shape / alignment");
+    int64_t nb = (npix * (C / 8) + 2047) / 2048;
+    if (nb > 2048) nb = 2048;
+    if (dtype == ABC_BF16) hipLaunchKernelGGL(absmax_cols_kernel<bf16>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, npix, ld, c_off, C, out);
+    else if (dtype == ABC_F32) hipLaunchKernelGGL(absmax_cols_kernel<float>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, npix, ld, c_off, C, out);
+    else return abc_fail(ABC_EUNSUPPORTED, "absmax_cols: f32 or bf16");
+    return abc_check_launch("absmax_cols");
 }
 extern "C" int abc_fp8_act_scale(const float* amax, float margin, float* s_out, float* inv_s_out, abc_stream_t stream) {
     if (!(margin > 0.f)) return abc_fail(ABC_EINVAL, "fp8_act_scale: margin");

@@ -135,6 +135,7 @@ class Engine:
         if self.fp8 and not (self.fold and dtype == "bf16"):
             raise ValueError("fp8 is a form of the BatchNorm-folded bf16 inference graph (fold_bn=True, dtype='bf16')")
         self.fp8_recs = []
+        self.hfeat_q = None
         self.fp8_calibrated = False
         self.guards = bool(guards)
         self._guarded = []
@@ -279,7 +280,7 @@ class Engine:
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
                   grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
-                  accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None):
+                  accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None, out_quant_stride=0):
         """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch;
         out_slope: not None -> the epilogue stores max(v, out_slope * v) (folded-BatchNorm eval graph);
         cdt / out_scale / out_quant: fp8 inference graph (abc_conv_desc.out_scale, .out_quant)"""
@@ -292,6 +293,7 @@ class Engine:
         d.stats = None
         d.out_scale = None if out_scale is None else out_scale.data_ptr()
         d.out_quant = None if out_quant is None else out_quant.data_ptr()
+        d.out_quant_stride = out_quant_stride
         d.dtype_in, d.dtype_c, d.dtype_out = src.dt, cdt, y_dt
         lh, lw = src.lh()
         d.B, d.Hin, d.Win = self.B, lh, lw
@@ -576,7 +578,7 @@ class Engine:
         """pack-time op (before the weight packing): per output row the e4m3 scale of the BatchNorm-folded weight --
         qmul = fold / s_w (what the packing multiplies the master weight with), deq = s_w * s_in (the convolution's out_scale)"""
         lib = self.lib
-        a = (self.P(wname), rows, K, fold.data_ptr(), s_in.data_ptr(), qmul.data_ptr(), deq.data_ptr())
+        a = (self.P(wname), rows, K, None if fold is None else fold.data_ptr(), s_in.data_ptr(), qmul.data_ptr(), deq.data_ptr())
         self.keep += [fold, s_in, qmul, deq]
         self.pack_ops.append((lambda _r, st, a=a: lib.abc_fp8_weight_scales(*a, st), None, "fp8 scales " + wname, (),
                               {"kernel": "fp8_weight_scales", "flops": 0, "bytes": 0}))
@@ -599,6 +601,14 @@ class Engine:
             L.check(lib.abc_fill_f32(amax.data_ptr(), 0.0, 1, stream), "fill")
             L.check(lib.abc_absmax(t.y.data_ptr(), L.BF16, t.y.numel(), amax.data_ptr(), stream), "absmax")
             L.check(lib.abc_fp8_act_scale(amax.data_ptr(), margin, s.data_ptr(), inv_s.data_ptr(), stream), "fp8_act_scale")
+        if self.hfeat_q is not None:      # the eight heads' features: 128 columns each of one tensor, each head its own scale
+            amax, s, inv_s = self.hfeat_q
+            nh = amax.numel()
+            npx = ref.hfeat.numel() // (128 * nh)
+            L.check(lib.abc_fill_f32(amax.data_ptr(), 0.0, nh, stream), "fill")
+            for i in range(nh):
+                L.check(lib.abc_absmax_cols(ref.hfeat.data_ptr(), L.BF16, npx, 128 * nh, 128 * i, 128, amax.data_ptr() + 4 * i, stream), "absmax_cols")
+                L.check(lib.abc_fp8_act_scale(amax.data_ptr() + 4 * i, margin, s.data_ptr() + 4 * i, inv_s.data_ptr() + 4 * i, stream), "fp8_act_scale")
         self.fp8_calibrated = True
 
     def double_conv(self, prefix, src, cout, k, dst_b=None):
@@ -774,7 +784,11 @@ class Engine:
         h, w = trunk.H, trunk.W
         nh = len(self.heads)
         self.h, self.w = h, w
-        self.hfeat, self.hcoef = self.act_buf(h, w, 128 * nh)
+        # (fp8 graph: the heads' features are e4m3 too when the merged conv1 and the heads' own 1x1 kernel serve them)
+        f8_feat = self.fp8 and trunk.dt == L.FP8 and trunk.C == 128 and nh <= 8 and self.batched_heads and (h * w) % 64 == 0
+        self.hfeat, self.hcoef = self.act_buf(h, w, 128 * nh, L.FP8 if f8_feat else None)
+        if f8_feat:
+            self.hfeat_q = (self.new((nh,), torch.float32, 0.0), self.new((nh,), torch.float32, 1.0), self.new((nh,), torch.float32, 1.0))
         # the list forward() returns: one contiguous NCHW f32 map per head (unet.py:119), written directly
         self.logits = [self.new((self.B, hc, h, w), torch.float32) for hc in self.heads]
         self.head_recs, self.head2 = [], []
@@ -800,6 +814,16 @@ class Engine:
             f.drop_p, f.drop_seed, f.drop_salt = self.drop_p, self.drop_seed, self.drop_salt
             if not fused:
                 rows_pad = -(-hc // 32) * 32
+                if self.hfeat_q is not None:
+                    f.dt, f.q = L.FP8, tuple(t[i:i + 1] for t in self.hfeat_q)
+                    qmul, deq = self._fp8_weight_scales(p + ".conv2.weight", hc, 128, None, f.q[1], self.new((hc,), torch.float32, 1.0),
+                                                        self.new((hc,), torch.float32, 1.0))
+                    w2 = self.packed(1, 128, rows_pad, cdt=L.FP8)
+                    self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128, row_scale=qmul.data_ptr(), cdt=L.FP8)
+                    self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
+                                   [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs, cdt=L.FP8, out_scale=deq)
+                    self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
+                    continue
                 w2 = self.packed(1, 128, rows_pad)
                 self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
                 self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
@@ -883,8 +907,9 @@ class Engine:
                 else:
                     self.emit_pack(p + ".conv1.weight", wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i,
                                    row_scale=scale_all[sl].data_ptr())
-            self.emit_conv(self.fwd_ops, trunk, wf, bias_all.data_ptr(), self.hfeat, self.dt, h, w, Ct, 0, Ct, taps,
-                           what="fwd out_modules.*.conv1", out_slope=0.01, cdt=L.FP8 if f8 else None, out_scale=deq_all if f8 else None)
+            self.emit_conv(self.fwd_ops, trunk, wf, bias_all.data_ptr(), self.hfeat, L.FP8 if self.hfeat_q is not None else self.dt, h, w, Ct, 0, Ct, taps,
+                           what="fwd out_modules.*.conv1", out_slope=0.01, cdt=L.FP8 if f8 else None, out_scale=deq_all if f8 else None,
+                           out_quant=None if self.hfeat_q is None else self.hfeat_q[2], out_quant_stride=0 if self.hfeat_q is None else 1)
             return None, 0
         for i in range(nh):
             self.emit_pack("out_modules.%d.conv1.weight" % i, wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i)

@@ -111,6 +111,8 @@ typedef struct abc_conv_desc {
      * Served by the weights-direct loop of the lean kernel only (3x3, stride 1, Cout a multiple of 128, Cin a multiple of 64). */
     const float* out_scale;
     const float* out_quant;
+    int32_t out_quant_stride; /* 0: one scalar; 1: one value per 128-channel block of the output (out_quant[n / 128]): the eight heads'
+                                 features side by side in one tensor, each head with its own scale */
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
@@ -170,6 +172,8 @@ int abc_pack_batch(const void* items_dev, int32_t nitems, int64_t total, abc_str
  *                          qmul[n] = fold[n] / s_w  (abc_pack_desc.row_scale of the fp8 packing),
  *                          deq[n] = s_w * (*s_in)   (abc_conv_desc.out_scale) */
 int abc_absmax(const void* x, int32_t dtype, int64_t n, float* out, abc_stream_t stream);
+/* the same over the columns [c_off, c_off + C) of an [npix][ld] tensor (C, ld, c_off multiples of 8) */
+int abc_absmax_cols(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C, float* out, abc_stream_t stream);
 int abc_fp8_act_scale(const float* amax, float margin, float* s_out, float* inv_s_out, abc_stream_t stream);
 int abc_fp8_weight_scales(const float* w, int32_t rows, int32_t K, const float* fold, const float* s_in, float* qmul, float* deq,
                           abc_stream_t stream);

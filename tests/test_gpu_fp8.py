@@ -163,7 +163,10 @@ def test_fp8_inference_graph_against_oracle_and_bf16_graph():
     x = synthetic_images(B, S, seed=7)
     run8, run16 = _runner(True, B, S), _runner(False, B, S)
     kinds = [op[4]["kernel"] for op in run8.eng.fwd_ops]
-    assert sum("fp8,fp8,fp8" in k for k in kinds) == 5 and sum("fp8,fp8,bf16" in k for k in kinds) == 1 and sum("bf16,bf16,fp8" in k for k in kinds) == 1, kinds
+    # up3.conv's first convolution enters the chain (bf16 compute, e4m3 out); five 128 -> 128 convolutions and the eight heads'
+    # merged conv1 compute in e4m3 and store e4m3; the heads' 1x1 convolutions read e4m3 features and write the f32 maps
+    assert sum("<fp8,fp8,fp8" in k for k in kinds) == 6 and sum("<bf16,bf16,fp8" in k for k in kinds) == 1 and "heads_fwd_batch" in kinds, kinds
+    assert run8.eng.hfeat.dtype == F8 and run8.eng.hfeat_q is not None
     assert not run8.eng.fp8_calibrated
     outs = []
     for run in (run8, run16):
