@@ -26,6 +26,8 @@ There is no CPU fallback: without the HIP library / a GPU the compute entry poin
 from __future__ import annotations
 
 import ctypes as C
+import threading
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -78,6 +80,7 @@ class _UNetFn(torch.autograd.Function):
             eng.chan_scale.fill_(1.0)
             eng.run_backward(st)
             g = model._flat_grad.clone()
+        model._dp_busy = False      # (multi-device nn.DataParallel: this replica's engine is free again)
         return (None, None) + tuple(g[off:off + cnt].view(shape) for off, cnt, shape in model._param_slices)
 
 
@@ -127,6 +130,13 @@ class UNetBase(nn.Module):
         self._flat_grad = None
         self._grad_store = None
         self._engines = {}
+        # multi-device nn.DataParallel (train.py:50, img2smiles2.py:43 on a multi-GPU box): the replicas torch makes every
+        # forward share this object's attributes; they find the master through _master_ref and their per-device shadow
+        # models (own arenas + engines) in _dp_shadows -- see _forward_replica
+        self._master_ref = weakref.ref(self)
+        self._dp_shadows = {}
+        self._dp_lock = threading.Lock()
+        self._dp_busy = False
         self._leaves = []          # (name, holder module, attribute, role)
         self._param_slices = []    # (offset, numel, shape) in parameters() order
         for name, shape, role in self._table:
@@ -303,7 +313,86 @@ class UNetBase(nn.Module):
         # reuses its buffers on the next call (the reference returns fresh tensors)
         return [t.clone() for t in eng.logits]
 
+    # ------------------------------------------------------------------ multi-device nn.DataParallel
+    def _replica_tensors(self):
+        """the broadcast copies torch.nn.parallel.replicate hung on this replica's module tree, in arena order"""
+        params, bufs, cnts = [], [], []
+        for name, shape, role in self._table:
+            *path, attr = name.split(".")
+            mod = self
+            for seg in path:
+                mod = mod._modules[seg]
+            if role == "param":
+                params.append(mod._former_parameters[attr])
+            elif role == "buffer":
+                bufs.append(mod._buffers[attr])
+            else:
+                cnts.append(mod._buffers[attr])
+        return params, bufs, cnts
+
+    def _dp_checkout(self, master, dev):
+        """an engine owner for one replica's forward (+ backward): the master itself for the first replica on its device,
+        else a shadow model of that device (own arenas, engines, gradient arena), created on first use"""
+        with master._dp_lock:
+            if dev == master._flat.device and not master._dp_busy:
+                master._dp_busy = True
+                return master
+            pool = master._dp_shadows.setdefault(dev, [])
+            for sh in pool:
+                if not sh._dp_busy:
+                    sh._dp_busy = True
+                    return sh
+            if len(pool) >= 4:
+                raise L.AbcNetHipError("nn.DataParallel: more than 4 unfinished forward passes on %s (a training forward holds its "
+                                       "engine until its backward has run)" % dev)
+            fn, args = master.__reduce__()
+            args = list(args)
+            args[8] = str(dev)
+            sh = fn(*args)
+            sh._dp_busy = True
+            pool.append(sh)
+            return sh
+
+    def _forward_replica(self, x):
+        """forward of a replica made by nn.DataParallel's replicate() (a shallow copy of the master whose module tree carries
+        broadcast copies of the parameters on this replica's device).  The parameter copies are packed into the arena of the
+        engine owner checked out for this device and passed to the autograd function, so that backward's gradients flow back
+        through torch's Broadcast to the master's parameters, as with any module under nn.DataParallel (train.py:50,139-141).
+        BatchNorm buffers: every replica normalises its own chunk; only the replica that runs on the master's own arenas
+        updates the running statistics that persist -- torch's DataParallel semantics."""
+        master = self._master_ref()
+        if master is None:
+            raise L.AbcNetHipError("nn.DataParallel replica without its master module")
+        dev = x.device
+        params, bufs, cnts = self._replica_tensors()
+        owner = self._dp_checkout(master, dev)
+        try:
+            if owner is not master:
+                with torch.no_grad():
+                    torch.cat([p.detach().reshape(-1) for p in params], out=owner._flat)
+                    torch.cat([b.reshape(-1).to(torch.float32) for b in bufs], out=owner._flat_buf)
+                    owner._counters.copy_(torch.stack([c.reshape(()) for c in cnts]))
+                from .distributed import rank_dropout_seed
+                owner.dropout_seed = rank_dropout_seed(master.dropout_seed_base, 1 + (dev.index or 0) + 16 * master._dp_shadows[dev].index(owner))
+            owner.train(self.training)
+            with torch.cuda.device(dev):
+                if torch.is_grad_enabled() and self.training:
+                    return list(_UNetFn.apply(owner, x, *params))      # (backward releases the owner)
+                eng = owner._engine_for(x, self.training)
+                st = torch.cuda.current_stream().cuda_stream
+                owner._load_image(eng, x)
+                eng.run_pack(st)
+                eng.run_forward(st)
+                outs = owner._export_logits(eng, st)
+            owner._dp_busy = False
+            return list(outs)
+        except Exception:
+            owner._dp_busy = False
+            raise
+
     def forward(self, x):
+        if getattr(self, "_is_replica", False):
+            return self._forward_replica(x)
         if torch.is_grad_enabled() and self.training:
             outs = _UNetFn.apply(self, x, *self.parameters())
         else:

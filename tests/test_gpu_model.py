@@ -816,3 +816,41 @@ def test_general_shapes_match_reference_golden_and_oracle(tag, cin, H, W, golden
         g, r = named[k].grad.cpu().double(), sd[k].grad.double()
         assert (g - r).norm().item() <= 2e-2 * r.norm().item() + 1e-12, (tag, k, (g - r).norm().item(), r.norm().item())
         assert abs(g.norm().item() - gold["%s_gnorm/%s" % (tag, k)].item()) <= 2e-2 * gold["%s_gnorm/%s" % (tag, k)].item() + 1e-12
+
+
+def test_multi_replica_dataparallel_matches_per_chunk_oracle():
+    """train.py:50 / img2smiles2.py:43 wrap the model in nn.DataParallel; with several device ids torch replicates the module
+    every forward, scatters the batch and gathers the outputs.  Here with device_ids=[0, 0] (two replicas, one GPU: the first
+    runs on the master's arenas, the second on a shadow model) -- forward == the oracle applied to each chunk on its own
+    (every replica normalises its own chunk: torch's DataParallel semantics), and loss.backward() leaves the SUM of the two
+    replicas' gradients in the master's parameters, as autograd through Broadcast does for any module."""
+    B, S = 4, 64
+    x = synthetic_images(B, S, seed=7)
+    sd0 = uo.filled_state("unet", 1, HEADS, seed=0)
+    m = make_model(dropout_p=0.0)
+    dp = torch.nn.DataParallel(m, device_ids=[0, 0])
+    m.train()
+    ys = dp(x.to(DEV))
+    assert len(ys) == 8 and ys[5].shape == (B, 360, S // 4, S // 4)
+    loss = sum((y ** 2).mean() for y in ys)
+    loss.backward()
+    sd = uo.clone_state(sd0, requires_grad=True)
+    halves = [uo.forward("unet", sd, x[i:i + 2], train=True) for i in (0, 2)]
+    ref = [torch.cat([a, b], 0) for a, b in zip(*halves)]
+    for y, r in zip(ys, ref):
+        assert (y.detach().cpu() - r.detach()).abs().max().item() < 1e-3
+    sum((y ** 2).mean() for y in ref).backward()
+    named = dict(m.named_parameters())
+    for k in ("inc1.double_conv.0.weight", "down3.maxpool_conv.1.double_conv.3.weight", "up2.up.weight", "dconv2.double_conv.4.weight",
+              "out_modules.5.conv2.weight", "out_modules.0.bn.bias"):
+        g, r = named[k].grad.cpu().double(), sd[k].grad.double()
+        assert (g - r).norm().item() <= 2e-2 * r.norm().item() + 1e-12, (k, (g - r).norm().item(), r.norm().item())
+    assert not m._dp_busy and all(not s._dp_busy for pool in m._dp_shadows.values() for s in pool) and len(m._dp_shadows[torch.device("cuda", 0)]) == 1
+    # eval through the wrapper: running statistics (updated by the replica on the master's arenas only), no gradients
+    m.eval()
+    with torch.no_grad():
+        ye = dp(x.to(DEV))
+    sde = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    re = uo.forward("unet", sde, x, train=False)
+    assert max((a.cpu() - b).abs().max().item() for a, b in zip(ye, re)) < 1e-3
+    assert int(sde["inc1.double_conv.1.num_batches_tracked"]) == 1
