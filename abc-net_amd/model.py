@@ -281,10 +281,10 @@ class UNetBase(nn.Module):
         if not x.is_cuda:
             raise L.AbcNetHipError("abcnet_amd runs on an MI355X only (got a %s tensor); there is no CPU fallback" % x.device)
         if x.device != self._flat.device:
-            # (this is also what a replica made by multi-device nn.DataParallel runs into: its engines, graphs and arenas
-            #  cannot be replicated -- use one process per GPU, abcnet_amd.distributed / multi_gpu_train.py's way)
-            raise L.AbcNetHipError("input on %s but the model lives on %s; multi-device nn.DataParallel is not supported -- "
-                                   "run one process per GPU (abcnet_amd.distributed.launch_ranks / torchrun)" % (x.device, self._flat.device))
+            # (nn.DataParallel's replicas do not come here: _forward_replica gives each device its own arenas and engines)
+            raise L.AbcNetHipError("input on %s but the model lives on %s (move one of them; several GPUs: nn.DataParallel(model, "
+                                   "device_ids=...) or, better, one process per GPU -- abcnet_amd.distributed.launch_ranks / torchrun)"
+                                   % (x.device, self._flat.device))
         B, Cc, H, W = x.shape
         if Cc != self.n_channels:
             raise ValueError("expected %d input channels, got %d" % (self.n_channels, Cc))

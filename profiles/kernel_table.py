@@ -161,7 +161,8 @@ def main():
     # SETUP launches are not step work: torch's fills / copies of the engine's buffer allocations, the one-off weight packing
     # of an inference run, calibration.  They are listed (role = "setup", launches counted per PASS) but kept out of the shares.
     def is_setup(name, nlaunch, nsteps):
-        return name.startswith(("at::native::", "__amd_rocclr_", "void at::native::")) or "FillFunctor" in name or nlaunch % max(nsteps, 1) != 0
+        # (torch's own kernels, and anything launched less than once per step: packing / folding / calibration of an inference run)
+        return name.startswith(("at::native::", "__amd_rocclr_", "void at::native::")) or "FillFunctor" in name or nlaunch < max(nsteps, 1)
 
     nsteps = steps_in(read_rows(opt["trace"], "*kernel_trace.csv"))
     setup_keys = set(k for k, o in trace.items() if is_setup(short(k[0]), sum(n for n, _s in o.values()), nsteps))
