@@ -107,6 +107,11 @@ def by_ordinal(rows, value):
         seq.setdefault(key(r), []).append(r)
     out = {}
     for k, rs in seq.items():
+        # launches before the first step (an inference run's calibration pass runs the same kernels once more): when the count
+        # is not a whole number of steps, the surplus launches are the EARLIEST ones -- dropped from the per-step statistics
+        extra = len(rs) % nsteps
+        if extra and len(rs) > nsteps:
+            rs = rs[extra:]
         per = max(len(rs) // nsteps, 1) if len(rs) % nsteps == 0 else len(rs)   # (setup-time launches: one ordinal each)
         o = out.setdefault(k, {})
         for i, r in enumerate(rs):

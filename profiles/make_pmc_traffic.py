@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json (what bench.py reports as roofline.traffic) from the per-shape kernel tables of one round:
 
-    python profiles/make_pmc_traffic.py TAG        (reads profiles/TAG_{unet,unet2,infer}_kernel_table.json and
+    python profiles/make_pmc_traffic.py TAG        (reads profiles/TAG_{unet,unet2,infer,infer8}_kernel_table.json and
                                                     profiles/TAG_{..}_bench.json, rewrites profiles/pmc_traffic.json)
 
 Per bench.py kernel label (one kernel instantiation; its launches of all shapes): mean HBM bytes per launch from the
@@ -13,7 +13,7 @@ import re
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-T = {"bf16": "bf16", "float": "f32"}
+T = {"bf16": "bf16", "float": "f32", "f8": "fp8"}
 
 
 def label_of(kernel):
@@ -30,7 +30,7 @@ def label_of(kernel):
 
 def main(tag):
     out = {}
-    for mode, variant, w in (("train", "unet", "unet"), ("train", "unet2", "unet2"), ("infer", "unet", "infer")):
+    for mode, variant, w in (("train", "unet", "unet"), ("train", "unet2", "unet2"), ("infer", "unet", "infer"), ("infer", "unet", "infer8")):
         tp = os.path.join(HERE, "%s_%s_kernel_table.json" % (tag, w))
         bp = os.path.join(HERE, "%s_%s_bench.json" % (tag, w))
         if not os.path.exists(tp):
