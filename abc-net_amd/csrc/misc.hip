@@ -132,9 +132,12 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackItem* items, 
     const int64_t i1 = (i0 + PACK_CHUNK < total) ? i0 + PACK_CHUNK : total;
     if (threadIdx.x == 0) { s_lo = pack_find(items, nitems, i0); s_hi = pack_find(items, nitems, i1 - 1); }
     __syncthreads();
-    const int lo = s_lo, hi = s_hi;
+    // (made provably wave-uniform, and the item copied BY VALUE: since the e4m3 packing the kernel contains a one-byte store, which
+    //  may alias anything -- through a reference the item's fields were re-read with vector loads after every store, and the
+    //  step's packing went 75 -> 139 us)
+    const int lo = __builtin_amdgcn_readfirstlane(s_lo), hi = __builtin_amdgcn_readfirstlane(s_hi);
     if (lo == hi) {
-        const PackItem& it = items[lo];
+        const PackItem it = items[lo];
         const unsigned base = (unsigned)(i0 - it.first);
         for (unsigned e = threadIdx.x; e < (unsigned)(i1 - i0); e += 256) pack_one(it, base + e);
     } else {
