@@ -41,7 +41,7 @@ namespace {
 __host__ __device__ inline size_t abc_pack_offset(size_t slice, int rows, int row, int CK, int k, int layout) {
     if (layout == 1) {   // 64-byte chunk rows (bf16 CK = 32, fp8 CK = 64): [row / 32][kk][h][row % 32][16 bytes] inside the slice (see abc_pack_desc.layout)
         // elements per 16 bytes: 8 (bf16, CK = 32) or 16 (fp8, CK = 64) -- shifts, not divisions: this runs once per packed
-        // element of every weight of the step (as runtime divisions the step's packing went 75 -> 139 us)
+        // element of every weight of the step
         const int sh = CK == 64 ? 4 : 3;
         const int h = k >> (sh + 1), kk = (k >> sh) & 1, e = k & ((1 << sh) - 1);
         return (slice * rows + (size_t)(row & ~31)) * CK + (size_t)((((kk * 2 + h) * 32 + (row & 31)) << sh) + e);
