@@ -44,12 +44,29 @@ __global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const abc_cbam_c
     double s = 0.0;
     float vmax = -3.0e38f, vmin = 3.0e38f;
     if (c < d.C) {
-        for (int k = grp; k < d.tiles_per_img; k += 4) {
-            const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k) * 4) * d.C + c;
-            s += (double)p[0];
-            vmax = fmaxf(vmax, p[2 * d.C]);
-            vmin = fminf(vmin, p[3 * d.C]);
+        // (four independent chains: at the 384 x 384 levels a group walks 144 of the 576 tiles of an image, and one chain of
+        //  dependent loads and f64 adds took 51-59 us for 3.6 MB)
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, mn4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+        int k = grp;
+        for (; k + 12 < d.tiles_per_img; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k + 4 * u) * 4) * d.C + c;
+                s4[u] += (double)p[0];
+                mx4[u] = fmaxf(mx4[u], p[2 * d.C]);
+                mn4[u] = fminf(mn4[u], p[3 * d.C]);
+            }
         }
+        for (; k < d.tiles_per_img; k += 4) {
+            const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k) * 4) * d.C + c;
+            s4[0] += (double)p[0];
+            mx4[0] = fmaxf(mx4[0], p[2 * d.C]);
+            mn4[0] = fminf(mn4[0], p[3 * d.C]);
+        }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        vmax = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        vmin = fminf(fminf(mn4[0], mn4[1]), fminf(mn4[2], mn4[3]));
     }
     ssum[grp][cl] = s; smax[grp][cl] = vmax; smin[grp][cl] = vmin;
     __syncthreads();
@@ -161,11 +178,10 @@ __global__ __launch_bounds__(256) void cbam_spatial_stats_kernel(const abc_cbam_
 
 // ------------------------------------------------------------------ 7x7 conv (2 -> 1) + sigmoid, and its backward
 __global__ __launch_bounds__(256) void cbam_conv7_fwd_kernel(const abc_cbam_conv7_desc d) {
-    __shared__ float tile[22][22][2];
-    __shared__ float w[98];
+    __shared__ __attribute__((aligned(8))) float tile[22][22][2];
     const int b = blockIdx.z, y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    if (threadIdx.x < 98) w[threadIdx.x] = d.w7[threadIdx.x];  // [ch][ky][kx]
+    const float* __restrict__ w = d.w7;  // [ch][ky][kx]: workgroup-uniform -> scalar registers
     for (int i = threadIdx.x; i < 22 * 22; i += 256) {
         const int hy = i / 22, hx = i % 22;
         const int yy = y0 + hy - 3, xx = x0 + hx - 3;
@@ -184,7 +200,10 @@ __global__ __launch_bounds__(256) void cbam_conv7_fwd_kernel(const abc_cbam_conv
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx)
-                s += w[ky * 7 + kx] * tile[ty + ky][tx + kx][0] + w[49 + ky * 7 + kx] * tile[ty + ky][tx + kx][1];
+            {
+                const float2 t2 = *(const float2*)&tile[ty + ky][tx + kx][0];
+                s += w[ky * 7 + kx] * t2.x + w[49 + ky * 7 + kx] * t2.y;
+            }
         d.sa[((size_t)b * d.H + yy) * d.W + xx] = sigmoidf_(s);
     }
 }
@@ -195,12 +214,16 @@ __global__ __launch_bounds__(256) void cbam_conv7_fwd_kernel(const abc_cbam_conv
 // (per tile it cost more than the 98 MACs per pixel it reduces: 89 us per call on average).
 __global__ __launch_bounds__(256) void cbam_conv7_bwd_kernel(const abc_cbam_conv7_desc d) {
     __shared__ float tdu[22][22];
-    __shared__ float tst[22][22][2];
-    __shared__ float w[98];
+    __shared__ __attribute__((aligned(8))) float tst[22][22][2];
     __shared__ float red[4][99];
     const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + 15) / 16;
     const int ntiles = tiles_x * tiles_y * d.B;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    // The pass is LDS-bound (per pixel 49 reads of du, 49 8-byte reads of st, 98 broadcast reads of the weights).  The weights
+    // stay in LDS: as workgroup-uniform values through the scalar path they were re-fetched inside the tile loop (beside 99
+    // accumulators the scalar file does not hold them: 0.65 -> 0.75 ms per step); pinned in 98 vector registers the kernel drops
+    // to two waves per SIMD and the LDS latency shows (0.80 ms).  Both measured, same box.
+    __shared__ float w[98];
     if (threadIdx.x < 98) w[threadIdx.x] = d.w7[threadIdx.x];
     float acc[99];
 #pragma unroll
@@ -229,8 +252,8 @@ __global__ __launch_bounds__(256) void cbam_conv7_bwd_kernel(const abc_cbam_conv
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx) {
                     const float u = tdu[ty + 6 - ky][tx + 6 - kx];  // du at (y + 3 - ky, x + 3 - kx)
-                    g0 += u * w[ky * 7 + kx];
-                    g1 += u * w[49 + ky * 7 + kx];
+                    g0 = fmaf(u, w[ky * 7 + kx], g0);
+                    g1 = fmaf(u, w[49 + ky * 7 + kx], g1);
                 }
             d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 0] = g0;
             d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 1] = g1;
@@ -241,8 +264,9 @@ __global__ __launch_bounds__(256) void cbam_conv7_bwd_kernel(const abc_cbam_conv
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
-                acc[ky * 7 + kx] = fmaf(u, tst[ty + ky][tx + kx][0], acc[ky * 7 + kx]);
-                acc[49 + ky * 7 + kx] = fmaf(u, tst[ty + ky][tx + kx][1], acc[49 + ky * 7 + kx]);
+                const float2 t2 = *(const float2*)&tst[ty + ky][tx + kx][0];
+                acc[ky * 7 + kx] = fmaf(u, t2.x, acc[ky * 7 + kx]);
+                acc[49 + ky * 7 + kx] = fmaf(u, t2.y, acc[49 + ky * 7 + kx]);
             }
         acc[98] += u;
     }
@@ -450,15 +474,22 @@ __global__ __launch_bounds__(256) void cbam_bwd2_kernel(const abc_cbam_pix_desc 
 //   pre2: d_hidden[n][j] for both pooled branches, one workgroup per image                              -> work[B C ..)
 //   main: weight / bias gradients summed over the images in REGISTERS in image order, and the per-image pool
 //         gradients, partitioned over the grid; the intermediates come from `work` into LDS.
+// (8 lanes per (image, channel), each summing every 8th partial: one thread walking up to 128 partials was a 32-43 us chain
+//  of dependent f64 adds for a few KB of data; the combination order is fixed -- lanes 0..7, then the xor tree)
 __global__ __launch_bounds__(256) void cbam_channel_bwd_pre1_kernel(const abc_cbam_channel_desc d) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= d.B * d.C) return;
-    const int n = idx / d.C, c = idx - n * d.C;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    const int idx = gt >> 3, sub = gt & 7;
+    const bool ok = idx < d.B * d.C;
+    const int n = ok ? idx / d.C : 0, c = ok ? idx - n * d.C : 0;
     const int T = d.tiles_per_img;
     double s = 0.0;
-    for (int k = 0; k < T; ++k) s += (double)d.partial[((size_t)n * T + k) * d.C + c];
-    const float ca = d.ca[idx];
-    d.work[idx] = (float)s * ca * (1.f - ca);
+    if (ok)
+        for (int k = sub; k < T; k += 8) s += (double)d.partial[((size_t)n * T + k) * d.C + c];
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (ok && sub == 0) {
+        const float ca = d.ca[idx];
+        d.work[idx] = (float)s * ca * (1.f - ca);
+    }
 }
 
 __global__ __launch_bounds__(256) void cbam_channel_bwd_pre2_kernel(const abc_cbam_channel_desc d) {
@@ -630,7 +661,7 @@ extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t
     // dependent global loads, so width beats depth (8 elements per thread cost 50 us per call)
     const int want = abc_cdiv(d->C * d->mid, 256);
     const int nb = want < 1 ? 1 : (want > 64 ? 64 : want);
-    hipLaunchKernelGGL(cbam_channel_bwd_pre1_kernel, dim3(abc_cdiv(d->B * d->C, 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(cbam_channel_bwd_pre1_kernel, dim3(abc_cdiv(d->B * d->C * 8, 256)), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_bwd_pre2_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(nb), dim3(256), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_bwd");
