@@ -32,7 +32,11 @@ class ConvDesc(C.Structure):
                 ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("stats_rows", i32), ("accumulate", i32),
                 ("planar_out", i32), ("ctot_out", i32), ("out_act", i32), ("out_slope", f32), ("pool_y", vp), ("ld_pool", i32),
                 ("stem_x", vp), ("stem_w", vp), ("stem_scale", vp), ("stem_bias", vp), ("stem_slope", f32),
-                ("out_scale", vp), ("out_quant", vp), ("out_quant_stride", i32)]
+                ("out_scale", vp), ("out_quant", vp), ("out_quant_stride", i32), ("heads_epi", vp)]
+
+
+class HeadsEpi(C.Structure):
+    _fields_ = [("w2", vp), ("bias", vp), ("oscale", vp), ("y", vp), ("Cout", i32), ("Cout_pad", i32)]
 
 
 class PackDesc(C.Structure):
@@ -150,7 +154,7 @@ class HeadsFusedDesc(C.Structure):
 
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
             LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc, ExtractDesc, RasterDesc,
-            HeadsFusedDesc]
+            HeadsFusedDesc, HeadsEpi]
 
 # every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER

@@ -374,6 +374,19 @@ struct HaloPrefetch {
 __device__ inline __amdgpu_buffer_rsrc_t abc_make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
 }
+// two values to two LDS places in the output type; bf16: ONE packed conversion, the halves written by ds_write_b16 / _d16_hi
+template <typename OutT> __device__ inline void abc_put2(char* p0, char* p1, float a, float b) { *(OutT*)p0 = (OutT)a; *(OutT*)p1 = (OutT)b; }
+template <> __device__ inline void abc_put2<bf16>(char* p0, char* p1, float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 pk = __builtin_convertvector((f32x2){a, b}, bf16x2);
+    *(bf16*)p0 = pk[0]; *(bf16*)p1 = pk[1];
+}
+template <> __device__ inline void abc_put2<f8>(char* p0, char* p1, float a, float b) {   // (saturating, as f8(float))
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    *(uint8_t*)p0 = (uint8_t)(pk & 0xFF); *(uint8_t*)p1 = (uint8_t)((pk >> 8) & 0xFF);
+}
 __device__ inline int abc_launder(int x) { asm volatile("" : "+v"(x)); return x; }
 
 template <typename InT, int NV> struct RawBuf;

@@ -51,6 +51,7 @@ struct FastK {
     const float* oscale;            // fp8 compute: per output channel, accumulator -> real value (s_in * s_w[n])
     const float* oquant;            // fp8 output: 1 / s_out (device), applied before the rounding to e4m3
     int oq_stride;                  // 0: a scalar; 1: one per n-block (128 output channels)
+    const abc_heads_epi* hepi;      // HEPI: per n-block (= head) the 1x1 convolution computed in this tile's epilogue
     unsigned bytesA, bytesW;
     long long* prof;  // debugging: per-workgroup phase timestamps (null in production)
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
@@ -62,7 +63,10 @@ __device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" :::
 
 // WD ("weights direct", 0 = off, else the tap count 9 or 25): the main loop below that streams the B operand from global
 // memory (see there).
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0>
+// HEPI ("heads in the epilogue", folded inference graph): the tile's 128 output channels are one head's finished features
+// (unet.py:66-69 with BatchNorm folded); the head's 1x1 convolution (unet.py:70) is computed from them right here and the f32
+// NCHW maps are stored -- the 8 x 128-channel feature tensor is never written or read (2 x 2.1 GB per batch of 64 at 512 x 512)
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, bool HEPI = false>
 __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const FastK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     constexpr bool F8C = sizeof(CT) == 1;    // e4m3 operands: one 32x32x64 MFMA per lane-half of a 64-byte chunk (weights-direct loop only)
     constexpr bool F8O = sizeof(OutT) == 1;  // e4m3 output: v * (1 / s_out), saturating
     static_assert(!F8C || WD == 9, "fp8 compute is served by the 9-tap weights-direct loop");
+    static_assert(!HEPI || (WD == 9 && BN == 128 && MT == 6 && sizeof(CT) <= 2), "heads epilogue: the 192 x 128 weights-direct tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -263,6 +268,14 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         if (!first_tile) __syncthreads();  // previous tile's epilogue staging (aliases the halo buffer) is drained
         apre.commit(sA, lcoef, a.cstride, tid);
         if constexpr (!STATIC && WD == 0) b_commit(breg[0], 0, sB);
+        // (the epilogue's lane constants are waited for HERE, where the halo's vmcnt(0) has just passed: first used in the
+        //  epilogue, their wait is a vmcnt(0) there -- the counter is in order -- which also waits for the NEXT tile's halo
+        //  prefetch issued during the last chunk)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bv[j]), "v"(osc[j]));
+        asm volatile("" :: "v"(oq));
+#endif
         first_tile = false;
         __syncthreads();
         if constexpr (STATIC) {
@@ -472,6 +485,100 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         }
 
         if (prof && tid == 0) prof[2] = wall_clock64();
+        if constexpr (HEPI) {
+            // ---- 1. the tile's activated features, [pixel][128 channels] in the compute type, into LDS (the halo buffers are dead)
+            constexpr int FROW = 128 * (int)sizeof(CT) + 16;
+            char* F = smem;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float v = F8C ? fmaf(acc[i][j][k], osc[j], bv[j]) : acc[i][j][k] + bv[j];
+                        float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                        if constexpr (F8C) vo *= oq;
+                        const int p = 32 * (wm * TM + i) + (k & 3) + 8 * (k >> 2) + 4 * h;
+                        *(CT*)(F + p * FROW + ((wn * TN + j) * 32 + r) * (int)sizeof(CT)) = (CT)vo;
+                    }
+            __syncthreads();
+            // ---- 2. the head's 1x1 convolution: logits[co][p] = b[co] + sum_c W2[co][c] F[p][c].  Work items = (m-tile of 32 output
+            // rows) x (one of the tile's six 32-pixel n-tiles), dealt to the four waves: m-tile-major when the head has >= 4 m-tiles
+            // (the weight fragments of an m-tile are fetched once and serve its six n-tiles), item by item for the narrow heads (one or
+            // two m-tiles: otherwise one wave would do all the work).  Stores: one raw buffer store per accumulator register -- the
+            // lane's part of the address (image, its pixel, its row half) is ONE offset per n-tile, the register's output row a
+            // scalar offset; rows past Cout and pixels past the map get the out-of-range offset and are dropped by the hardware.
+            // MEASURED (b64 at 512 x 512, same box): exact, and slower than conv1 + the separate heads kernel in both forms tried --
+            // 64-bit address per store, items dealt round-robin: 7.86 -> 9.02 ms bf16, 6.09 -> 7.68 ms e4m3; this form: 10.4 / 9.6 ms.
+            // The epilogue is a serial chain on the tile's critical path (head record -> weight fragments -> MFMAs -> 4-byte-per-lane
+            // stores in 64-byte runs) in a kernel with two workgroups per CU and nothing to cover it, and its arrays cost the main
+            // loop registers (25 / 92 spilled).  The engine therefore plans it only on request (Engine(heads_epilogue=True)).
+            const abc_heads_epi& he = a.hepi[nb];
+            const int mtiles = he.Cout_pad >> 5;
+            const unsigned HWp = (unsigned)(a.Hg * a.Wg);
+            const __amdgpu_buffer_rsrc_t rsW2 = abc_make_rsrc(he.w2, (unsigned)(128 * he.Cout_pad * (int)sizeof(CT)));
+            const __amdgpu_buffer_rsrc_t rsY = abc_make_rsrc(he.y, (unsigned)a.B * (unsigned)he.Cout * HWp * 4u);
+            const int nitems = mtiles * 6;
+            const bool mt_major = mtiles >= 4;
+            int last_mt = -1;
+            float bvv[16], os2[16];
+            i32x8 fa8[F8C ? 2 : 1];
+            bf16x8 fa16[F8C ? 1 : 8];
+            for (int it = mt_major ? wave * 6 : wave; it < nitems; it += mt_major ? (((it + 1) % 6) ? 1 : 19) : 4) {
+                const int mt = it / 6, nt = it - mt * 6;
+                if (mt != last_mt) {
+                    last_mt = mt;
+                    const int co = mt * 32 + r;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                        const bool ok = oc < he.Cout;
+                        bvv[k] = (he.bias && ok) ? he.bias[oc] : 0.f;
+                        os2[k] = (F8C && ok) ? he.oscale[oc] : 1.f;
+                    }
+                    if constexpr (F8C) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const unsigned off = (unsigned)((s2 * he.Cout_pad + co) * 64 + 32 * h);
+                            fa8[s2] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsW2, off, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsW2, off + 16, 0, 0));
+                        }
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) {
+                            const unsigned off = (unsigned)((((kk >> 1) * he.Cout_pad + co) * 32 + 16 * (kk & 1) + 8 * h) * 2);
+                            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsW2, off, 0, 0);
+                            fa16[kk] = *(const bf16x8*)&t;
+                        }
+                    }
+                }
+                f32x16 c2;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) c2[k] = 0.f;
+                if constexpr (F8C) {
+                    const char* fp = F + (32 * nt + r) * FROW + 32 * h;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        mma32B_f8(c2, fa8[s2], abc_join32B(*(const u32x4*)(fp + 64 * s2), *(const u32x4*)(fp + 64 * s2 + 16)));
+                } else {
+                    const char* fp = F + (32 * nt + r) * FROW + 16 * h;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa16[kk], *(const bf16x8*)(fp + 32 * kk), c2, 0, 0, 0);
+                }
+                const int pp = 32 * nt + r, gy = gy0 + (pp >> 4), gx = gx0 + (pp & 15);
+                // lane part: image b, output row 4 h of the m-tile's first row, pixel (gy, gx); register part: row (k & 3) + 8 (k >> 2)
+                const unsigned vlane = ((unsigned)(b * he.Cout + mt * 32 + 4 * h) * HWp + (unsigned)(gy * a.Wg + gx)) * 4u;
+                const bool pix_ok = gy < a.Hg && gx < a.Wg;
+                const bool full = mt * 32 + 32 <= he.Cout;     // (wave-uniform: only a head's last m-tile can be partial)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int rowk = (k & 3) + 8 * (k >> 2);
+                    const bool ok = pix_ok && (full || mt * 32 + rowk + 4 * h < he.Cout);
+                    const float v = F8C ? fmaf(c2[k], os2[k], bvv[k]) : c2[k] + bvv[k];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? vlane : 0xFFFFFFFCu, (unsigned)rowk * HWp * 4u, 0);
+                }
+            }
+            continue;      // (the next tile's prologue synchronises before it re-uses the LDS; no statistics in the folded graph)
+        }
         // ---- epilogue: bias, statistics of the f32 values, store through a wave-private LDS transpose
         // (a lane of the accumulator layout holds ONE channel of 16 pixels; the transpose turns that into 16-byte
         // stores of consecutive channels of one pixel).  The staging region aliases the halo / weight buffers: every
@@ -494,35 +601,75 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         const bool whole = (gy0 + 2 * MT <= a.Hg) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok;
         if (ABC_DBG(a.dbg) & 64) {
         } else if (whole) {
-            char* wbase = stg + 4 * h * ROWB + r * (int)sizeof(OutT);
-            const int lrow = lane / SEG_PER_ROW, lsg = lane % SEG_PER_ROW;   // this lane's (pixel row, segment) in the store sweep
+            // (laundered: computed from the plain thread index, the lane parts of the staging addresses and store offsets are hoisted
+            //  out of the tile loop, live through the main loop, get spilled, and come back as scratch round trips in front of the
+            //  stores -- each a vmcnt(0) wait that also drains the next tile's halo prefetch)
+            const int tl = abc_launder(tid), ll = tl & 63, wl = tl >> 6;
+            char* stgw = smem + a.stg_off + wl * (32 * ROWB);
+            char* wbase = stgw + 4 * (ll >> 5) * ROWB + (ll & 31) * (int)sizeof(OutT);
+            const int lrow = ll / SEG_PER_ROW, lsg = ll % SEG_PER_ROW;         // this lane's (pixel row, segment) in the store sweep
             constexpr int RSTEP = 64 / SEG_PER_ROW;                            // pixel rows covered per sweep step
-            const bool seg_ok = cbase + lsg * EV < a.Cout;
+            constexpr int NST = 32 / RSTEP;
+            const bool seg_ok = n0 + (wl % WN) * TW + lsg * EV < a.Cout;
+            // Stores: the tile's first pixel (wave-uniform) is the base of a buffer descriptor; a lane's part of the address is ONE
+            // 32-bit offset per sweep step for the whole tile (segments past Cout get an offset the hardware drops), the M-tile's
+            // two rows a scalar offset.  (64-bit address arithmetic and a predicated branch per store kept every
+            // ds_read -> global_store pair a serial LDS round trip: 12 per wave and tile.)
+            const OutT* ytile = yo + (((size_t)(b * a.Hout + gy0 * a.om + a.oy0) * a.Wout + gx0 * a.om + a.ox0) * a.ldy + a.cout_off + n0);
+            const __amdgpu_buffer_rsrc_t rsY = abc_make_rsrc(ytile, 0x80000000u);
+            const unsigned istep = (unsigned)(2 * a.om * a.Wout * a.ldy) * (unsigned)sizeof(OutT);   // bytes per M-tile (two pixel rows)
+            unsigned voff[NST];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int rit = lrow + RSTEP * st;       // pixel of the wave's 32: patch row (rit >> 4) of the M-tile, column rit & 15
+                voff[st] = seg_ok ? (unsigned)((wl / WN) * TM) * istep + (unsigned)((((rit >> 4) * a.Wout + (rit & 15)) * a.om * a.ldy + (wl % WN) * TW + lsg * EV) * (int)sizeof(OutT))
+                                  : 0xFFFFFFF0u;
+            }
+            // Values two at a time (accumulator registers k, k + 1 = two pixel rows of one channel): packed f32 add / multiply / fma,
+            // one conversion per pair.  Per M-tile: 32 writes, then the sweep's reads back to back and its stores behind them (a wave's
+            // LDS instructions execute in order: the reads see the writes, the next M-tile's writes cannot overtake the reads; the
+            // empty asm statements only pin the program order).
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 s1v[TN], s2v[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { s1v[j] = (f32x2){0.f, 0.f}; s2v[j] = (f32x2){0.f, 0.f}; }
+            const float slope = a.out_act ? a.out_slope : 1.f;      // (max(v, 1 * v) = v: no select per value)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    const f32x2 b2 = {bv[j], bv[j]};
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const float v = F8C ? fmaf(acc[i][j][k], osc[j], bv[j]) : acc[i][j][k] + bv[j];
-                        s1[j] += v; s2[j] = fmaf(v, v, s2[j]);
-                        float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
+                    for (int k = 0; k < 16; k += 2) {
+                        f32x2 v = {acc[i][j][k], acc[i][j][k + 1]};
+                        if constexpr (F8C) v = __builtin_elementwise_fma(v, (f32x2){osc[j], osc[j]}, b2); else v += b2;
+                        s1v[j] += v; s2v[j] = __builtin_elementwise_fma(v, v, s2v[j]);
+                        const f32x2 m = v * slope;
+                        f32x2 vo = {fmaxf(v.x, m.x), fmaxf(v.y, m.y)};
                         if constexpr (F8O) vo *= oq;
-                        *(OutT*)(wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT)) = (OutT)vo;
+                        char* p = wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT);
+                        abc_put2<OutT>(p, p + ROWB, vo.x, vo.y);
                     }
                 }
-                lds_wave_sync();
-                // pixel rit = lrow + RSTEP * step of the wave's 32: patch row 2 (wm TM + i) + (rit >> 4), column rit & 15
-                const int gyb = gy0 + 2 * (wm * TM + i);
+                // (the sums are pinned to their M-tile and the scheduler barriers keep the M-tiles apart: left free, the compiler
+                //  sinks the 2 x 96 accumulations behind the last store and hoists the bias adds to the front -- the biased values
+                //  of the whole tile live beside the accumulators, ~50 lane constants of the main loop spilled)
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-                for (int st = 0; st < 32 / RSTEP; ++st) {
-                    const int rit = lrow + RSTEP * st;
-                    const int gy = gyb + (rit >> 4), gx = gx0 + (rit & 15);
-                    const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cbase + lsg * EV;
-                    if (seg_ok) *(f32x4*)(yo + o) = *(const f32x4*)(stg + rit * ROWB + lsg * 16);
-                }
-                lds_wave_sync();
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(s1v[j]), "+v"(s2v[j]));
+#endif
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 rd[NST];
+#pragma unroll
+                for (int st = 0; st < NST; ++st) rd[st] = *(const u32x4*)(stgw + (lrow + RSTEP * st) * ROWB + lsg * 16);
+#pragma unroll
+                for (int st = 0; st < NST; ++st) __builtin_amdgcn_raw_buffer_store_b128(rd[st], rsY, voff[st], (unsigned)i * istep, 0);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { s1[j] = s1v[j].x + s1v[j].y; s2[j] = s2v[j].x + s2v[j].y; }
             if (a.stats_rows == 4) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -629,9 +776,9 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     }
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, bool HEPI = false>
 int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
-    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD>;
+    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, HEPI>;
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)fn, LDS_WG, &lds_ok)) return rc;
     hipLaunchKernelGGL(fn, dim3(g.nwg), dim3(FT), g.lds, st, k);
@@ -728,7 +875,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
             const int mt = cand_all[ci];
             if (force && atoi(force) != mt) continue;
             if (mt == 6 && (bn != 128 || d->stride != 1)) continue;
-            if (f8 && (mt != 6 || bn != 128)) continue;
+            if ((f8 || d->heads_epi != nullptr) && (mt != 6 || bn != 128)) continue;
             if (mt == 8 && bn == 128) continue;  // 4 x 2 tiles per wave + staging registers exceed 256 VGPRs
             if (mt == 2 && bn == 32) continue;   // 4 x 1 wave layout needs 4 m-tiles
             if (d->stride == 2 && mt != 4) continue;
@@ -822,6 +969,14 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     // persistent workgroups: three per CU with resident weights; two per CU (512 slots) on the weights-direct loop when
     // there are more tiles than slots (measured on one box, same run: 6144 tiles 482 -> 463 us, 5632 tiles 473 -> 448 us)
     g->nwg = g->b_static ? (g->ntiles < 768 ? g->ntiles : 768) : ((g->wd && g->ntiles > 512 && !abc_knob("ABC_CONV_NOPERSIST")) ? 512 : g->ntiles);
+    if (d->heads_epi != nullptr) {
+        // heads in the epilogue: the 192 x 128 weights-direct tile, finished input, every 128-channel block a head
+        if (!(g->wd == 9 && g->BN == 128 && g->MT == 6) || d->src.scale != nullptr || !d->out_act || d->stats != nullptr || d->accumulate ||
+            d->Cout % 128 || d->om != 1 || d->oy0 || d->ox0 || d->Hg != d->Hout || d->Wg != d->Wout) return ABC_OK;
+        const int need = 192 * (128 * csz + 16);
+        if (g->lds < need) g->lds = need;
+        if (g->lds > LDS_WG) return ABC_OK;
+    }
     g->eligible = 1;
     return ABC_OK;
 }
@@ -842,6 +997,7 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     k.accumulate = d->accumulate; k.b_static = g.b_static; k.stg_off = g.stg_off; k.red_off = g.red_off;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
     k.oscale = d->out_scale; k.oquant = d->out_quant; k.oq_stride = d->out_quant_stride ? 1 : 0;
+    k.hepi = d->heads_epi;
     { const char* e = abc_knob("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     k.prof = g_prof;
     { const char* e = abc_knob("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }
@@ -853,6 +1009,13 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     }
     hipStream_t st = (hipStream_t)stream;
     const int di = d->dtype_in, dc = d->dtype_c, dout = d->dtype_out;
+    if (d->heads_epi != nullptr) {
+        // the heads' 1x1 convolutions in the epilogue (geometry checked in abc_conv_fast_geom)
+        if (dc == ABC_FP8 && di == ABC_FP8 && d->out_scale != nullptr && d->out_quant != nullptr)
+            return launch_st<f8, f8, f8, 64, 128, 1, 6, false, 9, true>(k, g, st);
+        if (dc == ABC_BF16 && di == ABC_BF16 && g.CK == 32) return launch_st<bf16, bf16, bf16, 32, 128, 1, 6, false, 9, true>(k, g, st);
+        return abc_fail(ABC_EUNSUPPORTED, "conv: heads_epi needs bf16 or e4m3 (with out_scale / out_quant) operands");
+    }
     if (dc == ABC_FP8 || dout == ABC_FP8 || di == ABC_FP8) {
         // the fp8 inference graph (abc_conv_desc.out_scale / out_quant): the 192-pixel x 128-channel weights-direct tile only
         if (!(g.BN == 128 && g.MT == 6 && g.wd == 9 && d->stride == 1)) return abc_fail(ABC_EUNSUPPORTED, "conv: fp8 needs the 3x3 weights-direct tile");

@@ -552,6 +552,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
         if ((d->src.ldx * abc_dsize(d->dtype_in)) % 16 || (d->cin_off * abc_dsize(d->dtype_in)) % 16 || (d->ldy * abc_dsize(d->dtype_out)) % 16 || (d->cout_off * abc_dsize(d->dtype_out)) % 16)
             return abc_fail(ABC_EINVAL, "conv: fp8 tensors must keep 16-byte alignment");
         if ((d->Hg - 1) * d->om + d->oy0 >= d->Hout || (d->Wg - 1) * d->om + d->ox0 >= d->Wout) return abc_fail(ABC_EINVAL, "conv: output grid exceeds output tensor");
+        if (d->heads_epi != nullptr && d->dtype_out != ABC_FP8) return abc_fail(ABC_EINVAL, "conv: heads_epi with e4m3 operands needs dtype_out = ABC_FP8 (the features' type)");
         abc_fast_geom f;
         if (abc_conv_fast_geom(d, &f) != ABC_OK || !f.eligible) return abc_fail(ABC_EUNSUPPORTED, "conv: fp8 is served for 3x3, stride 1, Cin % 64 == 0, Cout % 128 == 0 only");
         return abc_conv_fast_launch(d, f, stream);
@@ -596,6 +597,11 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     // the kernel's grid must address only in-range output pixels
     if ((d->Hg - 1) * d->om + d->oy0 >= d->Hout || (d->Wg - 1) * d->om + d->ox0 >= d->Wout)
         return abc_fail(ABC_EINVAL, "conv: output grid exceeds output tensor");
+    if (d->heads_epi != nullptr) {
+        abc_fast_geom f;
+        if (abc_conv_fast_geom(d, &f) != ABC_OK || !f.eligible) return abc_fail(ABC_EUNSUPPORTED, "conv: heads_epi is served by the 3x3 weights-direct tile only");
+        return abc_conv_fast_launch(d, f, stream);
+    }
     if (d->stem_x != nullptr && !abc_conv_narrow_ok(d)) return abc_fail(ABC_EUNSUPPORTED, "conv: the fused first convolution (stem_x) is served by the narrow-level kernel only");
     if (d->pool_y != nullptr && !abc_conv_narrow_ok(d)) return abc_fail(ABC_EUNSUPPORTED, "conv: pool_y is served by the narrow-level kernel only (abc_conv_variant == 5)");
     if (abc_conv_stem_ok(d, nullptr)) return abc_conv_stem_launch(d, stream);

@@ -465,6 +465,7 @@ extern "C" int abc_sizeof(int which) {
         case 17: return (int)sizeof(abc_extract_desc);
         case 18: return (int)sizeof(abc_raster_desc);
         case 19: return (int)sizeof(abc_heads_fused_desc);
+        case 20: return (int)sizeof(abc_heads_epi);
         default: return -1;
     }
 }

@@ -108,7 +108,7 @@ class Rec:
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
-                 guards=False):
+                 guards=False, heads_epilogue=False):
         """batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
         batched one is tested against, tests/test_gpu_model.py::test_batched_heads_equal_one_by_one_launches)"""
         if variant not in ("unet", "unet2"):
@@ -139,6 +139,10 @@ class Engine:
         self.fp8_calibrated = False
         self.guards = bool(guards)
         self._guarded = []
+        # folded inference graph, opt-in: the heads' 1x1 convolutions in the epilogue of the merged conv1 (abc_conv_desc.heads_epi) --
+        # the 8 x 128-channel feature tensor is never written.  Bit-identical to the default plan (the separate heads kernel) and
+        # measured SLOWER than it (b64 at 512 x 512: 7.86 -> 9.0-10.4 ms bf16, 6.09 -> 7.7-9.6 ms e4m3), hence off
+        self.heads_epilogue = bool(heads_epilogue)
         self.dt = L.BF16 if dtype == "bf16" else L.F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         # the fused train step's heads (csrc/heads_fused.hip): conv2 forward + loss + the way back to the BatchNorm outputs as
@@ -280,7 +284,7 @@ class Engine:
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
                   grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
-                  accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None, out_quant_stride=0):
+                  accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None, out_quant_stride=0, heads_epi=None):
         """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch;
         out_slope: not None -> the epilogue stores max(v, out_slope * v) (folded-BatchNorm eval graph);
         cdt / out_scale / out_quant: fp8 inference graph (abc_conv_desc.out_scale, .out_quant)"""
@@ -294,6 +298,7 @@ class Engine:
         d.out_scale = None if out_scale is None else out_scale.data_ptr()
         d.out_quant = None if out_quant is None else out_quant.data_ptr()
         d.out_quant_stride = out_quant_stride
+        d.heads_epi = None if heads_epi is None else heads_epi.data_ptr()
         d.dtype_in, d.dtype_c, d.dtype_out = src.dt, cdt, y_dt
         lh, lw = src.lh()
         d.B, d.Hin, d.Win = self.B, lh, lw
@@ -786,9 +791,21 @@ class Engine:
         self.h, self.w = h, w
         # (fp8 graph: the heads' features are e4m3 too when the merged conv1 and the heads' own 1x1 kernel serve them)
         f8_feat = self.fp8 and trunk.dt == L.FP8 and trunk.C == 128 and nh <= 8 and self.batched_heads and (h * w) % 64 == 0
-        self.hfeat, self.hcoef = self.act_buf(h, w, 128 * nh, L.FP8 if f8_feat else None)
+        # folded graph: the heads' 1x1 convolutions in the epilogue of the merged conv1 (abc_conv_desc.heads_epi): no feature tensor
+        self.hepi = None
+        if self.fold and self.heads_epilogue and self.batched_heads and self.dt == L.BF16 and trunk.C == 128 and nh <= 8 and \
+                (trunk.dt == L.BF16 or f8_feat):
+            self.hepi = torch.zeros(nh * C.sizeof(L.HeadsEpi), dtype=torch.uint8, device=self.dev)
+            self.keep.append(self.hepi)
+        if self.hepi is not None:
+            # (a placeholder: with heads_epi the convolution does not write its y)
+            self.hfeat = self.new((1, 1, 1, 128 * nh), self._tdt(L.FP8) if f8_feat else None)
+            self.hcoef = None
+        else:
+            self.hfeat, self.hcoef = self.act_buf(h, w, 128 * nh, L.FP8 if f8_feat else None)
         if f8_feat:
             self.hfeat_q = (self.new((nh,), torch.float32, 0.0), self.new((nh,), torch.float32, 1.0), self.new((nh,), torch.float32, 1.0))
+        epi_items = []
         # the list forward() returns: one contiguous NCHW f32 map per head (unet.py:119), written directly
         self.logits = [self.new((self.B, hc, h, w), torch.float32) for hc in self.heads]
         self.head_recs, self.head2 = [], []
@@ -820,14 +837,20 @@ class Engine:
                                                         self.new((hc,), torch.float32, 1.0))
                     w2 = self.packed(1, 128, rows_pad, cdt=L.FP8)
                     self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128, row_scale=qmul.data_ptr(), cdt=L.FP8)
-                    self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
-                                   [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs, cdt=L.FP8, out_scale=deq)
+                    if self.hepi is not None:
+                        epi_items.append((w2, self.P(p + ".conv2.bias"), deq, self.logits[i], hc, rows_pad))
+                    else:
+                        self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
+                                       [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs, cdt=L.FP8, out_scale=deq)
                     self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
                     continue
                 w2 = self.packed(1, 128, rows_pad)
                 self.emit_pack(p + ".conv2.weight", w2, 0, hc, 128, 1, rows_pad, 128)
-                self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
-                               [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs)
+                if self.hepi is not None:
+                    epi_items.append((w2, self.P(p + ".conv2.bias"), None, self.logits[i], hc, rows_pad))
+                else:
+                    self.emit_conv(self.fwd_ops, f, w2, self.P(p + ".conv2.bias"), self.logits[i], L.F32, h, w, hc, 0, hc,
+                                   [(0, 0)], what="fwd %s.conv2" % p, planar_out=True, collect=head_convs)
             self.head2.append(Rec(kind="head2", cname=p + ".conv2", src=f, cout=hc, idx=i))
         if head_fins:
             arr = (L.BnFwdDesc * len(head_fins))()
@@ -840,6 +863,15 @@ class Engine:
                                  {"kernel": "bn", "flops": 0, "bytes": 0}))
         if fused:
             self._heads_fused_setup()
+            return
+        if self.hepi is not None:
+            # the table the merged conv1 reads in its epilogue: static pointers, written once
+            host = (L.HeadsEpi * nh)()
+            for i, (w2, bias_ptr, deq, lg, hc, rows_pad) in enumerate(epi_items):
+                host[i].w2, host[i].bias, host[i].oscale = w2.data_ptr(), bias_ptr, (None if deq is None else deq.data_ptr())
+                host[i].y, host[i].Cout, host[i].Cout_pad = lg.data_ptr(), hc, rows_pad
+            self.hepi.copy_(torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8))
+            self.keep.append(epi_items)
             return
         # (the eight conv1 launches above write the eight slices of hfeat; the eight 1x1 convolutions go as one launch)
         self.emit_heads_batch(self.fwd_ops, head_convs, 0, "fwd out_modules.*.conv2")
@@ -909,7 +941,8 @@ class Engine:
                                    row_scale=scale_all[sl].data_ptr())
             self.emit_conv(self.fwd_ops, trunk, wf, bias_all.data_ptr(), self.hfeat, L.FP8 if self.hfeat_q is not None else self.dt, h, w, Ct, 0, Ct, taps,
                            what="fwd out_modules.*.conv1", out_slope=0.01, cdt=L.FP8 if f8 else None, out_scale=deq_all if f8 else None,
-                           out_quant=None if self.hfeat_q is None else self.hfeat_q[2], out_quant_stride=0 if self.hfeat_q is None else 1)
+                           out_quant=None if self.hfeat_q is None else self.hfeat_q[2], out_quant_stride=0 if self.hfeat_q is None else 1,
+                           heads_epi=self.hepi)
             return None, 0
         for i in range(nh):
             self.emit_pack("out_modules.%d.conv1.weight" % i, wf, 0, 128, 128, 3, 128, 128, rows_total=Ct, rows_off=128 * i)

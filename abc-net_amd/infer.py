@@ -20,7 +20,7 @@ from . import _lib as L
 
 class InferenceRunner:
     def __init__(self, model, batch, height, width, use_graph=True, device=None, extract=False, cap_atoms=512, cap_bonds=16384,
-                 fold_bn=None, fp8=False, fp8_margin=1.0, guards=False):
+                 fold_bn=None, fp8=False, fp8_margin=1.0, guards=False, heads_epilogue=False):
         """fp8: the e4m3 form of the BatchNorm-folded graph (unet.py, bf16 model): the 128-channel 3x3 convolutions at the output
         resolution on the block-scaled MFMA over e4m3 activations and weights (Engine(fp8=True)); the per-tensor activation scales
         are calibrated on the FIRST batch loaded (calibrate(); again on demand) by running the bf16 folded graph on it.
@@ -46,8 +46,11 @@ class InferenceRunner:
             self.fp8_margin = float(fp8_margin)
             if self.fp8 and not (self.fold_bn and model.VARIANT == "unet" and model.compute_dtype == "bf16"):
                 raise L.AbcNetHipError("fp8 inference is a form of the BatchNorm-folded bf16 graph of unet.py")
-            self.eng = eng = model._engine_for(x0, False, fold_bn=self.fold_bn, fp8=self.fp8, guards=guards)
-            self._ref = model._engine_for(x0, False, fold_bn=True) if self.fp8 else None   # bf16 graph, calibration only
+            # heads_epilogue (folded graph, opt-in: exact but slower than the default plan): the heads' 1x1
+            # convolutions in the epilogue of the convolution that makes their features
+            self.eng = eng = model._engine_for(x0, False, fold_bn=self.fold_bn, fp8=self.fp8, guards=guards, heads_epilogue=heads_epilogue)
+            # (bf16 graph with its feature tensor materialised: calibration only)
+            self._ref = model._engine_for(x0, False, fold_bn=True, heads_epilogue=False) if self.fp8 else None
         lg = eng.logits
         self.atom_mask, self.bond_mask = torch.empty_like(lg[0]), torch.empty_like(lg[4])
         self.rho_abs, self.omega_mask = torch.empty_like(lg[6]), torch.empty_like(lg[7])

@@ -57,6 +57,15 @@ typedef struct abc_act_src {
                                   nn.Dropout does every forward (unet.py:69) */
 } abc_act_src;
 
+/* One head's 1x1 convolution (unet.py:70) computed in the epilogue of the convolution that produces its 128 features
+ * (abc_conv_desc.heads_epi; folded inference graph): w2 = the head's packed conv2 weights as abc_pack_conv_weights writes them
+ * for the heads' 1x1 kernel (layout 0: bf16 [1][4 chunks][Cout_pad][32] / e4m3 [1][2 chunks][Cout_pad][64]), bias [Cout],
+ * oscale [Cout] (e4m3 only: feature scale x weight-row scale), y = the head's NCHW f32 map [B][Cout][Hout][Wout]. */
+typedef struct abc_heads_epi {
+    const void* w2; const float* bias; const float* oscale; float* y;
+    int32_t Cout, Cout_pad;
+} abc_heads_epi;
+
 /* Generic tap-list convolution as implicit GEMM on MFMA.  One descriptor covers
  *   nn.Conv2d 3x3/5x5/1x1 forward   (unet.py:12,15,66,70; unet2.py:56,59,66)
  *   its data gradient               (autograd of the same, train.py:140)
@@ -113,6 +122,10 @@ typedef struct abc_conv_desc {
     const float* out_quant;
     int32_t out_quant_stride; /* 0: one scalar; 1: one value per 128-channel block of the output (out_quant[n / 128]): the eight heads'
                                  features side by side in one tensor, each head with its own scale */
+    const abc_heads_epi* heads_epi; /* NULL, or a DEVICE array of Cout / 128 entries: every 128-channel block of this convolution's output is
+                                 one head's finished feature slice (out_act set, BatchNorm folded) and the head's 1x1 convolution is computed
+                                 in the tile's epilogue -- y is not written at all, the heads' maps are.  3x3, stride 1, bf16 or e4m3 compute,
+                                 the weights-direct tile (abc_conv_variant == 1); abc_conv_fwd refuses it elsewhere */
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
@@ -531,7 +544,7 @@ int abc_concat_f32(const float* const* srcs, const int32_t* counts, int32_t n, f
 /* *p += inc (one thread): the per-step dropout salt */
 int abc_counter_add_u32(uint32_t* p, uint32_t inc, abc_stream_t stream);
 
-/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17, abc_raster_desc = 18):
+/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17, abc_raster_desc = 18, abc_heads_fused_desc = 19, abc_heads_epi = 20):
  * lets a foreign-language binding check its mirror structs at load time */
 int abc_sizeof(int which);
 const char* abc_last_error(void);

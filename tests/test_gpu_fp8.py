@@ -147,13 +147,35 @@ def test_fp8_conv_equals_conv2d_of_the_dequantised_operands(case):
     assert not badb.any(), (int(badb.sum()), gotb8[badb][:8].tolist(), refb8[badb][:8].tolist())
 
 
-def _runner(fp8, B, S, margin=1.0):
+def _runner(fp8, B, S, margin=1.0, heads_epilogue=False, H=None):
     from abcnet_amd.infer import InferenceRunner
     from abcnet_amd.unet import UNet
     m = UNet(1, HEADS, dtype="bf16")
     m.load_state_dict(uo.filled_state("unet", 1, HEADS, seed=0))
     m = m.to(DEV)
-    return InferenceRunner(m, B, S, S, use_graph=True, fold_bn=True, fp8=fp8, fp8_margin=margin)
+    return InferenceRunner(m, B, H or S, S, use_graph=True, fold_bn=True, fp8=fp8, fp8_margin=margin, heads_epilogue=heads_epilogue)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B,H,W", [(2, 128, 128), (3, 160, 96), (2, 384, 512)])
+def test_heads_in_the_epilogue_equal_the_separate_heads_kernel(fp8, B, H, W):
+    """abc_conv_desc.heads_epi: the heads' 1x1 convolutions (unet.py:70) computed in the epilogue of the convolution that makes
+    their features, the 8 x 128-channel feature tensor never written.  Same operand roundings (features to bf16 / e4m3 with the
+    head's scale), same K order of the MFMAs: the eight maps equal those of the plan with the separate heads kernel BIT FOR BIT
+    -- whole tiles, ragged tiles (40 x 24 and 96 x 128 maps), bf16 and e4m3.  (An opt-in plan, InferenceRunner(heads_epilogue=True):
+    exact, but measured slower than conv1 + the separate heads kernel -- DESIGN.md section 3, round 3.)"""
+    x = synthetic_images(B, max(H, W), seed=7)[:, :, :H, :W].contiguous().to(DEV)
+    outs = []
+    for epi in (True, False):
+        run = _runner(fp8, B, W, heads_epilogue=epi, H=H)
+        assert (run.eng.hepi is not None) == epi
+        run.load_batch(x)
+        run.step()
+        run.step()
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in run.logits] + [run.atom_mask.clone(), run.omega_mask.clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_fp8_inference_graph_against_oracle_and_bf16_graph():
@@ -166,7 +188,7 @@ def test_fp8_inference_graph_against_oracle_and_bf16_graph():
     # up3.conv's first convolution enters the chain (bf16 compute, e4m3 out); five 128 -> 128 convolutions and the eight heads'
     # merged conv1 compute in e4m3 and store e4m3; the heads' 1x1 convolutions read e4m3 features and write the f32 maps
     assert sum("<fp8,fp8,fp8" in k for k in kinds) == 6 and sum("<bf16,bf16,fp8" in k for k in kinds) == 1 and "heads_fwd_batch" in kinds, kinds
-    assert run8.eng.hfeat.dtype == F8 and run8.eng.hfeat_q is not None
+    assert run8.eng.hfeat_q is not None and run8.eng.hepi is None
     assert not run8.eng.fp8_calibrated
     outs = []
     for run in (run8, run16):
