@@ -32,7 +32,9 @@ class ConvDesc(C.Structure):
                 ("tap_dy", C.c_int8 * MAX_TAPS), ("tap_dx", C.c_int8 * MAX_TAPS), ("stats_rows", i32), ("accumulate", i32),
                 ("planar_out", i32), ("ctot_out", i32), ("out_act", i32), ("out_slope", f32), ("pool_y", vp), ("ld_pool", i32),
                 ("stem_x", vp), ("stem_w", vp), ("stem_scale", vp), ("stem_bias", vp), ("stem_slope", f32),
-                ("out_scale", vp), ("out_quant", vp), ("out_quant_stride", i32), ("heads_epi", vp)]
+                ("out_scale", vp), ("out_quant", vp), ("out_quant_stride", i32), ("heads_epi", vp),
+                ("actbwd_y", vp), ("actbwd_ld", i32), ("actbwd_coff", i32), ("actbwd_scale", vp), ("actbwd_shift", vp), ("actbwd_slope", vp),
+                ("actbwd_mean", vp), ("actbwd_invstd", vp)]
 
 
 class HeadsEpi(C.Structure):
@@ -160,6 +162,7 @@ _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnAppl
 P = C.POINTER
 SYMBOLS = {
     "abc_conv_stat_blocks": (C.c_int, [P(ConvDesc)]),
+    "abc_conv_actbwd_ok": (C.c_int, [P(ConvDesc)]),
     "abc_conv_variant": (C.c_int, [vp]),
     "abc_conv_weight_layout": (C.c_int, [vp]),
     "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),

@@ -52,6 +52,11 @@ struct FastK {
     const float* oquant;            // fp8 output: 1 / s_out (device), applied before the rounding to e4m3
     int oq_stride;                  // 0: a scalar; 1: one per n-block (128 output channels)
     const abc_heads_epi* hepi;      // HEPI: per n-block (= head) the 1x1 convolution computed in this tile's epilogue
+    // ACTB (abc_conv_desc.actbwd_*): this data gradient is d(activation output) of the producing layer; the epilogue turns it into
+    // d(BatchNorm output) and sums that layer's BatchNorm-backward statistics -- bn_act.hip's act_bwd pass, not run
+    const void* ab_y; int ab_ld;    // the producer's raw convolution output (already at its channel 0), its row length
+    const float *ab_sc, *ab_sh, *ab_sl, *ab_mu, *ab_is;
+    int ystg_off;                   // a second staging region (the y_raw tile's way into the accumulator layout)
     unsigned bytesA, bytesW;
     long long* prof;  // debugging: per-workgroup phase timestamps (null in production)
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
@@ -66,7 +71,7 @@ __device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" :::
 // HEPI ("heads in the epilogue", folded inference graph): the tile's 128 output channels are one head's finished features
 // (unet.py:66-69 with BatchNorm folded); the head's 1x1 convolution (unet.py:70) is computed from them right here and the f32
 // NCHW maps are stored -- the 8 x 128-channel feature tensor is never written or read (2 x 2.1 GB per batch of 64 at 512 x 512)
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, bool HEPI = false>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
 __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const FastK a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
@@ -84,7 +89,10 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     constexpr bool F8C = sizeof(CT) == 1;    // e4m3 operands: one 32x32x64 MFMA per lane-half of a 64-byte chunk (weights-direct loop only)
     constexpr bool F8O = sizeof(OutT) == 1;  // e4m3 output: v * (1 / s_out), saturating
     static_assert(!F8C || WD == 9, "fp8 compute is served by the 9-tap weights-direct loop");
+    constexpr bool HEPI = EPI == 1;     // the heads' 1x1 convolutions in the epilogue
+    constexpr bool ACTB = EPI == 2;     // the activation / BatchNorm-statistics backward pass of the PRODUCER of this data gradient in the epilogue
     static_assert(!HEPI || (WD == 9 && BN == 128 && MT == 6 && sizeof(CT) <= 2), "heads epilogue: the 192 x 128 weights-direct tile");
+    static_assert(!ACTB || (!STATIC && sizeof(OutT) == 2 && sizeof(CT) == 2), "act_bwd epilogue: bf16 gradients, streamed weights");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -199,6 +207,15 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
             osc[j] = (F8C && nval[j]) ? a.oscale[n] : 1.f;
         }
         const float oq = F8O ? a.oquant[nb * a.oq_stride] : 1.f;
+        float csc[ACTB ? TN : 1], csh[ACTB ? TN : 1], csl[ACTB ? TN : 1], cmu[ACTB ? TN : 1];
+        if constexpr (ACTB) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + r;
+                csc[j] = nval[j] ? a.ab_sc[n] : 0.f; csh[j] = nval[j] ? a.ab_sh[n] : 0.f;
+                csl[j] = nval[j] ? a.ab_sl[n] : 0.f; cmu[j] = nval[j] ? a.ab_mu[n] : 0.f;
+            }
+        }
 
         // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile).
         // Persistent (resident-weight) workgroups prefetched this tile's halo during the previous tile.
@@ -275,6 +292,10 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bv[j]), "v"(osc[j]));
         asm volatile("" :: "v"(oq));
+        if constexpr (ACTB) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(csc[j]), "v"(csh[j]), "v"(csl[j]), "v"(cmu[j]));
+        }
 #endif
         first_tile = false;
         __syncthreads();
@@ -598,7 +619,8 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         // 39 us on the 16-channel 384x384 layers).  Fast path for whole tiles with plain 16-byte stores: add bias,
         // sum, sum of squares, convert, one ds_write per value with an immediate offset; max / min in a second sweep
         // only when unet2's CBAM asks for them; the general path keeps every check.
-        const bool whole = (gy0 + 2 * MT <= a.Hg) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok;
+        // (ACTB launches consist of whole tiles only, checked on the host: the general path below is not compiled into them)
+        const bool whole = ACTB || ((gy0 + 2 * MT <= a.Hg) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok);
         if (ABC_DBG(a.dbg) & 64) {
         } else if (whole) {
             // (laundered: computed from the plain thread index, the lane parts of the staging addresses and store offsets are hoisted
@@ -634,8 +656,37 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 #pragma unroll
             for (int j = 0; j < TN; ++j) { s1v[j] = (f32x2){0.f, 0.f}; s2v[j] = (f32x2){0.f, 0.f}; }
             const float slope = a.out_act ? a.out_slope : 1.f;      // (max(v, 1 * v) = v: no select per value)
+            // ACTB: the producer's raw output y_raw at this tile -- per M-tile the sweep's 16-byte loads (the stores' lane mapping),
+            // through a second set of staging rows, read back one value per accumulator register (lane = channel, like the sums).
+            // The loads of M-tile i + 1 fly under the arithmetic of M-tile i.
+            char* ystg = smem + a.ystg_off + wl * (32 * ROWB);
+            const char* yrd = ystg + 4 * (ll >> 5) * ROWB + (ll & 31) * 2;
+            __amdgpu_buffer_rsrc_t rsYR = rsY;
+            unsigned voffy[ACTB ? NST : 1], istep_y = 0;
+            u32x4 yq[ACTB ? NST : 1];
+            if constexpr (ACTB) {
+                const bf16* yrt = (const bf16*)a.ab_y + (((size_t)(b * a.Hg + gy0) * a.Wg + gx0) * a.ab_ld + n0);
+                rsYR = abc_make_rsrc(yrt, 0x80000000u);
+                istep_y = (unsigned)(2 * a.Wg * a.ab_ld) * 2u;
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int rit = lrow + RSTEP * st;
+                    voffy[st] = seg_ok ? (unsigned)((wl / WN) * TM) * istep_y + (unsigned)((((rit >> 4) * a.Wg + (rit & 15)) * a.ab_ld + (wl % WN) * TW + lsg * EV) * 2)
+                                       : 0xFFFFFFF0u;
+                    yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], 0u, 0);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                if constexpr (ACTB) {
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) *(u32x4*)(ystg + (lrow + RSTEP * st) * ROWB + lsg * 16) = yq[st];
+                    if (i + 1 < TM) {
+#pragma unroll
+                        for (int st = 0; st < NST; ++st) yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], (unsigned)(i + 1) * istep_y, 0);
+                    }
+                    asm volatile("" ::: "memory");
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const f32x2 b2 = {bv[j], bv[j]};
@@ -643,12 +694,23 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     for (int k = 0; k < 16; k += 2) {
                         f32x2 v = {acc[i][j][k], acc[i][j][k + 1]};
                         if constexpr (F8C) v = __builtin_elementwise_fma(v, (f32x2){osc[j], osc[j]}, b2); else v += b2;
-                        s1v[j] += v; s2v[j] = __builtin_elementwise_fma(v, v, s2v[j]);
-                        const f32x2 m = v * slope;
-                        f32x2 vo = {fmaxf(v.x, m.x), fmaxf(v.y, m.y)};
-                        if constexpr (F8O) vo *= oq;
                         char* p = wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT);
-                        abc_put2<OutT>(p, p + ROWB, vo.x, vo.y);
+                        if constexpr (ACTB) {
+                            // g = dA where BatchNorm(y_raw) > 0, slope * dA elsewhere (unet.py:14,17 backward); sums of g and g (y_raw - mean)
+                            const char* q = yrd + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 64;
+                            const f32x2 x = {__uint_as_float((unsigned)*(const unsigned short*)q << 16), __uint_as_float((unsigned)*(const unsigned short*)(q + ROWB) << 16)};
+                            const f32x2 yv = __builtin_elementwise_fma(x, (f32x2){csc[j], csc[j]}, (f32x2){csh[j], csh[j]});
+                            const f32x2 f = {yv.x > 0.f ? 1.f : csl[j], yv.y > 0.f ? 1.f : csl[j]};
+                            const f32x2 gg = v * f;
+                            s1v[j] += gg; s2v[j] = __builtin_elementwise_fma(gg, x - (f32x2){cmu[j], cmu[j]}, s2v[j]);
+                            abc_put2<OutT>(p, p + ROWB, gg.x, gg.y);
+                        } else {
+                            s1v[j] += v; s2v[j] = __builtin_elementwise_fma(v, v, s2v[j]);
+                            const f32x2 m = v * slope;
+                            f32x2 vo = {fmaxf(v.x, m.x), fmaxf(v.y, m.y)};
+                            if constexpr (F8O) vo *= oq;
+                            abc_put2<OutT>(p, p + ROWB, vo.x, vo.y);
+                        }
                     }
                 }
                 // (the sums are pinned to their M-tile and the scheduler barriers keep the M-tiles apart: left free, the compiler
@@ -754,6 +816,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                     v1 += red[(w * 4 + 0) * BN + tid]; v2 += red[(w * 4 + 1) * BN + tid];
                     v3 = fmaxf(v3, red[(w * 4 + 2) * BN + tid]); v4 = fminf(v4, red[(w * 4 + 3) * BN + tid]);
                 }
+                if constexpr (ACTB) v2 *= a.ab_is[n0 + tid];      // (the row act_bwd writes: sum of g (y_raw - mean) / std)
                 if (STATIC && rows == 2) {      // (unet2's CBAM needs its four rows PER IMAGE: those stay per tile)
                     pst1 += v1; pst2 += v2;
                 } else {
@@ -776,52 +839,54 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     }
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, bool HEPI = false>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
 int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
-    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, HEPI>;
+    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI>;
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)fn, LDS_WG, &lds_ok)) return rc;
     hipLaunchKernelGGL(fn, dim3(g.nwg), dim3(FT), g.lds, st, k);
     return abc_check_launch("conv_fast");
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, int EPI = 0>
 int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
-    if constexpr (BN == 32) {  // resident weights exist for the narrow layers only
+    if constexpr (BN == 32 && EPI == 0) {  // resident weights exist for the narrow layers only
         if (g.b_static) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, true>(k, g, st);
     }
     if constexpr (BN >= 64 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
         // 3x3 (any 9-tap list) over 64-byte chunks: weights straight from global memory into the MFMA operands
-        if (g.wd == 9) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9>(k, g, st);
+        if (g.wd == 9) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9, EPI>(k, g, st);
     }
-    if constexpr (BN == 32 && MT == 8 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
+    if constexpr (BN == 32 && MT == 8 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2 && EPI == 0) {
         // unet2's 5x5 32 -> 32 convolutions: 25 taps, a ring of 5
         if (g.wd == 25) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 25>(k, g, st);
     }
-    return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false>(k, g, st);
+    return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 0, EPI>(k, g, st);
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int EPI = 0>
 int launch_mt(const FastK& k, const abc_fast_geom& g, int stride, hipStream_t st) {
     if constexpr (BN == 128) {
-        if (stride == 1 && g.MT == 6) return launch_inst<InT, CT, OutT, CK, BN, 1, 6>(k, g, st);
+        if (stride == 1 && g.MT == 6) return launch_inst<InT, CT, OutT, CK, BN, 1, 6, EPI>(k, g, st);
     }
-    if (stride == 2) return launch_inst<InT, CT, OutT, CK, BN, 2, 4>(k, g, st);
+    if constexpr (EPI == 0) {
+        if (stride == 2) return launch_inst<InT, CT, OutT, CK, BN, 2, 4>(k, g, st);
+    }
     if constexpr (BN >= 64) {
-        if (g.MT == 2) return launch_inst<InT, CT, OutT, CK, BN, 1, 2>(k, g, st);
+        if (g.MT == 2) return launch_inst<InT, CT, OutT, CK, BN, 1, 2, EPI>(k, g, st);
     }
     if constexpr (BN != 128) {
-        if (g.MT == 8) return launch_inst<InT, CT, OutT, CK, BN, 1, 8>(k, g, st);
+        if (g.MT == 8) return launch_inst<InT, CT, OutT, CK, BN, 1, 8, EPI>(k, g, st);
     }
-    return launch_inst<InT, CT, OutT, CK, BN, 1, 4>(k, g, st);
+    return launch_inst<InT, CT, OutT, CK, BN, 1, 4, EPI>(k, g, st);
 }
 
-template <typename InT, typename CT, typename OutT, int CK>
+template <typename InT, typename CT, typename OutT, int CK, int EPI = 0>
 int launch_bn(const FastK& k, const abc_fast_geom& g, int stride, hipStream_t st) {
     switch (g.BN) {
-        case 128: return launch_mt<InT, CT, OutT, CK, 128>(k, g, stride, st);
-        case 64: return launch_mt<InT, CT, OutT, CK, 64>(k, g, stride, st);
-        default: return launch_mt<InT, CT, OutT, CK, 32>(k, g, stride, st);
+        case 128: return launch_mt<InT, CT, OutT, CK, 128, EPI>(k, g, stride, st);
+        case 64: return launch_mt<InT, CT, OutT, CK, 64, EPI>(k, g, stride, st);
+        default: return launch_mt<InT, CT, OutT, CK, 32, EPI>(k, g, stride, st);
     }
 }
 
@@ -842,6 +907,12 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
                (d->dtype_c == ABC_FP8) != (d->dtype_in == ABC_FP8) || d->dtype_c == ABC_F32 || d->dtype_out == ABC_F32)) return ABC_OK;
     g->CK = abc_conv_chunk(d->dtype_c, d->Cin);
     if (g->CK <= 0 || d->Cin % g->CK) return ABC_OK;
+    // act_bwd in the epilogue (abc_conv_desc.actbwd_y): a plain stride-1 bf16 data gradient over whole tiles, 64-byte chunks
+    const bool actb = d->actbwd_y != nullptr;
+    if (actb && (d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16 || g->CK != 32 || d->stride != 1 || d->accumulate ||
+                 d->stats == nullptr || d->stats_rows != 2 || d->om != 1 || d->oy0 || d->ox0 || d->Hg != d->Hout || d->Wg != d->Wout || d->out_act ||
+                 d->Wg % 16 || d->Cout % 8 || (d->ldy | d->cout_off | d->actbwd_ld) % 8 || d->heads_epi != nullptr ||
+                 (int64_t)d->B * d->Hg * d->Wg * d->actbwd_ld * 2 >= (int64_t(1) << 31))) return ABC_OK;
     const int64_t bytes_a = (int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * abc_dsize(d->dtype_in);
     if (bytes_a >= (int64_t(1) << 31)) return ABC_OK;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
@@ -880,6 +951,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
             if (mt == 2 && bn == 32) continue;   // 4 x 1 wave layout needs 4 m-tiles
             if (d->stride == 2 && mt != 4) continue;
             const int prow = 2 * mt;
+            if (actb && d->Hg % prow) continue;      // (whole tiles only)
             const int hh = (prow - 1) * d->stride + (dymax - dymin) + 1, hw = 15 * d->stride + (dxmax - dxmin) + 1;
             if (abc_cdiv(hh * hw * segs, FT) > fa_max(mt) || hh * hw * hw >= 65536) continue;
             const int rs = abc_roundup(hw * g->PS, 256);
@@ -941,7 +1013,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     }
     if (g->wd) g->sB_bytes = 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
-    g->b_static = (!g->wd && g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget &&
+    g->b_static = (!actb && !g->wd && g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget &&
                    abc_cdiv(g->HH * g->HW * segs, FT) <= fa_static(g->MT)) ? 1 : 0;
     if (g->b_static && d->ntaps % 3 == 0 && d->ntaps > 3) {
         // resident weights are loaded once: tap groups of 3 leave no padding rows (9 taps in two groups of 8 cost 24.5 KB of
@@ -962,6 +1034,8 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->stg_off = g->b_static ? abc_roundup(g->lds, 256) : 0;
     g->red_off = g->stg_off + stg;
     if (g->lds < g->red_off + red) g->lds = g->red_off + red;
+    g->ystg_off = abc_roundup(g->lds, 256);      // (behind everything: the tap and coefficient tables outlive the tile)
+    if (actb) g->lds = g->ystg_off + stg;
     if (g->lds > LDS_WG) return ABC_OK;
     g->tiles_x = abc_cdiv(d->Wg, 16);
     g->tiles_y = abc_cdiv(d->Hg, prow);
@@ -998,6 +1072,9 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     k.out_act = d->out_act; k.out_slope = d->out_slope;
     k.oscale = d->out_scale; k.oquant = d->out_quant; k.oq_stride = d->out_quant_stride ? 1 : 0;
     k.hepi = d->heads_epi;
+    k.ab_y = d->actbwd_y ? (const char*)d->actbwd_y + (size_t)d->actbwd_coff * 2 : nullptr; k.ab_ld = d->actbwd_ld;
+    k.ab_sc = d->actbwd_scale; k.ab_sh = d->actbwd_shift; k.ab_sl = d->actbwd_slope; k.ab_mu = d->actbwd_mean; k.ab_is = d->actbwd_invstd;
+    k.ystg_off = g.ystg_off;
     { const char* e = abc_knob("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     k.prof = g_prof;
     { const char* e = abc_knob("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }
@@ -1012,9 +1089,16 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
     if (d->heads_epi != nullptr) {
         // the heads' 1x1 convolutions in the epilogue (geometry checked in abc_conv_fast_geom)
         if (dc == ABC_FP8 && di == ABC_FP8 && d->out_scale != nullptr && d->out_quant != nullptr)
-            return launch_st<f8, f8, f8, 64, 128, 1, 6, false, 9, true>(k, g, st);
-        if (dc == ABC_BF16 && di == ABC_BF16 && g.CK == 32) return launch_st<bf16, bf16, bf16, 32, 128, 1, 6, false, 9, true>(k, g, st);
+            return launch_st<f8, f8, f8, 64, 128, 1, 6, false, 9, 1>(k, g, st);
+        if (dc == ABC_BF16 && di == ABC_BF16 && g.CK == 32) return launch_st<bf16, bf16, bf16, 32, 128, 1, 6, false, 9, 1>(k, g, st);
         return abc_fail(ABC_EUNSUPPORTED, "conv: heads_epi needs bf16 or e4m3 (with out_scale / out_quant) operands");
+    }
+    if (d->actbwd_y != nullptr) {
+        // act_bwd in the epilogue (geometry and types checked in abc_conv_fast_geom)
+        if (!(dc == ABC_BF16 && di == ABC_BF16 && dout == ABC_BF16 && g.CK == 32 && d->stride == 1 && !g.b_static) || !d->actbwd_scale || !d->actbwd_shift ||
+            !d->actbwd_slope || !d->actbwd_mean || !d->actbwd_invstd)
+            return abc_fail(ABC_EINVAL, "conv: actbwd_y needs a bf16 stride-1 data gradient and all five coefficient rows");
+        return launch_bn<bf16, bf16, bf16, 32, 2>(k, g, 1, st);
     }
     if (dc == ABC_FP8 || dout == ABC_FP8 || di == ABC_FP8) {
         // the fp8 inference graph (abc_conv_desc.out_scale / out_quant): the 192-pixel x 128-channel weights-direct tile only

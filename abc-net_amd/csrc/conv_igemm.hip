@@ -517,7 +517,21 @@ extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, i
     return ABC_OK;
 }
 
+// descriptors only the lean kernel serves (the heads' epilogue, act_bwd in the epilogue): no other kernel is asked
+static bool lean_only(const abc_conv_desc* d) { return d->heads_epi != nullptr || d->actbwd_y != nullptr; }
+
+extern "C" int abc_conv_actbwd_ok(const abc_conv_desc* d) {
+    if (d->actbwd_y == nullptr) return 0;
+    // (only where the lean kernel would run the plain data gradient anyway: the narrow-level kernel is the faster one for its shapes)
+    abc_conv_desc p = *d;
+    p.actbwd_y = nullptr;
+    if (abc_conv_stem_ok(&p, nullptr) || abc_head_fwd_ok(&p) || abc_head_dgrad_ok(&p) || abc_conv_narrow_ok(&p)) return 0;
+    abc_fast_geom f;
+    return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) ? 1 : 0;
+}
+
 extern "C" int abc_conv_variant(const abc_conv_desc* d) {
+    if (lean_only(d)) { abc_fast_geom f; return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) ? 1 : 0; }
     if (abc_conv_stem_ok(d, nullptr)) return 2;
     if (abc_head_fwd_ok(d)) return 3;
     if (abc_head_dgrad_ok(d)) return 4;
@@ -528,14 +542,17 @@ extern "C" int abc_conv_variant(const abc_conv_desc* d) {
 }
 
 extern "C" int abc_conv_weight_layout(const abc_conv_desc* d) {
+    if (lean_only(d)) { abc_fast_geom f; return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible && f.wd) ? 1 : 0; }
     if (abc_conv_stem_ok(d, nullptr) || abc_head_fwd_ok(d) || abc_head_dgrad_ok(d) || abc_conv_narrow_ok(d)) return 0;
     abc_fast_geom f;
     return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible && f.wd) ? 1 : 0;   // the weights-direct loop of conv_fast.hip
 }
 
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
-    { int nb = 0; if (abc_conv_stem_ok(d, &nb)) return nb; }
-    if (abc_conv_narrow_ok(d)) return abc_conv_narrow_stat_blocks(d);
+    if (!lean_only(d)) {
+        { int nb = 0; if (abc_conv_stem_ok(d, &nb)) return nb; }
+        if (abc_conv_narrow_ok(d)) return abc_conv_narrow_stat_blocks(d);
+    }
     abc_fast_geom f;
     if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return (f.b_static && d->stats_rows != 4) ? f.nwg : f.tiles_x * f.tiles_y * d->B;   // (resident weights: one row per workgroup)
     Geom g;
@@ -600,6 +617,12 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     if (d->heads_epi != nullptr) {
         abc_fast_geom f;
         if (abc_conv_fast_geom(d, &f) != ABC_OK || !f.eligible) return abc_fail(ABC_EUNSUPPORTED, "conv: heads_epi is served by the 3x3 weights-direct tile only");
+        return abc_conv_fast_launch(d, f, stream);
+    }
+    if (d->actbwd_y != nullptr) {
+        abc_fast_geom f;
+        if (!abc_conv_actbwd_ok(d) || abc_conv_fast_geom(d, &f) != ABC_OK || !f.eligible)
+            return abc_fail(ABC_EUNSUPPORTED, "conv: actbwd_y is not served for this descriptor (ask abc_conv_actbwd_ok first)");
         return abc_conv_fast_launch(d, f, stream);
     }
     if (d->stem_x != nullptr && !abc_conv_narrow_ok(d)) return abc_fail(ABC_EUNSUPPORTED, "conv: the fused first convolution (stem_x) is served by the narrow-level kernel only");

@@ -108,8 +108,9 @@ class Rec:
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
-                 guards=False, heads_epilogue=False):
-        """batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
+                 guards=False, heads_epilogue=False, actbwd_epilogue=True):
+        """actbwd_epilogue=False: every act_bwd pass as a launch of its own (the form the fused epilogue is tested against);
+        batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
         batched one is tested against, tests/test_gpu_model.py::test_batched_heads_equal_one_by_one_launches)"""
         if variant not in ("unet", "unet2"):
             raise NotImplementedError("variant %r" % variant)
@@ -143,6 +144,9 @@ class Engine:
         # the 8 x 128-channel feature tensor is never written.  Bit-identical to the default plan (the separate heads kernel) and
         # measured SLOWER than it (b64 at 512 x 512: 7.86 -> 9.0-10.4 ms bf16, 6.09 -> 7.7-9.6 ms e4m3), hence off
         self.heads_epilogue = bool(heads_epilogue)
+        # training: the activation / BatchNorm-statistics backward pass of a layer in the epilogue of the data gradient that produces
+        # its input (abc_conv_desc.actbwd_*), where the layer has that one reader (_actbwd_target)
+        self.actbwd_epilogue = bool(actbwd_epilogue)
         self.dt = L.BF16 if dtype == "bf16" else L.F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         # the fused train step's heads (csrc/heads_fused.hip): conv2 forward + loss + the way back to the BatchNorm outputs as
@@ -284,8 +288,12 @@ class Engine:
 
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
                   grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
-                  accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None, out_quant_stride=0, heads_epi=None):
+                  accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None, out_quant_stride=0, heads_epi=None,
+                  actbwd=None):
         """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch;
+        actbwd: the Rec of the layer whose activation output this data gradient differentiates -> abc_conv_desc.actbwd_* (the
+        epilogue stores d(BatchNorm output) and that layer's BatchNorm-backward partial sums); returns None, emitting nothing, when
+        the library does not serve it for this shape;
         out_slope: not None -> the epilogue stores max(v, out_slope * v) (folded-BatchNorm eval graph);
         cdt / out_scale / out_quant: fp8 inference graph (abc_conv_desc.out_scale, .out_quant)"""
         cdt = self.dt if cdt is None else cdt
@@ -311,6 +319,15 @@ class Engine:
         d.stats_rows, d.accumulate = stats_rows, 1 if accumulate else 0
         L.set_taps(d, taps)
         self._last_conv_desc = d
+        if actbwd is not None:
+            p = actbwd
+            d.actbwd_y, d.actbwd_ld, d.actbwd_coff = p.y.data_ptr(), p.ld, p.coff
+            d.actbwd_scale, d.actbwd_shift, d.actbwd_slope = p.scale.data_ptr(), p.shift.data_ptr(), p.slopes.data_ptr()
+            d.actbwd_mean, d.actbwd_invstd = p.mean.data_ptr(), p.invstd.data_ptr()
+            d.stats = y.data_ptr()      # (placeholder for the query: the rows are allocated below)
+            stats = True
+            if not self.lib.abc_conv_actbwd_ok(C.byref(d)):
+                return None
         nblk = self.lib.abc_conv_stat_blocks(C.byref(d))
         st = None
         if stats:
@@ -323,6 +340,8 @@ class Engine:
         npx = self.B * gh * gw
         in_px = self.B * lh * lw * (4 if src.pool else 1)
         kname = ("conv_igemm", "conv_fast", "stem_conv", "head_fwd", "head_dgrad", "conv_narrow")[self.lib.abc_conv_variant(C.byref(d))]
+        if actbwd is not None:
+            kname += "+act_bwd"
         meta = {"kernel": "%s<%s,%s,%s,CK%d,BN%d,S%d,MT%d>" % (kname, self._dn(src.dt), self._dn(cdt), self._dn(y_dt), ck, bn, stride, mt),
                 "flops": 2.0 * npx * Cout * len(taps) * d.Cin,
                 "bytes": float(in_px * d.Cin * self._esz(src.dt) + npx * Cout * self._esz(y_dt))}
@@ -961,6 +980,11 @@ class Engine:
         defer=True: the apply pass is NOT emitted; returns (Src of g with coef = (ca, cc, cb) for a consumer that applies
         dY = ca*g + cb*y_raw + cc on load, emit_apply) where emit_apply() emits the classic in-place pass and returns
         the plain Src -- the caller picks one"""
+        fg = getattr(rec, "fused_g", None)
+        if fg is not None:
+            # the data gradient that produced d(activation output) already stored g and the partial sums (emit_conv(actbwd=rec))
+            assert pool is None and drop is None
+            return self._bn_finish(ops, rec, fg[1], fg[2], fg[0], defer=defer, keep_g=True)
         C_ = rec.cout
         g = self.new((self.B, rec.H, rec.W, C_))
         rec.g = g      # (handle for the in-situ parity tests)
@@ -1035,8 +1059,39 @@ class Engine:
         self.emit_pack(rec.cname + ".weight", wd, 1, rec.cout, rec.cin, rec.k, rows_pad, rec.cout)
         dsrc = self.new((self.B, lh, lw, rec.cin))
         rec.dsrc = dsrc
+        tgt = self._actbwd_target(rec)
+        if tgt is not None:
+            # the producer's act_bwd pass in this convolution's epilogue: dsrc holds d(BatchNorm output) of `tgt`, not d(src)
+            got = self.emit_conv(ops, dY, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, taps_mirror(rec.taps),
+                                 what="dgrad " + rec.cname + " + act_bwd " + tgt.bname, actbwd=tgt)
+            if got is not None:
+                tgt.fused_g = (dsrc, got[0], got[1])
+                tgt.g = dsrc
+                rec.dsrc_is_g = True
+                return dsrc
         self.emit_conv(ops, dY, wd, None, dsrc, self.dt, lh, lw, rec.cin, 0, rec.cin, taps_mirror(rec.taps), what="dgrad " + rec.cname)
         return dsrc
+
+    def _actbwd_target(self, rec):
+        """the layer whose act_bwd pass can ride in the epilogue of rec's data gradient: rec reads the WHOLE activated output of one
+        plain convolution + BatchNorm layer, at full resolution, without dropout, and is its only reader (no skip connection, no
+        pooled reader: those gradients meet in bn_act.hip's act_bwd) -- the second convolution of a DoubleConv reading the first
+        (unet.py:12-17), the trunk's layers"""
+        if not (self.actbwd_epilogue and self.train and self.dt == L.BF16):
+            return None
+        src = rec.src
+        p = src.producer
+        if not isinstance(p, Rec) or p.kind != "conv" or getattr(p, "is_head", False):
+            return None
+        if src.pool or getattr(src, "via_pool", False) or src.drop_p > 0 or src.planar or src.t is not p.y:
+            return None
+        if p.coff != 0 or p.ld != p.cout or src.coff != 0 or src.C != p.cout or rec.cin != p.cout or src.lh() != (p.H, p.W):
+            return None
+        readers = [r for r in self.recs + list(getattr(self, "head_recs", [])) if getattr(r, "src", None) is not None and
+                   (r.src.producer is p or r.src.t is p.y)]
+        if len({id(r) for r in readers}) != 1 or readers[0] is not rec:
+            return None
+        return p
 
     def _route(self, rec, dsrc):
         """hand d(src) of `rec` to whoever produced src"""
@@ -1548,9 +1603,11 @@ class Engine:
         else:
             src.producer.grad_same = (d_x, blk.cin, 0)
 
-    def _bn_finish(self, ops, rec, part, nblk, gbuf, defer=False):
-        """bn_finalize_bwd + bn_apply for a BN whose G and partials were produced elsewhere (CBAM bwd3).
-        defer=True: as _bn_backward(defer=True) -- the apply pass is left to the weight-gradient kernel's load where it can"""
+    def _bn_finish(self, ops, rec, part, nblk, gbuf, defer=False, keep_g=False):
+        """bn_finalize_bwd + bn_apply for a BN whose G and partials were produced elsewhere (CBAM bwd3; a data gradient with the
+        act_bwd pass in its epilogue).
+        defer=True: as _bn_backward(defer=True) -- the apply pass is left to the weight-gradient kernel's load where it can;
+        keep_g: the apply pass writes a buffer of its own (g stays intact for the in-situ parity tests)"""
         C_ = rec.cout
         k1, k2, gs = (self.new((C_,), torch.float32) for _ in range(3))
         f = L.BnBwdDesc()
@@ -1568,10 +1625,14 @@ class Engine:
         a.dtype, a.C, a.npix = self.dt, C_, self.B * rec.H * rec.W
 
         def emit_apply():
+            out = gbuf
+            if keep_g:
+                out = self.new((self.B, rec.H, rec.W, C_))
+                a.out, a.ld_out = out.data_ptr(), C_
             self._emit(ops, self.lib.abc_bn_apply_bwd, a, "bn_apply " + rec.bname,
                        meta={"kernel": "bn_apply", "flops": 0, "bytes": float(self.B * rec.H * rec.W * C_ * self._esz(self.dt) * 3)})
-            rec.dY = gbuf
-            return Src(gbuf, self.dt, rec.H, rec.W, C_, 0, C_)
+            rec.dY = out
+            return Src(out, self.dt, rec.H, rec.W, C_, 0, C_)
 
         if defer:
             return Src(gbuf, self.dt, rec.H, rec.W, C_, 0, C_, coef=(ca, cc, cb)), emit_apply

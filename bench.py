@@ -149,6 +149,8 @@ def main():
                     "(utils.py:83-228 on the GPU) instead of keeping pre-rasterised maps resident")
     ap.add_argument("--no-logits", action="store_true", help="(train) do not store the eight output maps: nothing reads them without "
                     "--metrics (Trainer(keep_logits=False)); NOT the default -- the headline line stores them as the reference does")
+    ap.add_argument("--no-actbwd-epilogue", action="store_true", help="(train) every act_bwd pass as a launch of its own "
+                    "(Trainer(actbwd_epilogue=False)): the A/B of the fused data-gradient epilogue, not the default")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -214,7 +216,8 @@ def main():
         tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract, fp8=(a.dtype == "fp8"))
         tr.load_batch(imgs.to(dev))
     else:
-        tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits)
+        tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits,
+                     actbwd_epilogue=not a.no_actbwd_epilogue)
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
         tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
         if a.raster:
@@ -279,7 +282,8 @@ def main():
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),
                    "device_rasteriser": bool(a.raster), "device_extraction": bool(a.extract),
-                   "logits_stored": bool(a.mode != "train" or a.metrics or not a.no_logits), "env_knobs": knobs},
+                   "logits_stored": bool(a.mode != "train" or a.metrics or not a.no_logits),
+                   "actbwd_epilogue": bool(a.mode == "train" and not a.no_actbwd_epilogue), "env_knobs": knobs},
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 

@@ -126,10 +126,23 @@ typedef struct abc_conv_desc {
                                  one head's finished feature slice (out_act set, BatchNorm folded) and the head's 1x1 convolution is computed
                                  in the tile's epilogue -- y is not written at all, the heads' maps are.  3x3, stride 1, bf16 or e4m3 compute,
                                  the weights-direct tile (abc_conv_variant == 1); abc_conv_fwd refuses it elsewhere */
+    /* act_bwd in the epilogue (training's data gradients): NULL, or the raw convolution output y_raw [B, Hout, Wout, actbwd_ld] (bf16) of the
+     * layer whose ACTIVATION OUTPUT this convolution differentiates (autograd of unet.py:12-17 under train.py:140).  The kernel then stores
+     *   g = dA * (BatchNorm(y_raw) > 0 ? 1 : slope),   BatchNorm(y_raw) = actbwd_scale * y_raw + actbwd_shift,
+     * instead of dA, and writes that layer's BatchNorm-backward partial sums to `stats` (stats_rows = 2; abc_conv_stat_blocks rows of
+     * [2][Cout]: sum of g, sum of g * (y_raw - actbwd_mean) * actbwd_invstd) -- exactly what abc_act_bwd computes from dA in a pass of its
+     * own (abc_act_bwd_desc: y_raw, scale, shift, slope, mean, invstd, partial), so abc_bn_finalize_bwd consumes them unchanged.
+     * Served where abc_conv_actbwd_ok() says so (bf16, stride 1, whole tiles of the lean kernel); abc_conv_fwd refuses it elsewhere. */
+    const void* actbwd_y;
+    int32_t actbwd_ld, actbwd_coff;        /* y_raw's row length and first channel (elements) */
+    const float *actbwd_scale, *actbwd_shift, *actbwd_slope, *actbwd_mean, *actbwd_invstd;   /* per output channel of THIS convolution */
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
 int abc_conv_stat_blocks(const abc_conv_desc* d);
+/* 1 when abc_conv_fwd honours d->actbwd_* for this descriptor (fill everything first, `stats` included), else 0: the caller then clears
+ * actbwd_y and runs abc_act_bwd as a pass of its own (the engine's fallback; same results up to the rounding of dA to bf16) */
+int abc_conv_actbwd_ok(const abc_conv_desc* d);
 /* which kernel abc_conv_fwd runs for this descriptor: 0 = general implicit GEMM (pool / dropout / planar / ragged
  * inputs), 1 = lean 4-wave kernel for plain NHWC inputs, 2 = one-channel first layer, 3 = heads' 1x1 into NCHW f32, 4 = its data gradient from NCHW f32.  Labels only. */
 int abc_conv_variant(const abc_conv_desc* d);

@@ -48,7 +48,9 @@ def pack(lib, w, mode, dt, Cout, Cin, k, rows_pad, red_real, py=0, px=0):
 
 def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, Hout, Wout, ldy=None, cout_off=0, coef=None,
          pool=False, stride=1, grid=None, om=1, oy0=0, ox0=0, out=None, out_dt=None, stats=False, drop_p=0.0, drop_seed=0,
-         planar_in=0, planar_out=False, out_slope=None, pool_out=None, stem=None):
+         planar_in=0, planar_out=False, out_slope=None, pool_out=None, stem=None, actbwd=None):
+    """actbwd: (y_raw, ld, coff, scale, shift, slope, mean, invstd) -> abc_conv_desc.actbwd_*; conv.last_actbwd_ok tells whether the
+    library honoured it (else the plain convolution ran)"""
     out_dt = dt if out_dt is None else out_dt
     ldy = Cout if ldy is None else ldy
     if out is None:
@@ -71,6 +73,18 @@ def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, 
     if stem is not None:   # (image, first-layer weights, scale, bias, slope): device f32 tensors
         d.stem_x, d.stem_w, d.stem_scale, d.stem_bias, d.stem_slope = stem[0].data_ptr(), stem[1].data_ptr(), stem[2].data_ptr(), stem[3].data_ptr(), stem[4]
     L.set_taps(d, taps)
+    conv.last_actbwd_ok = False
+    if actbwd is not None:
+        yr, ld_y, coff, sc, sh, sl, mu, istd = actbwd
+        d.actbwd_y, d.actbwd_ld, d.actbwd_coff = yr.data_ptr(), ld_y, coff
+        d.actbwd_scale, d.actbwd_shift, d.actbwd_slope, d.actbwd_mean, d.actbwd_invstd = (t.data_ptr() for t in (sc, sh, sl, mu, istd))
+        d.stats = out.data_ptr()      # (any non-null pointer: the geometry query looks at it; the real buffer is set below)
+        d.stats_rows = 2
+        conv.last_actbwd_ok = bool(lib.abc_conv_actbwd_ok(C.byref(d)))
+        if not conv.last_actbwd_ok:
+            d.actbwd_y = None
+            d.stats = None
+        assert stats, "actbwd needs stats=True (the BatchNorm-backward partial sums)"
     conv.last_variant = lib.abc_conv_variant(C.byref(d))
     if lib.abc_conv_weight_layout(C.byref(d)) == 1:
         # the kernel serving this descriptor reads abc_pack_desc.layout 1: re-order the row-major packing here (an independent

@@ -117,6 +117,22 @@ def _bn_backward_ref(rec, m, rep, tag):
     return dY.permute(0, 3, 1, 2).contiguous()
 
 
+def _dgrad_tag(rec):
+    return " dgrad + act_bwd" if getattr(rec, "dsrc_is_g", False) else " dgrad"
+
+
+def _dgrad_ref(rec, dX):
+    """what rec's data-gradient launch stores: d(input) by autograd -- times the producing layer's activation derivative where
+    that layer's act_bwd pass rides in the launch's epilogue (engine: rec.dsrc_is_g; the decisions from the engine's own y_raw and
+    BatchNorm coefficients)"""
+    if not getattr(rec, "dsrc_is_g", False):
+        return dX
+    p = rec.src.producer
+    a = p.y.float()[..., p.coff:p.coff + p.cout] * p.scale + p.shift
+    f = torch.where(a > 0, torch.ones_like(a), p.slopes.expand_as(a))
+    return dX * f.permute(0, 3, 1, 2)
+
+
 def _conv_links(rec, m, rep, sd):
     """g -> BatchNorm backward -> dY; then conv2d's adjoints by torch autograd on (activated input, bf16 weights, dY)"""
     tag = rec.cname
@@ -127,9 +143,10 @@ def _conv_links(rec, m, rep, sd):
     F.conv2d(X, W, padding=(k - 1) // 2).backward(_r(dY))
     rep.close(tag + " wgrad", m.grad_of(rec.cname + ".weight"), W.grad, 5e-3)
     if getattr(rec, "dsrc", None) is not None:
-        rep.close(tag + " dgrad", nchw(rec.dsrc), X.grad, 5e-3)
+        rep.close(tag + _dgrad_tag(rec), nchw(rec.dsrc), _dgrad_ref(rec, X.grad), 5e-3)
     # the g of this layer itself: dA * act'(bn(y)) from the engine's own dA (same + pooled routes)
-    if rec.grad_pool is None and rec.grad_same is not None:
+    # (not where the data gradient in front of it stored g itself -- abc_conv_desc.actbwd_*: checked there, against autograd)
+    if rec.grad_pool is None and rec.grad_same is not None and getattr(rec, "fused_g", None) is None:
         t, ld, co = rec.grad_same
         dA = t.float()[..., co:co + rec.cout]
         y = rec.y.float()[..., rec.coff:rec.coff + rec.cout]
@@ -304,7 +321,7 @@ def _conv2_links(eng, rec, m, rep, sd):
             rep.close(tag[:-len("double_conv.0")] + "res_conv wgrad", m.grad_of(blk.prefix + ".res_conv.weight"), Wr.grad, 5e-3)
         rep.close(tag + " dgrad + residual", nchw(rec.dsrc), ref, 8e-3)
     else:
-        rep.close(tag + " dgrad", nchw(rec.dsrc), X.grad, 5e-3)
+        rep.close(tag + _dgrad_tag(rec), nchw(rec.dsrc), _dgrad_ref(rec, X.grad), 5e-3)
 
 
 def _cbam_links(eng, blk, m, rep, sd):

@@ -760,3 +760,68 @@ def test_pack_layout_for_the_weights_direct_loop(lib):
         torch.cuda.synchronize()
         want = ref.view(-1, 32, 2, 2, 8).permute(0, 3, 2, 1, 4).contiguous().view(-1)
         assert torch.equal(got, want), mode
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,slope", [(2, 48, 48, 128, 128, 0.0), (3, 24, 32, 64, 64, 0.01), (2, 32, 16, 128, 256, 0.2),
+                                                  (1, 32, 48, 256, 96, 0.0), (5, 96, 96, 128, 128, 0.0)])
+def test_act_bwd_in_the_data_gradient_epilogue(lib, B, H, W, Cin, Cout, slope):
+    """abc_conv_desc.actbwd_*: a 3x3 data-gradient convolution that stores g = dA * act'(BatchNorm(y_raw)) and the BatchNorm-backward
+    partial sums of the layer it differentiates (autograd of unet.py:12-17) -- against the same convolution followed by abc_act_bwd
+    (g within one bf16 rounding of it: the fused form rounds once; sums against f64 sums of the device's own g) and against torch.
+    Shapes: whole 192/128/64-pixel tiles of 128- and 64-channel blocks, a 96-channel block with padding lanes, several rounds of
+    persistent workgroups (5 x 96 x 96); a ragged shape must be refused (abc_conv_actbwd_ok == 0) and then runs the plain convolution."""
+    dt = L.BF16
+    g = torch.Generator().manual_seed(11)
+    dy = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(U.DEV)          # gradient entering the convolution
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3.0 * Cin ** 0.5)
+    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, 3, -(-Cout // 32) * 32, Cin)
+    yraw = (torch.randn((B, H, W, Cout), generator=g) * 1.5 + 0.3).to(torch.bfloat16).to(U.DEV)
+    sc = (torch.rand(Cout, generator=g) + 0.5) * (torch.randint(0, 2, (Cout,), generator=g) * 2 - 1).float()      # (both signs)
+    sh = torch.randn(Cout, generator=g) * 0.5
+    mu = torch.randn(Cout, generator=g) * 0.3 + 0.3
+    istd = torch.rand(Cout, generator=g) + 0.5
+    sl = torch.full((Cout,), slope)
+    scd, shd, sld, mud, isd = (t.to(U.DEV) for t in (sc, sh, sl, mu, istd))
+    taps = taps_square(3)
+    gfused, part = U.conv(lib, dy, dt, dt, B, H, W, Cin, 0, Cin, wp, None, Cout, taps, H, W, stats=True,
+                          actbwd=(yraw, Cout, 0, scd, shd, sld, mud, isd))
+    assert U.conv.last_actbwd_ok and U.conv.last_variant == 1
+    dA, _ = U.conv(lib, dy, dt, dt, B, H, W, Cin, 0, Cin, wp, None, Cout, taps, H, W)
+    torch.cuda.synchronize()
+    # torch on the device's own tensors
+    dA_ref = F.conv2d(dy.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1)
+    ybn = yraw.float().cpu() * sc + sh
+    fac = torch.where(ybn > 0, torch.ones(()), sl)
+    g_ref = dA_ref * fac
+    got = gfused.float().cpu()
+    assert U.relerr(got, g_ref) < 3e-2
+    # against the separate pass on the device's own (rounded) dA: equal up to one more bf16 rounding where slope != 0, 1
+    g_two = dA.float().cpu() * fac
+    assert (got - g_two).abs().max().item() <= 2.0 ** -7 * g_two.abs().max().item() + 1e-6
+    if slope == 0.0:
+        assert torch.equal(got, g_two.to(torch.bfloat16).float())
+    # partial sums: f64 sums of the values the kernel summed (its f32 g before the rounding ~ g_ref), per channel
+    s1 = part[:, 0].double().sum(0).cpu()
+    s2 = part[:, 1].double().sum(0).cpu()
+    r1 = g_ref.double().sum((0, 1, 2))
+    r2 = (g_ref.double() * (yraw.double().cpu() - mu.double())).sum((0, 1, 2)) * istd.double()
+    scale1 = g_ref.abs().double().sum((0, 1, 2)) + 1e-6
+    scale2 = (g_ref.abs().double() * (yraw.double().cpu() - mu.double()).abs()).sum((0, 1, 2)) * istd.double() + 1e-6
+    assert ((s1 - r1).abs() / scale1).max().item() < 2e-3, ((s1 - r1).abs() / scale1).max().item()
+    assert ((s2 - r2).abs() / scale2).max().item() < 2e-3, ((s2 - r2).abs() / scale2).max().item()
+
+
+def test_act_bwd_epilogue_refuses_ragged_shapes(lib):
+    dt = L.BF16
+    B, H, W, Cin, Cout = 1, 30, 40, 64, 64
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(U.DEV)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / 20
+    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, 3, 64, Cin)
+    yraw = torch.randn((B, H, W, Cout), generator=g).to(torch.bfloat16).to(U.DEV)
+    one = torch.ones(Cout, device=U.DEV)
+    out, _ = U.conv(lib, dy, dt, dt, B, H, W, Cin, 0, Cin, wp, None, Cout, taps_square(3), H, W, stats=True,
+                    actbwd=(yraw, Cout, 0, one, one, one, one, one))
+    assert not U.conv.last_actbwd_ok
+    ref = F.conv2d(dy.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1)
+    assert U.relerr(out.float().cpu(), ref) < 3e-2
