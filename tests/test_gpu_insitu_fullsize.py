@@ -107,7 +107,9 @@ def _bn_backward_ref(rec, m, rep, tag):
     # a layer with TWO gradient routes (skip connection + max-pool: inc3, down3, down4) rounds g = bf16(dA_same + dA_pool) once
     # more AFTER the kernel took its f32 sums; these sums cancel heavily (both signs), so the rounding noise of 147456 addends
     # shows at ~3e-3 of the sum (measured: 3.0e-3 / 2.6e-3 on inc3.double_conv.3; 1e-7 where g = dA * act' is exact in bf16)
-    tol = 1e-2 if (rec.grad_pool is not None and rec.grad_same is not None) else 2e-3
+    # (the same holds where g comes out of a data gradient's epilogue, abc_conv_desc.actbwd_*: the kernel sums the f32 values it then
+    #  rounds to bf16, this check re-sums the stored bf16 g -- measured 5e-4 .. 2.1e-3 on the twelve such layers of unet.py)
+    tol = 1e-2 if ((rec.grad_pool is not None and rec.grad_same is not None) or getattr(rec, "fused_g", None) is not None) else 2e-3
     rep.close(tag + " dbeta", m.grad_of(rec.bname + ".bias"), dbeta, tol)
     rep.close(tag + " dgamma", m.grad_of(rec.bname + ".weight"), dgamma, tol)
     gamma = m.state_dict()[rec.bname + ".weight"]
