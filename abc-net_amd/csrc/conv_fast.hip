@@ -657,10 +657,14 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
             for (int j = 0; j < TN; ++j) { s1v[j] = (f32x2){0.f, 0.f}; s2v[j] = (f32x2){0.f, 0.f}; }
             const float slope = a.out_act ? a.out_slope : 1.f;      // (max(v, 1 * v) = v: no select per value)
             // ACTB: the producer's raw output y_raw at this tile -- per M-tile the sweep's 16-byte loads (the stores' lane mapping),
-            // through a second set of staging rows, read back one value per accumulator register (lane = channel, like the sums).
+            // through a second staging region, read back in the accumulator layout (lane = channel, like the sums).
             // The loads of M-tile i + 1 fly under the arithmetic of M-tile i.
+            // (the y_raw tile is staged TRANSPOSED, [channel][32 pixels + pad]: sixteen-bit writes need no answer, and a lane reads the four
+            //  consecutive pixels of an accumulator-register group with one ds_read_b64 -- 8 reads per M-tile instead of 32 ds_read_u16)
+            constexpr int YROW = 32 * 2 + 8;
+            static_assert(!ACTB || TW * YROW <= 32 * ROWB, "the transposed y_raw tile fits the staging region");
             char* ystg = smem + a.ystg_off + wl * (32 * ROWB);
-            const char* yrd = ystg + 4 * (ll >> 5) * ROWB + (ll & 31) * 2;
+            const char* yrd = ystg + (ll & 31) * YROW + 8 * (ll >> 5);
             __amdgpu_buffer_rsrc_t rsYR = rsY;
             unsigned voffy[ACTB ? NST : 1], istep_y = 0;
             u32x4 yq[ACTB ? NST : 1];
@@ -680,12 +684,41 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
             for (int i = 0; i < TM; ++i) {
                 if constexpr (ACTB) {
 #pragma unroll
-                    for (int st = 0; st < NST; ++st) *(u32x4*)(ystg + (lrow + RSTEP * st) * ROWB + lsg * 16) = yq[st];
+                    for (int st = 0; st < NST; ++st) {
+                        char* w0 = ystg + (lsg * EV) * YROW + (lrow + RSTEP * st) * 2;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            *(unsigned short*)(w0 + (2 * c) * YROW) = (unsigned short)(yq[st][c] & 0xFFFFu);
+                            *(unsigned short*)(w0 + (2 * c + 1) * YROW) = (unsigned short)(yq[st][c] >> 16);
+                        }
+                    }
                     if (i + 1 < TM) {
 #pragma unroll
                         for (int st = 0; st < NST; ++st) yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], (unsigned)(i + 1) * istep_y, 0);
                     }
                     asm volatile("" ::: "memory");
+                }
+                // (ACTB: the M-tile's y_raw values read back in ONE batch, two bf16 per register -- read pair by pair between the
+                //  staging writes, which the compiler must keep in program order, every pair was a serial LDS round trip)
+                unsigned xq[ACTB ? TN : 1][ACTB ? 8 : 1];
+                if constexpr (ACTB) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            // pixels 8 g4 + 4 h + (0..3) of channel 32 j + r = accumulator registers 4 g4 .. 4 g4 + 3
+                            const u32x2 t = *(const u32x2*)(yrd + j * 32 * YROW + 16 * g4);
+                            xq[j][2 * g4] = t[0]; xq[j][2 * g4 + 1] = t[1];
+                        }
+                    asm volatile("" ::: "memory");
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // (all eight reads issued back to back, ONE wait: left to itself the compiler sinks each read to its use)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(xq[j][q]));
+#endif
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -697,8 +730,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                         char* p = wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT);
                         if constexpr (ACTB) {
                             // g = dA where BatchNorm(y_raw) > 0, slope * dA elsewhere (unet.py:14,17 backward); sums of g and g (y_raw - mean)
-                            const char* q = yrd + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 64;
-                            const f32x2 x = {__uint_as_float((unsigned)*(const unsigned short*)q << 16), __uint_as_float((unsigned)*(const unsigned short*)(q + ROWB) << 16)};
+                            const f32x2 x = {__uint_as_float(xq[j][k >> 1] << 16), __uint_as_float(xq[j][k >> 1] & 0xFFFF0000u)};
                             const f32x2 yv = __builtin_elementwise_fma(x, (f32x2){csc[j], csc[j]}, (f32x2){csh[j], csh[j]});
                             const f32x2 f = {yv.x > 0.f ? 1.f : csl[j], yv.y > 0.f ? 1.f : csl[j]};
                             const f32x2 gg = v * f;
