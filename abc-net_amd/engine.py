@@ -345,6 +345,8 @@ class Engine:
         meta = {"kernel": "%s<%s,%s,%s,CK%d,BN%d,S%d,MT%d>" % (kname, self._dn(src.dt), self._dn(cdt), self._dn(y_dt), ck, bn, stride, mt),
                 "flops": 2.0 * npx * Cout * len(taps) * d.Cin,
                 "bytes": float(in_px * d.Cin * self._esz(src.dt) + npx * Cout * self._esz(y_dt))}
+        if actbwd is not None:
+            meta["bytes"] += float(npx * Cout * self._esz(self.dt))      # (the producer's y_raw, read by the epilogue)
         if collect is not None:
             collect.append((d, what, meta))
         else:

@@ -38,7 +38,16 @@ def main(tag):
         rows = json.load(open(tp))["rows"]
         algo = {}
         if os.path.exists(bp):
-            algo = json.load(open(bp)).get("kernel_algorithmic", {})
+            b = json.load(open(bp))
+            calls = b.get("kernel_calls", {})
+            # a convolution kernel with the producer's act_bwd pass in its epilogue ("conv_fast+act_bwd<...>") is an instantiation of
+            # the same kernel family: one entry, the call-weighted mean of both labels (as bench.py's roofline row)
+            fam = {}
+            for k, (gf, mb) in b.get("kernel_algorithmic", {}).items():
+                n = calls.get(k, 1.0)
+                f = fam.setdefault(k.replace("+act_bwd<", "<"), [0.0, 0.0, 0.0])
+                f[0] += n; f[1] += n * gf; f[2] += n * mb
+            algo = {k: [f[1] / f[0], f[2] / f[0]] for k, f in fam.items() if f[0] > 0}
         acc = {}
         for r in rows:
             lab = label_of(r["kernel"])
