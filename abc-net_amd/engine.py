@@ -1195,8 +1195,28 @@ class Engine:
             self.emit_pack(rec.cname + ".weight", wd_all, 1, 128, 128, 3, 128, 128, red_total=128 * nh, red_off=128 * i)
         dtrunk = self.new((B, h, w, 128))
         dy_all = Src(dyh, self.dt, h, w, 128 * nh, 0, 128 * nh)
-        self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
-        self.trunk.producer.grad_same = (dtrunk, 128, 0)
+        self._heads_conv1_dgrad(ops, dy_all, wd_all, dtrunk, taps)
+
+    def _heads_conv1_dgrad(self, ops, dy_all, wd_all, dtrunk, taps):
+        """the eight heads' conv1 data gradients as ONE 8 x 128 -> 128 convolution (unet.py:66,116-118 backward); the trunk's last layer
+        has no reader but the heads, so its act_bwd pass rides in this launch's epilogue where the library serves it"""
+        h, w = self.h, self.w
+        p = self.trunk.producer
+        what = "dgrad heads.conv1"
+        if (self.actbwd_epilogue and self.train and self.dt == L.BF16 and isinstance(p, Rec) and p.kind == "conv" and self.trunk.t is p.y and
+                not self.trunk.pool and self.trunk.drop_p == 0 and p.coff == 0 and p.ld == p.cout == 128 and (p.H, p.W) == (h, w) and
+                all(getattr(r, "is_head", False) for r in self.recs + list(self.head_recs)
+                    if getattr(r, "src", None) is not None and (r.src.producer is p or r.src.t is p.y))):
+            got = self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps),
+                                 what=what + " + act_bwd " + p.bname, actbwd=p)
+            if got is not None:
+                p.fused_g = (dtrunk, got[0], got[1])
+                p.g = dtrunk
+                self.heads_dgrad_is_g = True
+                p.grad_same = (dtrunk, 128, 0)
+                return
+        self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what=what)
+        p.grad_same = (dtrunk, 128, 0)
 
     def _heads_backward_fused(self, ops):
         """backward plan behind the fused heads pass: conv2's weight / bias gradients from the blocked d(logits), the eight
@@ -1238,8 +1258,7 @@ class Engine:
         dtrunk = self.new((B, h, w, 128))
         self.dyh, self.dtrunk = dyh, dtrunk
         dy_all = Src(dyh, self.dt, h, w, Ct, 0, Ct)
-        self.emit_conv(ops, dy_all, wd_all, None, dtrunk, self.dt, h, w, 128, 0, 128, taps_mirror(taps), what="dgrad heads.conv1")
-        self.trunk.producer.grad_same = (dtrunk, 128, 0)
+        self._heads_conv1_dgrad(ops, dy_all, wd_all, dtrunk, taps)
 
     def _heads_conv1_wgrad_merged(self, ops, merged, dyh, taps):
         """The eight heads' conv1 weight gradients (unet.py:66, 8 x [128,128,3,3]) as ONE weight gradient with 8 x 128

@@ -327,3 +327,66 @@ def test_rank_dropout_seeds_differ_and_rank0_keeps_the_base():
     base = 0x1234ABCD
     seeds = [D.rank_dropout_seed(base, r) for r in range(8)]
     assert seeds[0] == base and len(set(seeds)) == 8 and all(0 <= s < 2 ** 32 for s in seeds)
+
+
+def test_act_bwd_epilogue_plan_and_its_refusals():
+    """Engine._actbwd_target / abc_conv_actbwd_ok (host logic only): at the benchmarked shape the bf16 training plan lets 11 of
+    unet.py's 26 act_bwd passes (7 of unet2.py's 14) ride in the epilogue of the data gradient in front of them -- the first BatchNorm
+    of a DoubleConv, a trunk layer, the trunk's last layer behind the heads' merged data gradient: layers whose activated output has
+    exactly one reader (unet.py:12-17); layers
+    with a skip or a pooled reader, the narrow levels (another kernel) and the 24 x 24 / 12 x 12 levels (no whole 16-pixel tile
+    columns) keep the pass of their own; fp32 plans and actbwd_epilogue=False have none; the library refuses ragged shapes."""
+    import ctypes as C
+    from abcnet_amd import _lib as L
+    from abcnet_amd.engine import Engine, taps_square
+    from abcnet_amd.unet import UNet
+    from abcnet_amd.unet2 import UNet as UNet2
+
+    def plan(cls, variant, dtype, **kw):
+        m = cls(1, HEADS, dtype=dtype)
+        m._flat_grad = torch.zeros_like(m._flat.data)
+        e = Engine(variant, 1, HEADS, m._flat.data, m._flat_grad, m._flat_buf, m._counters, (m._lay_p, m._lay_b, m._lay_c), 16, 384, 384,
+                   dtype, True, device="cpu", **kw)
+        names = [op[2] for op in e.bwd_ops]
+        return e, [n for n in names if "+ act_bwd" in n], [n for n in names if n.startswith("act_bwd")]
+
+    e, fused, plain = plan(UNet, "unet", "bf16", fused_heads=True)
+    assert len(fused) == 11 and len(plain) == 15, (fused, plain)
+    for n in fused:
+        # "dgrad X.double_conv.3 + act_bwd X.double_conv.1" (inside a DoubleConv) or "dgrad Y.double_conv.0 + act_bwd X.double_conv.4"
+        assert n.endswith("double_conv.1") or n.endswith("double_conv.4"), n
+    assert fused[0] == "dgrad heads.conv1 + act_bwd dconv2.double_conv.4"
+    tg = [r for r in e.recs if getattr(r, "fused_g", None) is not None]
+    assert len(tg) == 11 and all(r.ld == r.cout and r.coff == 0 and r.grad_pool is None for r in tg)
+    assert not any("inc1" in n or "inc2" in n or "down4" in n or "down5" in n or "up1" in n for n in fused)
+    _e, fused0, plain0 = plan(UNet, "unet", "bf16", fused_heads=True, actbwd_epilogue=False)
+    assert not fused0 and len(plain0) == 26
+    _e, fused32, _p = plan(UNet, "unet", "fp32")
+    assert not fused32
+    _e, fused2, plain2 = plan(UNet2, "unet2", "bf16")
+    assert len(fused2) == 7 and len(plain2) == 7, (fused2, plain2)
+    # the library's own answer for single descriptors
+    lib = L.load()
+
+    def ok(B, H, W, Cin, Cout, **kw):
+        d = L.ConvDesc()
+        d.src.x, d.src.Hx, d.src.Wx, d.src.ldx = 4096, H, W, Cin
+        d.w = d.y = d.stats = 4096
+        d.stats_rows = 2
+        d.dtype_in = d.dtype_c = d.dtype_out = L.BF16
+        d.B, d.Hin, d.Win, d.cin_off, d.Cin = B, H, W, 0, Cin
+        d.Hg, d.Wg, d.Hout, d.Wout, d.ldy, d.cout_off, d.Cout, d.Cout_pad = H, W, H, W, Cout, 0, Cout, -(-Cout // 32) * 32
+        d.stride, d.om = 1, 1
+        L.set_taps(d, taps_square(3))
+        d.actbwd_y, d.actbwd_ld = 4096, Cout
+        d.actbwd_scale = d.actbwd_shift = d.actbwd_slope = d.actbwd_mean = d.actbwd_invstd = 4096
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.abc_conv_actbwd_ok(C.byref(d)), lib.abc_conv_variant(C.byref(d))
+
+    assert ok(16, 96, 96, 128, 128) == (1, 1) and ok(16, 192, 192, 64, 64) == (1, 1) and ok(2, 48, 48, 256, 256) == (1, 1)
+    assert ok(16, 24, 24, 512, 512)[0] == 0          # 24 columns: no whole 16-pixel tiles
+    assert ok(1, 30, 48, 64, 64)[0] == 0             # 30 rows: no tile height divides it
+    assert ok(16, 384, 384, 16, 16)[0] == 0          # the narrow-level kernel serves this shape
+    assert ok(16, 96, 96, 128, 128, dtype_out=L.F32)[0] == 0 and ok(16, 96, 96, 128, 128, accumulate=1)[0] == 0
+    assert ok(16, 96, 96, 128, 128, stats=None)[0] == 0 and ok(16, 96, 96, 128, 128, actbwd_ld=100)[0] == 0

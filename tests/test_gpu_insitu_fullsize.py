@@ -229,7 +229,13 @@ def _heads_links(eng, m, rep, sd, tg, B, h, w):
     for i in range(nh):
         rep.close("heads conv1[%d] wgrad (1024-row merged launch)" % i, m.grad_of("out_modules.%d.conv1.weight" % i),
                   Wall.grad[128 * i:128 * (i + 1)], 5e-3)
-    rep.close("heads conv1 dgrad (8 x 128 -> 128)", nchw(eng.dtrunk), X.grad, 5e-3)
+    ref = X.grad
+    if getattr(eng, "heads_dgrad_is_g", False):
+        # the trunk's last layer has no reader but the heads: its act_bwd pass rides in this launch's epilogue (abc_conv_desc.actbwd_*)
+        p = eng.trunk.producer
+        a = p.y.float()[..., p.coff:p.coff + p.cout] * p.scale + p.shift
+        ref = ref * torch.where(a > 0, torch.ones_like(a), p.slopes.expand_as(a)).permute(0, 3, 1, 2)
+    rep.close("heads conv1 dgrad (8 x 128 -> 128)" + (" + act_bwd" if getattr(eng, "heads_dgrad_is_g", False) else ""), nchw(eng.dtrunk), ref, 5e-3)
 
 
 UNET_SAMPLE = ("dconv2.double_conv.3", "dconv2.double_conv.0", "up3.conv.double_conv.0", "inc3.double_conv.3",
