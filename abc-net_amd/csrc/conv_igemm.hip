@@ -517,20 +517,25 @@ extern "C" int abc_conv_tile(const abc_conv_desc* d, int32_t* bn, int32_t* mt, i
     return ABC_OK;
 }
 
-// descriptors only the lean kernel serves (the heads' epilogue, act_bwd in the epilogue): no other kernel is asked
-static bool lean_only(const abc_conv_desc* d) { return d->heads_epi != nullptr || d->actbwd_y != nullptr; }
+// the heads' epilogue is served by the lean kernel only; act_bwd in the epilogue by the kernel that would run the plain data gradient
+// anyway -- the narrow-level kernel for its shapes, else the lean kernel -- and by no other
+static bool lean_only(const abc_conv_desc* d) { return d->heads_epi != nullptr; }
 
-extern "C" int abc_conv_actbwd_ok(const abc_conv_desc* d) {
-    if (d->actbwd_y == nullptr) return 0;
-    // (only where the lean kernel would run the plain data gradient anyway: the narrow-level kernel is the faster one for its shapes)
+// 0: not served; 1: conv_fast.hip; 5: conv_narrow.hip
+static int actbwd_server(const abc_conv_desc* d) {
+    if (d->actbwd_y == nullptr || d->heads_epi != nullptr) return 0;
     abc_conv_desc p = *d;
     p.actbwd_y = nullptr;
-    if (abc_conv_stem_ok(&p, nullptr) || abc_head_fwd_ok(&p) || abc_head_dgrad_ok(&p) || abc_conv_narrow_ok(&p)) return 0;
+    if (abc_conv_stem_ok(&p, nullptr) || abc_head_fwd_ok(&p) || abc_head_dgrad_ok(&p)) return 0;
+    if (abc_conv_narrow_ok(&p)) return abc_conv_narrow_ok(d) ? 5 : 0;
     abc_fast_geom f;
     return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) ? 1 : 0;
 }
 
+extern "C" int abc_conv_actbwd_ok(const abc_conv_desc* d) { return actbwd_server(d) != 0 ? 1 : 0; }
+
 extern "C" int abc_conv_variant(const abc_conv_desc* d) {
+    if (d->actbwd_y != nullptr) return actbwd_server(d);
     if (lean_only(d)) { abc_fast_geom f; return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) ? 1 : 0; }
     if (abc_conv_stem_ok(d, nullptr)) return 2;
     if (abc_head_fwd_ok(d)) return 3;
@@ -542,14 +547,16 @@ extern "C" int abc_conv_variant(const abc_conv_desc* d) {
 }
 
 extern "C" int abc_conv_weight_layout(const abc_conv_desc* d) {
-    if (lean_only(d)) { abc_fast_geom f; return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible && f.wd) ? 1 : 0; }
+    if (d->actbwd_y != nullptr && actbwd_server(d) == 5) return 0;
+    if (lean_only(d) || d->actbwd_y != nullptr) { abc_fast_geom f; return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible && f.wd) ? 1 : 0; }
     if (abc_conv_stem_ok(d, nullptr) || abc_head_fwd_ok(d) || abc_head_dgrad_ok(d) || abc_conv_narrow_ok(d)) return 0;
     abc_fast_geom f;
     return (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible && f.wd) ? 1 : 0;   // the weights-direct loop of conv_fast.hip
 }
 
 extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
-    if (!lean_only(d)) {
+    if (d->actbwd_y != nullptr && actbwd_server(d) == 5) return abc_conv_narrow_stat_blocks(d);
+    if (!lean_only(d) && d->actbwd_y == nullptr) {
         { int nb = 0; if (abc_conv_stem_ok(d, &nb)) return nb; }
         if (abc_conv_narrow_ok(d)) return abc_conv_narrow_stat_blocks(d);
     }
@@ -620,8 +627,10 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
         return abc_conv_fast_launch(d, f, stream);
     }
     if (d->actbwd_y != nullptr) {
+        const int srv = actbwd_server(d);
         abc_fast_geom f;
-        if (!abc_conv_actbwd_ok(d) || abc_conv_fast_geom(d, &f) != ABC_OK || !f.eligible)
+        if (srv == 5) return abc_conv_narrow_launch(d, stream);
+        if (srv != 1 || abc_conv_fast_geom(d, &f) != ABC_OK || !f.eligible)
             return abc_fail(ABC_EUNSUPPORTED, "conv: actbwd_y is not served for this descriptor (ask abc_conv_actbwd_ok first)");
         return abc_conv_fast_launch(d, f, stream);
     }

@@ -35,6 +35,10 @@ struct NarrowK {
     int tiles_x, tiles_y, ntiles, tpw;         // tiles per wave (contiguous runs)
     int out_act; float out_slope;
     unsigned bytesX;
+    // ACTB (abc_conv_desc.actbwd_*): this data gradient is d(activation output) of the producing 16-channel layer; the epilogue stores
+    // d(BatchNorm output) and sums that layer's BatchNorm-backward statistics (bn_act.hip's act_bwd pass, not run)
+    const bf16* ab_y; int ab_ld; unsigned bytesY; int cf_off;      // cf_off: LDS offset of the [4][16] coefficient table
+    const float *ab_sc, *ab_sh, *ab_sl, *ab_mu, *ab_is;
     int8_t ty[25], tx[25];                     // tap offsets + R (0 .. 2 R)
 };
 
@@ -44,9 +48,10 @@ struct NarrowK {
 // STEM (inference, 16 channels): the halo is not loaded but COMPUTED from the one-channel image -- the network's first
 // convolution + folded BatchNorm + ReLU (unet.py:12-14) fused in front of its second one: the 16-channel full-resolution
 // tensor between them (0.5 GB written + read at 512 x 512, batch 64) never exists
-template <int CK, bool XF, int NST, int R = 1, bool STEM = false>
+template <int CK, bool XF, int NST, int R = 1, bool STEM = false, bool ACTB = false>
 __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const NarrowK a) {
     static_assert(!STEM || (CK == 16 && !XF && R == 1), "stem fusion: 16 channels, 3x3");
+    static_assert(!ACTB || (CK == 16 && !XF && R == 1 && !STEM && NST == 1), "act_bwd epilogue: the plain 16-channel 3x3 data gradient");
     constexpr int NTAP = (2 * R + 1) * (2 * R + 1), HR = 8 + 2 * R, HC = 16 + 2 * R;
     constexpr int CKB = CK * 2;                // bytes of a pixel's channels
     constexpr int PS = CKB + 16;               // padded pixel stride: 16 consecutive pixels = 16 distinct 16-byte bank slots
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     // 36 registers for the whole kernel; 32: 72 would not leave room for the prefetch -- they sit in LDS in fragment order
     // ([tap][K-step][lane] x 16 bytes: one conflict-free ds_read_b128 per four MFMAs)
     const int rw = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
-    constexpr bool WREG = CK == 16 && R == 1 && !STEM;   // (STEM keeps the FIRST convolution's weights in registers instead)
+    constexpr bool WREG = CK == 16 && R == 1 && !STEM && !ACTB;   // (STEM keeps the FIRST convolution's weights in registers instead; ACTB needs the 36 registers for the y_raw prefetch and the coefficients)
     bf16x8 wf[WREG ? 9 : 1][WREG ? KS : 1];
     char* swt = smem + 4 * HR * RS + 128;
     if constexpr (WREG) {
@@ -81,6 +86,13 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     // bias -> LDS (read back per tile as the accumulators' initial value: register k <-> channel (k & 7) + 8 h + 16 (k >> 3))
     float* sbias = (float*)(smem + 4 * HR * RS);
     if (threadIdx.x < 32) sbias[threadIdx.x] = (a.bias != nullptr && (int)threadIdx.x < a.Cout) ? a.bias[threadIdx.x] : 0.f;
+    if constexpr (ACTB) {
+        if (threadIdx.x >= 64 && threadIdx.x < 128) {
+            const int which = (threadIdx.x - 64) >> 4, n = threadIdx.x & 15;
+            const float* src = which == 0 ? a.ab_sc : (which == 1 ? a.ab_sh : (which == 2 ? a.ab_sl : a.ab_mu));
+            ((float*)(smem + a.cf_off))[which * 16 + n] = n < a.Cout ? src[n] : 0.f;
+        }
+    }
     // STEM: folded first-layer weights [tap][16 channels] + bias [16] (f32), and a 12 x 20 image patch per wave
     float* stw = (float*)(smem + 4 * HR * RS + 128 + (WREG ? 0 : NTAP * KS * 1024));
     float* simg = stw + 160 + wave * 240;
@@ -111,6 +123,12 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     float st1[NST ? 8 * NST : 1], st2[NST ? 8 * NST : 1];
 #pragma unroll
     for (int k = 0; k < (NST ? 8 * NST : 1); ++k) { st1[k] = 0.f; st2[k] = 0.f; }
+    // ACTB: a lane's accumulator registers 0..7 are channels 8 h .. 8 h + 7 of ITS pixel -- the producer's y_raw of that pixel is one
+    // 16-byte load at the store's own address pattern (no transposition).  The layer's coefficients sit in LDS ([scale | shift | slope |
+    // mean][16], written before the barrier above) and are read per tile in the epilogue: as registers through the MFMA loop they
+    // cost 32 VGPRs the kernel does not have (61 spilled)
+    __amdgpu_buffer_rsrc_t rsYR = abc_make_rsrc(a.x, 0u);
+    if constexpr (ACTB) rsYR = abc_make_rsrc(a.ab_y, a.bytesY);
     auto seg_rc = [&](int i, int& hr, int& hc) {
         const int pix = p0 + (64 / SEGS) * i;
         hr = (pix * (R == 1 ? 3641 : 3277)) >> 16;          // pix / HC (18 or 20) for pix < 1024
@@ -216,6 +234,16 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
         const int tx_i = id % a.tiles_x; id /= a.tiles_x;
         const int ty_i = id % a.tiles_y;
         const int b = id / a.tiles_y;
+        u32x4 yq[ACTB ? 4 : 1];
+        if constexpr (ACTB) {
+            // (issued here: they land under the tile's 36 MFMAs)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gy = ty_i * 8 + 2 * i + (r >> 4), gx = tx_i * 16 + (r & 15);
+                const bool ok = gy < a.H && gx < a.W && 8 * h < a.Cout;
+                yq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.ab_ld + 8 * h) * 2) : 0x80000000u, 0, 0);
+            }
+        }
         f32x16 acc[4];
         {
             const f32x4 b0 = *(const f32x4*)(sbias + 8 * h), b1 = *(const f32x4*)(sbias + 8 * h + 4),
@@ -267,6 +295,17 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
             }
         }
         // ---- epilogue: lane = pixel r of each 32-pixel tile, registers = channels
+        float asc[ACTB ? 8 : 1], ash[ACTB ? 8 : 1], asl[ACTB ? 8 : 1], amu[ACTB ? 8 : 1];
+        if constexpr (ACTB) {
+            const float* scf = (const float*)(smem + abc_launder(a.cf_off + 32 * h));     // (laundered: the reads are loop-invariant and would be hoisted)
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+                const f32x4 t0 = *(const f32x4*)(scf + 0 * 16 + 4 * q4), t1 = *(const f32x4*)(scf + 1 * 16 + 4 * q4),
+                            t2 = *(const f32x4*)(scf + 2 * 16 + 4 * q4), t3 = *(const f32x4*)(scf + 3 * 16 + 4 * q4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { asc[4 * q4 + k] = t0[k]; ash[4 * q4 + k] = t1[k]; asl[4 * q4 + k] = t2[k]; amu[4 * q4 + k] = t3[k]; }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gy = ty_i * 8 + 2 * i + (r >> 4), gx = tx_i * 16 + (r & 15);
@@ -279,10 +318,19 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const float v = acc[i][8 * g8 + q];
-                        if constexpr (NST > 0) {
-                            if (g8 < NST && valid) { st1[8 * (g8 < NST ? g8 : 0) + q] += v; st2[8 * (g8 < NST ? g8 : 0) + q] = fmaf(v, v, st2[8 * (g8 < NST ? g8 : 0) + q]); }
+                        if constexpr (ACTB) {
+                            // g = dA where BatchNorm(y_raw) > 0, slope * dA elsewhere; sums of g and g (y_raw - mean)  (channels 0..15 only)
+                            const unsigned w2 = yq[i][q >> 1];
+                            const float x = __uint_as_float((q & 1) ? (w2 & 0xFFFF0000u) : (w2 << 16));
+                            const float gg = v * (fmaf(x, asc[q], ash[q]) > 0.f ? 1.f : asl[q]);
+                            if (g8 == 0 && valid) { st1[q] += gg; st2[q] = fmaf(gg, x - amu[q], st2[q]); }
+                            vo[q] = gg;
+                        } else {
+                            if constexpr (NST > 0) {
+                                if (g8 < NST && valid) { st1[8 * (g8 < NST ? g8 : 0) + q] += v; st2[8 * (g8 < NST ? g8 : 0) + q] = fmaf(v, v, st2[8 * (g8 < NST ? g8 : 0) + q]); }
+                            }
+                            vo[q] = a.out_act ? fmaxf(v, a.out_slope * v) : v;
                         }
-                        vo[q] = a.out_act ? fmaxf(v, a.out_slope * v) : v;
                     }
                     const bool chan = 16 * g8 + 8 * h < a.Cout;
                     if (valid && chan) *(bf16x8*)(dst + 16 * g8) = pack_frag<bf16>(vo);
@@ -320,7 +368,9 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
         __syncthreads();
         if (threadIdx.x < 64 && (int)(threadIdx.x & 31) < a.Cout) {
             const int row = threadIdx.x >> 5, n = threadIdx.x & 31;
-            a.stats[((size_t)blockIdx.x * 2 + row) * a.Cout + n] = (red[(0 * 2 + row) * 32 + n] + red[(1 * 2 + row) * 32 + n]) + (red[(2 * 2 + row) * 32 + n] + red[(3 * 2 + row) * 32 + n]);
+            float v = (red[(0 * 2 + row) * 32 + n] + red[(1 * 2 + row) * 32 + n]) + (red[(2 * 2 + row) * 32 + n] + red[(3 * 2 + row) * 32 + n]);
+            if constexpr (ACTB) { if (row == 1) v *= a.ab_is[n]; }      // (the row act_bwd writes: sum of g (y_raw - mean) / std)
+            a.stats[((size_t)blockIdx.x * 2 + row) * a.Cout + n] = v;
         }
     }
 }
@@ -350,6 +400,11 @@ int abc_conv_narrow_ok(const abc_conv_desc* d) {
     if ((d->src.ldx | d->cin_off | d->ldy | d->cout_off) % 8) return 0;
     // (must not depend on the statistics POINTER: abc_conv_stat_blocks is asked before that buffer exists)
     if (d->stats_rows == 4) return 0;                                   // unet2's CBAM rows: per image, per tile
+    // act_bwd in the epilogue: the plain 16 -> <= 16 channel 3x3 data gradient only
+    if (d->actbwd_y != nullptr && (d->Cin != 16 || d->ntaps != 9 || d->Cout > 16 || d->src.scale != nullptr || d->stem_x != nullptr || d->pool_y != nullptr ||
+                                   d->out_act || d->stats_rows != 2 || d->actbwd_ld % 8 || d->actbwd_coff % 8 || !d->actbwd_scale || !d->actbwd_shift ||
+                                   !d->actbwd_slope || !d->actbwd_mean || !d->actbwd_invstd ||
+                                   (int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2 >= (int64_t(1) << 31))) return 0;
     if (d->src.scale != nullptr && d->Cin == 32) return 0;             // transform + sums + 72 weight registers do not fit
     if (d->src.scale != nullptr && abc_knob("ABC_CONV_NONARROW_XF")) return 0;
     if (d->stem_x != nullptr && (d->Cin != 16 || d->ntaps != 9 || d->src.scale != nullptr || d->stats != nullptr || !d->stem_w || !d->stem_scale || !d->stem_bias)) return 0;
@@ -366,9 +421,9 @@ int abc_conv_narrow_stat_blocks(const abc_conv_desc* d) {
     return nwg;
 }
 
-template <int CK, bool XF, int NST, int R, bool STEM = false>
+template <int CK, bool XF, int NST, int R, bool STEM = false, bool ACTB = false>
 static int narrow_launch_inst(const NarrowK& k, int nwg, int lds, hipStream_t st) {
-    auto fn = conv_narrow_kernel<CK, XF, NST, R, STEM>;
+    auto fn = conv_narrow_kernel<CK, XF, NST, R, STEM, ACTB>;
     if (lds > 64 * 1024) {
         static unsigned long long lds_ok = 0;
         if (int rc = abc_allow_lds((const void*)fn, lds, &lds_ok)) return rc;
@@ -386,12 +441,17 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
     k.tiles_x = abc_cdiv(k.W, 16); k.tiles_y = abc_cdiv(k.H, 8); k.ntiles = k.tiles_x * k.tiles_y * k.B;
     k.out_act = d->out_act; k.out_slope = d->out_slope;
     k.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
+    k.ab_y = d->actbwd_y ? (const bf16*)d->actbwd_y + d->actbwd_coff : nullptr; k.ab_ld = d->actbwd_ld;
+    k.bytesY = d->actbwd_y ? (unsigned)((int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2) : 0u;
+    k.ab_sc = d->actbwd_scale; k.ab_sh = d->actbwd_shift; k.ab_sl = d->actbwd_slope; k.ab_mu = d->actbwd_mean; k.ab_is = d->actbwd_invstd;
     const int R = d->ntaps == 9 ? 1 : 2;
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] + R); k.tx[t] = (int8_t)(d->tap_dx[t] + R); }
     int nwg;
     narrow_grid(d, &nwg, &k.tpw);
-    const int wlds = (d->Cin == 32 || R == 2 || d->stem_x != nullptr) ? d->ntaps * (d->Cin / 16) * 1024 : 0;
+    const int wlds = (d->Cin == 32 || R == 2 || d->stem_x != nullptr || d->actbwd_y != nullptr) ? d->ntaps * (d->Cin / 16) * 1024 : 0;
     const int lds = 4 * (8 + 2 * R) * (16 + 2 * R) * (d->Cin * 2 + 16) + 128 + wlds + (d->stem_x ? (160 + 4 * 240) * 4 : 0);
+    k.cf_off = (lds + 15) & ~15;
+    const int lds_all = d->actbwd_y ? k.cf_off + 256 : lds;
     hipStream_t st = (hipStream_t)stream;
     const bool xf = d->src.scale != nullptr;
     const int nst = d->stats != nullptr ? (d->Cout <= 16 ? 1 : 2) : 0;
@@ -399,6 +459,10 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         if (nst == 0) return narrow_launch_inst<32, false, 0, 2>(k, nwg, lds, st);
         if (nst == 1) return narrow_launch_inst<32, false, 1, 2>(k, nwg, lds, st);
         return narrow_launch_inst<32, false, 2, 2>(k, nwg, lds, st);
+    }
+    if (d->actbwd_y != nullptr) {
+        if (d->stats == nullptr) return abc_fail(ABC_EINVAL, "conv: actbwd_y needs stats (the BatchNorm-backward partial sums)");
+        return narrow_launch_inst<16, false, 1, 1, false, true>(k, nwg, lds_all, st);
     }
     if (d->stem_x != nullptr) return narrow_launch_inst<16, false, 0, 1, true>(k, nwg, lds, st);
     if (d->Cin == 16) {

@@ -763,13 +763,15 @@ def test_pack_layout_for_the_weights_direct_loop(lib):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,slope", [(2, 48, 48, 128, 128, 0.0), (3, 24, 32, 64, 64, 0.01), (2, 32, 16, 128, 256, 0.2),
-                                                  (1, 32, 48, 256, 96, 0.0), (5, 96, 96, 128, 128, 0.0)])
+                                                  (1, 32, 48, 256, 96, 0.0), (5, 96, 96, 128, 128, 0.0),
+                                                  (2, 64, 64, 16, 16, 0.0), (3, 40, 56, 16, 16, 0.01), (16, 96, 96, 16, 16, 0.0)])
 def test_act_bwd_in_the_data_gradient_epilogue(lib, B, H, W, Cin, Cout, slope):
     """abc_conv_desc.actbwd_*: a 3x3 data-gradient convolution that stores g = dA * act'(BatchNorm(y_raw)) and the BatchNorm-backward
     partial sums of the layer it differentiates (autograd of unet.py:12-17) -- against the same convolution followed by abc_act_bwd
     (g within one bf16 rounding of it: the fused form rounds once; sums against f64 sums of the device's own g) and against torch.
     Shapes: whole 192/128/64-pixel tiles of 128- and 64-channel blocks, a 96-channel block with padding lanes, several rounds of
-    persistent workgroups (5 x 96 x 96); a ragged shape must be refused (abc_conv_actbwd_ok == 0) and then runs the plain convolution."""
+    persistent workgroups (5 x 96 x 96), the 16-channel levels (conv_narrow.hip: whole and ragged tiles, runs of tiles per wave); a
+    ragged shape of the lean kernel must be refused (abc_conv_actbwd_ok == 0) and then runs the plain convolution."""
     dt = L.BF16
     g = torch.Generator().manual_seed(11)
     dy = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(U.DEV)          # gradient entering the convolution
@@ -785,7 +787,9 @@ def test_act_bwd_in_the_data_gradient_epilogue(lib, B, H, W, Cin, Cout, slope):
     taps = taps_square(3)
     gfused, part = U.conv(lib, dy, dt, dt, B, H, W, Cin, 0, Cin, wp, None, Cout, taps, H, W, stats=True,
                           actbwd=(yraw, Cout, 0, scd, shd, sld, mud, isd))
-    assert U.conv.last_actbwd_ok and U.conv.last_variant == 1
+    # (16 -> 16 channels: the narrow-level kernel, whose accumulator layout -- lane = pixel -- needs no staging for y_raw and serves
+    #  ragged shapes too; everything else: the lean kernel, whole tiles)
+    assert U.conv.last_actbwd_ok and U.conv.last_variant == (5 if Cin == 16 else 1)
     dA, _ = U.conv(lib, dy, dt, dt, B, H, W, Cin, 0, Cin, wp, None, Cout, taps, H, W)
     torch.cuda.synchronize()
     # torch on the device's own tensors
