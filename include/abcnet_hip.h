@@ -132,7 +132,8 @@ typedef struct abc_conv_desc {
      * instead of dA, and writes that layer's BatchNorm-backward partial sums to `stats` (stats_rows = 2; abc_conv_stat_blocks rows of
      * [2][Cout]: sum of g, sum of g * (y_raw - actbwd_mean) * actbwd_invstd) -- exactly what abc_act_bwd computes from dA in a pass of its
      * own (abc_act_bwd_desc: y_raw, scale, shift, slope, mean, invstd, partial), so abc_bn_finalize_bwd consumes them unchanged.
-     * Served where abc_conv_actbwd_ok() says so (bf16, stride 1, whole tiles of the lean kernel); abc_conv_fwd refuses it elsewhere. */
+     * Served where abc_conv_actbwd_ok() says so (bf16, stride 1: whole tiles of the lean kernel, any shape of the 16-channel narrow-level
+     * kernel); abc_conv_fwd refuses it elsewhere. */
     const void* actbwd_y;
     int32_t actbwd_ld, actbwd_coff;        /* y_raw's row length and first channel (elements) */
     const float *actbwd_scale, *actbwd_shift, *actbwd_slope, *actbwd_mean, *actbwd_invstd;   /* per output channel of THIS convolution */
