@@ -223,6 +223,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
                 const int part = lt & (SEGS - 1), cch = part * NV;
                 const bool chan = cch < cvalP;
                 float ka[NV], kb[NV], kc[NV];
+                const float kzero[NV] = {};
 #pragma unroll
                 for (int j = 0; j < NV; ++j) { ka[j] = sCoefP[cch + j]; kc[j] = sCoefP[a.cstrP + cch + j]; kb[j] = sCoefP[2 * a.cstrP + cch + j]; }
                 const bool store = (bt == 0) && (blockIdx.y == 0) && a.p_out != nullptr;
@@ -234,9 +235,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
                         float v1[NV], v2[NV];
                         pp.raw[i].get(v1); pp2.raw[i].get(v2);
                         const bool in = chan && ((pp.inb >> i) & 1u);
-#pragma unroll
-                        for (int j = 0; j < NV; ++j) v1[j] = in ? fmaf(ka[j], v1[j], fmaf(kb[j], v2[j], kc[j])) : 0.f;
-                        const typename Frag<CT>::type f = pack_frag<CT>(v1);
+                        abc_fma2_n<NV>(v1, v2, ka, kb, kc);
+                        typename Frag<CT>::type f = pack_frag<CT>(v1);
+                        if (!in) f = pack_frag<CT>(kzero);      // (a select on the packed words: 4 instead of 8)
                         *(typename Frag<CT>::type*)(sP + (hy * 16 + hx) * PSWP + part * 16) = f;
                         if (store && in)
                             *(typename Frag<CT>::type*)((CT*)a.p_out + ((size_t)(b * a.Hg + gy0 + hy) * a.Wg + gx0 + hx) * a.ld_pout + ca0 + cch) = f;
