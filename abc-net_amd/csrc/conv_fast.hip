@@ -620,7 +620,10 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
         // sum, sum of squares, convert, one ds_write per value with an immediate offset; max / min in a second sweep
         // only when unet2's CBAM asks for them; the general path keeps every check.
         // (ACTB launches consist of whole tiles only, checked on the host: the general path below is not compiled into them)
-        const bool whole = ACTB || ((gy0 + 2 * MT <= a.Hg) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok);
+        // (tiles that are short in ROWS only -- the last tile row of a 128 x 128 map under 12-row tiles, one tile in eleven of the
+        //  inference graph -- take the fast path too when no statistics are asked for: their missing rows get the dropped offset)
+        const bool rows_ok = gy0 + 2 * MT <= a.Hg;
+        const bool whole = ACTB || ((rows_ok || a.stats == nullptr) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok);
         if (ABC_DBG(a.dbg) & 64) {
         } else if (whole) {
             // (laundered: computed from the plain thread index, the lane parts of the staging addresses and store offsets are hoisted
@@ -648,14 +651,14 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
                                   : 0xFFFFFFF0u;
             }
             // Values two at a time (accumulator registers k, k + 1 = two pixel rows of one channel): packed f32 add / multiply / fma,
-            // one conversion per pair.  Per M-tile: 32 writes, then the sweep's reads back to back and its stores behind them (a wave's
-            // LDS instructions execute in order: the reads see the writes, the next M-tile's writes cannot overtake the reads; the
-            // empty asm statements only pin the program order).
+            // one conversion per pair.  Per M-tile: 32 writes, a wait for them, then the sweep's reads back to back and its stores
+            // behind them (the stores consume the reads, so the next M-tile's writes cannot overtake them).
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 s1v[TN], s2v[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) { s1v[j] = (f32x2){0.f, 0.f}; s2v[j] = (f32x2){0.f, 0.f}; }
             const float slope = a.out_act ? a.out_slope : 1.f;      // (max(v, 1 * v) = v: no select per value)
+            const int rlim = (ACTB || rows_ok) ? 0x7FFFFFFF : a.Hg - gy0;    // rows of this tile inside the map
             // ACTB: the producer's raw output y_raw at this tile -- per M-tile the sweep's 16-byte loads (the stores' lane mapping),
             // through a second staging region, read back in the accumulator layout (lane = channel, like the sums).
             // The loads of M-tile i + 1 fly under the arithmetic of M-tile i.
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 #pragma unroll
                         for (int st = 0; st < NST; ++st) yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], (unsigned)(i + 1) * istep_y, 0);
                     }
-                    asm volatile("" ::: "memory");
+                    lds_wave_sync();      // (the 16-bit writes have landed before other lanes' 8-byte reads)
                 }
                 // (ACTB: the M-tile's y_raw values read back in ONE batch, two bf16 per register -- read pair by pair between the
                 //  staging writes, which the compiler must keep in program order, every pair was a serial LDS round trip)
@@ -752,13 +755,27 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(s1v[j]), "+v"(s2v[j]));
 #endif
-                asm volatile("" ::: "memory");
+                // (a wait, not program order alone: the rows are read by other lanes than wrote them)
+                lds_wave_sync();
                 __builtin_amdgcn_sched_barrier(0);
                 u32x4 rd[NST];
 #pragma unroll
                 for (int st = 0; st < NST; ++st) rd[st] = *(const u32x4*)(stgw + (lrow + RSTEP * st) * ROWB + lsg * 16);
 #pragma unroll
-                for (int st = 0; st < NST; ++st) __builtin_amdgcn_raw_buffer_store_b128(rd[st], rsY, voff[st], (unsigned)i * istep, 0);
+                for (int st = 0; st < NST; ++st) {
+                    const int prow = 2 * ((wl / WN) * TM + i) + ((lrow + RSTEP * st) >> 4);      // pixel row of the tile
+                    __builtin_amdgcn_raw_buffer_store_b128(rd[st], rsY, prow < rlim ? voff[st] : 0xFFFFFFF0u, (unsigned)i * istep, 0);
+                }
+                // HAZARD (seen on gfx950, ROCm 7.2): a VALU write to the first data register of a 16-byte buffer store IN THE NEXT
+                // INSTRUCTION reaches the stored data -- the compiler had picked that register for the next store's offset select
+                // (`buffer_store_dwordx4 v[98:101], ..; v_cndmask_b32 v98, ..`: intermittently two channels of a pixel came out as
+                // the bits of an offset); LLVM's hazard recogniser covers this only for stores without a scalar offset register.
+                // Keep the data registers live past the last store and two wait states behind it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int st = 0; st < NST; ++st) asm volatile("" :: "v"(rd[st]));
+                asm volatile("s_nop 1");
+#endif
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
