@@ -107,10 +107,13 @@ def test_fp8_conv_equals_conv2d_of_the_dequantised_operands(case):
     ref = F.conv2d(xq.float(), wq, padding=1) * deq.cpu().view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
     ref = torch.relu(ref)
     bd = bias.to(DEV)
-    y16 = _conv(lib, xq_d, L.FP8, L.FP8, L.BF16, B, H, W, Cin, Cout, p1, bd, deq, None)
-    torch.cuda.synchronize()
-    got = y16.float().cpu().permute(0, 3, 1, 2)
-    assert (got - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6        # one bf16 rounding
+    # (launched several times: the multi-tile case once failed INTERMITTENTLY, in a few hundred of 18.9 M outputs per launch -- a
+    #  store-data hazard of the epilogue's 16-byte buffer stores, DESIGN.md section 3 -- and a single launch can miss such a thing)
+    for _rep in range(4):
+        y16 = _conv(lib, xq_d, L.FP8, L.FP8, L.BF16, B, H, W, Cin, Cout, p1, bd, deq, None)
+        torch.cuda.synchronize()
+        got = y16.float().cpu().permute(0, 3, 1, 2)
+        assert (got - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6        # one bf16 rounding
     amax_o, s_o, inv_o = (torch.zeros(1, device=DEV) for _ in range(3))
     L.check(lib.abc_absmax(y16.data_ptr(), L.BF16, y16.numel(), amax_o.data_ptr(), st()), "absmax")
     L.check(lib.abc_fp8_act_scale(amax_o.data_ptr(), 1.0, s_o.data_ptr(), inv_o.data_ptr(), st()), "act_scale")
