@@ -106,6 +106,37 @@ def measure_train(variant, with_autocast=False):
     return out
 
 
+@pytest.mark.parametrize("variant", ["unet", "unet2"])
+def test_benchmark_step_is_bit_reproducible(variant):
+    """The step the benchmark times (b16 @ 384 x 384, bf16, hipGraph replay, the default plan), run twice from the same state on the
+    same batch for three steps: parameters, BatchNorm buffers, Adam moments, gradients and logits equal BIT FOR BIT.  Every kernel is
+    order-deterministic by construction (no float atomics, fixed-order split-K), so any difference is a race or a hardware hazard -- the
+    kind of fault that shows in a few hundred of 19 M outputs of one launch in three (the store-data hazard of DESIGN.md section 3 was
+    found by an fp8 kernel test going red intermittently); the launch shapes that exist only at this size (persistent multi-tile
+    workgroups, the 1024-row merged weight gradient, 2 M-thread fused heads pass) are otherwise only held to tolerances."""
+    from abcnet_amd.train import Trainer
+    B, S = 16, 384
+    x = synthetic_images(B, S, seed=7).to(DEV)
+    tg = [t.to(DEV) for t in synthetic_targets(B, S // 4, seed=1)]
+
+    def run():
+        m = _model(variant, "bf16", 0.2 if variant == "unet" else 0.0)
+        tr = Trainer(m, B, S, S, lr=2.5e-4, use_graph=True)
+        tr.load_batch(x, tg)
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        return (m._flat.data.clone(), m._flat_buf.clone(), m._flat_grad.clone(), tr.opt.m.clone(), tr.opt.v.clone(),
+                [t.clone() for t in tr.eng.logits], tr.loss_value()["total"])
+
+    a, b = run(), run()
+    for name, ta, tb in zip(("parameters", "buffers", "gradients", "adam m", "adam v"), a[:5], b[:5]):
+        assert torch.equal(ta, tb), (name, int((ta != tb).sum()))
+    for i, (la, lb) in enumerate(zip(a[5], b[5])):
+        assert torch.equal(la, lb), ("logits", i, int((la != lb).sum()))
+    assert a[6] == b[6]
+
+
 SAMPLE = (0, 21, 42, 63)
 
 
