@@ -170,6 +170,34 @@ def measure_infer(fold_bn=True, fp8=False):
             "nms_on_device_logits_exact": bool(exact)}
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_benchmark_inference_is_bit_reproducible(fp8):
+    """config 5's graph (b64 @ 512 x 512, BatchNorm folded, bf16 and e4m3), built twice and replayed four times each on the same
+    batch: the eight maps and the NMS outputs equal bit for bit between all eight replays (see the training twin above: the net for
+    races and hazards; the 128 x 128 maps under 12-row tiles also put one tile in eleven on the row-short epilogue path)"""
+    from abcnet_amd.infer import InferenceRunner
+    B, S = 64, 512
+    x = synthetic_images(B, S, seed=7).to(DEV)
+    ref = None
+    for _build in range(2):
+        m = _model("unet", "bf16", 0.2)
+        run = InferenceRunner(m, B, S, S, use_graph=True, fold_bn=True, fp8=fp8)
+        run.load_batch(x)
+        for rep in range(5):
+            run.step()
+            torch.cuda.synchronize()
+            if rep == 0:
+                continue      # (eager; the others replay the captured graph)
+            out = [t.clone() for t in run.logits] + [run.atom_mask.clone(), run.bond_mask.clone(), run.omega_mask.clone(), run.rho_abs.clone()]
+            if ref is None:
+                ref = out
+            else:
+                for i, (a, b) in enumerate(zip(ref, out)):
+                    assert torch.equal(a, b), (_build, rep, i, int((a != b).sum()))
+        del run, m
+        torch.cuda.empty_cache()
+
+
 def _bounds():
     with open(BOUNDS) as f:
         return json.load(f)
