@@ -30,6 +30,9 @@ constexpr int FT = 256;      // threads per workgroup
 // halo segments a thread may hold (3x3 taps, 64-byte chunks: (2*MT+2) x 18 pixels x 4 segments over 256 threads;
 // MT = 8 also takes unet2's 5x5 taps: 20 x 20 pixels x 4 segments = 6.25 per thread)
 __host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 7 : (mt >= 6 ? 4 : (mt >= 4 ? 3 : 2)); }
+// stride 2 (the data gradients of the transposed convolutions, unet.py:44 under autograd: a 17 x 33 pixel halo per 8 x 16 tile):
+// 9 segments per thread -- these kernels hold 64 accumulator registers, the staging fits
+__host__ __device__ constexpr int fa_stride2() { return 9; }
 // resident-weight (persistent, narrow-layer) workgroups only ever see 3x3 / 1x1 taps: 6 segments, and three of them per CU
 __host__ __device__ constexpr int fa_static(int mt) { return mt >= 8 ? 6 : fa_max(mt); }
 constexpr int SR_MAX = 256;  // weight rows per stage (tap group x BN)
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
     const unsigned bvoff0 = (unsigned)tl0 * tap_stride + (unsigned)rem0 * 16u;
     const int bdst0 = (tl0 * BN + rem0 / SEGS) * PS + (rem0 % SEGS) * 16;
     u32x4 breg[2][NB];
-    HaloTile<InT, CT, CK, STATIC ? fa_static(MT) : fa_max(MT), FT> apre;
+    HaloTile<InT, CT, CK, STATIC ? fa_static(MT) : (STRIDE == 2 ? fa_stride2() : fa_max(MT)), FT> apre;
 
     unsigned w_n0 = 0;  // byte offset of the n-block's first weight row
     auto b_issue = [&](u32x4* set, int c, int g) {
@@ -1002,7 +1005,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
             const int prow = 2 * mt;
             if (actb && d->Hg % prow) continue;      // (whole tiles only)
             const int hh = (prow - 1) * d->stride + (dymax - dymin) + 1, hw = 15 * d->stride + (dxmax - dxmin) + 1;
-            if (abc_cdiv(hh * hw * segs, FT) > fa_max(mt) || hh * hw * hw >= 65536) continue;
+            if (abc_cdiv(hh * hw * segs, FT) > (d->stride == 2 ? fa_stride2() : fa_max(mt)) || hh * hw * hw >= 65536) continue;
             const int rs = abc_roundup(hw * g->PS, 256);
             const int sa = abc_roundup(hh * rs, 256);
             if (sa + 2 * 128 * g->PS + coef_bytes + 256 > LDS_WG) continue;
