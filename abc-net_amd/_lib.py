@@ -163,6 +163,8 @@ P = C.POINTER
 SYMBOLS = {
     "abc_conv_stat_blocks": (C.c_int, [P(ConvDesc)]),
     "abc_conv_actbwd_ok": (C.c_int, [P(ConvDesc)]),
+    "abc_conv_fwd_batch": (C.c_int, [P(ConvDesc), C.c_int32, C.c_void_p]),
+    "abc_conv_batch_ok": (C.c_int, [P(ConvDesc), C.c_int32]),
     "abc_conv_variant": (C.c_int, [vp]),
     "abc_conv_weight_layout": (C.c_int, [vp]),
     "abc_conv_fwd": (C.c_int, [P(ConvDesc), vp]),

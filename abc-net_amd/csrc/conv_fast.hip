@@ -75,7 +75,7 @@ __device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" :::
 // (unet.py:66-69 with BatchNorm folded); the head's 1x1 convolution (unet.py:70) is computed from them right here and the f32
 // NCHW maps are stored -- the 8 x 128-channel feature tensor is never written or read (2 x 2.1 GB per batch of 64 at 512 x 512)
 template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
-__global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const FastK a) {
+__device__ __forceinline__ void conv_fast_body(const FastK& a) {
     constexpr int CKB = CK * (int)sizeof(CT);
     constexpr int PS = CKB + 16;
     constexpr int LHB = CKB / 2;
@@ -892,6 +892,20 @@ __global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const 
 }
 
 template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
+__global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const FastK a) {
+    conv_fast_body<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI>(a);
+}
+
+// Up to four convolutions of ONE geometry as one launch, blockIdx.y picks the descriptor: the four output-parity phases of a
+// ConvTranspose2d(k3, s2) forward (unet.py:44) -- each a 1 / 2 / 2 / 4-tap convolution over the same input into interleaved output
+// pixels, 100-400 workgroups of a few microseconds: as four launches they ran one after the other on a quarter-filled chip
+struct FastKB { FastK k[4]; };
+template <typename InT, typename CT, typename OutT, int CK, int BN, int MT>
+__global__ __launch_bounds__(256, 2) void conv_fast_batch_kernel(const FastKB b) {
+    conv_fast_body<InT, CT, OutT, CK, BN, 1, MT, false, 0, 0>(b.k[blockIdx.y]);
+}
+
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
 int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI>;
     static unsigned long long lds_ok = 0;
@@ -1107,8 +1121,7 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     return ABC_OK;
 }
 
-int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_stream_t stream) {
-    FastK k;
+static void fill_fastk(const abc_conv_desc* d, const abc_fast_geom& g, FastK& k) {
     k.x = d->src.x; k.scale = d->src.scale; k.shift = d->src.shift; k.slope = d->src.slope;
     k.w = d->w; k.bias = d->bias; k.y = d->y; k.stats = d->stats;
     k.B = d->B; k.Hin = d->Hin; k.Win = d->Win; k.Hx = d->src.Hx; k.Wx = d->src.Wx; k.ldx = d->src.ldx;
@@ -1136,6 +1149,66 @@ int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_str
         k.ty[t] = (int8_t)(d->tap_dy[t] - g.dy_min);
         k.tx[t] = (int8_t)(d->tap_dx[t] - g.dx_min);
     }
+}
+
+template <typename InT, typename CT, typename OutT, int CK, int BN, int MT>
+static int launch_batch_inst(const FastKB& b, int n, const abc_fast_geom& g, hipStream_t st) {
+    auto fn = conv_fast_batch_kernel<InT, CT, OutT, CK, BN, MT>;
+    static unsigned long long lds_ok = 0;
+    if (int rc = abc_allow_lds((const void*)fn, LDS_WG, &lds_ok)) return rc;
+    hipLaunchKernelGGL(fn, dim3(g.nwg, n), dim3(FT), g.lds, st, b);
+    return abc_check_launch("conv_fast_batch");
+}
+
+// 1: n (2..4) descriptors the batched launch serves -- plain bf16 stride-1 convolutions on the LDS-staged loop with the same tile
+// geometry (taps, weights, bias and output placement may differ); 0: launch them one by one
+int abc_conv_fast_batch_ok(const abc_conv_desc* d, int n, abc_fast_geom* g0) {
+    if (n < 2 || n > 4) return 0;
+    abc_fast_geom g[4];
+    for (int i = 0; i < n; ++i) {
+        if (d[i].heads_epi != nullptr || d[i].actbwd_y != nullptr || d[i].dtype_in != ABC_BF16 || d[i].dtype_c != ABC_BF16 || d[i].dtype_out != ABC_BF16) return 0;
+        if (abc_conv_fast_geom(&d[i], &g[i]) != ABC_OK || !g[i].eligible) return 0;
+        if (g[i].wd || g[i].b_static || d[i].stride != 1 || g[i].CK != 32) return 0;
+        if (i && (g[i].BN != g[0].BN || g[i].MT != g[0].MT || g[i].nwg != g[0].nwg || g[i].ntiles != g[0].ntiles)) return 0;
+    }
+    const int bn = g[0].BN, mt = g[0].MT;
+    if (!((bn == 128 && (mt == 2 || mt == 4 || mt == 6)) || (bn == 64 && (mt == 2 || mt == 4 || mt == 8)) || (bn == 32 && (mt == 4 || mt == 8)))) return 0;
+    int lds = 0;
+    for (int i = 0; i < n; ++i) lds = g[i].lds > lds ? g[i].lds : lds;
+    *g0 = g[0];
+    g0->lds = lds;
+    return 1;
+}
+
+int abc_conv_fast_launch_batch(const abc_conv_desc* d, int n, abc_stream_t stream) {
+    abc_fast_geom g0;
+    if (!abc_conv_fast_batch_ok(d, n, &g0)) return abc_fail(ABC_EUNSUPPORTED, "conv batch: not one geometry of the lean kernel");
+    FastKB b;
+    for (int i = 0; i < 4; ++i) {
+        abc_fast_geom gi;
+        const abc_conv_desc* di = &d[i < n ? i : 0];
+        abc_conv_fast_geom(di, &gi);
+        fill_fastk(di, gi, b.k[i]);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int bn = g0.BN, mt = g0.MT;
+    if (bn == 128) {
+        if (mt == 2) return launch_batch_inst<bf16, bf16, bf16, 32, 128, 2>(b, n, g0, st);
+        if (mt == 4) return launch_batch_inst<bf16, bf16, bf16, 32, 128, 4>(b, n, g0, st);
+        return launch_batch_inst<bf16, bf16, bf16, 32, 128, 6>(b, n, g0, st);
+    }
+    if (bn == 64) {
+        if (mt == 2) return launch_batch_inst<bf16, bf16, bf16, 32, 64, 2>(b, n, g0, st);
+        if (mt == 4) return launch_batch_inst<bf16, bf16, bf16, 32, 64, 4>(b, n, g0, st);
+        return launch_batch_inst<bf16, bf16, bf16, 32, 64, 8>(b, n, g0, st);
+    }
+    if (mt == 4) return launch_batch_inst<bf16, bf16, bf16, 32, 32, 4>(b, n, g0, st);
+    return launch_batch_inst<bf16, bf16, bf16, 32, 32, 8>(b, n, g0, st);
+}
+
+int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_stream_t stream) {
+    FastK k;
+    fill_fastk(d, g, k);
     hipStream_t st = (hipStream_t)stream;
     const int di = d->dtype_in, dc = d->dtype_c, dout = d->dtype_out;
     if (d->heads_epi != nullptr) {

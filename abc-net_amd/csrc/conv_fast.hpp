@@ -10,6 +10,9 @@ struct abc_fast_geom {
 
 int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g);
 int abc_conv_fast_launch(const abc_conv_desc* d, const abc_fast_geom& g, abc_stream_t stream);
+// n (2..4) convolutions of one lean-kernel geometry as ONE launch (the four phases of a ConvTranspose2d forward)
+int abc_conv_fast_batch_ok(const abc_conv_desc* d, int n, abc_fast_geom* g0);
+int abc_conv_fast_launch_batch(const abc_conv_desc* d, int n, abc_stream_t stream);
 
 // plain-input 16 / 32-channel 3x3 convolution without statistics (conv_narrow.hip)
 int abc_conv_narrow_ok(const abc_conv_desc* d);

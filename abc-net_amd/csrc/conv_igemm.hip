@@ -567,6 +567,27 @@ extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
     return g.tiles_x * g.tiles_y * d->B;
 }
 
+extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream);
+static bool batchable(const abc_conv_desc* d, int n) {
+    // (only descriptors the lean kernel would run anyway)
+    for (int i = 0; i < n; ++i)
+        if (d[i].stem_x != nullptr || d[i].pool_y != nullptr || d[i].stats != nullptr || abc_conv_stem_ok(&d[i], nullptr) || abc_head_fwd_ok(&d[i]) ||
+            abc_head_dgrad_ok(&d[i]) || abc_conv_narrow_ok(&d[i]) || (d[i].Hg - 1) * d[i].om + d[i].oy0 >= d[i].Hout || (d[i].Wg - 1) * d[i].om + d[i].ox0 >= d[i].Wout)
+            return false;
+    abc_fast_geom g0;
+    return abc_conv_fast_batch_ok(d, n, &g0) != 0;
+}
+
+extern "C" int abc_conv_batch_ok(const abc_conv_desc* d, int32_t n) { return (d != nullptr && batchable(d, n)) ? 1 : 0; }
+
+extern "C" int abc_conv_fwd_batch(const abc_conv_desc* d, int32_t n, abc_stream_t stream) {
+    if (d == nullptr || n < 1) return abc_fail(ABC_EINVAL, "conv_fwd_batch: no descriptors");
+    if (batchable(d, n)) return abc_conv_fast_launch_batch(d, n, stream);
+    for (int i = 0; i < n; ++i)
+        if (int rc = abc_conv_fwd(&d[i], stream)) return rc;
+    return ABC_OK;
+}
+
 extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     if (d->dtype_c == ABC_FP8 || d->dtype_out == ABC_FP8 || d->dtype_in == ABC_FP8) {
         // the fp8 inference graph: the heads' 1x1 convolution into NCHW f32 (heads.hip), else the lean kernel's weights-direct tile

@@ -353,6 +353,24 @@ class Engine:
             self._emit(ops, self.lib.abc_conv_fwd, d, what, meta=meta)
         return st, nblk
 
+    def emit_conv_batch(self, ops, items, what):
+        """convolutions collected by emit_conv(collect=...) as ONE launch where the library serves them so (abc_conv_fwd_batch: the four
+        output-parity phases of a ConvTranspose2d forward, unet.py:44, share a tile geometry of the lean kernel), else one launch each"""
+        arr = (L.ConvDesc * len(items))()
+        for i, (d, _w, _m) in enumerate(items):
+            arr[i] = d
+        if not self.lib.abc_conv_batch_ok(arr, len(items)):
+            for d, w, m in items:
+                self._emit(ops, self.lib.abc_conv_fwd, d, w, meta=m)
+            return
+        self.keep.append(arr)
+        self.keep.append([d for d, _w, _m in items])
+        lib, n = self.lib, len(items)
+        k0 = items[0][2]["kernel"]
+        meta = {"kernel": k0.replace("<", "_x%d<" % n, 1), "flops": sum(m["flops"] for _d, _w, m in items),
+                "bytes": sum(m["bytes"] for _d, _w, m in items)}
+        ops.append((lambda _r, st, a=arr: lib.abc_conv_fwd_batch(a, n, st), None, what, (), meta))
+
     def emit_heads_batch(self, ops, items, which, what):
         """the heads' 1x1 convolutions collected by emit_conv(collect=...) as ONE launch (abc_heads_batch) when every one of
         them is served by the dedicated heads kernel (which = 0 forward / 1 data gradient), else one launch each"""
@@ -707,7 +725,7 @@ class Engine:
             raise ValueError("skip tensor %dx%d does not fit the transposed conv of %dx%d" % (Hs, Ws, lh, lw))
         crop_y, crop_x = Hs == 2 * lh, Ws == 2 * lw
         rows_pad = -(-half // 32) * 32
-        phases = []
+        phases, items = [], []
         for py in (0, 1):
             for px in (0, 1):
                 taps = convT_phase_taps(py, px, crop_y, crop_x)
@@ -717,8 +735,9 @@ class Engine:
                 # output rows 2a + py < Hs: without the crop the even parity has one row more than the input
                 gh, gw = (Hs - py + 1) // 2, (Ws - px + 1) // 2
                 self.emit_conv(self.fwd_ops, low, wp, self.P(name + ".up.bias"), cat, self.dt, Hs, Ws, Ctot, half, half, taps,
-                               grid=(gh, gw), om=2, oy0=py, ox0=px, what="fwd %s.up phase %d%d" % (name, py, px))
+                               grid=(gh, gw), om=2, oy0=py, ox0=px, what="fwd %s.up phase %d%d" % (name, py, px), collect=items)
                 phases.append(wp)
+        self.emit_conv_batch(self.fwd_ops, items, "fwd %s.up (4 phases)" % name)
         rec = Rec(kind="convT", cname=name + ".up", src=low, cin=cin, cout=half, H=Hs, W=Ws, ld=Ctot, coff=half, y=cat,
                   taps_bwd=convT_dgrad_taps(crop_y, crop_x))
         self.recs.append(rec)

@@ -141,6 +141,12 @@ typedef struct abc_conv_desc {
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */
 int abc_conv_stat_blocks(const abc_conv_desc* d);
+/* n convolutions (an array of descriptors) issued as ONE launch where they share a tile geometry of the lean kernel -- the four
+ * output-parity phases of nn.ConvTranspose2d(k3, s2) (unet.py:44: four 1 / 2 / 2 / 4-tap convolutions of the same input into
+ * interleaved output pixels) -- and one after the other otherwise: the result is that of n abc_conv_fwd calls either way.
+ * abc_conv_batch_ok tells which of the two it will be (1: one launch). */
+int abc_conv_fwd_batch(const abc_conv_desc* d, int32_t n, abc_stream_t stream);
+int abc_conv_batch_ok(const abc_conv_desc* d, int32_t n);
 /* 1 when abc_conv_fwd honours d->actbwd_* for this descriptor (fill everything first, `stats` included), else 0: the caller then clears
  * actbwd_y and runs abc_act_bwd as a pass of its own (the engine's fallback; same results up to the rounding of dA to bf16) */
 int abc_conv_actbwd_ok(const abc_conv_desc* d);

@@ -48,7 +48,7 @@ def pack(lib, w, mode, dt, Cout, Cin, k, rows_pad, red_real, py=0, px=0):
 
 def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, Hout, Wout, ldy=None, cout_off=0, coef=None,
          pool=False, stride=1, grid=None, om=1, oy0=0, ox0=0, out=None, out_dt=None, stats=False, drop_p=0.0, drop_seed=0,
-         planar_in=0, planar_out=False, out_slope=None, pool_out=None, stem=None, actbwd=None):
+         planar_in=0, planar_out=False, out_slope=None, pool_out=None, stem=None, actbwd=None, defer=None):
     """actbwd: (y_raw, ld, coff, scale, shift, slope, mean, invstd) -> abc_conv_desc.actbwd_*; conv.last_actbwd_ok tells whether the
     library honoured it (else the plain convolution ran)"""
     out_dt = dt if out_dt is None else out_dt
@@ -96,6 +96,9 @@ def conv(lib, x, dt_in, dt, B, Hx, Wx, ldx, cin_off, Cin, wp, bias, Cout, taps, 
         nblk = lib.abc_conv_stat_blocks(C.byref(d))
         st = torch.zeros((nblk, 2, Cout), dtype=torch.float32, device=DEV)
         d.stats = st.data_ptr()
+    if defer is not None:
+        defer.append((d, wp, st))      # (the launch is the caller's: abc_conv_fwd_batch over several descriptors)
+        return out, st
     L.check(lib.abc_conv_fwd(C.byref(d), stream()), "conv_fwd")
     return out, st
 

@@ -829,3 +829,45 @@ def test_act_bwd_epilogue_refuses_ragged_shapes(lib):
     assert not U.conv.last_actbwd_ok
     ref = F.conv2d(dy.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1)
     assert U.relerr(out.float().cpu(), ref) < 3e-2
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Chalf", [(2, 24, 24, 256, 128), (16, 48, 48, 128, 64), (3, 12, 20, 512, 256), (1, 9, 11, 64, 32)])
+def test_conv_transpose_phases_as_one_launch(lib, B, H, W, Cin, Chalf):
+    """abc_conv_fwd_batch: the four output-parity phases of ConvTranspose2d(k3, s2) + the reference's crop (unet.py:44,51-56) issued as
+    ONE launch where they share a tile geometry of the lean kernel (abc_conv_batch_ok), one by one otherwise -- the same bytes as four
+    abc_conv_fwd calls either way, and torch's conv_transpose2d within the bf16 bar"""
+    from abcnet_amd.engine import convT_pack_parity
+    dt = L.BF16
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(U.DEV)
+    w = torch.randn((Cin, Chalf, 3, 3), generator=g) / (2.0 * Cin ** 0.5)       # ConvTranspose2d weight layout
+    bias = torch.randn(Chalf, generator=g).to(U.DEV)
+    Hs, Ws, Ctot = 2 * H, 2 * W, 2 * Chalf
+    rows_pad = -(-Chalf // 32) * 32
+
+    def run(batched):
+        cat = torch.zeros((B, Hs, Ws, Ctot), dtype=torch.bfloat16, device=U.DEV)
+        items = []
+        for py in (0, 1):
+            for px in (0, 1):
+                taps = convT_phase_taps(py, px, True, True)
+                wp = U.pack(lib, w.to(U.DEV), 2, dt, Chalf, Cin, 3, rows_pad, Cin, py=convT_pack_parity(py, True), px=convT_pack_parity(px, True))
+                U.conv(lib, x, dt, dt, B, H, W, Cin, 0, Cin, wp, bias, Chalf, taps, Hs, Ws, ldy=Ctot, cout_off=Chalf, grid=((Hs - py + 1) // 2, (Ws - px + 1) // 2),
+                       om=2, oy0=py, ox0=px, out=cat, defer=items if batched else None)
+        ok = None
+        if batched:
+            arr = (L.ConvDesc * 4)(*[d for d, _w, _s in items])
+            ok = bool(lib.abc_conv_batch_ok(arr, 4))
+            L.check(lib.abc_conv_fwd_batch(arr, 4, U.stream()), "conv_fwd_batch")
+        torch.cuda.synchronize()
+        return cat, ok
+
+    one, ok = run(True)
+    four, _ = run(False)
+    assert torch.equal(one, four)
+    if (B, H) in ((2, 24), (16, 48)):
+        assert ok          # (the benchmark's up-layers: one launch)
+    y = F.conv_transpose2d(x.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), bias.cpu(), stride=2)
+    y = y[:, :, y.shape[2] - Hs:, y.shape[3] - Ws:]
+    assert U.relerr(one[..., Chalf:].float().cpu().permute(0, 3, 1, 2), y) < 3e-2
+    assert float(one[..., :Chalf].abs().max()) == 0.0
