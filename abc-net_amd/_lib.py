@@ -201,6 +201,7 @@ SYMBOLS = {
     "abc_wgrad_tile": (C.c_int, [P(WgradDesc), P(i32), P(i32)]),
     "abc_wgrad": (C.c_int, [P(WgradDesc), vp]),
     "abc_wgrad_reduce": (C.c_int, [P(WgradReduceDesc), vp]),
+    "abc_wgrad_reduce_bn_bwd": (C.c_int, [P(WgradReduceDesc), P(BnBwdDesc), vp]),
     "abc_wgrad_heads_batch": (C.c_int, [vp, i32, vp]),
     "abc_wgrad_reduce_batch": (C.c_int, [vp, i32, vp]),
     "abc_colsum_blocks": (C.c_int, [i64]),

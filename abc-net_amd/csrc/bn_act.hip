@@ -8,22 +8,12 @@
 #include "common.hpp"
 #include "../../include/abcnet_hip.h"
 #include "capi_util.hpp"
+#include "reduce_bn.hpp"
 #include <stdlib.h>
 
 namespace {
 
 // ------------------------------------------------------------------ helpers
-__device__ inline double block_sum_f64(double v, double* sm) {
-    // 256 threads
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[w] = v;
-    __syncthreads();
-    return sm[0] + sm[1] + sm[2] + sm[3];
-}
-
 // pstride = floats between consecutive partial rows (the layer's own C, or the width of a shared partial buffer)
 __device__ inline void bn_finalize_fwd_body(const abc_bn_fwd_desc& d, int pstride) {
     __shared__ double sm[4];
@@ -82,39 +72,10 @@ __global__ void bn_eval_fold_kernel(const float* gamma, const float* beta, const
     bias_out[c] = ((cb ? cb[c] : 0.f) - rm[c]) * sc + beta[c];
 }
 
-__device__ inline void bn_finalize_bwd_body(const abc_bn_bwd_desc& d, int pstride) {
-    __shared__ double sm[4];
-    const int c = blockIdx.x;
-    if (c >= d.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = threadIdx.x; k < d.nblk; k += 256) {
-        s1 += (double)d.partial[((size_t)k * 2 + 0) * pstride + c];
-        s2 += (double)d.partial[((size_t)k * 2 + 1) * pstride + c];
-    }
-    s1 = block_sum_f64(s1, sm);
-    s2 = block_sum_f64(s2, sm);
-    if (threadIdx.x == 0) {
-        const float fin = d.in_scale != nullptr ? *d.in_scale : 1.f;   // the producer's gradient lacked this factor
-        s1 *= (double)fin; s2 *= (double)fin;
-        if (d.dbeta != nullptr) d.dbeta[c] = (float)s1;
-        if (d.dgamma != nullptr) d.dgamma[c] = (float)s2;
-        d.k1[c] = (float)(s1 / d.count);
-        d.k2[c] = (float)(s2 / d.count);
-        const float gs = d.gamma[c] * d.invstd[c];
-        d.gscale[c] = gs;
-        if (d.ca != nullptr) {
-            const float k1 = (float)(s1 / d.count), k2 = (float)(s2 / d.count), is = d.invstd[c];
-            d.ca[c] = gs * fin;
-            d.cb[c] = -gs * k2 * is;
-            d.cc[c] = gs * (d.mean[c] * is * k2 - k1);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const abc_bn_bwd_desc d) { bn_finalize_bwd_body(d, d.C); }
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const abc_bn_bwd_desc d) { bn_finalize_bwd_body(d, d.C, blockIdx.x); }
 struct BnBwdBatch { abc_bn_bwd_desc d[MAX_BNB]; int pstride; };
 __global__ __launch_bounds__(256) void bn_finalize_bwd_batch_kernel(const BnBwdBatch bt) {
-    bn_finalize_bwd_body(bt.d[blockIdx.y], bt.pstride > 0 ? bt.pstride : bt.d[blockIdx.y].C);
+    bn_finalize_bwd_body(bt.d[blockIdx.y], bt.pstride > 0 ? bt.pstride : bt.d[blockIdx.y].C, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ pass 1

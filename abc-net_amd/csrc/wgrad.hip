@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "../../include/abcnet_hip.h"
 #include "capi_util.hpp"
+#include "reduce_bn.hpp"
 #include "heads_fused.hpp"
 #include <stdlib.h>
 
@@ -380,79 +381,19 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
 // Sum the split-K slabs.  One thread per (tap, a, b) output element; consecutive threads walk
 // b, so every slab read is a coalesced 4-byte stream and the whole reduction is one pass at
 // HBM/L2 speed (slab order fixed -> bitwise reproducible).  Output = reference layout [a][b][tap].
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const abc_wgrad_reduce_desc d) {
-    const int64_t n = (int64_t)d.ntaps * d.Ca * d.Cb;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    const int bi = (int)(idx % d.Cb);
-    const int ai = (int)((idx / d.Cb) % d.Ca);
-    const int t = (int)(idx / ((int64_t)d.Cb * d.Ca));
-    const size_t slab = (size_t)d.Ca_pad * d.Cb_pad;
-    const float* p = d.partial + (size_t)t * slab + (size_t)ai * d.Cb_pad + bi;
-    const size_t step = (size_t)d.ntaps * slab;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= d.nsplit; k += 4) {
-        s0 += p[(size_t)k * step]; s1 += p[(size_t)(k + 1) * step]; s2 += p[(size_t)(k + 2) * step]; s3 += p[(size_t)(k + 3) * step];
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const abc_wgrad_reduce_desc d) { wgrad_reduce_body(d, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const abc_wgrad_reduce_desc d) { wgrad_reduce_vec_body(d, blockIdx.x); }
+
+// one launch: the slab reduction of one layer (blocks [0, nr)) beside the BatchNorm-backward finaliser of the next (reduce_bn.hpp)
+struct ReduceBn { abc_wgrad_reduce_desc r; abc_bn_bwd_desc f; int nr, vec; };
+__global__ __launch_bounds__(256) void wgrad_reduce_bn_kernel(const ReduceBn a) {
+    if ((int)blockIdx.x < a.nr) {
+        if (a.vec) wgrad_reduce_vec_body(a.r, blockIdx.x); else wgrad_reduce_body(a.r, blockIdx.x);
+    } else {
+        bn_finalize_bwd_body(a.f, a.f.C, (int)blockIdx.x - a.nr);
     }
-    for (; k < d.nsplit; ++k) s0 += p[(size_t)k * step];
-    const float s = (s0 + s1) + (s2 + s3);
-    float* o = d.dw + ((size_t)ai * d.Cb + bi) * d.ntaps + t;
-    *o = d.accumulate ? (*o + s) : s;
 }
-
-
-// The same sums with more bytes in flight (the element-per-thread form keeps ~2.4 MB outstanding and stays latency-bound at
-// ~5.2 TB/s on slabs that still sit in the Infinity Cache): a thread owns FOUR consecutive b (16-byte loads) and one quarter
-// of the slabs (wave g of the block: slabs [g*ns/4, (g+1)*ns/4)), eight loads deep; the four quarters meet in LDS and are
-// added in order g = 0..3, so the result is reproducible (not bit-equal to the scalar form: different association).
-__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const abc_wgrad_reduce_desc d) {
-    __shared__ float4 sm[3][64];
-    const int cb4 = d.Cb >> 2;
-    const int64_t n4 = (int64_t)d.ntaps * d.Ca * cb4;
-    const int64_t idx = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int g = threadIdx.x >> 6;
-    const bool live = idx < n4;
-    const int bi = live ? (int)(idx % cb4) * 4 : 0;
-    const int ai = live ? (int)((idx / cb4) % d.Ca) : 0;
-    const int t = live ? (int)(idx / ((int64_t)cb4 * d.Ca)) : 0;
-    const size_t slab = (size_t)d.Ca_pad * d.Cb_pad;
-    const size_t step = (size_t)d.ntaps * slab;
-    const int k0 = (int)((int64_t)d.nsplit * g / 4), k1 = (int)((int64_t)d.nsplit * (g + 1) / 4);
-    const float* p = d.partial + (size_t)t * slab + (size_t)ai * d.Cb_pad + bi + (size_t)k0 * step;
-    float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    int k = k0;
-    if (live) {
-        for (; k + 8 <= k1; k += 8, p += 8 * step) {
-            float4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *(const float4*)(p + (size_t)j * step);
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                s0.x += v[j].x; s0.y += v[j].y; s0.z += v[j].z; s0.w += v[j].w;
-                s1.x += v[j + 1].x; s1.y += v[j + 1].y; s1.z += v[j + 1].z; s1.w += v[j + 1].w;
-            }
-        }
-        for (; k < k1; ++k, p += step) {
-            const float4 v = *(const float4*)p;
-            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-        }
-    }
-    s0.x += s1.x; s0.y += s1.y; s0.z += s1.z; s0.w += s1.w;
-    if (g > 0) sm[g - 1][threadIdx.x & 63] = s0;
-    __syncthreads();
-    if (g > 0 || !live) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w) {
-        const float4 v = sm[w][threadIdx.x];
-        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-    }
-    float* o = d.dw + ((size_t)ai * d.Cb + bi) * d.ntaps + t;
-    const float r[4] = {s0.x, s0.y, s0.z, s0.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[(size_t)j * d.ntaps] = d.accumulate ? (o[(size_t)j * d.ntaps] + r[j]) : r[j];
-}
-
 
 // ---------------------------------------------------------------------------
 // Weight gradient of a head's 1x1 convolution: dW[a][b] = sum_p dL[a][p] * act(H[p][b]) with dL the channel-planar
@@ -1359,6 +1300,24 @@ extern "C" int abc_wgrad_reduce_batch(const abc_wgrad_reduce_desc* descs, int32_
     for (int i = n; i < MAX_RB; ++i) bt.d[i] = descs[0];
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((int)gx, n), dim3(256), 0, (hipStream_t)stream, bt);
     return abc_check_launch("wgrad_reduce_batch");
+}
+
+extern "C" int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream);
+// The slab reduction of one weight gradient and the BatchNorm-backward finaliser of ANOTHER layer (both inputs complete, neither
+// reads the other's output) as one launch; the small-output reduction form (one wave per element) is launched on its own.
+extern "C" int abc_wgrad_reduce_bn_bwd(const abc_wgrad_reduce_desc* d, const abc_bn_bwd_desc* f, abc_stream_t stream) {
+    if (f->C < 1 || f->nblk < 1) return abc_fail(ABC_EINVAL, "wgrad_reduce_bn_bwd: empty finaliser");
+    const int64_t n = (int64_t)d->ntaps * d->Ca * d->Cb;
+    if (n <= 4096 && d->nsplit >= 128) {
+        if (int rc = abc_wgrad_reduce(d, stream)) return rc;
+        return abc_bn_finalize_bwd(f, stream);
+    }
+    ReduceBn a;
+    a.r = *d; a.f = *f;
+    a.vec = (d->Cb % 4 == 0 && d->Cb_pad % 4 == 0 && ((uintptr_t)d->partial & 15) == 0 && d->nsplit >= 16 && n >= 16384) ? 1 : 0;
+    a.nr = a.vec ? (int)((n / 4 + 63) / 64) : (int)((n + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(a.nr + f->C), dim3(256), 0, (hipStream_t)stream, a);
+    return abc_check_launch("wgrad_reduce_bn_bwd");
 }
 
 extern "C" int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream) {

@@ -108,8 +108,9 @@ class Rec:
 class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
-                 guards=False, heads_epilogue=False, actbwd_epilogue=True):
-        """actbwd_epilogue=False: every act_bwd pass as a launch of its own (the form the fused epilogue is tested against);
+                 guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True):
+        """merge_reduce=False: every slab reduction and every BatchNorm-backward finaliser a launch of its own;
+        actbwd_epilogue=False: every act_bwd pass as a launch of its own (the form the fused epilogue is tested against);
         batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
         batched one is tested against, tests/test_gpu_model.py::test_batched_heads_equal_one_by_one_launches)"""
         if variant not in ("unet", "unet2"):
@@ -147,6 +148,8 @@ class Engine:
         # training: the activation / BatchNorm-statistics backward pass of a layer in the epilogue of the data gradient that produces
         # its input (abc_conv_desc.actbwd_*), where the layer has that one reader (_actbwd_target)
         self.actbwd_epilogue = bool(actbwd_epilogue)
+        self.merge_reduce = bool(merge_reduce)
+        self._pending_reduce = None
         self.dt = L.BF16 if dtype == "bf16" else L.F32
         self.tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
         # the fused train step's heads (csrc/heads_fused.hip): conv2 forward + loss + the way back to the BatchNorm outputs as
@@ -248,6 +251,30 @@ class Engine:
         self.keep.append(desc)
         ref = C.byref(desc)
         ops.append((fn, ref, what, tuple(writes), meta or {"kernel": what.split(" ")[0], "flops": 0, "bytes": 0}))
+
+    # ---- a weight gradient's slab reduction is independent of everything until the optimiser: it waits (_pending_reduce) for the
+    # next BatchNorm-backward finaliser of the plan -- a dependent ~5 us launch of C blocks -- and rides in ITS launch
+    # (abc_wgrad_reduce_bn_bwd); flushed on its own before the next weight gradient (the slabs share one workspace) and at the end
+    def _flush_reduce(self, ops):
+        pr = getattr(self, "_pending_reduce", None)
+        if pr is not None:
+            self._pending_reduce = None
+            pops, rd, what, writes, meta = pr
+            self._emit(pops, self.lib.abc_wgrad_reduce, rd, what, writes=writes, meta=meta)
+
+    def _emit_bn_bwd(self, ops, f, what, writes):
+        pr = getattr(self, "_pending_reduce", None)
+        if pr is None or pr[0] is not ops or not self.merge_reduce:
+            self._flush_reduce(ops)
+            self._emit(ops, self.lib.abc_bn_finalize_bwd, f, what, writes=writes)
+            return
+        self._pending_reduce = None
+        _pops, rd, rwhat, rwrites, rmeta = pr
+        self.keep += [rd, f]
+        lib = self.lib
+        meta = {"ws": rmeta.get("ws", 0), "kernel": "wgrad_reduce+bn_bwd", "flops": 0, "bytes": rmeta["bytes"]}
+        ops.append((lambda _r, st, a=(rd, f): lib.abc_wgrad_reduce_bn_bwd(C.byref(a[0]), C.byref(a[1]), st), None,
+                    rwhat + " + " + what, tuple(rwrites) + tuple(writes), meta))
 
     def _dn(self, dt):
         return {L.BF16: "bf16", L.F32: "f32", L.FP8: "fp8"}[dt]
@@ -447,6 +474,7 @@ class Engine:
                                + need * 4 + (2 * self.B * gh * gw * Ca * self._esz(self.dt) if dual is not None else 0))}
         post = []
         if collect is None:
+            self._flush_reduce(ops)      # (the previous layer's slabs sit in the workspace this launch overwrites)
             self._emit(ops, self.lib.abc_wgrad, d, what, meta=meta)
         fused_rowsum = False
         if rowsum_to is not None and self.lib.abc_wgrad_rowsum_ok(C.byref(d)):
@@ -464,8 +492,12 @@ class Engine:
         if collect is not None:
             collect.append({"d": d, "what": what, "meta": meta, "post": post})
         else:
-            for rd, w, wr, m in post:
-                self._emit(ops, self.lib.abc_wgrad_reduce, rd, w, writes=wr, meta=m)
+            for k, (rd, w, wr, m) in enumerate(post):
+                if k == 0 and self.merge_reduce and self.train:
+                    self.keep.append(rd)
+                    self._pending_reduce = (ops, rd, w, wr, m)
+                else:
+                    self._emit(ops, self.lib.abc_wgrad_reduce, rd, w, writes=wr, meta=m)
         return "rowsum" if fused_rowsum else True
 
     def emit_wgrad_heads_batch(self, ops, items, what):
@@ -798,6 +830,7 @@ class Engine:
         self._build_heads(trunk)
         if self.train:
             self._build_backward()
+            self._flush_reduce(self.bwd_ops)
         self._finish_build()
 
     def _finish_build(self):
@@ -1036,7 +1069,7 @@ class Engine:
         if defer:
             ca, cb, cc = (self.new((C_,), torch.float32) for _ in range(3))
             f.mean, f.ca, f.cb, f.cc = rec.mean.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
-        self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
+        self._emit_bn_bwd(ops, f, "bn_bwd " + rec.bname, (rec.bname + ".weight", rec.bname + ".bias"))
         a = L.BnApplyDesc()
         a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = g.data_ptr(), C_, rec.y.data_ptr(), rec.ld, rec.coff
         a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
@@ -1426,7 +1459,7 @@ class Engine:
         f.gamma, f.invstd = self.P(rec.bname + ".weight"), rec.invstd.data_ptr()
         f.dgamma, f.dbeta = self.G(rec.bname + ".weight"), self.G(rec.bname + ".bias")
         f.k1, f.k2, f.gscale = k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
-        self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
+        self._emit_bn_bwd(ops, f, "bn_bwd " + rec.bname, (rec.bname + ".weight", rec.bname + ".bias"))
         a = L.BnApplyDesc()
         a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = gptr, ld_g, rec.y.data_ptr(), rec.ld, rec.coff
         a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()
@@ -1534,6 +1567,7 @@ class Engine:
         self._build_heads(trunk)
         if self.train:
             self._build_backward2()
+            self._flush_reduce(self.bwd_ops)
         self._finish_build()
 
     def _build_backward2(self):
@@ -1658,7 +1692,7 @@ class Engine:
         if defer:
             ca, cb, cc = (self.new((C_,), torch.float32) for _ in range(3))
             f.mean, f.ca, f.cb, f.cc = rec.mean.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr()
-        self._emit(ops, self.lib.abc_bn_finalize_bwd, f, "bn_bwd " + rec.bname, writes=(rec.bname + ".weight", rec.bname + ".bias"))
+        self._emit_bn_bwd(ops, f, "bn_bwd " + rec.bname, (rec.bname + ".weight", rec.bname + ".bias"))
         a = L.BnApplyDesc()
         a.g, a.ld_g, a.y_raw, a.ld_y, a.cy_off = gbuf.data_ptr(), C_, rec.y.data_ptr(), rec.ld, rec.coff
         a.mean, a.invstd, a.k1, a.k2, a.gscale = rec.mean.data_ptr(), rec.invstd.data_ptr(), k1.data_ptr(), k2.data_ptr(), gs.data_ptr()

@@ -21,7 +21,7 @@ from .ops import FusedAdam, FusedHeadsLoss, FusedLoss, FusedMetrics
 class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
                  process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True, keep_logits=True,
-                 batched_heads=True, exchange="rs_ag", force_exchange=False, guards=False, actbwd_epilogue=True):
+                 batched_heads=True, exchange="rs_ag", force_exchange=False, guards=False, actbwd_epilogue=True, merge_reduce=True):
         """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
         mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
         as DDP does; "lazy" (default): right before they are read (state_dict(), sync_buffers()), which is observably the
@@ -30,6 +30,7 @@ class Trainer:
         (`eng.logits` is stale) -- the loss and every gradient are unchanged.
         batched_heads=False: one launch per head (the plain form the batched / merged heads launches are tested against).
         actbwd_epilogue=False: every act_bwd pass as a launch of its own (Engine(actbwd_epilogue=...)).
+        merge_reduce=False: every slab reduction and BatchNorm-backward finaliser as a launch of its own (Engine(merge_reduce=...)).
         exchange: how a gradient bucket is summed over the ranks -- "rs_ag" (reduce-scatter + all-gather in place on the
         arena), "direct" (all-to-all + local sum + all-gather), "all_reduce"; see distributed.GradReducer.
         force_exchange: segment the plan and run the bucket exchanges although the group has one rank (testing RCCL's launch
@@ -59,7 +60,7 @@ class Trainer:
             # (fused_heads: the heads' 1x1 convolutions, the loss and the way back as one pass where the engine can -- bf16)
             # (guards: the debug plan -- every buffer between guard bands, Engine.check_guards())
             self.eng = model._engine_for(x0, True, fused_heads=fused_heads, batched_heads=batched_heads, guards=guards,
-                                         actbwd_epilogue=actbwd_epilogue)
+                                         actbwd_epilogue=actbwd_epilogue, merge_reduce=merge_reduce)
         eng = self.eng
         h, w = eng.h, eng.w
         B = batch

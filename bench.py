@@ -151,6 +151,8 @@ def main():
                     "--metrics (Trainer(keep_logits=False)); NOT the default -- the headline line stores them as the reference does")
     ap.add_argument("--no-actbwd-epilogue", action="store_true", help="(train) every act_bwd pass as a launch of its own "
                     "(Trainer(actbwd_epilogue=False)): the A/B of the fused data-gradient epilogue, not the default")
+    ap.add_argument("--no-merge-reduce", action="store_true", help="(train) slab reductions and BatchNorm-backward finalisers as launches of "
+                    "their own (Trainer(merge_reduce=False)): the A/B of the merged launch, not the default")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -217,7 +219,7 @@ def main():
         tr.load_batch(imgs.to(dev))
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits,
-                     actbwd_epilogue=not a.no_actbwd_epilogue)
+                     actbwd_epilogue=not a.no_actbwd_epilogue, merge_reduce=not a.no_merge_reduce)
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
         tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
         if a.raster:

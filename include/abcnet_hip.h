@@ -322,6 +322,9 @@ typedef struct abc_wgrad_reduce_desc {
 /* the heads' 1x1 weight gradients of all heads in one launch (each descriptor with its own partial / rowsum slabs) */
 int abc_wgrad_heads_batch(const abc_wgrad_desc* descs, int32_t n, abc_stream_t stream);
 int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t stream);
+/* abc_wgrad_reduce(r) and abc_bn_finalize_bwd(f) of two DIFFERENT layers as one launch (both inputs complete, neither reads the other's
+ * output): in the backward chain the finaliser is a dependent ~5 us launch and the slab reduction of the layer above is independent of it */
+int abc_wgrad_reduce_bn_bwd(const abc_wgrad_reduce_desc* r, const abc_bn_bwd_desc* f, abc_stream_t stream);
 /* up to 16 (small) reductions in one launch; results bit-identical to abc_wgrad_reduce item by item */
 int abc_wgrad_reduce_batch(const abc_wgrad_reduce_desc* descs, int32_t n, abc_stream_t stream);
 

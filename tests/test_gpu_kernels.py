@@ -871,3 +871,38 @@ def test_conv_transpose_phases_as_one_launch(lib, B, H, W, Cin, Chalf):
     y = y[:, :, y.shape[2] - Hs:, y.shape[3] - Ws:]
     assert U.relerr(one[..., Chalf:].float().cpu().permute(0, 3, 1, 2), y) < 3e-2
     assert float(one[..., :Chalf].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Ca,Cb,ntaps,nsplit,C_,nblk", [(128, 128, 9, 128, 128, 768), (64, 32, 9, 33, 64, 2304), (16, 16, 9, 256, 16, 512), (256, 128, 4, 17, 256, 48)])
+def test_slab_reduction_and_bn_finaliser_as_one_launch(lib, Ca, Cb, ntaps, nsplit, C_, nblk):
+    """abc_wgrad_reduce_bn_bwd == abc_wgrad_reduce + abc_bn_finalize_bwd of two unrelated layers, bit for bit (vector and scalar reduction
+    forms, and the small-output form that is launched on its own)"""
+    g = torch.Generator().manual_seed(9)
+    ca_pad, cb_pad = -(-Ca // 32) * 32, -(-Cb // 32) * 32
+    part = torch.randn((nsplit, ntaps, ca_pad, cb_pad), generator=g).to(U.DEV)
+    bnp = (torch.randn((nblk, 2, C_), generator=g) * 2).to(U.DEV)
+    f32 = lambda n, v=0.0: torch.full((n,), v, dtype=torch.float32, device=U.DEV)
+    gamma, invstd, mean = (torch.rand(C_, generator=g) + 0.5).to(U.DEV), (torch.rand(C_, generator=g) + 0.5).to(U.DEV), torch.randn(C_, generator=g).to(U.DEV)
+
+    def descs():
+        dw = torch.zeros((Ca, Cb, ntaps), dtype=torch.float32, device=U.DEV)
+        r = L.WgradReduceDesc()
+        r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), nsplit, ntaps, Ca, Cb, ca_pad, cb_pad, dw.data_ptr(), 0
+        outs = [f32(C_) for _ in range(8)]
+        f = L.BnBwdDesc()
+        f.partial, f.nblk, f.C, f.count, f.gamma, f.invstd, f.mean = bnp.data_ptr(), nblk, C_, float(nblk * 37), gamma.data_ptr(), invstd.data_ptr(), mean.data_ptr()
+        f.dgamma, f.dbeta, f.k1, f.k2, f.gscale, f.ca, f.cb, f.cc = (t.data_ptr() for t in outs)
+        return r, f, dw, outs
+
+    r1, f1, dw1, o1 = descs()
+    L.check(lib.abc_wgrad_reduce_bn_bwd(C.byref(r1), C.byref(f1), U.stream()), "reduce+bn_bwd")
+    r2, f2, dw2, o2 = descs()
+    L.check(lib.abc_wgrad_reduce(C.byref(r2), U.stream()), "reduce")
+    L.check(lib.abc_bn_finalize_bwd(C.byref(f2), U.stream()), "bn_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2) and float(dw1.abs().max()) > 0
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    assert float(o1[0].abs().max()) > 0 and float(o1[5].abs().max()) > 0
+    ref = part[:, :, :Ca, :Cb].double().sum(0).permute(1, 2, 0)
+    assert U.relerr(dw1.cpu(), ref.cpu()) < 1e-5
