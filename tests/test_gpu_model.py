@@ -621,6 +621,32 @@ def test_act_bwd_epilogue_step_equals_separate_passes(variant):
 
 
 @pytest.mark.parametrize("variant", ["unet", "unet2"])
+def test_merged_reduction_and_finaliser_launches_are_the_same_step(variant):
+    """Trainer(merge_reduce=True), the default: a layer's split-K slab reduction waits for the next BatchNorm-backward finaliser of the plan
+    and shares its launch (abc_wgrad_reduce_bn_bwd).  Same kernels' bodies on the same inputs, only grouped and ordered differently:
+    gradients, logits and loss equal those of the plan with separate launches BIT FOR BIT."""
+    from abcnet_amd.train import Trainer
+    B, S = 2, 128
+    x, tg = synthetic_images(B, S, seed=7), synthetic_targets(B, S // 4, seed=1)
+
+    def one_step(merge):
+        m = make_model(dtype="bf16", dropout_p=0.2, variant=variant)
+        tr = Trainer(m, B, S, S, lr=0.0, use_graph=False, merge_reduce=merge)
+        tr.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+        tr.step()
+        torch.cuda.synchronize()
+        return [t.clone() for t in tr.eng.logits], m._flat_grad.clone(), tr.loss_value()["total"], [op[2] for op in tr.eng.bwd_ops]
+
+    lg_m, g_m, loss_m, names_m = one_step(True)
+    lg_s, g_s, loss_s, names_s = one_step(False)
+    nm = sum(" reduce + bn_bwd " in n for n in names_m)
+    assert nm >= 15 and not any(" reduce + bn_bwd " in n for n in names_s) and len(names_s) == len(names_m) + nm, (nm, len(names_m), len(names_s))
+    assert torch.equal(g_m, g_s) and loss_m == loss_s
+    for a, b in zip(lg_m, lg_s):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant", ["unet", "unet2"])
 def test_fused_heads_step_equals_unfused_step(variant):
     """The Trainer's default bf16 step runs the heads' conv2 + loss + way back as ONE pass (csrc/heads_fused.hip).  Against
     the same step on the separate kernels (fused_heads=False): logits to f32 rounding order, the loss to the hardware
