@@ -245,6 +245,8 @@ SYMBOLS = {
     "abc_sizeof": (C.c_int, [C.c_int]),
     "abc_last_error": (C.c_char_p, []),
     "abc_version": (C.c_int, []),
+    "abc_set_reserved_cus": (C.c_int, [i32]),
+    "abc_get_reserved_cus": (C.c_int, []),
 }
 
 _lib = None

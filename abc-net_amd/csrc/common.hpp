@@ -127,6 +127,13 @@ __host__ inline uint32_t abc_drop_threshold(float p) {
     return (double)f < t ? f + 1u : f;
 }
 
+// Compute units left OUT of the persistent grids (abc_set_reserved_cus; process-wide, 0 by default).  Two 256-VGPR workgroups
+// per CU fill the register file of every SIMD, so a kernel of another stream -- RCCL's, during the data-parallel exchange --
+// cannot start on a CU before one of them ends; a persistent convolution workgroup lives for up to 12 tiles (~330 us).
+// A multiple of 4, so that n workgroups per CU stay a multiple of the 8 XCDs.
+inline int& abc_reserved_cus_ref() { static int v = 0; return v; }
+inline int abc_wg_slots(int per_cu) { return per_cu * (256 - abc_reserved_cus_ref()); }
+
 // XCD-aware, bijective block remap: blocks with equal (bid % 8) share an XCD (and
 // its L2) under round-robin placement, so give each such group a contiguous range of
 // logical ids.  Placement only affects speed, never results.

@@ -1031,9 +1031,9 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
             const double mfma_stage = (double)d->ntaps / ngroups * (CKB / 32) * tm * tnn * (csz == 2 ? 1 : 8);
             const double share = tiles > 256 ? 2.0 : 1.0;
             const double t_stage = fmax(0.47, 0.0168 * share * mfma_stage);
-            const double rounds = ceil((double)tiles / 512.0);
+            const double rounds = ceil((double)tiles / (double)abc_wg_slots(2));
             // (ties: the shape with more workgroups covers more CUs and wastes fewer rows)
-            const double cost = rounds * (nstages * t_stage + 12.0) - 1e-3 * (double)(tiles < 512 ? tiles : 512);
+            const double cost = rounds * (nstages * t_stage + 12.0) - 1e-3 * (double)(tiles < abc_wg_slots(2) ? tiles : abc_wg_slots(2));
             if (best < 0 || cost < best_cost) { best = mt; best_bn = bn; best_cost = cost; }
         }
     }
@@ -1108,7 +1108,8 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->ntiles = g->nbn * g->tiles_x * g->tiles_y * d->B;
     // persistent workgroups: three per CU with resident weights; two per CU (512 slots) on the weights-direct loop when
     // there are more tiles than slots (measured on one box, same run: 6144 tiles 482 -> 463 us, 5632 tiles 473 -> 448 us)
-    g->nwg = g->b_static ? (g->ntiles < 768 ? g->ntiles : 768) : ((g->wd && g->ntiles > 512 && !abc_knob("ABC_CONV_NOPERSIST")) ? 512 : g->ntiles);
+    const int slots3 = abc_wg_slots(3), slots2 = abc_wg_slots(2);      // (768 / 512 unless CUs are reserved, abc_set_reserved_cus)
+    g->nwg = g->b_static ? (g->ntiles < slots3 ? g->ntiles : slots3) : ((g->wd && g->ntiles > slots2 && !abc_knob("ABC_CONV_NOPERSIST")) ? slots2 : g->ntiles);
     if (d->heads_epi != nullptr) {
         // heads in the epilogue: the 192 x 128 weights-direct tile, finished input, every 128-channel block a head
         if (!(g->wd == 9 && g->BN == 128 && g->MT == 6) || d->src.scale != nullptr || !d->out_act || d->stats != nullptr || d->accumulate ||

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
 // geometry shared by the eligibility test, abc_conv_stat_blocks and the launch
 static void narrow_grid(const abc_conv_desc* d, int* nwg, int* tpw) {
     const int ntiles = abc_cdiv(d->Win, 16) * abc_cdiv(d->Hin, 8) * d->B;
-    int n = 256 * (d->ntaps == 9 ? 2 : 1);      // workgroups per CU: two (3x3), one (5x5: 128 KB of LDS)
+    int n = abc_wg_slots(d->ntaps == 9 ? 2 : 1);      // workgroups per CU: two (3x3), one (5x5: 128 KB of LDS)
     if (n * 4 > ntiles) n = abc_cdiv(ntiles, 4);
     *tpw = abc_cdiv(ntiles, n * 4);
     *nwg = abc_cdiv(ntiles, *tpw * 4);

@@ -32,7 +32,13 @@ int abc_check_launch(const char* what) {
     return ABC_OK;
 }
 extern "C" const char* abc_last_error(void) { return g_err; }
-extern "C" int abc_version(void) { return 100; }
+extern "C" int abc_version(void) { return 101; }
+extern "C" int abc_set_reserved_cus(int n) {
+    if (n < 0 || n > 128) return abc_fail(ABC_EINVAL, "abc_set_reserved_cus: 0 <= n <= 128");
+    abc_reserved_cus_ref() = (n + 3) & ~3;
+    return ABC_OK;
+}
+extern "C" int abc_get_reserved_cus(void) { return abc_reserved_cus_ref(); }
 
 namespace {
 

@@ -126,6 +126,26 @@ def reduce_mean(t, world):
     return r / world
 
 
+def reduce_meters(totals, group=None):
+    """The cross-rank half of the periodic eval pass (multi_gpu_train.py:280-302: `barrier()` + eleven `reduce_mean` calls on
+    eleven scalars) as ONE all-reduce.  totals: [n, 2] float64, this rank's (sum, count) per meter (AverageMeter's fields,
+    meter.py:12-16).  Returns (global_totals [n, 2] = sums over the ranks -- the meter over ALL test images --, rank_mean [n] =
+    mean over the ranks of each rank's own average, which is what the reference prints: multi_gpu_train.py:280-302 averages the
+    per-rank averages, equal to the global one only when every rank's counts are equal; ranks whose count is 0 are left out).
+    Device-agnostic (CPU tensors over gloo in the tests); a COLLECTIVE when world > 1."""
+    t = totals.to(torch.float64)
+    valid = (t[:, 1] != 0).to(torch.float64)
+    avg = torch.where(t[:, 1] != 0, t[:, 0] / torch.where(t[:, 1] != 0, t[:, 1], torch.ones_like(t[:, 1])), torch.zeros_like(t[:, 0]))
+    n = t.shape[0]
+    pack = torch.cat([t.reshape(-1), avg, valid])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
+    glob = pack[:2 * n].reshape(n, 2)
+    nv = pack[3 * n:]
+    rank_mean = torch.where(nv > 0, pack[2 * n:3 * n] / torch.where(nv > 0, nv, torch.ones_like(nv)), torch.full_like(nv, float("nan")))
+    return glob, rank_mean
+
+
 def plan_buckets(ready, sizes, bucket_elems):
     """Split the flat arena [0, sum(sizes)) into contiguous buckets, walking from the END of the arena
     (gradients of the last-registered tensors, the heads, are produced first by backward).
@@ -232,19 +252,26 @@ class GradReducer:
         dist.all_gather_into_tensor(view, shard, group=self.group)
 
     def _self_check(self):
-        """the chosen mode against all_reduce on 64 x world elements; returns None or the reason for falling back"""
+        """the chosen mode against all_reduce, first on 64 x world elements (does the backend serve it at all?), then on
+        a scratch tensor of every DISTINCT REAL bucket size of the plan (the aliased in-place collectives at the sizes, shard
+        boundaries and padded tail they will run with; small-integer values, so that the sums are exact in any order and the
+        comparison is bit for bit); returns None or the reason for falling back"""
         w = self.world
+        sizes = [64 * w] + sorted(set(hi - lo for lo, hi, _ in self.buckets))
         try:
-            t = (torch.arange(64 * w, dtype=self.g.dtype, device=self.dev) % 7 + 1) * (self.rank + 1)
-            want = t.clone()
-            dist.all_reduce(want, op=dist.ReduceOp.SUM, group=self.group)
-            stage = torch.empty_like(t) if self.mode == "direct" else None
-            self._exchange(t, self.mode, stage)
-            ok = torch.tensor([1.0 if torch.equal(t, want) else 0.0], dtype=torch.float32, device=self.dev)
+            for n in sizes:
+                t = (torch.arange(n, dtype=torch.int64, device=self.dev) % 7 + 1).to(self.g.dtype) * (self.rank + 1)
+                want = t.clone()
+                dist.all_reduce(want, op=dist.ReduceOp.SUM, group=self.group)
+                stage = torch.empty_like(t) if self.mode == "direct" else None
+                self._exchange(t, self.mode, stage)
+                ok = torch.tensor([1.0 if torch.equal(t, want) else 0.0], dtype=torch.float32, device=self.dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+                if ok.item() != 1.0:
+                    return "self-check against all_reduce failed at %d elements" % n
         except (RuntimeError, NotImplementedError, ValueError) as e:  # the backend does not serve it: all ranks fail alike
             return "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:120])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
-        return None if ok.item() == 1.0 else "self-check against all_reduce failed"
+        return None
 
     def bucket_ready(self, lo, hi):
         if not self.active:

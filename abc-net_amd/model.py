@@ -80,7 +80,7 @@ class _UNetFn(torch.autograd.Function):
             eng.chan_scale.fill_(1.0)
             eng.run_backward(st)
             g = model._flat_grad.clone()
-        model._dp_busy = False      # (multi-device nn.DataParallel: this replica's engine is free again)
+        model._dp_release()         # (multi-device nn.DataParallel: this replica's engine is free again)
         return (None, None) + tuple(g[off:off + cnt].view(shape) for off, cnt, shape in model._param_slices)
 
 
@@ -289,7 +289,8 @@ class UNetBase(nn.Module):
         B, Cc, H, W = x.shape
         if Cc != self.n_channels:
             raise ValueError("expected %d input channels, got %d" % (self.n_channels, Cc))
-        key = (B, H, W, bool(train), self.compute_dtype, self.dropout_seed, bool(fold_bn), bool(fused_heads), bool(batched_heads), bool(fp8), bool(guards), bool(heads_epilogue), bool(actbwd_epilogue), bool(merge_reduce))
+        key = (B, H, W, bool(train), self.compute_dtype, self.dropout_seed, bool(fold_bn), bool(fused_heads), bool(batched_heads), bool(fp8), bool(guards), bool(heads_epilogue), bool(actbwd_epilogue), bool(merge_reduce),
+               L.load().abc_get_reserved_cus())     # (grid sizes and statistics rows follow abc_set_reserved_cus)
         eng = self._engines.get(key)
         if eng is None or eng.params.data_ptr() != self._flat.data_ptr():
             if self._flat_grad is None or self._flat_grad.device != x.device:
@@ -331,6 +332,18 @@ class UNetBase(nn.Module):
             else:
                 cnts.append(mod._buffers[attr])
         return params, bufs, cnts
+
+    def _dp_release(self, token=None):
+        """give an engine owner back (token: only if it is still checked out by THAT forward -- a stale finaliser must not
+        free a later checkout)"""
+        lock = getattr(self, "_dp_lock", None)
+        if lock is None:
+            self._dp_busy = False
+            return
+        with lock:
+            if token is None or getattr(self, "_dp_token", None) is token:
+                self._dp_busy = False
+                self._dp_token = None
 
     def _dp_checkout(self, master, dev):
         """an engine owner for one replica's forward (+ backward): the master itself for the first replica on its device,
@@ -379,17 +392,27 @@ class UNetBase(nn.Module):
             owner.train(self.training)
             with torch.cuda.device(dev):
                 if torch.is_grad_enabled() and self.training:
-                    return list(_UNetFn.apply(owner, x, *params))      # (backward releases the owner)
+                    outs = list(_UNetFn.apply(owner, x, *params))      # (backward releases the owner ...)
+                    # ... and so does the END OF THE GRAPH'S LIFE: a forward whose graph is dropped without a backward (an
+                    # exception in the loss, a loss only inspected) would otherwise keep its owner checked out for ever -- the
+                    # master's running statistics would silently stop updating, the fifth such forward per device raise
+                    token = owner._dp_token = object()
+                    node = outs[0].grad_fn
+                    if node is not None:
+                        weakref.finalize(node, owner._dp_release, token)
+                    else:
+                        owner._dp_release()
+                    return outs
                 eng = owner._engine_for(x, self.training)
                 st = torch.cuda.current_stream().cuda_stream
                 owner._load_image(eng, x)
                 eng.run_pack(st)
                 eng.run_forward(st)
                 outs = owner._export_logits(eng, st)
-            owner._dp_busy = False
+            owner._dp_release()
             return list(outs)
         except Exception:
-            owner._dp_busy = False
+            owner._dp_release()
             raise
 
     def forward(self, x):

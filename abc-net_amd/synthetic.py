@@ -124,3 +124,121 @@ def random_annotations(n_atoms, n_bonds, seed, size=512):
         bonds.append("%d:%d,%d,%d,%d,%d,%d" % (int(rng.choice([1, 2, 3, 4, 7])), x, y, dx, dy, int(rng.choice([0, 0, 1, 5, 6])),
                                                 int(rng.choice([0, 1]))))
     return ";".join(atoms) + ";", ";".join(bonds) + ";"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Drawn molecules: images whose ink DEPENDS on the annotations (the Bernoulli images above carry no information about the
+# targets, so nothing can be learnt from them).  Used to train a network for a few hundred steps on the device: trained
+# weights are what an accuracy statement about the bf16 / fp8 inference graphs has to be measured on (at random
+# initialisation a BatchNorm + ReLU network amplifies any perturbation by ~1.2x per layer -- 1e-3 relative weight noise moves
+# the output maps by 8 % of their spread -- so there every reduced-precision arithmetic, the reference's own autocast run
+# included, looks 20 % wrong).
+
+_ELEMS = ['C', 'N', 'O', 'P', 'F', 'Cl', 'S', 'Br', 'B', 'Se', 'I', 'H', 'Si']
+
+
+def _glyphs():
+    """one fixed 9 x 9 binary glyph per element (seeded; denser than a line so that the network can tell them apart)"""
+    rng = np.random.RandomState(20240923)
+    g = (rng.rand(len(_ELEMS), 9, 9) < 0.55).astype(np.float32)
+    g[:, 0, :] = g[:, -1, :] = g[:, :, 0] = g[:, :, -1] = 0
+    return g
+
+
+_GLYPHS = _glyphs()
+
+
+def _stamp(img, x, y, r):
+    img[max(x - r, 0):x + r + 1, max(y - r, 0):y + r + 1] = 1.0
+
+
+def _line(img, p, q, width=1, taper=None, dash=False):
+    """ink along p -> q (row, col); width = half-width in pixels; taper: half-width grows from 0 to `taper` (a wedge)"""
+    n = int(max(abs(q[0] - p[0]), abs(q[1] - p[1])) * 2) + 2
+    t = np.linspace(0.0, 1.0, n)
+    xs = np.rint(p[0] + (q[0] - p[0]) * t).astype(int)
+    ys = np.rint(p[1] + (q[1] - p[1]) * t).astype(int)
+    S = img.shape[0]
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        if dash and (i // 6) % 2:
+            continue
+        if 0 <= x < S and 0 <= y < S:
+            _stamp(img, x, y, int(round(taper * t[i])) if taper is not None else width)
+
+
+def drawn_molecules(batch, size, seed, n_atoms=(8, 22), margin=20, min_dist=30, max_bond=96):
+    """seeded line drawings + their annotation strings in the reference's format (utils.py:94-163: atoms
+    "El:x,y,charge[,hs];", bonds "order:x,y,dx,dy,stereo,direction;" with (x, y) the bond centre and (dx, dy) the half
+    vector; x indexes rows).  Returns (images f32 [B,1,S,S] in {0,1}, ink = 1; list of (atoms_string, bonds_string))."""
+    rng = np.random.RandomState(seed)
+    imgs = np.zeros((batch, 1, size, size), dtype=np.float32)
+    notes = []
+    for b in range(batch):
+        img = imgs[b, 0]
+        want = int(rng.randint(n_atoms[0], n_atoms[1] + 1))
+        pts = []
+        for _ in range(want * 30):
+            if len(pts) == want:
+                break
+            c = rng.randint(margin, size - margin, size=2)
+            c = (c // 4) * 4 + 2          # cell centres: the 1/4-resolution target cell is unambiguous
+            if all((c[0] - p[0]) ** 2 + (c[1] - p[1]) ** 2 >= min_dist ** 2 for p in pts):
+                pts.append((int(c[0]), int(c[1])))
+        n = len(pts)
+        P = np.array(pts)
+        # bonds: every atom to its (up to) two nearest neighbours within max_bond pixels, whose midpoint cell is free
+        pairs = set()
+        d2 = ((P[:, None, :] - P[None, :, :]) ** 2).sum(-1)
+        for i in range(n):
+            for j in np.argsort(d2[i])[1:3]:
+                if d2[i, j] <= max_bond ** 2:
+                    pairs.add((min(i, int(j)), max(i, int(j))))
+        bonds = []
+        for (i, j) in sorted(pairs):
+            a, c = P[i], P[j]
+            order = int(rng.choice([1, 1, 1, 2, 2, 3, 4]))
+            stereo = int(rng.choice([0, 0, 0, 0, 1, 6])) if order == 1 else 0
+            direction = int(rng.randint(0, 2))
+            mid = (a + c) // 2
+            half = (c - a) // 2
+            if half[0] == 0 and half[1] == 0:
+                continue
+            u = np.array([-(c - a)[1], (c - a)[0]], dtype=np.float64)
+            u /= np.linalg.norm(u) + 1e-9
+            if stereo in (1, 6):
+                p, q = (a, c) if direction == 0 else (c, a)
+                _line(img, p, q, taper=4, dash=(stereo == 6))
+            elif order == 1:
+                _line(img, a, c)
+            elif order == 2:
+                _line(img, a + 3 * u, c + 3 * u)
+                _line(img, a - 3 * u, c - 3 * u)
+            elif order == 3:
+                _line(img, a, c)
+                _line(img, a + 5 * u, c + 5 * u)
+                _line(img, a - 5 * u, c - 5 * u)
+            else:                      # aromatic: a full and a dashed line
+                _line(img, a + 3 * u, c + 3 * u)
+                _line(img, a - 3 * u, c - 3 * u, dash=True)
+            bonds.append("%d:%d,%d,%d,%d,%d,%d" % (order, mid[0], mid[1], half[0], half[1], stereo, direction))
+        atoms = []
+        for (x, y) in pts:
+            e = int(rng.choice(len(_ELEMS), p=[0.5] + [0.5 / (len(_ELEMS) - 1)] * (len(_ELEMS) - 1)))
+            charge = int(rng.choice([0, 0, 0, 0, 1, -1]))
+            hs = int(rng.choice([-1, 0, 0, 1]))
+            if e != 0 or charge != 0:      # a hetero atom or a charged carbon: clear the junction, draw the glyph
+                img[x - 7:x + 8, y - 7:y + 8] = 0.0
+                img[x - 4:x + 5, y - 4:y + 5] = _GLYPHS[e]
+                if charge == 1:
+                    img[x - 7, y + 5:y + 8] = 1.0
+                    img[x - 8:x - 5, y + 6] = 1.0
+                elif charge == -1:
+                    img[x - 7, y + 5:y + 8] = 1.0
+                if hs == 1:
+                    img[x + 6:x + 8, y - 1:y + 2] = 1.0
+            s = "%s:%d,%d,%d" % (_ELEMS[e], x, y, charge)
+            if hs >= 0:
+                s += ",%d" % hs
+            atoms.append(s)
+        notes.append((";".join(atoms) + ";", ";".join(bonds) + ";" if bonds else ""))
+    return torch.from_numpy(imgs), notes

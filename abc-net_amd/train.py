@@ -21,18 +21,27 @@ from .ops import FusedAdam, FusedHeadsLoss, FusedLoss, FusedMetrics
 class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
                  process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True, keep_logits=True,
-                 batched_heads=True, exchange="rs_ag", force_exchange=False, guards=False, actbwd_epilogue=True, merge_reduce=True):
+                 batched_heads=True, exchange="all_reduce", force_exchange=False, guards=False, actbwd_epilogue=True, merge_reduce=True,
+                 reserve_cus=0):
         """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
         mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
-        as DDP does; "lazy" (default): right before they are read (state_dict(), sync_buffers()), which is observably the
-        same because train-mode arithmetic never reads them; False: never (each rank keeps its own shard's statistics).
+        as DDP does; "lazy" (default): when sync_buffers() is called -- evaluate() calls it; before a checkpoint of a rank
+        other than 0 or an eval forward outside evaluate() the caller does (state_dict() itself performs NO collective:
+        rank 0 saves alone as the reference does, any other rank raises until sync_buffers() has run since the last step)
+        -- which is observably the same because train-mode arithmetic never reads the buffers; False: never (each rank keeps
+        its own shard's statistics).
         keep_logits=False (fused heads only, ignored with metrics=True): the eight output maps are not stored by the step
         (`eng.logits` is stale) -- the loss and every gradient are unchanged.
         batched_heads=False: one launch per head (the plain form the batched / merged heads launches are tested against).
         actbwd_epilogue=False: every act_bwd pass as a launch of its own (Engine(actbwd_epilogue=...)).
         merge_reduce=False: every slab reduction and BatchNorm-backward finaliser as a launch of its own (Engine(merge_reduce=...)).
-        exchange: how a gradient bucket is summed over the ranks -- "rs_ag" (reduce-scatter + all-gather in place on the
-        arena), "direct" (all-to-all + local sum + all-gather), "all_reduce"; see distributed.GradReducer.
+        exchange: how a gradient bucket is summed over the ranks -- "all_reduce" (default: one RCCL all-reduce per bucket,
+        RCCL picks the algorithm), "rs_ag" (reduce-scatter + all-gather in place on the arena), "direct" (all-to-all + local
+        sum + all-gather); see distributed.GradReducer.  The two alternatives are self-checked against all_reduce on scratch
+        tensors of the plan's real bucket sizes when the reducer is built and fall back (reducer.fallback_reason) -- neither
+        has run at world > 1 on RCCL hardware yet, which is why they are not the default.
+        reserve_cus: leave this many CUs out of the persistent convolution grids so that RCCL's kernels can start beside
+        them (abc_set_reserved_cus: PROCESS-wide, applied before the plan is built; 0 = the single-GPU grids).
         force_exchange: segment the plan and run the bucket exchanges although the group has one rank (testing RCCL's launch
         mechanics between graph segments on a one-GPU box)."""
         if not torch.cuda.is_available():
@@ -55,6 +64,8 @@ class Trainer:
         # single-process stream)
         model.dropout_seed = D.rank_dropout_seed(model.dropout_seed_base, self.rank)
         model.train()
+        self.reserve_cus = int(reserve_cus)
+        L.check(L.load().abc_set_reserved_cus(self.reserve_cus), "set_reserved_cus")
         with torch.cuda.device(dev):
             x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
             # (fused_heads: the heads' 1x1 convolutions, the loss and the way back as one pass where the engine can -- bf16)
@@ -224,6 +235,46 @@ class Trainer:
     def loss_value(self):
         return self.loss.result()
 
+    # ------------------------------------------------------------------ periodic evaluation
+    def evaluate(self, batches, fold_bn=None):
+        """The eval pass the reference runs every 100 steps (train.py:217-433; multi_gpu_train.py:121-316 per rank):
+        `model.eval()` forward over this rank's test batches with the 17 meters of train.py:335-393 (the same arithmetic as the
+        training meters, csrc/metrics.hip) accumulated on the device, then the cross-rank reduction of multi_gpu_train.py:
+        280-302 as one collective (distributed.reduce_meters).  batches: iterable of (imgs [B,C,H,W], the 8 target maps) of the
+        Trainer's batch shape, host or device tensors.  The training plan, its graphs and the optimiser are untouched; the eval
+        engine reads the CURRENT weights and -- as every DDP rank does, broadcast_buffers -- rank 0's running statistics
+        (sync_buffers(): a COLLECTIVE when world > 1, so every rank has to call evaluate(), as every rank runs the reference's
+        eval loop).  One host sync at the end.  Returns {meter: {"sum", "count", "avg": over all ranks' images,
+        "rank_mean": the reference's mean of per-rank averages}}."""
+        from .ops import METER_NAMES
+        model, eng_t = self.model, self.eng
+        with torch.cuda.device(self.dev):
+            if self.world > 1 and self.broadcast_buffers:
+                self.sync_buffers()
+            if getattr(self, "_eval", None) is None:
+                x0 = torch.zeros_like(eng_t.img).reshape(eng_t.B, model.n_channels, eng_t.H, eng_t.W)
+                fold = (model.VARIANT == "unet") if fold_bn is None else bool(fold_bn)
+                eng = model._engine_for(x0, False, fold_bn=fold)
+                tg = [torch.zeros_like(t) for t in self.targets]
+                self._eval = (eng, tg, FusedMetrics(eng.logits, tg))
+            eng, tg, meters = self._eval
+            st = torch.cuda.current_stream().cuda_stream
+            meters.reset()
+            eng.run_pack(st)                    # the weights moved since the last call: re-pack (and re-fold BatchNorm) once
+            for imgs, targets in batches:
+                eng.img.copy_(imgs.reshape(eng.img.shape), non_blocking=True)
+                for dst, src in zip(tg, targets):
+                    dst.copy_(src, non_blocking=True)
+                eng.run_forward(st)
+                meters.run(st)
+            glob, rank_mean = D.reduce_meters(meters.totals, self.group)
+            glob, rank_mean = glob.cpu(), rank_mean.cpu()
+        out = {}
+        for i, n in enumerate(METER_NAMES):
+            s, c = glob[i, 0].item(), glob[i, 1].item()
+            out[n] = {"sum": s, "count": c, "avg": s / c if c else float("nan"), "rank_mean": rank_mean[i].item()}
+        return out
+
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self):
         """everything a bit-exact resume needs: the model in the REFERENCE's state_dict layout (loads into
@@ -258,6 +309,8 @@ class Trainer:
         salt = (int(sd["drop_salt"].item()) + delta) & 0xFFFFFFFF
         self.eng.drop_salt.fill_(salt - (1 << 32) if salt >= (1 << 31) else salt)
         self.steps = max(self.steps, 1) if self._graphs is not None else self.steps
+        # a checkpoint's buffers are the ones DDP would hold (rank 0's): a resume on all ranks leaves every rank in sync
+        self._buffers_synced_at = self.steps
         if self.metrics is not None and "meters" in sd:
             self.metrics.totals.copy_(sd["meters"])
 

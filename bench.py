@@ -153,6 +153,13 @@ def main():
                     "(Trainer(actbwd_epilogue=False)): the A/B of the fused data-gradient epilogue, not the default")
     ap.add_argument("--no-merge-reduce", action="store_true", help="(train) slab reductions and BatchNorm-backward finalisers as launches of "
                     "their own (Trainer(merge_reduce=False)): the A/B of the merged launch, not the default")
+    ap.add_argument("--exchange", default=None, choices=["all_reduce", "rs_ag", "direct"],
+                    help="(train, N > 1) how a gradient bucket is summed over the ranks (Trainer(exchange=...)); default all_reduce.  "
+                         "A mode asked for here that the run fell back from is an ERROR, not a silent substitution")
+    ap.add_argument("--bucket-mb", type=float, default=8.0, help="(train, N > 1) gradient bucket size in MB of f32 (Trainer(bucket_mb=...))")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="(N > 1) leave this many of the 256 CUs out of the persistent convolution "
+                    "grids (2 workgroups per CU x 256 VGPRs fill a SIMD's register file: a communication kernel cannot co-reside with "
+                    "them), so that RCCL's kernels start at once instead of behind a draining workgroup (abc_set_reserved_cus)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -219,7 +226,10 @@ def main():
         tr.load_batch(imgs.to(dev))
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits,
-                     actbwd_epilogue=not a.no_actbwd_epilogue, merge_reduce=not a.no_merge_reduce)
+                     actbwd_epilogue=not a.no_actbwd_epilogue, merge_reduce=not a.no_merge_reduce, bucket_mb=a.bucket_mb,
+                     exchange=a.exchange or "all_reduce", reserve_cus=a.reserve_cus)
+        if world > 1 and a.exchange is not None and tr.reducer.mode != a.exchange:
+            raise SystemExit("bench.py --exchange %s: the reducer runs %r (%s)" % (a.exchange, tr.reducer.mode, tr.reducer.fallback_reason))
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)
         tr.load_batch(imgs.to(dev), [t.to(dev) for t in tgs])
         if a.raster:
@@ -258,15 +268,16 @@ def main():
     # what makes a multi-GPU line checkable from the line alone: who joined, on which device, over which backend and
     # exchange, and that the replicas hold identical parameters after the averaged updates (after the clock stopped)
     chk = model._flat.double().sum().item()
-    me = {"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(), "param_checksum": chk}
+    import socket
+    me = {"rank": rank, "device": torch.cuda.current_device(), "host": socket.gethostname(), "name": torch.cuda.get_device_name(), "param_checksum": chk}
     ranks = [me]
     if world > 1:
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
         if a.mode == "train" and not all(r["param_checksum"] == ranks[0]["param_checksum"] for r in ranks):
             raise SystemExit("replicas diverged: parameter checksums %s" % [r["param_checksum"] for r in ranks])
-        if backend == "nccl" and len(set(r["device"] for r in ranks)) != world:
-            raise SystemExit("ranks share a GPU: devices %s" % [r["device"] for r in ranks])
+        if backend == "nccl" and len(set((r["host"], r["device"]) for r in ranks)) != world:     # (local indices repeat across nodes)
+            raise SystemExit("ranks share a GPU: (host, device) %s" % [(r["host"], r["device"]) for r in ranks])
 
     if a.mode == "train":
         metric = "training images/sec (%dx%d, b%d/GPU)" % (a.size, a.size, a.batch)
@@ -279,7 +290,9 @@ def main():
         "n_gpus": world, "ranks_joined": dist.get_world_size() if world > 1 else 1, "backend": backend,
         "rank_devices": [r["device"] for r in ranks], "replica_checksum": ranks[0]["param_checksum"],
         "exchange": (tr.reducer.mode if (a.mode == "train" and world > 1) else None),
-        "exchange_fallback": (tr.reducer.fallback_reason if (a.mode == "train" and world > 1) else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
+        "exchange_fallback": (tr.reducer.fallback_reason if (a.mode == "train" and world > 1) else None),
+        "bucket_mb": (a.bucket_mb if (a.mode == "train" and world > 1) else None), "n_buckets": (len(tr.buckets) if (a.mode == "train" and world > 1) else None),
+        "reserved_cus": a.reserve_cus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),

@@ -36,4 +36,15 @@ for f in conv_igemm conv_fast conv_narrow stem heads heads_fused wgrad bn_act lo
 done
 for p in $pids; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+# The gfx950 store-data hazard (a >8-byte buffer store WITH a scalar offset register, then a VALU write to its
+# data registers within two instructions -- outside LLVM's hazard recogniser; the kernels keep the data registers live past such
+# stores by hand): disassemble every code object of the library just built and fail the build on a hit.
+if [ -z "$ABC_SKIP_HAZARD_SCAN" ]; then
+  SCAN=$(mktemp -d)
+  cp $OUT $SCAN/lib.so
+  /opt/rocm/lib/llvm/bin/llvm-objdump --offloading $SCAN/lib.so > /dev/null
+  for co in $SCAN/lib.so.*gfx950; do /opt/rocm/lib/llvm/bin/llvm-objdump -d $co > $co.s; done
+  python3 ../../profiles/tools/store_hazard_scan.py --uncovered $SCAN/*.s || { echo "store-data hazard in the built library (see above)"; rm -rf $SCAN; rm -f $OUT; exit 1; }
+  rm -rf $SCAN
+fi
 echo "built $(readlink -f $OUT)"

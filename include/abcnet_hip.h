@@ -572,6 +572,12 @@ int abc_counter_add_u32(uint32_t* p, uint32_t inc, abc_stream_t stream);
 int abc_sizeof(int which);
 const char* abc_last_error(void);
 int abc_version(void);
+/* Leave `n` (rounded up to a multiple of 4; 0 <= n <= 128) of the 256 compute units out of the PERSISTENT convolution grids
+ * (the launches sized to 2 or 3 workgroups per CU): process-wide, read when a launch sizes its grid -- set it before a plan is
+ * built or captured.  For the data-parallel step (multi_gpu_train.py:44-53 / DDP's NCCL kernels beside backward): two 256-VGPR
+ * workgroups per CU leave no registers for a communication kernel, which would wait for a persistent workgroup to drain. */
+int abc_set_reserved_cus(int32_t n);
+int abc_get_reserved_cus(void);
 
 #ifdef __cplusplus
 }

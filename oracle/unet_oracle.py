@@ -168,6 +168,40 @@ def filled_state(variant: str, in_channels: int = 1, heads=None, seed: int = 0):
     return sd
 
 
+CALIB_STEPS, CALIB_SIZE, CALIB_BATCH, CALIB_SEED0 = 60, 256, 2, 1000
+
+
+def bn_stat_keys(sd):
+    return [k for k in sd if k.endswith(("running_mean", "running_var"))]
+
+
+def calibrated_state(variant: str, in_channels: int = 1, heads=None, seed: int = 0, steps: int = CALIB_STEPS,
+                     size: int = CALIB_SIZE, batch: int = CALIB_BATCH, stats=None):
+    """filled_state() whose BatchNorm running statistics MATCH its activations: the statistics the reference module
+    ends up with after `steps` train-mode forwards (nn.BatchNorm2d's own update, momentum 0.1, unet.py:13,16,67) over
+    seeded Bernoulli images (seed CALIB_SEED0 + i).  With the random running statistics of filled_state() the eval
+    forward collapses (atom map spanning 0.05); with these the eval maps have the range of the train-mode ones.
+    `stats` (a flat f32 vector in bn_stat_keys order, e.g. tests/golden/calibrated_*.npz: produced by the REFERENCE
+    import) is loaded instead of recomputed when given."""
+    sd = filled_state(variant, in_channels, heads, seed)
+    if stats is not None:
+        off = 0
+        flat = torch.as_tensor(stats, dtype=torch.float32)
+        for k in bn_stat_keys(sd):
+            n = sd[k].numel()
+            sd[k] = flat[off:off + n].clone()
+            off += n
+        assert off == flat.numel()
+        for k in sd:
+            if k.endswith("num_batches_tracked"):
+                sd[k] = torch.tensor(steps, dtype=torch.int64)
+        return sd
+    with torch.no_grad():
+        for i in range(steps):
+            forward(variant, sd, synthetic_image(batch, size, seed=CALIB_SEED0 + i, in_channels=in_channels), train=True)
+    return sd
+
+
 def synthetic_image(batch: int, size: int, seed: int = 7, in_channels: int = 1, p: float = 0.1):
     """Bernoulli(p) ink image in {0,1} f32 (contract of utils_for_test.py:26-39)."""
     g = torch.Generator().manual_seed(seed)

@@ -2,10 +2,16 @@
 """Scan device ISA (hipcc -S --cuda-device-only) for the store-data hazard seen on gfx950: a vector-memory store of
 more than 8 bytes whose data registers are written by a VALU instruction within the next WINDOW instructions.
 
-    python profiles/tools/store_hazard_scan.py file.s [...]
+    python profiles/tools/store_hazard_scan.py file.s [...]                 every store of 3+ dwords, window 2 (a report)
+    python profiles/tools/store_hazard_scan.py --uncovered file.s [...]     only the stores LLVM's hazard recogniser does NOT cover --
+                                                                            buffer stores WITH a scalar offset register -- and exit 1
+                                                                            on a hit: the check build_hip.sh runs on the disassembly
+                                                                            of the built library (llvm-objdump -d of every gfx950
+                                                                            code object in libabcnet_hip.so)
 
 Prints kernel, line, the store and the offending instruction.  (LLVM's hazard recogniser inserts the wait states for buffer stores
-WITHOUT a scalar offset register only; this scan looks at every buffer / global / flat / scratch store of 3+ dwords.)"""
+WITHOUT a scalar offset register and for global / flat / scratch stores; the report mode looks at every store of 3+ dwords anyway.)
+Accepts compiler output (hipcc -S) and llvm-objdump disassembly alike."""
 import re
 import sys
 
@@ -40,7 +46,23 @@ def dst_regs(line):
     return regs(parts[1].split(",")[0])
 
 
+def uncovered(op, args):
+    """a buffer store whose soffset operand is an SGPR (vdata, vaddr, srsrc, soffset [modifiers])"""
+    if not op.startswith("buffer_store"):
+        return False
+    a = [t.strip() for t in args.split("//")[0].split(";")[0].split(",")]
+    # srsrc is the s[..:..] quad; soffset is the operand after it
+    for i, t in enumerate(a):
+        if t.startswith("s[") and i + 1 < len(a):
+            so = a[i + 1].split()[0]
+            return bool(re.match(r"s\d+$|m0$", so))
+    return False
+
+
 def main(paths):
+    only_uncovered = False
+    if paths and paths[0] == "--uncovered":
+        only_uncovered, paths = True, paths[1:]
     total = 0
     for p in paths:
         kern = "?"
@@ -56,6 +78,8 @@ def main(paths):
             m = ST.match(l)
             if not m:
                 continue
+            if only_uncovered and not uncovered(m.group(1), m.group(2)):
+                continue
             d = data_regs(m.group(1), m.group(2))
             for q in range(1, WINDOW + 1):
                 if j + q >= len(code):
@@ -68,8 +92,9 @@ def main(paths):
                     total += 1
                     print("%s:%d  %s\n    %s\n    -> +%d %s   (v%s)" % (p, ln, k[:90], l.strip(), q, nl.strip(), sorted(hit)))
                     break
-    print("%d suspicious sites" % total)
+    print("%d suspicious sites%s" % (total, " (stores outside LLVM's hazard recogniser)" if only_uncovered else ""))
+    return 1 if (only_uncovered and total) else 0
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    sys.exit(main(sys.argv[1:]))

@@ -23,6 +23,11 @@ from abcnet_amd.train import Trainer  # noqa: E402
 HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
 
 
+def _eval_batches(rank, batch, size):
+    """two test batches of rank `rank`: images + targets + logits-independent (the meters compare predictions with targets)"""
+    return [(synthetic_images(batch, size, seed=300 + 10 * rank + j), synthetic_targets(batch, size // 4, seed=400 + 10 * rank + j)) for j in range(2)]
+
+
 def main():
     out, variant, dtype, size, batch, steps, bucket_mb = sys.argv[1:8]
     size, batch, steps, bucket_mb = int(size), int(batch), int(steps), float(bucket_mb)
@@ -80,6 +85,12 @@ def main():
     res["buffers_ckpt"] = torch.cat([ck["model"][k].reshape(-1).float().cpu() for k in ck["model"] if "running_" in k])
     res["nbt_ckpt"] = int(ck["model"]["inc1.double_conv.1.num_batches_tracked"])
     res["adam_m"] = tr.opt.m.cpu().clone()
+    # the periodic eval pass (train.py:217-433 per rank, multi_gpu_train.py:280-302 across ranks): this rank's two test batches
+    ev = tr.evaluate(_eval_batches(rank, batch, size))
+    res["eval"] = ev
+    tr.step()                                        # the training plan / graphs survive an eval pass
+    torch.cuda.synchronize()
+    res["loss_after_eval"] = tr.loss_value()["total"]
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

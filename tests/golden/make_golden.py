@@ -23,6 +23,9 @@ What is produced (all float32 unless noted):
   adam.npz                 one torch.optim.Adam step (train.py:55 settings)
   shapes_unet.npz          unet.py at an input size that is not a multiple of 32 (72x88, 104x40) and with 3 input channels:
                            head-map samples / statistics (eval, train) and gradient norms under a surrogate loss
+  calibrated_<variant>.npz BatchNorm running statistics after CALIB_STEPS train-mode forwards of the reference module (statistics that
+                           match the activations: the eval maps then have their train-mode range), eval head maps with them at 64x64
+                           (full) and for two images of the 512x512 benchmark batch (samples, statistics, NMS decisions)
   meta.json                state_dict key/shape lists, parameter counts
 """
 import json
@@ -339,6 +342,49 @@ def adam_goldens():
     print("wrote adam")
 
 
+def calibrated_goldens(variant):
+    """BatchNorm running statistics that MATCH the activations, made by the reference module itself: `CALIB_STEPS` train-mode
+    forwards of mod.UNet over seeded images (nn.BatchNorm2d's own momentum update), then eval head maps with those
+    statistics: full at 2x1x64x64, and for images 0 and 21 of the 64x1x512x512 benchmark batch (config 5) strided samples,
+    statistics and the NMS decisions of img2smiles2.py:61-79 (bit-packed)."""
+    mod = ref_module(variant)
+    sd = uo.filled_state(variant, 1, HEADS, seed=0)
+    m = mod.UNet(1, HEADS)
+    m.load_state_dict(sd, strict=True)
+    for om in m.out_modules:
+        if hasattr(om, "drop"):
+            om.drop.p = 0.0
+    m.train()
+    with torch.no_grad():
+        for i in range(uo.CALIB_STEPS):
+            m(synthetic_images(uo.CALIB_BATCH, uo.CALIB_SIZE, seed=uo.CALIB_SEED0 + i))
+    msd = m.state_dict()
+    res = {"bn_stats": torch.cat([msd[k].reshape(-1) for k in uo.bn_stat_keys(msd)]).numpy(),
+           "calib": np.array([uo.CALIB_STEPS, uo.CALIB_SIZE, uo.CALIB_BATCH, uo.CALIB_SEED0]),
+           "nbt": np.array(msd["inc1.double_conv.1.num_batches_tracked"].item())}
+    m.eval()
+    with torch.no_grad():
+        ys = m(synthetic_images(2, 64, seed=7))
+        for i, y in enumerate(ys):
+            res["eval64_head%d" % i] = y.numpy()
+        x = synthetic_images(64, 512, seed=7)[[0, 21]]
+        ys = m(x)
+    for i, y in enumerate(ys):
+        res["eval512_head%d_sample" % i] = sample(y, 4099)
+        res["eval512_head%d_stats" % i] = np.array([y.min().item(), y.max().item(), y.double().mean().item(), y.double().norm().item()])
+    ns = {"torch": torch, "atom_targets_pred": ys[0], "bond_targets_pred": ys[4], "bond_rhos_pred": ys[6], "bond_types_pred": ys[5],
+          "bond_omega_types_pred": ys[7]}
+    exec(slice_text(os.path.join(REF, "img2smiles2.py"), 61, 79), ns)
+    res["nms512_atom"] = np.packbits(ns["atom_targets_pred"].numpy().astype(np.uint8))
+    res["nms512_bond"] = np.packbits(ns["bond_targets_pred"].numpy().astype(np.uint8))
+    res["nms512_omega"] = np.packbits(ns["bond_omega_types_pred2"].numpy().astype(np.uint8))
+    res["nms512_counts"] = np.array([ns["atom_targets_pred"].sum().item(), ns["bond_targets_pred"].sum().item(),
+                                     ns["bond_omega_types_pred2"].sum().item()])
+    np.savez_compressed(os.path.join(HERE, "calibrated_%s.npz" % variant), **res)
+    print("wrote calibrated", variant, res["nms512_counts"],
+          [(float(res["eval512_head%d_stats" % i][0]), float(res["eval512_head%d_stats" % i][1])) for i in range(8)])
+
+
 def meta():
     out = {}
     for variant in ("unet", "unet2"):
@@ -357,6 +403,10 @@ def meta():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "calibrated":
+        for v in ("unet", "unet2"):
+            calibrated_goldens(v)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("metrics", "decode", "raster", "shapes"):   # (added after the other fixtures: regenerate one alone)
         {"metrics": metrics_goldens, "decode": decode_goldens, "raster": raster_goldens, "shapes": shape_goldens}[sys.argv[1]]()
         sys.exit(0)
@@ -371,3 +421,4 @@ if __name__ == "__main__":
     for v in ("unet", "unet2"):
         model_goldens(v)
         grad_goldens(v)
+        calibrated_goldens(v)

@@ -35,20 +35,20 @@ def main():
     tg = [t.to(dev) for t in synthetic_targets(batch, size // 4, seed=1)]
     res = {"backend": dist.get_backend()}
 
-    def run(**kw):
+    def run(x=x, tg=tg, batch=batch, size=size, timed=5, bucket_mb=4.0, **kw):
         m = UNet(1, HEADS, dtype="bf16")
         m.reset_parameters(seed=1)
         m = m.to(dev)
-        tr = Trainer(m, batch, size, size, use_graph=True, bucket_mb=4.0, **kw)
+        tr = Trainer(m, batch, size, size, use_graph=True, bucket_mb=bucket_mb, **kw)
         tr.load_batch(x, tg)
         for _ in range(steps):
             tr.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(timed):
             tr.step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 5 * 1e3
+        ms = (time.perf_counter() - t0) / timed * 1e3
         return m._flat.clone(), tr, ms
 
     p_plain, tr0, ms0 = run()
@@ -58,6 +58,20 @@ def main():
         res[mode] = {"used": tr.reducer.mode, "fallback": tr.reducer.fallback_reason, "buckets": len(tr.buckets),
                      "segments": len(tr._segments), "graphs": tr._graphs is not None, "ms_per_step": ms,
                      "identical_to_plain": bool(torch.equal(p, p_plain))}
+    # what the exchange machinery costs at the BENCHMARK workload (b16 @ 384 x 384, 8 MB buckets) when there is nothing to exchange:
+    # graph segmentation, RCCL launches on the communication stream, event joins
+    del tr0, tr
+    torch.cuda.empty_cache()
+    xb = synthetic_images(16, 384, seed=7).to(dev)
+    tgb = [t.to(dev) for t in synthetic_targets(16, 96, seed=1)]
+    bench = {}
+    for mode in (None,) + tuple(D.GradReducer.MODES):
+        kw = {} if mode is None else {"exchange": mode, "force_exchange": True}
+        _p, trb, ms = run(x=xb, tg=tgb, batch=16, size=384, timed=20, bucket_mb=8.0, **kw)
+        bench["plain" if mode is None else mode] = {"ms_per_step": ms, "segments": len(trb._segments), "buckets": len(trb.buckets)}
+        del trb, _p
+        torch.cuda.empty_cache()
+    res["bench_b16_384"] = bench
     with open(out, "w") as f:
         json.dump(res, f)
     dist.destroy_process_group()

@@ -203,7 +203,10 @@ def _ddp_worker(rank, world, port, q):
     D.broadcast_parameters(p)
     # scalar loss for logging (multi_gpu_train.py:116)
     lm = D.reduce_mean(torch.tensor([float(rank + 1)]), world)
-    q.put((rank, torch.allclose(g, want, atol=1e-6), p.sum().item(), lm.item(), modes, ab, pad))
+    # the eval pass's meters over the ranks (multi_gpu_train.py:280-302) as one collective
+    tot = torch.tensor([[3.0 + rank, 4.0], [1.0, 2.0 + 2 * rank], [0.0, 0.0], [5.0 * rank, 1.0 * rank]], dtype=torch.float64)
+    glob, rmean = D.reduce_meters(tot)
+    q.put((rank, torch.allclose(g, want, atol=1e-6), p.sum().item(), lm.item(), modes, ab, pad, glob.tolist(), rmean.tolist()))
     dist.destroy_process_group()
 
 
@@ -234,6 +237,13 @@ def test_gloo_world2_bucketed_allreduce_and_broadcast():
             assert used == mode or why is not None, (mode, used, why)
         assert modes["all_reduce"][0] == "all_reduce"
     print("exchange modes used over gloo:", {m: v[:2] for m, v in res[0][4].items()})
+    # reduce_meters: sums over the ranks, and the reference's mean of per-rank averages (a rank with count 0 left out; a meter
+    # nobody counted is nan), identical on both ranks
+    for r in res:
+        glob, rmean = r[7], r[8]
+        assert glob == [[7.0, 8.0], [2.0, 6.0], [0.0, 0.0], [5.0, 1.0]]
+        assert abs(rmean[0] - (3 / 4 + 4 / 4) / 2) < 1e-12 and abs(rmean[1] - (1 / 2 + 1 / 4) / 2) < 1e-12
+        assert rmean[2] != rmean[2] and rmean[3] == 5.0
 
 
 def test_align_buckets_ready_is_max_over_overlapped_tensors():

@@ -135,6 +135,15 @@ def _dgrad_ref(rec, dX):
     return dX * f.permute(0, 3, 1, 2)
 
 
+def _forward_link(rec, rep, sd, tag, Y):
+    """the FORWARD launch of the layer in situ: the raw (pre-BatchNorm) tensor the training-forward kernel stored -- transform of
+    the producer's BatchNorm + activation on load, persistent multi-tile workgroups, 768 / 6144 tiles at this size -- against
+    conv2d of the engine's OWN activated input and the bf16 weights, + bias; one bf16 rounding of the output (2e-3 relative)"""
+    y = nchw(rec.y[..., rec.coff:rec.coff + rec.cout])
+    ref = Y.detach() + sd[rec.cname + ".bias"].float().reshape(1, -1, 1, 1)
+    rep.close(tag + " forward (y_raw)", y, ref, 4e-3, 1.2e-2)
+
+
 def _conv_links(rec, m, rep, sd):
     """g -> BatchNorm backward -> dY; then conv2d's adjoints by torch autograd on (activated input, bf16 weights, dY)"""
     tag = rec.cname
@@ -142,7 +151,9 @@ def _conv_links(rec, m, rep, sd):
     X = _r(_activated(rec.src)).requires_grad_(True)
     W = _r(sd[rec.cname + ".weight"]).requires_grad_(True)
     k = W.shape[-1]
-    F.conv2d(X, W, padding=(k - 1) // 2).backward(_r(dY))
+    Y = F.conv2d(X, W, padding=(k - 1) // 2)
+    _forward_link(rec, rep, sd, tag, Y)
+    Y.backward(_r(dY))
     rep.close(tag + " wgrad", m.grad_of(rec.cname + ".weight"), W.grad, 5e-3)
     if getattr(rec, "dsrc", None) is not None:
         rep.close(tag + _dgrad_tag(rec), nchw(rec.dsrc), _dgrad_ref(rec, X.grad), 5e-3)
@@ -310,7 +321,9 @@ def _conv2_links(eng, rec, m, rep, sd):
     X = _r(_activated(rec.src)).requires_grad_(True)
     W = _r(sd[rec.cname + ".weight"]).requires_grad_(True)
     k = W.shape[-1]
-    F.conv2d(X, W, padding=(k - 1) // 2).backward(_r(dY))
+    Y = F.conv2d(X, W, padding=(k - 1) // 2)
+    _forward_link(rec, rep, sd, tag, Y)
+    Y.backward(_r(dY))
     rep.close(tag + " wgrad", m.grad_of(rec.cname + ".weight"), W.grad, 5e-3)
     if getattr(rec, "dsrc", None) is None:
         return

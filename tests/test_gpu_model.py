@@ -924,3 +924,23 @@ def test_multi_replica_dataparallel_matches_per_chunk_oracle():
     re = uo.forward("unet", sde, x, train=False)
     assert max((a.cpu() - b).abs().max().item() for a, b in zip(ye, re)) < 1e-3
     assert int(sde["inc1.double_conv.1.num_batches_tracked"]) == 1
+
+
+def test_dataparallel_forward_without_backward_returns_its_engine():
+    """a train-mode forward under nn.DataParallel whose graph is dropped without a backward (an exception in the loss, a loss
+    that is only looked at) gives its engine owner back when the graph dies: six such forwards in a row work (five leaked
+    checkouts per device used to raise), the master keeps updating ITS running statistics, nothing stays checked out"""
+    import gc
+    B, S = 4, 64
+    x = synthetic_images(B, S, seed=7).to(DEV)
+    m = make_model(dropout_p=0.0)
+    dp = torch.nn.DataParallel(m, device_ids=[0, 0])
+    m.train()
+    for i in range(6):
+        ys = dp(x)
+        _ = float(ys[0].mean())     # inspected, never back-propagated
+        del ys
+        gc.collect()
+        assert not m._dp_busy, i
+    assert int(m.state_dict()["inc1.double_conv.1.num_batches_tracked"]) == 6
+    assert all(not s._dp_busy for pool in m._dp_shadows.values() for s in pool) and len(m._dp_shadows[torch.device("cuda", 0)]) == 1

@@ -1,0 +1,143 @@
+"""Config 5 (img2smiles2.py:42-79 + 113-191) on TRAINED weights -- the accuracy statement about the bf16 and fp8 (e4m3) inference
+graphs that can fail.
+
+A unet.py is trained on the device for TRAIN_STEPS steps on drawn molecules (tests/trained_fixture.py: deterministic), which
+gives what the path serves in practice: peaked atom / bond heat maps, heavy-tailed activations for the per-tensor e4m3
+calibration to cope with, and -- unlike any random-weight network, tests/test_gpu_calibrated.py -- a function that does not
+amplify a 1e-3 perturbation eighty-fold.  Then, at the benchmarked size (b64 @ 512 x 512) and against the fp32 oracle on the
+host (bit-equal to the reference, tests/test_oracle_golden.py) with the SAME trained weights:
+
+  * every head's logits relative to the head's range;
+  * NMS decisions and the extracted candidate lists (atoms: position, type, charge, hs; bonds: position, omega bin, type, rho) as
+    missed + spurious (+ wrong class) out of the oracle's, under hard ceilings (tests/golden/trained_deviation.json);
+  * the same with ONE 128-channel convolution 5 % off in the device model must break the ceilings.
+"""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import abcnet_amd  # noqa: E402,F401
+from abcnet_amd.synthetic import drawn_molecules  # noqa: E402
+import infer_accuracy as IA  # noqa: E402
+import trained_fixture as TF  # noqa: E402
+
+HEADS = TF.HEADS
+DEV = "cuda"
+BOUNDS = os.path.join(HERE, "golden", "trained_deviation.json")
+TRAIN_STEPS = 1500
+SAMPLE = (0, 21, 42, 63)
+_CACHE = {}
+
+
+def _trained():
+    """(device model, true state on the CPU, eval images, oracle maps of the sampled images, training info): once per session"""
+    if "m" not in _CACHE:
+        m, sd, info = TF.train_unet(steps=TRAIN_STEPS, log=lambda s: print(s, file=sys.stderr, flush=True))
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
+        x, _notes = drawn_molecules(64, 512, seed=777)
+        _CACHE.update(m=m, sd=sd_cpu, x=x, oracle=IA.oracle_maps(sd_cpu, x[list(SAMPLE)]), info=info)
+    c = _CACHE
+    return c["m"], c["sd"], c["x"], c["oracle"], c["info"]
+
+
+def _perturbed(sd, name, factor):
+    from abcnet_amd.unet import UNet
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2[name] = sd2[name] * factor
+    m = UNet(1, HEADS, dtype="bf16", dropout_p=0.2)
+    m.load_state_dict(sd2)
+    return m.to(DEV).eval()
+
+
+def measure(fp8=False, perturb=None, fold_bn=True):
+    m, sd, x, oracle, _info = _trained()
+    dev_model = m if perturb is None else _perturbed(sd, *perturb)
+    res = IA.measure(dev_model, x, SAMPLE, oracle, fp8=fp8, fold_bn=fold_bn, extract=True)
+    res["perturb"] = list(perturb) if perturb else None
+    return res
+
+
+CHECKED = ("worst_linf_over_range", "worst_rms_over_std")
+
+
+def _violations(got, ceil):
+    bad = [(k, got[k], ceil[k]) for k in CHECKED if got[k] > ceil[k]]
+    for k in ("atom", "bond", "omega"):
+        if got[k + "_peaks"]["rate"] > ceil[k + "_peak_rate"]:
+            bad.append((k + "_peak_rate", got[k + "_peaks"]["rate"], ceil[k + "_peak_rate"]))
+    for k in ("atoms_rate", "bonds_rate"):
+        if got["candidates"][k] > ceil["candidate_" + k]:
+            bad.append(("candidate_" + k, got["candidates"][k], ceil["candidate_" + k]))
+    return bad
+
+
+def _bounds():
+    with open(BOUNDS) as f:
+        return json.load(f)
+
+
+def test_training_on_drawn_molecules_learns():
+    """the fixture is what it claims to be: the loss fell, the network finds the atoms and bonds of unseen drawings"""
+    _m, _sd, _x, (ref, (ra, rb, _rr, _ro)), info = _trained()
+    first, last = info["loss"][0][1], info["loss"][-1][1]
+    assert last < 0.2 * first, info["loss"]
+    mt = info["meters"]
+    assert mt["atom_targets_recall"] > 0.9 and mt["atom_targets_precision"] > 0.9, mt
+    # peaked maps: tens of atom peaks per 128 x 128 map, not thousands
+    n = int(ra.sum().item()) / len(SAMPLE)
+    assert 4 <= n <= 60, n
+
+
+@pytest.mark.parametrize("key", ["bf16", "fp8"])
+def test_inference_accuracy_on_trained_weights(key):
+    ceil = _bounds()["ceilings"][key]
+    got = measure(fp8=(key == "fp8"))
+    print("trained %s: %s" % (key, json.dumps({k: got[k] for k in CHECKED + ("atom_peaks", "bond_peaks", "omega_peaks", "candidates")})), file=sys.stderr)
+    assert got["nms_on_device_logits_exact"], "device NMS != oracle NMS on the device's own logits"
+    assert got["candidates"]["truncated"] == 0
+    bad = _violations(got, ceil)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("key", ["bf16", "fp8"])
+def test_a_five_percent_error_in_one_conv_is_caught(key):
+    """one 128-channel convolution's weights 5 % off in the DEVICE model (the trunk's dconv1; the bond-type head's conv1) must
+    violate the ceilings the intact graph meets"""
+    ceil = _bounds()["ceilings"][key]
+    for name in ("dconv1.double_conv.0.weight", "out_modules.5.conv1.weight"):
+        got = measure(fp8=(key == "fp8"), perturb=(name, 1.05))
+        assert _violations(got, ceil), ("a 5 %% error in %s passes the %s ceilings" % (name, key), {k: got[k] for k in CHECKED}, got["candidates"])
+
+
+if __name__ == "__main__":
+    if "--measure" in sys.argv:
+        import time
+        if "--steps" in sys.argv:
+            TRAIN_STEPS = int(sys.argv[sys.argv.index("--steps") + 1])
+        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(HERE)), "gpurun_out", "trained_measured_%d.json" % TRAIN_STEPS)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        res = {"train_steps": TRAIN_STEPS}
+        t0 = time.time()
+        info = _trained()[4]
+        res["info"] = {"loss": info["loss"], "meters": info["meters"], "train_s": info["train_s"], "gen_s": info["gen_s"]}
+        print("trained in %.1f s" % (time.time() - t0), json.dumps(res["info"]), flush=True)
+        for key, kw in (("bf16", {}), ("fp8", {"fp8": True}), ("bf16_unfolded", {"fold_bn": False}),
+                        ("bf16_trunk_x1.05", {"perturb": ("dconv1.double_conv.0.weight", 1.05)}),
+                        ("fp8_trunk_x1.05", {"fp8": True, "perturb": ("dconv1.double_conv.0.weight", 1.05)}),
+                        ("bf16_head5_x1.05", {"perturb": ("out_modules.5.conv1.weight", 1.05)}),
+                        ("fp8_head5_x1.05", {"fp8": True, "perturb": ("out_modules.5.conv1.weight", 1.05)}),
+                        ("bf16_trunk_x1.01", {"perturb": ("dconv1.double_conv.0.weight", 1.01)})):
+            t0 = time.time()
+            res[key] = measure(**kw)
+            print(key, "%.1f s" % (time.time() - t0), json.dumps(res[key]), flush=True)
+            with open(out, "w") as f:
+                json.dump(res, f, indent=1)

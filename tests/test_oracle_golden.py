@@ -243,3 +243,36 @@ def test_general_shapes_match_reference(tag, cin, H, W, golden_dir):
                 ref_n = gold["%s_gnorm/%s" % (tag, k)].item()
                 assert abs(g.double().norm().item() - ref_n) <= 1e-4 * ref_n + 1e-9, k
                 np.testing.assert_allclose(g.reshape(-1)[:64].double().numpy(), gold["%s_ghead/%s" % (tag, k)], rtol=2e-3, atol=1e-6 * ref_n + 1e-9)
+
+
+@pytest.mark.parametrize("variant", ["unet", "unet2"])
+def test_calibrated_statistics_and_eval_maps_match_reference(variant, golden_dir):
+    """tests/golden/calibrated_*.npz (reference module: 60 train-mode forwards fill its BatchNorm running statistics, then
+    eval maps): the oracle's own calibration run reproduces the reference's statistics bit for bit, and its eval forward on
+    them reproduces the stored maps (64 x 64 full; two 512 x 512 images of config 5's batch: samples, norms, NMS decisions)."""
+    gold = np.load(os.path.join(golden_dir, "calibrated_%s.npz" % variant))
+    assert list(gold["calib"]) == [uo.CALIB_STEPS, uo.CALIB_SIZE, uo.CALIB_BATCH, uo.CALIB_SEED0]
+    sd = uo.calibrated_state(variant, 1, HEADS, seed=0)
+    mine = torch.cat([sd[k].reshape(-1) for k in uo.bn_stat_keys(sd)]).numpy()
+    assert np.array_equal(mine, gold["bn_stats"]), float(np.abs(mine - gold["bn_stats"]).max())
+    assert int(sd["inc1.double_conv.1.num_batches_tracked"]) == int(gold["nbt"])
+    # (the short cut the GPU tests take: statistics loaded from the fixture)
+    sd2 = uo.calibrated_state(variant, 1, HEADS, seed=0, stats=gold["bn_stats"])
+    for k in sd:
+        assert torch.equal(sd[k], sd2[k]), k
+    with torch.no_grad():
+        ys = uo.forward(variant, sd, synthetic_images(2, 64, seed=7), train=False)
+        for i, y in enumerate(ys):
+            np.testing.assert_allclose(y.numpy(), gold["eval64_head%d" % i], rtol=0, atol=2e-6)
+        ys = uo.forward(variant, sd, synthetic_images(64, 512, seed=7)[[0, 21]], train=False)
+    for i, y in enumerate(ys):
+        np.testing.assert_allclose(_sample(y, 4099), gold["eval512_head%d_sample" % i], rtol=0, atol=1e-5)
+        st = gold["eval512_head%d_stats" % i]
+        assert abs(y.double().norm().item() - st[3]) <= 1e-5 * st[3]
+        # the point of the fixture: eval maps with a real range (filled_state's atom map spans 0.05)
+        assert st[1] - st[0] > 1.5, (i, st)
+    am, bm, _r, omm = nms_oracle.nms(ys[0], ys[4], ys[6], ys[7])
+    for name, m in (("atom", am), ("bond", bm), ("omega", omm)):
+        got = np.packbits(m.numpy().astype(np.uint8))
+        # NMS decisions are discontinuous: a 1e-6 difference in summation order may flip a tie; none seen, allow 2 per map
+        assert int(np.unpackbits(got ^ gold["nms512_" + name]).sum()) <= 2, name
