@@ -471,7 +471,10 @@ class Engine:
                 "flops": 2.0 * self.B * gh * gw * Ca * Cb * len(taps),
                 # both operands once, the split-K slabs this launch writes, and (DUAL) the y_raw it reads + the dY it writes
                 "bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt)
-                               + need * 4 + (2 * self.B * gh * gw * Ca * self._esz(self.dt) if dual is not None else 0))}
+                               + need * 4 + (2 * self.B * gh * gw * Ca * self._esz(self.dt) if dual is not None else 0)),
+                # the OPERANDS alone: dY + X read once, dW written once (what a weight gradient has to move whatever its algorithm)
+                "operand_bytes": float(self.B * gh * gw * Ca * self._esz(p.dt) + self.B * qh * qw * (4 if q.pool else 1) * Cb * self._esz(q.dt)
+                                       + Ca * Cb * len(taps) * 4)}
         post = []
         if collect is None:
             self._flush_reduce(ops)      # (the previous layer's slabs sit in the workspace this launch overwrites)

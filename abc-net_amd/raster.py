@@ -110,6 +110,11 @@ class TargetRasterizer:
         """records = list of B (atoms, bonds, rho) triples from parse_record; async H2D of a few KB"""
         if len(records) != self.B:
             raise ValueError("expected %d records" % self.B)
+        # the pinned staging buffers are reused: the previous load's asynchronous copies must have left them before they are
+        # overwritten (a loop that never syncs runs many steps ahead of the device -- the maps would be rasterised from a
+        # LATER batch's records)
+        if getattr(self, "_copied", None) is not None:
+            self._copied.synchronize()
         for b, (a, q, r) in enumerate(records):
             if len(a) > self.max_atoms or len(q) > self.max_bonds:
                 raise ValueError("record %d has %d atoms / %d bonds (capacity %d / %d)" % (b, len(a), len(q), self.max_atoms, self.max_bonds))
@@ -123,6 +128,8 @@ class TargetRasterizer:
         self.d_bonds.copy_(self.h_bonds, non_blocking=True)
         self.d_rho.copy_(self.h_rho, non_blocking=True)
         self.d_cnt.copy_(self.h_cnt, non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record(torch.cuda.current_stream(self.d_cnt.device))
 
     def run(self, stream=None):
         if stream is None:

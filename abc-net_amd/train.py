@@ -346,21 +346,24 @@ class Trainer:
                     e1.record(stream)
                     if rc != 0:
                         L.check(rc, what)
-                    marks.append((meta["kernel"] + " | " + what if by_op else meta["kernel"], meta["flops"], meta["bytes"], e0, e1))
+                    marks.append((meta["kernel"] + " | " + what if by_op else meta["kernel"], meta["flops"], meta["bytes"], e0, e1,
+                                  meta.get("operand_bytes", meta["bytes"])))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             self.opt.step(st)
             e1.record(stream)
             marks.append(("adam", 0.0, float(self.model._flat.numel() * 28), e0, e1))
             torch.cuda.synchronize()
-            for k, fl, by, a, b in marks:
-                r = acc.setdefault(k, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for mk in marks:
+                k, fl, by, a, b = mk[:5]
+                r = acc.setdefault(k, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "operand_bytes": 0.0})
                 r["calls"] += 1
                 r["ms"] += a.elapsed_time(b)
                 r["flops"] += fl
                 r["bytes"] += by
+                r["operand_bytes"] += mk[5] if len(mk) > 5 else by
         for r in acc.values():
-            for f in ("calls", "ms", "flops", "bytes"):
+            for f in ("calls", "ms", "flops", "bytes", "operand_bytes"):
                 r[f] /= iters
         self.steps += iters
         return acc

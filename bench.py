@@ -330,7 +330,7 @@ def main():
             # (a mixed graph: the dominant kernel is priced against the peak of ITS operand type)
             peak = MFMA_PEAK["fp8" if "<fp8,fp8," in dom else ("bf16" if a.dtype == "fp8" else a.dtype)]
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom, a.mode, a.variant),
+                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom, "infer8" if (a.mode == "infer" and a.dtype == "fp8") else a.mode, a.variant),
                                "algorithmic_mb_per_launch": round(r["bytes"] / r["calls"] / 1e6, 2),
                                "launches_per_step": r["calls"], "avg_launch_us": round(1000 * r["ms"] / r["calls"], 2),
                                "algorithmic_gflop_per_launch": round(r["flops"] / r["calls"] / 1e9, 3)}
@@ -342,6 +342,7 @@ def main():
                 out["kernel_calls"] = {k: v["calls"] for k, v in prof.items()}
                 # per launch: algorithmic GFLOP and MB of every kernel label (the plan's own accounting; profiles/ joins it
                 # with the PMC bytes)
+                out["kernel_operand_mb"] = {k: round(v.get("operand_bytes", v["bytes"]) / max(v["calls"], 1) / 1e6, 2) for k, v in prof.items()}
                 out["kernel_algorithmic"] = {k: [round(v["flops"] / max(v["calls"], 1) / 1e9, 3), round(v["bytes"] / max(v["calls"], 1) / 1e6, 2)]
                                              for k, v in prof.items()}
             out["eager_step_ms_sum_of_kernels"] = round(tot, 3)

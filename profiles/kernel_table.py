@@ -20,6 +20,7 @@ that shape in the pass):
   mfma_util    SQ_VALU_MFMA_BUSY_CYCLES / (us x 2.4 GHz x 1024 SIMDs): the counter is in shader cycles summed over the SIMDs
                (= 32 per v_mfma_f32_32x32x16_bf16), so this is the fraction of the chip's matrix-pipe cycles at the NOMINAL clock
                that carried an MFMA = achieved / peak for bf16 (2.5 PFLOP/s dense = 1024 SIMDs x 1024 FLOP/clk x 2.4 GHz)
+  mfma_util_held  the same counter against the cycles at the clock the chip HELD (clk_ghz) instead of the nominal 2.4 GHz
   clk_ghz      GRBM_GUI_ACTIVE / 8 XCDs / duration of the SAME (profiled) pass: the clock the chip held (reads high below ~0.3 ms)
   wait/stall/active  SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY as fractions of SQ_WAVE_CYCLES
 """
@@ -200,6 +201,11 @@ def main():
                 gui, squs = mean("GRBM_GUI_ACTIVE"), mean("_sq_us")
                 if gui is not None and squs:
                     r["clk_ghz"] = round(gui / 8.0 / (squs * 1e-6) / 1e9, 3)
+                    # against the matrix-pipe cycles the chip actually offered at the clock it HELD during this launch (DVFS: the
+                    # long MFMA-dense launches hold 1.7-2.1 GHz): the utilisation a kernel change can still move.  Only where the
+                    # clock estimate is sane (short launches read high, see clk_ghz).
+                    if 1.2e9 <= r["clk_ghz"] * 1e9 <= 2.6e9:
+                        r["mfma_util_held"] = round(mf / (us * 1e-6 * r["clk_ghz"] * 1e9 * SIMDS), 4)
                 wc = mean("SQ_WAVE_CYCLES")
                 if wc:
                     for name, c in (("wait", "SQ_WAIT_ANY"), ("stall", "SQ_WAIT_INST_ANY"), ("active", "SQ_ACTIVE_INST_ANY")):
@@ -214,7 +220,7 @@ def main():
                               "within 15 % (one launch SHAPE); mfma_util is against the nominal 2.4 GHz x 1024 SIMD matrix-pipe cycles "
                               "(= fraction of the 2.5 PFLOP/s dense bf16 peak for bf16 MFMAs), hbm_frac against 8 TB/s"}, f, indent=1)
     top = int(opt.get("top", 48))
-    cols = ["kernel", "grid", "role", "launches_per_step", "us", "share", "hbm_mb", "hbm_gbs", "hbm_frac", "mfma_util", "clk_ghz", "wait", "stall", "active"]
+    cols = ["kernel", "grid", "role", "launches_per_step", "us", "share", "hbm_mb", "hbm_gbs", "hbm_frac", "mfma_util", "mfma_util_held", "clk_ghz", "wait", "stall", "active"]
     with open(prefix + ".md", "w") as f:
         f.write("| " + " | ".join(cols) + " |\n|" + "---|" * len(cols) + "\n")
         for r in rows[:top]:

@@ -30,13 +30,14 @@ def label_of(kernel):
 
 def main(tag):
     out = {}
-    for mode, variant, w in (("train", "unet", "unet"), ("train", "unet2", "unet2"), ("infer", "unet", "infer"), ("infer", "unet", "infer8")):
+    # (the fp8 graph keeps bf16 launches of the same instantiations as the bf16 graph: its own key space, "infer8:unet:...")
+    for mode, variant, w in (("train", "unet", "unet"), ("train", "unet2", "unet2"), ("infer", "unet", "infer"), ("infer8", "unet", "infer8")):
         tp = os.path.join(HERE, "%s_%s_kernel_table.json" % (tag, w))
         bp = os.path.join(HERE, "%s_%s_bench.json" % (tag, w))
         if not os.path.exists(tp):
             continue
         rows = json.load(open(tp))["rows"]
-        algo = {}
+        algo, pure = {}, {}
         if os.path.exists(bp):
             b = json.load(open(bp))
             calls = b.get("kernel_calls", {})
@@ -48,6 +49,12 @@ def main(tag):
                 f = fam.setdefault(k.replace("+act_bwd<", "<"), [0.0, 0.0, 0.0])
                 f[0] += n; f[1] += n * gf; f[2] += n * mb
             algo = {k: [f[1] / f[0], f[2] / f[0]] for k, f in fam.items() if f[0] > 0}
+            pf = {}
+            for k, mb in b.get("kernel_operand_mb", {}).items():
+                n = calls.get(k, 1.0)
+                f = pf.setdefault(k.replace("+act_bwd<", "<"), [0.0, 0.0])
+                f[0] += n; f[1] += n * mb
+            pure = {k: f[1] / f[0] for k, f in pf.items() if f[0] > 0}
         acc = {}
         for r in rows:
             lab = label_of(r["kernel"])
@@ -64,6 +71,11 @@ def main(tag):
                  "avg_launch_us": round(us / n, 2), "achieved_hbm_gbs": round(by / us / 1e3, 1),
                  "source": "profiles/%s_%s_kernel_table.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate --kernel-trace-only "
                            "passes; FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024; mean over every launch of the instantiation)" % (tag, w)}
+            if lab in pure:
+                # the OPERANDS alone (the plan's accounting also counts what the chosen algorithm adds: split-K slabs, y_raw / dY of the
+                # BatchNorm-fused weight gradient): bench.py `kernel_operand_mb`
+                e["operand_bytes_per_launch"] = int(pure[lab] * 1e6)
+                e["traffic_over_operands"] = round(by / n / (pure[lab] * 1e6), 3) if pure[lab] else None
             if lab in algo:
                 e["algorithmic_bytes_per_launch"] = int(algo[lab][1] * 1e6)
                 e["traffic_over_algorithmic"] = round(by / n / (algo[lab][1] * 1e6), 3) if algo[lab][1] else None

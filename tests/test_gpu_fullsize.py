@@ -224,8 +224,11 @@ def test_inference_at_benchmark_config(key):
     got = measure_infer(fp8=key.endswith("fp8"))
     assert got["nms_on_device_logits_exact"], "device NMS != oracle NMS on the device's own logits"
     assert got["logits_linf"] <= 1.5 * b["logits_linf"], (got["logits_linf"], b["logits_linf"])
-    for k in ("atom_mask_flips", "bond_mask_flips", "omega_mask_flips"):
-        assert got[k] <= 1.5 * b[k] + 8, (k, got[k], b[k])
+    # (no bound on the mask flips here any more: with filled_state()'s random running statistics the eval maps are almost
+    #  constant -- the atom map spans 0.05 -- a quarter of the pixels are "peaks" and the flip counts are noise.  The accuracy of
+    #  the bf16 / fp8 graphs is held on weights where it means something: tests/test_gpu_calibrated.py (reference-generated
+    #  statistics that match the activations) and tests/test_gpu_trained.py (a trained network: hard ceilings relative to each
+    #  head's range and to the oracle's peak / candidate lists, which a 5 % error in one convolution breaks))
 
 
 if __name__ == "__main__":

@@ -56,6 +56,12 @@ def train_unet(steps=3000, batch=16, size=384, lr=5e-4, lr_drop=(0.7, 1e-4), poo
         imgs.append(x)
         recs.append([parse_record(a, b, h=size // 4) for a, b in notes])
     imgs = torch.stack(imgs).to(DEV)
+    # the whole pool's records on the device (the loop below must not reuse pinned host staging without a sync)
+    drec = []
+    for p in range(pool):
+        rz.load(recs[p])
+        torch.cuda.synchronize()
+        drec.append((rz.d_atoms.clone(), rz.d_bonds.clone(), rz.d_rho.clone(), rz.d_cnt.clone()))
     info = {"gen_s": time.time() - t0, "loss": []}
     drop_at = int(lr_drop[0] * steps) if lr_drop else -1
     t0 = time.time()
@@ -64,23 +70,26 @@ def train_unet(steps=3000, batch=16, size=384, lr=5e-4, lr_drop=(0.7, 1e-4), poo
             tr.reset_optimizer(lr_drop[1])
         p = it % pool
         tr.eng.img.copy_(imgs[p].reshape(tr.eng.img.shape))
-        rz.load(recs[p])
+        for dst, src in zip((rz.d_atoms, rz.d_bonds, rz.d_rho, rz.d_cnt), drec[p]):
+            dst.copy_(src)
         rz.run()
         tr.step()
         if (it + 1) % log_every == 0 or it == 0:
             torch.cuda.synchronize()
             lv = tr.loss_value()
             info["loss"].append((it + 1, lv["total"]))
+            mt = tr.metrics.result()
             if log:
-                mt = tr.metrics.result()
                 log("   terms " + " ".join("%s %.3f" % (k, v) for k, v in lv.items() if k != "total"))
                 log("step %d loss %.4f  atom P/R %.3f/%.3f  bond P/R %.3f/%.3f  types acc %.3f  (%.1f s)" % (
                     it + 1, lv["total"], mt["atom_targets_precision"]["avg"], mt["atom_targets_recall"]["avg"],
                     mt["bond_targets_precision"]["avg"], mt["bond_targets_recall"]["avg"], mt["atom_types_acc"]["avg"], time.time() - t0))
-                tr.metrics.reset()
+            info["meters"] = {k: v["avg"] for k, v in mt.items()}      # (the meters over the last log_every steps)
+            tr.metrics.reset()
     torch.cuda.synchronize()
     info["train_s"] = time.time() - t0
-    info["meters"] = {k: v["avg"] for k, v in tr.metrics.result().items()}
+    if "meters" not in info:
+        info["meters"] = {k: v["avg"] for k, v in tr.metrics.result().items()}
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     del tr, rz
     torch.cuda.empty_cache()
