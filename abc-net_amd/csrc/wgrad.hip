@@ -277,10 +277,38 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
         if (it >= 0 && !(ABC_DBG(a.dbg) & 4)) {
             const char* sP = smem + ((a.nbuf == 2) ? (it & 1) * buf_bytes : 0);
             const char* sQ = sP + a.sP_bytes;
+            // ROT (stride 1, fully unrolled K-steps): tap (dy, dx) of patch row r reads the SAME fragment as tap (dy - 1, dx) of row
+            // r + 1 (same halo pixels, same lanes), so only the three fragments of the NEW halo row are read per K-step and the
+            // other six are carried in their registers: tap t of K-step rr lives in slot (t + 3 rr) mod 9.  4 instead of 10
+            // transposing LDS reads per K-step (SQ_WAIT_INST_LDS 7.9 M -> 2.6 M wave-cycles per launch; the launch itself gains 4 %:
+            // the LDS was not what bound the matrix phase -- profiles/r04_wgrad_pingpong.md).
+            constexpr bool ROT = SPREAD && STRIDE == 1;
+            bf16x8 fbr[9];
 #pragma unroll(SPREAD ? ROWS : 1)
             for (int rr = 0; rr < ROWS; ++rr) {
                 const int row = row_lo + rr;
-                if constexpr (sizeof(CT) == 2 && FAST && K3) {
+                if constexpr (sizeof(CT) == 2 && FAST && K3 && ROT) {
+                    constexpr int HW3 = 15 * STRIDE + 3;
+                    constexpr int PQ = CWQ == 32 ? 64 : (CWQ == 64 ? 192 : 320);
+                    constexpr int PP = CWP == 32 ? 64 : (CWP == 64 ? 192 : 320);
+                    const int kq = 8 * h + ((lane & 15) >> 2);
+                    const char* pa = sP + (row * 16 + kq) * PP + pch;
+                    const char* qb = sQ + (row * HW3 + kq) * PQ + qch;
+                    const bf16x8 fa = tr_read8(pa, pa + 4 * PP);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        if (rr == 0 || t >= 6) {
+                            const int off = ((t / 3) * HW3 + (t % 3)) * PQ;
+                            fbr[(t + 3 * rr) % 9] = tr_read8(qb + off, qb + off + 4 * PQ);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbr[(t + 3 * rr) % 9], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rr < NPH) fire_slice(rr);   // (unconditional: without a next patch the offsets are out of range)
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if constexpr (sizeof(CT) == 2 && FAST && K3) {
                     {
                         // the usual case, a full 3x3 tap square: tap offsets are immediates, all 10 fragments of the
                         // K-step are read first (one wait), then 9 MFMAs back to back; the generic loop below pays a

@@ -302,6 +302,20 @@ def main():
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }
 
+    if a.mode == "infer" and a.variant == "unet":
+        # what the reduced-precision graph costs in accuracy, measured on TRAINED weights (tests/test_gpu_trained.py): the e4m3 graph
+        # holds the peak decisions, not the maps -- a throughput line in fp8 is not a drop-in for the bf16 one
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "trained_deviation.json")) as f:
+                m = json.load(f)["measured"]["fp8" if a.dtype == "fp8" else "bf16"]
+            out["config"]["accuracy"] = {"source": "tests/golden/trained_deviation.json (device-trained unet.py, b64 @ 512x512, vs the fp32 oracle)",
+                                         "worst_head_rms_over_std": round(m["worst_rms_over_std"], 4),
+                                         "atom_peaks_missed_spurious_of": [m["atom_peaks"]["missed"], m["atom_peaks"]["spurious"], m["atom_peaks"]["oracle"]],
+                                         "omega_mask_rate": round(m["omega_peaks"]["rate"], 4),
+                                         "note": ("e4m3: decision-level accuracy only (atom / bond peaks and classes), the maps carry ~9 % rms noise"
+                                                  if a.dtype == "fp8" else "bf16: maps within 1 % rms of the fp32 oracle")}
+        except (OSError, KeyError, ValueError):
+            pass
     sr = SURVEY_ROOFLINE.get((a.mode, a.variant, a.size))
     if sr is not None and a.dtype in ("bf16", "fp8"):
         per_gpu = out["value"] / world
