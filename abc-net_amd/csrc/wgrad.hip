@@ -40,6 +40,9 @@ struct WgK {
     int cp_off, Ca, cq_off, Cb, Ca_pad, Cb_pad;
     int ntaps, tgw, nsplit, npatch, tiles_x, tiles_y;
     int dy_min, dx_min, HH, HW, PSWP, PSWQ, sP_bytes, sQ_bytes, coef_off, cstrP, cstrQ, nta, ntb, fast_p, fast_q, nbuf, dbg, magicQ, k3;
+    unsigned mg_tx, mg_ty;   // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y): the patch index is split by two multiply-highs (scalar), not divisions
+    int regP;                // P's patches are whole and P has no halo: its segment offsets are affine in the segment index
+    int qtab_off;            // > 0: LDS byte offset of Q's segment table (HaloFetch::table_setup): whole patches, 3x3 halo, stride 1
     unsigned bytesP, bytesQ, bytesP2;
     const void* p2; void* p_out; int ld_p2, cp2_off, ld_pout;  // BN-backward correction fused into the load of P (DUAL)
     int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
     for (int t = 0; t < MAXT; ++t)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    unsigned* const qtab = (unsigned*)(smem + a.qtab_off);
 
     int tapoff[MAXT];  // LDS byte offset of each tap inside the Q halo
 #pragma unroll
@@ -155,11 +159,23 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
     const HaloGeom gP = {PROWS, 16, 4097, a.Hg, a.Wg, a.p.Hx, a.p.Wx, a.p.ldx};
     const HaloGeom gQ = {a.HH, a.HW, a.magicQ, a.Hq, a.Wq, a.q.Hx, a.q.Wx, a.q.ldx};
 
+    // (patch < 2^16 and tiles <= 2^12: the multiply-high by ceil(2^32 / d) is the exact quotient; wave-uniform, stays on the scalar
+    //  unit -- the two runtime divisions cost ~50 vector instructions per call, twice per patch)
+    // Q's segment geometry once per kernel (FAST && the host found room for the table: a.qtab_off)
+    // (compiled into the instantiations whose waves own a tile pair each: the narrow-layer forms are at their register limit)
+    constexpr bool QTAB = FAST && K3 && STRIDE == 1 && NW == 8 && !TS && sizeof(CT) == 2 && sizeof(QT) == 2 && AT * BT >= 4;
+    unsigned qmask = 0;
+    if constexpr (QTAB) {
+        if (a.qtab_off) qmask = pq.table_setup(qtab, gQ, a.HW * PSWQ, PSWQ, tid, cvalQ, PROWS, a.dy_min, a.dx_min);
+    }
     auto patch_origin = [&](int patch, int& b, int& gy0, int& gx0) {
-        int pid = patch;
-        const int tx_i = pid % a.tiles_x; pid /= a.tiles_x;
-        const int ty_i = pid % a.tiles_y; pid /= a.tiles_y;
-        b = pid; gy0 = ty_i * PROWS; gx0 = tx_i * 16;
+        const unsigned pid = (unsigned)patch;
+        // (a divisor of 1 has no 32-bit magic: ceil(2^32 / 1) = 2^32)
+        const unsigned q1 = a.tiles_x == 1 ? pid : __umulhi(pid, a.mg_tx);
+        const unsigned tx_i = pid - q1 * (unsigned)a.tiles_x;
+        const unsigned q2 = a.tiles_y == 1 ? q1 : __umulhi(q1, a.mg_ty);
+        const unsigned ty_i = q1 - q2 * (unsigned)a.tiles_y;
+        b = (int)q2; gy0 = (int)ty_i * PROWS; gx0 = (int)tx_i * 16;
     };
     // SPREAD: the next patch's loads are not issued as one batch in front of the MFMA block but a few at a time between
     // its K-steps.  A CU's memory pipeline holds far less than a patch (55 .. 87 KB from 8 waves): the waves of a batch sat
@@ -172,7 +188,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
         if constexpr (FAST) {
             // all address arithmetic first (see HaloFetch::prepare)
             if (live) {
-                pp.prepare(gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
+                if (a.regP) pp.prepare_regular(gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
+                else pp.prepare(gP, b, gy0, gx0, a.cp_off + ca0, tid, cvalP);
                 if constexpr (DUAL) {
                     // (g and y_raw: same patch, same segments; with equal pixel strides the offsets differ by a constant)
                     if (a.ld_p2 == a.p.ldx && a.p.Hx == a.Hg && a.p.Wx == a.Wg)
@@ -180,7 +197,14 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
                     else
                         pp2.prepare(gP2, b, gy0, gx0, a.cp2_off + ca0, tid, cvalP);
                 }
-                pq.prepare(gQ, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.cq_off + cb0, tid, cvalQ);
+                if (QTAB && a.qtab_off) {
+                    const unsigned sbase = (unsigned)(((b * a.q.Hx + gy0 + a.dy_min) * a.q.Wx + gx0 + a.dx_min) * a.q.ldx + a.cq_off + cb0) * (unsigned)sizeof(QT);
+                    const unsigned border = (gy0 == 0 ? 0x1Fu << 5 : 0u) | (gy0 + PROWS == a.Hq ? 0x1Fu << 10 : 0u) | (gx0 == 0 ? 0x1Fu << 15 : 0u) |
+                                            (gx0 + 16 == a.Wq ? 0x1Fu << 20 : 0u);
+                    pq.prepare_tab(qtab, qmask, sbase, border, tid);
+                } else {
+                    pq.prepare(gQ, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.cq_off + cb0, tid, cvalQ);
+                }
             } else {
                 pp.prepare_none();
                 if constexpr (DUAL) pp2.prepare_none();
@@ -228,6 +252,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
 #pragma unroll
                 for (int j = 0; j < NV; ++j) { ka[j] = sCoefP[cch + j]; kc[j] = sCoefP[a.cstrP + cch + j]; kb[j] = sCoefP[2 * a.cstrP + cch + j]; }
                 const bool store = (bt == 0) && (blockIdx.y == 0) && a.p_out != nullptr;
+                // dY goes out through a buffer store with a 32-bit offset (an out-of-range offset drops it: no branch, no 64-bit
+                // address arithmetic per segment; soffset 0 -- the store form LLVM's hazard recogniser covers)
+                const __amdgpu_buffer_rsrc_t rsO = abc_make_rsrc(store ? a.p_out : a.p.x, store ? (unsigned)((size_t)a.B * a.Hg * a.Wg * a.ld_pout * sizeof(CT)) : 0u);
+                const int obase = ((b * a.Hg + gy0) * a.Wg + gx0) * a.ld_pout + ca0 + cch;
 #pragma unroll
                 for (int i = 0; i < NPF_P; ++i) {
                     const int sidx = lt + i * WTHR;
@@ -240,14 +268,16 @@ __global__ __launch_bounds__(NW * 64, 2) void wgrad_kernel(const WgK a) {
                         typename Frag<CT>::type f = pack_frag<CT>(v1);
                         if (!in) f = pack_frag<CT>(kzero);      // (a select on the packed words: 4 instead of 8)
                         *(typename Frag<CT>::type*)(sP + (hy * 16 + hx) * PSWP + part * 16) = f;
-                        if (store && in)
-                            *(typename Frag<CT>::type*)((CT*)a.p_out + ((size_t)(b * a.Hg + gy0 + hy) * a.Wg + gx0 + hx) * a.ld_pout + ca0 + cch) = f;
+                        static_assert(sizeof(f) == 16, "one 16-byte segment");
+                        __builtin_amdgcn_raw_buffer_store_b128(*(u32x4*)&f, rsO,
+                                                               (store && in) ? (unsigned)(obase + (hy * a.Wg + hx) * a.ld_pout) * (unsigned)sizeof(CT) : 0xFFFFFFF0u, 0, 0);
                     }
                 }
             } else {
                 pp.commit(sP, 16 * PSWP, PSWP, gP, coefP ? sCoefP : nullptr, a.cstrP, tid, cvalP);
             }
-            pq.commit(sQ, a.HW * PSWQ, PSWQ, gQ, coefQ ? sCoefQ : nullptr, a.cstrQ, tid, cvalQ);
+            if (QTAB && a.qtab_off) pq.commit_tab(sQ, qtab, qmask, coefQ ? sCoefQ : nullptr, a.cstrQ, tid, cvalQ);
+            else pq.commit(sQ, a.HW * PSWQ, PSWQ, gQ, coefQ ? sCoefQ : nullptr, a.cstrQ, tid, cvalQ);
         } else {
             stage_slow<PT, CT, CWP>(sP, 16 * PSWP, PSWP, PROWS, 16, b, gy0, gx0, a.Hg, a.Wg, &a.p, a.cp_off + ca0, tid, cvalP, WTHR);
             stage_slow<QT, CT, CWQ>(sQ, a.HW * PSWQ, PSWQ, a.HH, a.HW, b, gy0 * STRIDE + a.dy_min, gx0 * STRIDE + a.dx_min, a.Hq, a.Wq,
@@ -953,6 +983,7 @@ static bool dual_ok(const abc_wgrad_desc* d, const WGeom& g) {
     if (d->dtype_p != ABC_BF16 || d->dtype_q != ABC_BF16 || d->dtype_c != ABC_BF16) return false;
     if (d->p.scale == nullptr || d->p2 == nullptr || (d->ld_p2 % 8) || (d->cp2_off % 8) || (d->p_out && (d->ld_pout % 8))) return false;
     if ((int64_t)d->B * d->Hg * d->Wg * d->ld_p2 * 2 >= (int64_t(1) << 31)) return false;
+    if (d->p_out && (int64_t)d->B * d->Hg * d->Wg * d->ld_pout * 2 >= (int64_t(1) << 31)) return false;   // (32-bit store offsets)
     // (the correction is applied where P is committed to LDS: independent of the taps, so the tap-split form of the 5x5
     //  layers takes it as well as the static 3x3 K-step)
     if (g.ts) return g.fast_p && g.fast_q && d->stride == 1;
@@ -1016,7 +1047,8 @@ static int wlaunch3(const WgK& k, const WGeom& g, int nsplit, hipStream_t st) {
     auto fn = wgrad_kernel<PT, QT, CT, AT, BT, STRIDE, FAST, PM, K3, DUAL, TS, NW>;
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)fn, 160 * 1024, &lds_ok)) return rc;
-    hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(NW * 64), g.lds, st, k);
+    const int lds = k.qtab_off ? k.qtab_off + (PM > 1 ? 5 : 4) * WTHR_HOST * 4 : g.lds;     // (+ Q's segment table)
+    hipLaunchKernelGGL(fn, dim3(g.nta * g.ntb * nsplit, g.ngroups), dim3(NW * 64), lds, st, k);
     return abc_check_launch("wgrad");
 }
 
@@ -1291,6 +1323,20 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
     k.sP_bytes = g.sP_bytes; k.sQ_bytes = g.sQ_bytes; k.coef_off = g.coef_off; k.cstrP = g.cstrP; k.cstrQ = g.cstrQ;
     k.nta = g.nta; k.ntb = g.ntb; k.fast_p = g.fast_p; k.fast_q = g.fast_q; k.nbuf = g.nbuf;
     k.magicQ = 65536 / g.HW + 1;
+    if (g.npatch >= 65536 || g.tiles_x > 4096 || g.tiles_y > 4096) return abc_fail(ABC_EUNSUPPORTED, "wgrad: more than 65535 patches");
+    k.mg_tx = (unsigned)((0x100000000ull + (unsigned)g.tiles_x - 1) / (unsigned)g.tiles_x);
+    k.mg_ty = (unsigned)((0x100000000ull + (unsigned)g.tiles_y - 1) / (unsigned)g.tiles_y);
+    k.regP = (d->Hg % (8 * g.PM) == 0 && d->Wg % 16 == 0 && d->p.Hx == d->Hg && d->p.Wx == d->Wg) ? 1 : 0;
+    // Q's segment table: the static 3x3 step of the 8-wave bf16 prefetch path over whole patches of a same-size image whose offsets
+    // fit the entry (relative offset < 16 MB, LDS image < 64 KB), when the table (segments per thread x 512 x 4 bytes) fits the LDS
+    k.qtab_off = 0;
+    if (k.k3 && d->stride == 1 && g.fast_p && g.fast_q && g.nw == 8 && !g.ts && g.AT * g.BT >= 4 && d->dtype_c == ABC_BF16 && d->dtype_q == ABC_BF16 &&
+        d->Hg % (8 * g.PM) == 0 && d->Wg % 16 == 0 && d->Hq == d->Hg && d->Wq == d->Wg && d->q.Hx == d->Hq && d->q.Wx == d->Wq &&
+        (int64_t)(g.HH * d->q.Wx + g.HW) * d->q.ldx * 2 < (int64_t(1) << 24) && g.sQ_bytes < 65536) {
+        const int npf_q = g.PM > 1 ? 5 : 4;
+        const int off = abc_roundup(g.lds, 16);
+        if (off + npf_q * WTHR_HOST * 4 <= 160 * 1024) k.qtab_off = off;
+    }
     k.p2 = nullptr; k.p_out = nullptr; k.ld_p2 = 0; k.cp2_off = 0; k.ld_pout = 0; k.bytesP2 = 0;
     if (d->p_dual) {
         if (!dual_ok(d, g)) return abc_fail(ABC_EUNSUPPORTED, "wgrad: p_dual is not served for this descriptor (abc_wgrad_fuses_apply)");

@@ -106,6 +106,8 @@ class Rec:
 
 
 class Engine:
+    DUAL_WGRAD = True      # class-wide measurement switch (profiles/tools): False = BatchNorm-backward apply as a pass of its own
+
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
                  guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True):
@@ -1095,6 +1097,8 @@ class Engine:
         dY is a plain Src, or the deferred pair of _bn_backward(defer=True): then the weight-gradient kernel applies the
         BatchNorm-backward correction on load and writes dY for the data-gradient conv (one pass less over g and y);
         layers whose weight gradient runs on another kernel fall back to the separate apply pass."""
+        if isinstance(dY, tuple) and not Engine.DUAL_WGRAD:      # (measurement switch: the separate apply pass everywhere)
+            dY = dY[1]()
         if isinstance(dY, tuple):
             gsrc, emit_apply = dY
             out = self.new((self.B, rec.H, rec.W, rec.cout))

@@ -204,6 +204,10 @@ def main():
     else:
         from abcnet_amd.unet import UNet
 
+    if os.environ.get("ABC_BENCH_NODUAL"):      # (measurement hook, echoed: the BatchNorm-backward apply as passes of their own)
+        from abcnet_amd.engine import Engine
+        Engine.DUAL_WGRAD = False
+        knobs = dict(knobs, ABC_BENCH_NODUAL="1")
     backend = None
     if world > 1:
         D.init_process_group(backend=os.environ.get("ABC_BENCH_BACKEND"), rank=rank, world_size=world, device=local)
