@@ -843,18 +843,20 @@ class Engine:
         lib = self.lib
         isz = lib.abc_pack_item_bytes()
         host = (C.c_char * (isz * len(self._pack_descs)))()
-        first = 0
+        first, elems = 0, 0
         for i, pd in enumerate(self._pack_descs):
             pd.layout = self._w_layout.get(pd.dst, 0)
             n = lib.abc_pack_item_fill(C.addressof(host) + i * isz, C.byref(pd), first)
             if n < 0:
                 L.check(-1, "pack_item_fill")
-            first += n
+            first += n      # (0 for the items the source-major tile kernel packs: they take no range of the dest-major kernel)
+            ntaps = {0: pd.kh * pd.kw, 1: pd.kh * pd.kw, 2: (2 if pd.py else 1) * (2 if pd.px else 1), 3: 9}[pd.mode]
+            elems += ntaps * pd.red_pad * pd.rows_pad
         table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.dev)
         self.keep.append(table)
         a = (table.data_ptr(), len(self._pack_descs), first)
         self.pack_ops.append((lambda _r, st, a=a: lib.abc_pack_batch(a[0], a[1], a[2], st), None, "pack weights", (),
-                              {"kernel": "pack_batch", "flops": 0, "bytes": float(first * (2 if self.dt == L.BF16 else 4) + first * 4)}))
+                              {"kernel": "pack_batch", "flops": 0, "bytes": float(elems * (2 if self.dt == L.BF16 else 4) + elems * 4)}))
         # shared workspaces
         self.ws = [self.new((max(self._ws_need, 4),), torch.float32)]
         for d, k in self._ws_users:

@@ -906,3 +906,86 @@ def test_slab_reduction_and_bn_finaliser_as_one_launch(lib, Ca, Cb, ntaps, nspli
     assert float(o1[0].abs().max()) > 0 and float(o1[5].abs().max()) > 0
     ref = part[:, :, :Ca, :Cb].double().sum(0).permute(1, 2, 0)
     assert U.relerr(dw1.cpu(), ref.cpu()) < 1e-5
+
+
+def test_batched_packing_tile_form_is_bit_identical_to_the_single_kernel():
+    """abc_pack_batch sends Conv2d forward / data-gradient packings with 32-multiple channel counts through the source-major tile
+    kernel (32 x 32 x taps tiles transposed in LDS); everything else through the dest-major gather.  Both against
+    abc_pack_conv_weights (the single-weight dest-major kernel): bit for bit -- both layouts, padded rows, several weights side
+    by side along rows (the eight heads' conv1) and along the reduction axis (the merged data gradient), a per-row scale, 1x1 and
+    3x3, and items the tile form does not take (16 channels, transposed convolutions) in the same table."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    st = U.stream()
+    items, singles, keep = [], [], []
+
+    def add(w, mode, Cout, Cin, k, rows_pad, red_total=None, red_off=0, rows_total=0, rows_off=0, layout=0, row_scale=None, dst=None, py=0, px=0):
+        red = {0: Cin, 1: Cout, 2: Cin, 3: Cout}[mode]
+        rt = red if red_total is None else red_total
+        ck = lib.abc_conv_chunk(L.BF16, rt)
+        red_pad = -(-red // ck) * ck
+        ntaps = {0: k * k, 1: k * k, 2: (2 if py else 1) * (2 if px else 1), 3: 9}[mode]
+        n = ntaps * (-(-rt // ck) * ck) * (rows_total or rows_pad)
+        if dst is None:
+            dst = (torch.zeros(n, dtype=torch.bfloat16, device=U.DEV), torch.zeros(n, dtype=torch.bfloat16, device=U.DEV))
+            keep.append(dst)
+        ds = []
+        for which in (0, 1):
+            d = L.PackDesc()
+            d.w, d.dst, d.mode, d.dtype_c = w.data_ptr(), dst[which].data_ptr(), mode, L.BF16
+            d.Cout, d.Cin, d.kh, d.kw, d.py, d.px = Cout, Cin, k, k, py, px
+            d.rows_pad, d.red_pad, d.red_total, d.red_off, d.ck = rows_pad, red_pad, rt, red_off, ck
+            d.rows_total, d.rows_off, d.layout = rows_total, rows_off, layout
+            d.row_scale = row_scale.data_ptr() if row_scale is not None else None
+            ds.append(d)
+        items.append(ds[0])
+        singles.append(ds[1])
+        return dst
+
+    rnd = lambda *s: torch.randn(*s, generator=g).to(U.DEV)
+    w1 = rnd(128, 128, 3, 3); keep.append(w1)
+    arena = rnd(10 + 64 * 64 * 9); keep.append(arena)
+    wu = arena[10:].view(64, 64, 3, 3)               # a view at an odd element offset of a flat arena: not 16-byte aligned
+    assert wu.data_ptr() % 16 != 0
+    add(wu, 0, 64, 64, 3, 64, layout=1)
+    add(wu, 1, 64, 64, 3, 64)
+    add(w1, 0, 128, 128, 3, 128)
+    add(w1, 1, 128, 128, 3, 128)
+    add(w1, 0, 128, 128, 3, 128, layout=1)
+    w2 = rnd(64, 96, 3, 3); keep.append(w2)
+    add(w2, 0, 64, 96, 3, 128)                       # padded rows (Cout_pad 128)
+    add(w2, 1, 64, 96, 3, 96)
+    sc = (torch.rand(64, generator=g) + 0.5).to(U.DEV); keep.append(sc)
+    add(w2, 0, 64, 96, 3, 64, row_scale=sc, layout=1)
+    w3 = rnd(32, 64, 1, 1); keep.append(w3)
+    add(w3, 0, 32, 64, 1, 32)
+    # two heads' conv1 one below the other (rows_total / rows_off), and their data gradient side by side along the reduction axis
+    wa, wb = rnd(128, 128, 3, 3), rnd(128, 128, 3, 3); keep += [wa, wb]
+    dst = add(wa, 0, 128, 128, 3, 128, rows_total=256, rows_off=0, layout=1)
+    add(wb, 0, 128, 128, 3, 128, rows_total=256, rows_off=128, layout=1, dst=dst)
+    dst = add(wa, 1, 128, 128, 3, 128, red_total=256, red_off=0)
+    add(wb, 1, 128, 128, 3, 128, red_total=256, red_off=128, dst=dst)
+    # not tile material: 16 channels, a transposed convolution's phase and data-gradient packing
+    w4 = rnd(16, 16, 3, 3); keep.append(w4)
+    add(w4, 0, 16, 16, 3, 32)
+    add(w4, 1, 16, 16, 3, 32)
+    wt = rnd(64, 32, 3, 3); keep.append(wt)          # ConvTranspose2d weight [Cin][Cout][3][3]
+    add(wt, 2, 32, 64, 3, 32, py=1, px=1)
+    add(wt, 3, 32, 64, 3, 64)
+    isz = lib.abc_pack_item_bytes()
+    host = (C.c_char * (isz * len(items)))()
+    first = 0
+    for i, d in enumerate(items):
+        n = lib.abc_pack_item_fill(C.addressof(host) + i * isz, C.byref(d), first)
+        assert n >= 0          # (0: the item goes through the tile kernel and takes no range of the dest-major one)
+        first += n
+    assert 0 < first
+    table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(U.DEV)
+    L.check(lib.abc_pack_batch(table.data_ptr(), len(items), first, st), "pack_batch")
+    for d in singles:
+        L.check(lib.abc_pack_conv_weights(C.byref(d), st), "pack")
+    torch.cuda.synchronize()
+    for i, pair in enumerate(keep):
+        if isinstance(pair, tuple):
+            assert torch.equal(pair[0].view(torch.int16), pair[1].view(torch.int16)), i
+            assert pair[0].float().abs().sum().item() > 0
