@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("stem_x", vp), ("stem_w", vp), ("stem_scale", vp), ("stem_bias", vp), ("stem_slope", f32),
                 ("out_scale", vp), ("out_quant", vp), ("out_quant_stride", i32), ("heads_epi", vp),
                 ("actbwd_y", vp), ("actbwd_ld", i32), ("actbwd_coff", i32), ("actbwd_scale", vp), ("actbwd_shift", vp), ("actbwd_slope", vp),
-                ("actbwd_mean", vp), ("actbwd_invstd", vp)]
+                ("actbwd_mean", vp), ("actbwd_invstd", vp), ("head_aux", vp), ("head_aux_mode", i32)]
 
 
 class HeadsEpi(C.Structure):

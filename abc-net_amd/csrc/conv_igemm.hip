@@ -657,6 +657,7 @@ extern "C" int abc_conv_fwd(const abc_conv_desc* d, abc_stream_t stream) {
     }
     if (d->stem_x != nullptr && !abc_conv_narrow_ok(d)) return abc_fail(ABC_EUNSUPPORTED, "conv: the fused first convolution (stem_x) is served by the narrow-level kernel only");
     if (d->pool_y != nullptr && !abc_conv_narrow_ok(d)) return abc_fail(ABC_EUNSUPPORTED, "conv: pool_y is served by the narrow-level kernel only (abc_conv_variant == 5)");
+    if (d->head_aux != nullptr && !abc_head_fwd_ok(d)) return abc_fail(ABC_EUNSUPPORTED, "conv: head_aux is served by the heads' 1x1 kernel only (abc_conv_variant == 3)");
     if (abc_conv_stem_ok(d, nullptr)) return abc_conv_stem_launch(d, stream);
     if (abc_head_fwd_ok(d)) return abc_head_fwd_launch(d, stream);
     if (abc_head_dgrad_ok(d)) return abc_head_dgrad_launch(d, stream);

@@ -27,6 +27,8 @@ struct HeadFwdK {
     unsigned bytesX, bytesW;
     int f8;                // e4m3 features and weights (the fp8 inference graph): oscale[co] = s_x * s_w[co]
     const float* oscale;
+    float* aux;            // abc_conv_desc.head_aux: [B][Cout][HW]
+    int aux_mode;          // 1: |v|; 2: circular 3-tap local maximum along the channel axis and v > -1
 };
 
 // e4m3 form (fp8 inference graph: finished features, no transform on load): a pixel's 128 channels are 128 bytes = two K = 64
@@ -74,7 +76,11 @@ __device__ inline void head_fwd_f8_body(const HeadFwdK& a) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
-                if (oc < a.Cout) a.y[((size_t)(b * a.ctot + a.cout_off + oc)) * a.HW + pp + t * 32 + r] = fmaf(acc[k], osc[k], bvv[k]);
+                if (oc < a.Cout) {
+                    const float v = fmaf(acc[k], osc[k], bvv[k]);
+                    if (a.y) a.y[((size_t)(b * a.ctot + a.cout_off + oc)) * a.HW + pp + t * 32 + r] = v;
+                    if (a.aux_mode == 1) a.aux[((size_t)(b * a.Cout + oc)) * a.HW + pp + t * 32 + r] = fabsf(v);
+                }
             }
         }
     }
@@ -148,7 +154,8 @@ __device__ inline void head_fwd_body(const HeadFwdK& a) {
                 const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
                 if (oc < a.Cout) {
                     const float v = acc[k] + bvv[k];
-                    a.y[((size_t)(b * a.ctot + a.cout_off + oc)) * a.HW + pp + t * 32 + r] = v;
+                    if (a.y) a.y[((size_t)(b * a.ctot + a.cout_off + oc)) * a.HW + pp + t * 32 + r] = v;
+                    if (a.aux_mode == 1) a.aux[((size_t)(b * a.Cout + oc)) * a.HW + pp + t * 32 + r] = fabsf(v);
                 }
             }
         }
@@ -157,6 +164,115 @@ __device__ inline void head_fwd_body(const HeadFwdK& a) {
 
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdK a) { head_fwd_body(a); }
+
+// ---- the omega head with its NMS mask (abc_conv_desc.head_aux_mode == 2; img2smiles2.py:75-79): a kernel of its own -- the mask
+// needs all 60 channels of a pixel at once, 2 x 16 accumulator values per lane and as many from the partner lane, which the plain
+// form's register budget (both pixel tiles' fragments resident) does not have.  Here a wave walks its two 32-pixel tiles one
+// after the other.  The lane (pixel r, half h) holds the channels 32 mt + (k & 3) + 8 (k >> 2) + 4 h of its pixel; the partner lane
+// r + 32 the other half of every group of eight (one cross-lane exchange).  mask = (max(prev, cur, next) == cur && cur > -1) over
+// the circular channel axis -- on the very f32 values that are stored as the raw map (when y is given).
+__global__ __launch_bounds__(256) void head_fwd_omega_kernel(const HeadFwdK a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.npairs) return;
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX), rsW = abc_make_rsrc(a.w, a.bytesW);
+    const int b = (pair * 64) / a.HW, pp = pair * 64 - b * a.HW;
+    const bool tr = a.sc != nullptr;
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t pix = (uint32_t)pair * 64u + t * 32 + r;
+        float v[2][16];
+        if (a.f8) {
+            const uint32_t e0 = pix * (uint32_t)a.ldx + (uint32_t)a.cin_off + 32 * h;
+            i32x8 fb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                fb[s] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsX, e0 + 64 * s, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsX, e0 + 64 * s + 16, 0, 0));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                i32x8 fa[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const unsigned off = (unsigned)((s * a.Cout_pad + mt * 32 + r) * 64 + 32 * h);
+                    fa[s] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsW, off + 16, 0, 0));
+                }
+                f32x16 acc;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) mma32B_f8(acc, fa[s], fb[s]);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                    const bool ok = oc < a.Cout;
+                    v[mt][k] = fmaf(acc[k], ok ? a.oscale[oc] : 0.f, (a.bias && ok) ? a.bias[oc] : 0.f);
+                }
+            }
+        } else {
+            const uint32_t e0 = pix * (uint32_t)a.ldx + (uint32_t)a.cin_off + 8 * h;
+            bf16x8 fb[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsX, (e0 + 16 * kk) * 2u, 0, 0);
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(raw[j] << 16); f[2 * j + 1] = __uint_as_float(raw[j] & 0xFFFF0000u); }
+                if (tr) {
+                    const int c = a.cin_off + 16 * kk + 8 * h;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = abc_act(f[j], a.sc[c + j], a.sh[c + j], a.sl[c + j]);
+                }
+                fb[kk] = pack_frag<bf16>(f);      // (no dropout: an evaluation-time output)
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16 acc;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const unsigned off = (unsigned)((((kk >> 1) * a.Cout_pad + mt * 32 + r) * 32 + 16 * (kk & 1) + 8 * h) * 2);
+                    const u32x4 tw = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&tw, fb[kk], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                    v[mt][k] = acc[k] + ((a.bias && oc < a.Cout) ? a.bias[oc] : 0.f);
+                }
+            }
+        }
+        float o[2][16];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) o[m][k] = __shfl_xor(v[m][k], 32);
+        // value of channel cc as a lane of half hh sees it (compile-time cc, hh: one fixed register of v or o)
+        auto at = [&](int cc, int hh) -> float {
+            const int mm = cc >> 5, rem = cc & 31, hc = (rem >> 2) & 1, kk = (rem & 3) + 4 * (rem >> 3);
+            return hc == hh ? v[mm][kk] : o[mm][kk];
+        };
+        const size_t p0 = (size_t)pp + t * 32 + r;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int c0 = 32 * m + (k & 3) + 8 * (k >> 2), c1 = c0 + 4;      // this register's channel for h = 0 / h = 1
+                float l0 = 0.f, r0 = 0.f, l1 = 0.f, r1 = 0.f;                      // (60 channels: the wrap-around pairs 59 with 0)
+                if (c0 < 60) { l0 = at(c0 == 0 ? 59 : c0 - 1, 0); r0 = at(c0 == 59 ? 0 : c0 + 1, 0); }
+                if (c1 < 60) { l1 = at(c1 - 1, 1); r1 = at(c1 == 59 ? 0 : c1 + 1, 1); }
+                const float cur = v[m][k];
+                const float l = h ? l1 : l0, rr = h ? r1 : r0;
+                const int c = h ? c1 : c0;
+                if (c < 60) {
+                    if (a.y) a.y[((size_t)(b * a.ctot + a.cout_off + c)) * a.HW + p0] = cur;
+                    a.aux[((size_t)(b * 60 + c)) * a.HW + p0] = (cur >= l && cur >= rr && cur > -1.f) ? 1.f : 0.f;
+                }
+            }
+        }
+    }
+}
 
 // All heads of the network in ONE launch (blockIdx.y = head): eight back-to-back launches each drained the chip before the
 // next began, and the five small heads (1 .. 14 channels) are far too short to fill it on their own.
@@ -292,6 +408,7 @@ static void fill_fwd(HeadFwdK& k, const abc_conv_desc* d) {
     k.ctot = d->ctot_out; k.cout_off = d->cout_off; k.npairs = d->B * k.HW / 64;
     k.drop_p = d->src.drop_p; k.drop_seed = d->src.drop_seed; k.drop_salt = d->src.drop_salt;
     k.f8 = d->dtype_c == ABC_FP8 ? 1 : 0; k.oscale = d->out_scale;
+    k.aux = d->head_aux; k.aux_mode = d->head_aux != nullptr ? d->head_aux_mode : 0;
     k.bytesX = (unsigned)((int64_t)d->B * k.HW * d->src.ldx * (k.f8 ? 1 : 2));
     k.bytesW = (unsigned)((int64_t)128 * d->Cout_pad * (k.f8 ? 1 : 2));
 }
@@ -316,6 +433,8 @@ int abc_head_fwd_ok(const abc_conv_desc* d) {
     if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr || d->out_act) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
     if ((d->src.ldx % 8) || (d->cin_off % 8) || d->Cout_pad % 32) return 0;
+    if (d->head_aux != nullptr && !(d->head_aux_mode == 1 || (d->head_aux_mode == 2 && d->Cout == 60 && d->Cout_pad == 64 && d->src.drop_p <= 0.f))) return 0;
+    if (d->y == nullptr && d->head_aux == nullptr) return 0;
     // (all offsets in the kernel are unsigned 32-bit bytes: a batch-64 512x512 feature buffer of 8 x 128 channels is 2^31)
     const int64_t bx = (int64_t)d->B * d->Hg * d->Wg * d->src.ldx * (f8 ? 1 : 2);
     return bx < (int64_t(1) << 32) - 4096;
@@ -324,7 +443,8 @@ int abc_head_fwd_ok(const abc_conv_desc* d) {
 int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream) {
     HeadFwdK k;
     fill_fwd(k, d);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+    if (k.aux_mode == 2) hipLaunchKernelGGL(head_fwd_omega_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(head_fwd_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
     return abc_check_launch("head_fwd");
 }
 
@@ -356,10 +476,19 @@ extern "C" int abc_heads_batch(const abc_conv_desc* descs, int32_t n, int32_t wh
     }
     const int npairs = descs->B * descs->Hg * descs->Wg / 64;
     if (which == 0) {
+        // (a head with the channel-axis NMS mask runs on its own kernel, beside the batch of the others)
         HeadFwdBatch bt;
-        for (int i = 0; i < n; ++i) fill_fwd(bt.k[i], descs + i);
-        for (int i = n; i < MAX_HEADS; ++i) bt.k[i] = bt.k[0];
-        hipLaunchKernelGGL(head_fwd_batch_kernel, dim3(abc_cdiv(npairs, 4), n), dim3(256), 0, (hipStream_t)stream, bt);
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            HeadFwdK k;
+            fill_fwd(k, descs + i);
+            if (k.aux_mode == 2) hipLaunchKernelGGL(head_fwd_omega_kernel, dim3(abc_cdiv(npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+            else bt.k[m++] = k;
+        }
+        if (m > 0) {
+            for (int i = m; i < MAX_HEADS; ++i) bt.k[i] = bt.k[0];
+            hipLaunchKernelGGL(head_fwd_batch_kernel, dim3(abc_cdiv(npairs, 4), m), dim3(256), 0, (hipStream_t)stream, bt);
+        }
     } else {
         HeadDgBatch bt;
         for (int i = 0; i < n; ++i) fill_dg(bt.k[i], descs + i);

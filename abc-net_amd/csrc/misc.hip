@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const abc_nms_desc d) {
         o[(size_t)b * hw + yx] = (m == v && v > -1.f) ? 1.f : 0.f;
     }
     const int n = d.n_omega;
+    if (n <= 0) return;      // (the channel-axis outputs come from the heads' kernel itself: abc_conv_desc.head_aux)
     const float* R = d.rho + (size_t)b * n * hw + yx;
     const float* O = d.omega + (size_t)b * n * hw + yx;
     float prev = O[(size_t)(n - 1) * hw], cur = O[0];

@@ -110,7 +110,7 @@ class Engine:
 
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
-                 guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True):
+                 guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True, nms_heads=False):
         """merge_reduce=False: every slab reduction and every BatchNorm-backward finaliser a launch of its own;
         actbwd_epilogue=False: every act_bwd pass as a launch of its own (the form the fused epilogue is tested against);
         batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
@@ -147,6 +147,10 @@ class Engine:
         # the 8 x 128-channel feature tensor is never written.  Bit-identical to the default plan (the separate heads kernel) and
         # measured SLOWER than it (b64 at 512 x 512: 7.86 -> 9.0-10.4 ms bf16, 6.09 -> 7.7-9.6 ms e4m3), hence off
         self.heads_epilogue = bool(heads_epilogue)
+        # eval graph: |rho| and the omega-bin NMS mask (img2smiles2.py:73-79) as second outputs of the heads' 1x1 kernel
+        # (abc_conv_desc.head_aux) -- nms_rho / nms_omega; the NMS kernel then reads the two one-channel centre maps only
+        self.nms_heads = bool(nms_heads) and not train
+        self.nms_rho = self.nms_omega = None
         # training: the activation / BatchNorm-statistics backward pass of a layer in the epilogue of the data gradient that produces
         # its input (abc_conv_desc.actbwd_*), where the layer has that one reader (_actbwd_target)
         self.actbwd_epilogue = bool(actbwd_epilogue)
@@ -954,6 +958,18 @@ class Engine:
             self.keep.append(epi_items)
             return
         # (the eight conv1 launches above write the eight slices of hfeat; the eight 1x1 convolutions go as one launch)
+        if self.nms_heads and self.heads == [1, 14, 3, 2, 1, 360, 60, 60] and len(head_convs) == 8 and self.drop_p >= 0:
+            d6, d7 = head_convs[6][0], head_convs[7][0]
+            rho, om = self.new((self.B, 60, h, w), torch.float32), self.new((self.B, 60, h, w), torch.float32)
+            d6.head_aux, d6.head_aux_mode = rho.data_ptr(), 1
+            d7.head_aux, d7.head_aux_mode = om.data_ptr(), 2
+            if self.lib.abc_conv_variant(C.byref(d6)) == 3 and self.lib.abc_conv_variant(C.byref(d7)) == 3:
+                self.nms_rho, self.nms_omega = rho, om
+                head_convs[7][2]["bytes"] += float(self.B * 60 * h * w * 4)
+                head_convs[6][2]["bytes"] += float(self.B * 60 * h * w * 4)
+            else:
+                d6.head_aux = d7.head_aux = None
+                d6.head_aux_mode = d7.head_aux_mode = 0
         self.emit_heads_batch(self.fwd_ops, head_convs, 0, "fwd out_modules.*.conv2")
 
     def _heads_fused_setup(self):

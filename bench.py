@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0, help="(N > 1) leave this many of the 256 CUs out of the persistent convolution "
                     "grids (2 workgroups per CU x 256 VGPRs fill a SIMD's register file: a communication kernel cannot co-reside with "
                     "them), so that RCCL's kernels start at once instead of behind a draining workgroup (abc_set_reserved_cus)")
+    ap.add_argument("--no-nms-in-heads", action="store_true", help="(infer) the round-3 plan: the NMS kernel reads the stored rho / omega maps back "
+                    "(InferenceRunner(nms_in_heads=False)): the A/B of the heads kernel's second outputs, not the default")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -226,7 +228,8 @@ def main():
     imgs = synthetic_images(a.batch, a.size, seed=7 + rank)
     if a.mode == "infer":
         from abcnet_amd.infer import InferenceRunner
-        tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract, fp8=(a.dtype == "fp8"))
+        tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract, fp8=(a.dtype == "fp8"),
+                             nms_in_heads=not a.no_nms_in_heads)
         tr.load_batch(imgs.to(dev))
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits,

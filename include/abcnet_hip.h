@@ -137,6 +137,16 @@ typedef struct abc_conv_desc {
     const void* actbwd_y;
     int32_t actbwd_ld, actbwd_coff;        /* y_raw's row length and first channel (elements) */
     const float *actbwd_scale, *actbwd_shift, *actbwd_slope, *actbwd_mean, *actbwd_invstd;   /* per output channel of THIS convolution */
+    /* The peak-NMS outputs of img2smiles2.py:61-79 straight from the heads' 1x1 kernel (abc_conv_variant == 3 only; abc_conv_fwd and
+     * abc_heads_batch refuse it elsewhere): head_aux = a second NCHW f32 output [B][Cout][Hout][Wout] holding
+     *   head_aux_mode 1: |v|                                        (img2smiles2.py:73, the rho head)
+     *   head_aux_mode 2: 1.0 where v >= both circular neighbours along the CHANNEL axis and v > -1, else 0.0
+     *                    (img2smiles2.py:75-79, the omega head: Cout <= 64)
+     * of the value v this launch stores to y -- the lane that computed v holds its channel neighbours (or gets them by one
+     * cross-lane exchange), so the maps are not read back (abc_nms_peaks with n_omega = 0 then does the two 3x3 spatial masks
+     * alone).  With head_aux set, y may be NULL: the raw map is then not stored. */
+    float* head_aux;
+    int32_t head_aux_mode;
 } abc_conv_desc;
 
 /* number of per-block stat partials abc_conv_fwd writes for this descriptor */

@@ -218,3 +218,28 @@ def test_fp8_inference_graph_against_oracle_and_bf16_graph():
     da, db, dr, do = nms_oracle.nms(outs[0][0], outs[0][4], outs[0][6], outs[0][7])
     assert torch.equal(run8.atom_mask.cpu(), da) and torch.equal(run8.bond_mask.cpu(), db) and torch.equal(run8.omega_mask.cpu(), do)
     assert torch.equal(run8.rho_abs.cpu(), dr)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_nms_outputs_from_the_heads_kernel_equal_the_nms_kernel(fp8):
+    """img2smiles2.py:73-79 as second outputs of the heads' 1x1 kernel (abc_conv_desc.head_aux: |rho|, the omega-bin mask with its
+    circular neighbours exchanged between the two lanes of a pixel) against the round-3 plan where the NMS kernel reads the stored
+    maps back: logits, all four NMS outputs equal bit for bit, bf16 and e4m3 graphs, a size whose maps are not a multiple of the
+    kernel's 64-pixel pairs per image row"""
+    a = _runner(fp8, 3, 160)
+    from abcnet_amd.infer import InferenceRunner
+    assert a.nms_in_heads
+    x = synthetic_images(3, 160, seed=7).to(DEV)
+    b = InferenceRunner(a.model, 3, 160, 160, use_graph=True, fold_bn=True, fp8=fp8, nms_in_heads=False)
+    assert not b.nms_in_heads
+    for run in (a, b):
+        run.load_batch(x)
+        run.step()
+        run.step()
+    torch.cuda.synchronize()
+    for i, (p, q) in enumerate(zip(a.logits, b.logits)):
+        assert torch.equal(p, q), i
+    for name in ("atom_mask", "bond_mask", "rho_abs", "omega_mask"):
+        p, q = getattr(a, name), getattr(b, name)
+        assert torch.equal(p, q), (name, int((p != q).sum()))
+    assert a.omega_mask.sum().item() > 0 and a.rho_abs.abs().sum().item() > 0
