@@ -102,6 +102,27 @@ def test_training_on_drawn_molecules_learns():
     assert 6 <= n <= 30, n
 
 
+def test_fp32_forward_on_trained_weights_is_within_1e_3():
+    """the north-star tolerance (logits within 1e-3 of the fp32 reference arithmetic) on TRAINED weights -- peaked maps, logits
+    spanning tens of units, heavy-tailed activations -- with the exact-f32 HIP path: eval forward of two 512 x 512 drawings against
+    the oracle, every head, absolute"""
+    from abcnet_amd.unet import UNet
+    _m, sd, x, (ref, _nms), _info = _trained()
+    m32 = UNet(1, HEADS, dtype="fp32", dropout_p=0.2)
+    m32.load_state_dict(sd)
+    m32 = m32.to(DEV).eval()
+    with torch.no_grad():
+        ys = m32(x[list(SAMPLE[:2])].to(DEV))
+    worst, span = 0.0, 0.0
+    for i, (y, r) in enumerate(zip(ys, ref)):
+        err = (y.cpu() - r[:2]).abs().max().item()
+        worst, span = max(worst, err), max(span, (r.max() - r.min()).item())
+        assert err < 1e-3, (i, err)
+    print("fp32 on trained weights: worst |dlogit| %.2e over maps spanning up to %.1f" % (worst, span), file=sys.stderr)
+    del m32
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("key", ["bf16", "fp8"])
 def test_inference_accuracy_on_trained_weights(key):
     ceil = _bounds()["ceilings"][key]
