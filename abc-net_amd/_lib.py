@@ -265,6 +265,15 @@ def load():
         raise AbcNetHipError(
             "libabcnet_hip.so not found at %s -- build it with ./build_hip.sh (or __graft_entry__.build()); "
             "abcnet_amd has no CPU fallback" % LIB_PATH)
+    # On a GPU box the HIP runtime has to be up (through torch, whose bundled runtime this library binds to) BEFORE the library is
+    # mapped: loaded first -- __graft_entry__.build() followed by smoke() in one process did that -- its kernels' first launch fails
+    # with "no ROCm-capable device is detected" (measured, round 4).  No-op without a GPU.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:      # noqa: BLE001  (the check below still reports a missing / mismatched library)
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
