@@ -209,78 +209,202 @@ __global__ __launch_bounds__(256) void cbam_conv7_fwd_kernel(const abc_cbam_conv
 }
 
 // d_st[pix][ch] = sum_taps du[pix - off] * w[ch][tap]; weight/bias gradient partials per workgroup.
-// Persistent workgroups: a thread keeps its 99 weight-gradient sums in registers over ALL the 16x16 tiles its
-// workgroup walks and the cross-lane reduction (99 x 6 shuffles) runs once per workgroup, not once per tile
-// (per tile it cost more than the 98 MACs per pixel it reduces: 89 us per call on average).
-__global__ __launch_bounds__(256) void cbam_conv7_bwd_kernel(const abc_cbam_conv7_desc d) {
-    __shared__ float tdu[22][22];
-    __shared__ __attribute__((aligned(8))) float tst[22][22][2];
-    __shared__ float red[4][99];
-    const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + 15) / 16;
+// Persistent workgroups: a thread keeps its 99 weight-gradient sums in registers over ALL the tiles its workgroup walks and the
+// cross-lane reduction runs once per workgroup, not once per tile.
+//
+// PX pixels of one row per thread (tile = 16 rows x 16 PX columns).  PX = 1 was the round-1..3 kernel: per pixel 49 reads of du,
+// 49 8-byte reads of st and 98 broadcast reads of the weights for 196 FMAs -- LDS-issue-bound, 118 us per call at 384 x 384 (b16)
+// against 12 us of FMAs.  With PX = 4 the 7 taps of a kernel row of four neighbouring pixels share one 10-pixel window: per
+// kernel row 3 reads of du (2 x 16 bytes + 8), 5 reads of st (16 bytes) and 4 reads of the weight row (kept [tap][channel], so
+// that (d_mean, d_max) and the (dW_mean, dW_max) pair of a tap are one packed FMA each) serve 56 packed FMAs, whose broadcast
+// operand (du, du) is a half of a register pair picked by op_sel (the compiler builds every such pair with two moves).
+// The next tile's halo is in flight (registers) under the FMAs of this one.
+typedef float c7x2 __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+// acc += (a.x, a.x) * b   /   acc += (a.y, a.y) * b
+__device__ inline void pk_fma_lo(c7x2& acc, const c7x2 a, const c7x2 b) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b)); }
+__device__ inline void pk_fma_hi(c7x2& acc, const c7x2 a, const c7x2 b) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b)); }
+template <int CTRL> __device__ inline float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
+#else
+__device__ inline void pk_fma_lo(c7x2& acc, const c7x2 a, const c7x2 b) { acc += (c7x2){a[0], a[0]} * b; }
+__device__ inline void pk_fma_hi(c7x2& acc, const c7x2 a, const c7x2 b) { acc += (c7x2){a[1], a[1]} * b; }
+template <int CTRL> __device__ inline float dpp_mov(float v) { return v; }
+#endif
+// sum over the 16 lanes of a DPP row, in every lane of the row (rotations by 8, 4, 2, 1: fixed order)
+__device__ inline float row_sum16(float v) {
+    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
+    return v;
+}
+
+template <int PX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cbam_conv7_bwd_kernel(const abc_cbam_conv7_desc d) {
+    typedef c7x2 f32x2;
+    constexpr int TW = 16 * PX, HWD = TW + 6;                         // tile / halo width
+    constexpr int NI = (22 * HWD + 255) / 256;                        // halo elements per thread
+    constexpr bool SWZ = PX == 4;
+    // row strides: 16-byte aligned windows; PX = 4: a multiple of 256 bytes, so that the lanes of the two tile rows that meet in one
+    // ds_read_b128 lane group fall on distinct 16-byte slots.  A lane's st window is 80 bytes at a lane stride of 32: slots
+    // 16 .. 31 of a row are stored with their lowest bit flipped, which puts lanes tx and tx + 8 on different banks.
+    constexpr int SU = PX == 4 ? 128 : 24, SS = PX == 4 ? 96 : 24;   // floats per du row, float2 per st row
+    __shared__ __attribute__((aligned(16))) float tdu[22 * SU];
+    __shared__ __attribute__((aligned(16))) f32x2 tst[22 * SS];
+    __shared__ __attribute__((aligned(16))) f32x2 w2[7 * 8];         // [ky][kx (7, padded to 8)] = (w[0][ky][kx], w[1][ky][kx])
+    __shared__ float red[16][100];
+    const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + 15) / 16;
     const int ntiles = tiles_x * tiles_y * d.B;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    // The pass is LDS-bound (per pixel 49 reads of du, 49 8-byte reads of st, 98 broadcast reads of the weights).  The weights
-    // stay in LDS: as workgroup-uniform values through the scalar path they were re-fetched inside the tile loop (beside 99
-    // accumulators the scalar file does not hold them: 0.65 -> 0.75 ms per step); pinned in 98 vector registers the kernel drops
-    // to two waves per SIMD and the LDS latency shows (0.80 ms).  Both measured, same box.
-    __shared__ float w[98];
-    if (threadIdx.x < 98) w[threadIdx.x] = d.w7[threadIdx.x];
-    float acc[99];
-#pragma unroll
-    for (int t = 0; t < 99; ++t) acc[t] = 0.f;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x < 56) {
+        const int ky = threadIdx.x >> 3, kx = threadIdx.x & 7;
+        w2[threadIdx.x] = kx < 7 ? (f32x2){d.w7[ky * 7 + kx], d.w7[49 + ky * 7 + kx]} : (f32x2){0.f, 0.f};
+    }
+    float pu[NI];
+    f32x2 ps[NI];
+    auto issue = [&](int tile) {
         const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-        const int y0 = by * 16, x0 = bx * 16;
-        __syncthreads();   // previous tile's readers are done (and w[] is visible on the first pass)
-        for (int i = threadIdx.x; i < 22 * 22; i += 256) {
-            const int hy = i / 22, hx = i % 22;
-            const int yy = y0 + hy - 3, xx = x0 + hx - 3;
-            const bool in = yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
-            const size_t o = ((size_t)b * d.H + yy) * d.W + xx;
-            tdu[hy][hx] = in ? d.du[o] : 0.f;
-            tst[hy][hx][0] = in ? d.st[o * 2] : 0.f;
-            tst[hy][hx][1] = in ? d.st[o * 2 + 1] : 0.f;
-        }
-        __syncthreads();
-        const int yy = y0 + ty, xx = x0 + tx;
-        const bool valid = yy < d.H && xx < d.W;
-        // data gradient: correlation with the flipped kernel
-        if (valid) {
-            float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky)
+        for (int k = 0; k < NI; ++k) {
+            const int i = (int)threadIdx.x + 256 * k;
+            const int hy = i / HWD, hx = i - hy * HWD;
+            const int yy = by * 16 + hy - 3, xx = bx * TW + hx - 3;
+            const bool in = i < 22 * HWD && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
+            const size_t o = ((size_t)b * d.H + yy) * d.W + xx;
+            pu[k] = in ? d.du[o] : 0.f;
+            ps[k] = in ? *(const f32x2*)(d.st + o * 2) : (f32x2){0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = (int)threadIdx.x + 256 * k;
+            const int hy = i / HWD, hx = i - hy * HWD;
+            if (i < 22 * HWD) {
+                tdu[hy * SU + hx] = pu[k];
+                const int slot = hx >> 1;
+                tst[hy * SS + (SWZ ? ((slot ^ ((slot >> 4) & 1)) << 1) + (hx & 1) : hx)] = ps[k];
+            }
+        }
+    };
+    int soff[SWZ ? 5 : 1];    // this lane's five 16-byte st slots of a window row (f32x2 index)
+#pragma unroll
+    for (int c = 0; c < (SWZ ? 5 : 1); ++c) { const int slot = 2 * tx + c; soff[c] = (slot ^ ((slot >> 4) & 1)) << 1; }
+    f32x2 acc[49];
+    float accb = 0.f;
+#pragma unroll
+    for (int t = 0; t < 49; ++t) acc[t] = (f32x2){0.f, 0.f};
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    while (tile < ntiles) {
+        const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        __syncthreads();   // previous tile's readers are done (and w2[] is visible on the first pass)
+        commit();
+        __syncthreads();
+        const int next = tile + (int)gridDim.x;
+        if (next < ntiles) issue(next);
+        const int yy = by * 16 + ty, xx = bx * TW + tx * PX;
+        f32x2 g[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) g[p] = (f32x2){0.f, 0.f};
+        if constexpr (PX == 4) {
+            // du at this thread's pixels (zero outside the map: the halo fill), as two register pairs
+            const float* ucp = &tdu[(ty + 3) * SU + tx * 4 + 3];
+            const f32x2 uc01 = (f32x2){ucp[0], ucp[1]}, uc23 = (f32x2){ucp[2], ucp[3]};
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                // window row j of the halo: du for the data gradient's kernel row 6 - j, st for the weight gradient's kernel row j
+                f32x2 dw_[5], st_w[10], wr[8];
+                {
+                    const f32x4 a0 = *(const f32x4*)&tdu[(ty + j) * SU + tx * 4], a1 = *(const f32x4*)&tdu[(ty + j) * SU + tx * 4 + 4];
+                    dw_[0] = (f32x2){a0[0], a0[1]}; dw_[1] = (f32x2){a0[2], a0[3]}; dw_[2] = (f32x2){a1[0], a1[1]}; dw_[3] = (f32x2){a1[2], a1[3]};
+                    dw_[4] = *(const f32x2*)&tdu[(ty + j) * SU + tx * 4 + 8];
+                }
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const f32x4 s4 = *(const f32x4*)&tst[(ty + j) * SS + soff[c]];
+                    st_w[2 * c] = (f32x2){s4[0], s4[1]}; st_w[2 * c + 1] = (f32x2){s4[2], s4[3]};
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 q = *(const f32x4*)&w2[(6 - j) * 8 + 2 * c];
+                    wr[2 * c] = (f32x2){q[0], q[1]}; wr[2 * c + 1] = (f32x2){q[2], q[3]};
+                }
+                // data gradient (correlation with the flipped kernel): g[p] += du[y + 3 - ky][x + p + 3 - kx] * w[:, ky, kx], ky = 6 - j
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int c = p + 6 - kx;
+                        if (c & 1) pk_fma_hi(g[p], dw_[c >> 1], wr[kx]); else pk_fma_lo(g[p], dw_[c >> 1], wr[kx]);
+                    }
+                // weight gradient: dW[:, ky, kx] += sum_p du[pix p] * st[pix p + (ky - 3, kx - 3)], ky = j
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx) {
-                    const float u = tdu[ty + 6 - ky][tx + 6 - kx];  // du at (y + 3 - ky, x + 3 - kx)
-                    g0 = fmaf(u, w[ky * 7 + kx], g0);
-                    g1 = fmaf(u, w[49 + ky * 7 + kx], g1);
+                    pk_fma_lo(acc[j * 7 + kx], uc01, st_w[kx]);
+                    pk_fma_hi(acc[j * 7 + kx], uc01, st_w[kx + 1]);
+                    pk_fma_lo(acc[j * 7 + kx], uc23, st_w[kx + 2]);
+                    pk_fma_hi(acc[j * 7 + kx], uc23, st_w[kx + 3]);
                 }
-            d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 0] = g0;
-            d.dst[(((size_t)b * d.H + yy) * d.W + xx) * 2 + 1] = g1;
-        }
-        // weight gradient: dW[ch][ky][kx] = sum_pix st[pix + (ky-3, kx-3)][ch] * du[pix]
-        const float u = valid ? tdu[ty + 3][tx + 3] : 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const float2 t2 = *(const float2*)&tst[ty + ky][tx + kx][0];
-                acc[ky * 7 + kx] = fmaf(u, t2.x, acc[ky * 7 + kx]);
-                acc[49 + ky * 7 + kx] = fmaf(u, t2.y, acc[49 + ky * 7 + kx]);
+                __builtin_amdgcn_sched_barrier(0);   // one window row at a time (hoisted, the seven rows' reads took 240 more registers)
             }
-        acc[98] += u;
+            accb += (uc01[0] + uc01[1]) + (uc23[0] + uc23[1]);
+        } else {
+            float uc[PX];
+#pragma unroll
+            for (int p = 0; p < PX; ++p) uc[p] = tdu[(ty + 3) * SU + tx * PX + p + 3];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                float du_w[PX + 6];
+                f32x2 st_w[PX + 6], wr[8];
+#pragma unroll
+                for (int c = 0; c < PX + 6; ++c) { du_w[c] = tdu[(ty + j) * SU + tx * PX + c]; st_w[c] = tst[(ty + j) * SS + tx * PX + c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 q = *(const f32x4*)&w2[(6 - j) * 8 + 2 * c];
+                    wr[2 * c] = (f32x2){q[0], q[1]}; wr[2 * c + 1] = (f32x2){q[2], q[3]};
+                }
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) {
+                        const float u = du_w[p + 6 - kx];
+                        g[p] = __builtin_elementwise_fma((f32x2){u, u}, wr[kx], g[p]);
+                    }
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) acc[j * 7 + kx] = __builtin_elementwise_fma((f32x2){uc[p], uc[p]}, st_w[p + kx], acc[j * 7 + kx]);
+                // (the compiler sinks the FMAs of all seven rows behind the last row's reads otherwise: an empty asm that "modifies" the
+                //  row's sums pins them here -- no instruction)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int p = 0; p < PX; ++p) asm volatile("" : "+v"(g[p]));
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) asm volatile("" : "+v"(acc[j * 7 + kx]));
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < PX; ++p) accb += uc[p];
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+            if (yy < d.H && xx + p < d.W) *(f32x2*)(d.dst + (((size_t)b * d.H + yy) * d.W + xx + p) * 2) = g[p];
+        tile = next;
     }
+    // 99 sums over the workgroup: the 16 lanes of a row by DPP rotations, then the 16 rows through LDS in row order
+    // (594 ds_bpermute round trips, six deep per sum, were ~20 us of the 25 us a small map's call took)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < 99; ++t) {
-        float v = acc[t];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wave][t] = v;
+        const float v = row_sum16(t < 49 ? acc[t][0] : (t < 98 ? acc[t - 49][1] : accb));
+        if ((lane & 15) == 0) red[wave * 4 + (lane >> 4)][t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 99)
-        d.dw_partial[(size_t)blockIdx.x * 99 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 99) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+        d.dw_partial[(size_t)blockIdx.x * 99 + threadIdx.x] = s;
+    }
 }
 
 // one workgroup per output (98 weights + bias): 256 lanes stride the per-workgroup partials, fixed tree -> reproducible
@@ -751,13 +875,17 @@ extern "C" int abc_cbam_conv7_fwd(const abc_cbam_conv7_desc* d, abc_stream_t str
     return abc_check_launch("cbam_conv7_fwd");
 }
 
+// four pixels per thread (16 x 64 tiles) from 48 columns up; the narrow maps of the deep levels keep one pixel per thread
+static int conv7_px(const abc_cbam_conv7_desc* d) { return d->W >= 48 ? 4 : 1; }
+
 extern "C" int abc_cbam_conv7_blocks(const abc_cbam_conv7_desc* d) {
-    const int ntiles = abc_cdiv(d->W, 16) * abc_cdiv(d->H, 16) * d->B;
-    return ntiles < 1024 ? ntiles : 1024;   // persistent: 4 workgroups per CU
+    const int ntiles = abc_cdiv(d->W, 16 * conv7_px(d)) * abc_cdiv(d->H, 16) * d->B;
+    return ntiles < 512 ? ntiles : 512;   // persistent: 2 workgroups per CU (178 registers), all resident
 }
 
 extern "C" int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream) {
-    hipLaunchKernelGGL(cbam_conv7_bwd_kernel, dim3(abc_cbam_conv7_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d);
+    if (conv7_px(d) == 4) hipLaunchKernelGGL(cbam_conv7_bwd_kernel<4>, dim3(abc_cbam_conv7_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(cbam_conv7_bwd_kernel<1>, dim3(abc_cbam_conv7_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_conv7_reduce_kernel, dim3(99), dim3(256), 0, (hipStream_t)stream, (const float*)d->dw_partial,
                        abc_cbam_conv7_blocks(d), d->dw7, d->db7);
     return abc_check_launch("cbam_conv7_bwd");

@@ -989,3 +989,39 @@ def test_batched_packing_tile_form_is_bit_identical_to_the_single_kernel():
         if isinstance(pair, tuple):
             assert torch.equal(pair[0].view(torch.int16), pair[1].view(torch.int16)), i
             assert pair[0].float().abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (3, 40, 72), (2, 18, 9), (1, 12, 12), (2, 96, 200), (16, 48, 48), (1, 17, 131)])
+def test_cbam_conv7_forward_and_backward(lib, B, H, W):
+    """SpatialAttentionModule's 7x7 convolution (unet2.py:27,34) against torch: sa = sigmoid(conv2d(st)), and -- given du = d(pre-sigmoid) --
+    the data gradient d(st) and the weight / bias gradients (both tile forms of abc_cbam_conv7_bwd: four pixels per thread from 48
+    columns up, one below; sizes that are no multiple of the tile, many tiles per persistent workgroup)."""
+    g = torch.Generator().manual_seed(11)
+    st = torch.randn(B, H, W, 2, generator=g)
+    du = torch.randn(B, H, W, generator=g)
+    w7 = torch.randn(1, 2, 7, 7, generator=g) * 0.1
+    b7 = torch.randn(1, generator=g)
+    d = L.CbamConv7Desc()
+    std, dud, wd, bd = st.to("cuda"), du.to("cuda"), w7.to("cuda"), b7.to("cuda")
+    sa = torch.empty(B, H, W, device="cuda")
+    dst = torch.full((B, H, W, 2), float("nan"), device="cuda")
+    dw, db = torch.empty(98, device="cuda"), torch.empty(1, device="cuda")
+    d.st, d.w7, d.b7, d.sa, d.du, d.dst = std.data_ptr(), wd.data_ptr(), bd.data_ptr(), sa.data_ptr(), dud.data_ptr(), dst.data_ptr()
+    d.B, d.H, d.W = B, H, W
+    nb = lib.abc_cbam_conv7_blocks(C.byref(d))
+    part = torch.empty(nb, 99, device="cuda")
+    d.dw_partial, d.dw7, d.db7 = part.data_ptr(), dw.data_ptr(), db.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    L.check(lib.abc_cbam_conv7_fwd(C.byref(d), stream), "conv7_fwd")
+    L.check(lib.abc_cbam_conv7_bwd(C.byref(d), stream), "conv7_bwd")
+    torch.cuda.synchronize()
+    x = st.permute(0, 3, 1, 2).double().requires_grad_(True)
+    w = w7.double().requires_grad_(True)
+    b = b7.double().requires_grad_(True)
+    pre = F.conv2d(x, w, b, padding=3)
+    assert (sa.cpu().double() - torch.sigmoid(pre)[:, 0]).abs().max() < 1e-5
+    pre.backward(du.double().unsqueeze(1))
+    ref_dst = x.grad.permute(0, 2, 3, 1)
+    assert (dst.cpu().double() - ref_dst).abs().max() < 1e-4 * max(1.0, ref_dst.abs().max().item())
+    assert (dw.cpu().double() - w.grad.reshape(-1)).abs().max() < 2e-5 * max(1.0, w.grad.abs().max().item())
+    assert abs(db.cpu().double().item() - b.grad.item()) < 2e-5 * max(1.0, abs(b.grad.item()))
