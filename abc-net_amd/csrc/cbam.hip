@@ -219,22 +219,7 @@ __global__ __launch_bounds__(256) void cbam_conv7_fwd_kernel(const abc_cbam_conv
 // that (d_mean, d_max) and the (dW_mean, dW_max) pair of a tap are one packed FMA each) serve 56 packed FMAs, whose broadcast
 // operand (du, du) is a half of a register pair picked by op_sel (the compiler builds every such pair with two moves).
 // The next tile's halo is in flight (registers) under the FMAs of this one.
-typedef float c7x2 __attribute__((ext_vector_type(2)));
-#if defined(__HIP_DEVICE_COMPILE__)
-// acc += (a.x, a.x) * b   /   acc += (a.y, a.y) * b
-__device__ inline void pk_fma_lo(c7x2& acc, const c7x2 a, const c7x2 b) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b)); }
-__device__ inline void pk_fma_hi(c7x2& acc, const c7x2 a, const c7x2 b) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b)); }
-template <int CTRL> __device__ inline float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
-#else
-__device__ inline void pk_fma_lo(c7x2& acc, const c7x2 a, const c7x2 b) { acc += (c7x2){a[0], a[0]} * b; }
-__device__ inline void pk_fma_hi(c7x2& acc, const c7x2 a, const c7x2 b) { acc += (c7x2){a[1], a[1]} * b; }
-template <int CTRL> __device__ inline float dpp_mov(float v) { return v; }
-#endif
-// sum over the 16 lanes of a DPP row, in every lane of the row (rotations by 8, 4, 2, 1: fixed order)
-__device__ inline float row_sum16(float v) {
-    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);
-    return v;
-}
+typedef f32pair c7x2;
 
 template <int PX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void cbam_conv7_bwd_kernel(const abc_cbam_conv7_desc d) {

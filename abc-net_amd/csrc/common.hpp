@@ -145,6 +145,34 @@ __device__ inline int abc_xcd_remap(int bid, int nwg) {
 
 // ---------------------------------------------------------------------------
 // load NV consecutive channels of InT as floats
+// ---------------------------------------------------------------------------
+// Packed f32 FMAs with a broadcast operand.  acc += (a.x, a.x) * b / acc += (a.y, a.y) * b as ONE v_pk_fma_f32 whose first
+// source is a half of a register pair picked by op_sel (built from (f32pair){u, u} the compiler spends two moves per pair);
+// the plain-FMA kernels (one-channel stem, its weight gradient, CBAM's 7x7) keep sliding windows of consecutive pixels in
+// such pairs.  Each half is a fused multiply-add: bit-identical to fmaf.
+typedef float f32pair __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline void pk_fma_lo(f32pair& acc, const f32pair a, const f32pair b) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b)); }
+__device__ inline void pk_fma_hi(f32pair& acc, const f32pair a, const f32pair b) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b)); }
+template <int CTRL> __device__ inline float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
+#else
+__device__ inline void pk_fma_lo(f32pair& acc, const f32pair a, const f32pair b) { acc += (f32pair){a[0], a[0]} * b; }
+__device__ inline void pk_fma_hi(f32pair& acc, const f32pair a, const f32pair b) { acc += (f32pair){a[1], a[1]} * b; }
+template <int CTRL> __device__ inline float dpp_mov(float v) { return v; }
+#endif
+// element e (compile-time) of a window kept as pairs
+template <int E> __device__ inline void pk_fma_el(f32pair& acc, const f32pair* win, const f32pair b) {
+    if constexpr (E & 1) pk_fma_hi(acc, win[E >> 1], b); else pk_fma_lo(acc, win[E >> 1], b);
+}
+// sum over the lanes i, i + m, i + 2m, ... of a 16-lane DPP row, in every lane (rotations by 8 .. m: fixed order); m = 1: the whole row
+__device__ inline float row_sum16(float v, int m = 1) {
+    v += dpp_mov<0x128>(v);
+    if (m <= 4) v += dpp_mov<0x124>(v);
+    if (m <= 2) v += dpp_mov<0x122>(v);
+    if (m <= 1) v += dpp_mov<0x121>(v);
+    return v;
+}
+
 template <typename InT, int NV> struct LoadVec;
 template <> struct LoadVec<float, 4> {
     __device__ static inline void ld(const float* p, float* v) {

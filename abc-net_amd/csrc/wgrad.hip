@@ -21,6 +21,7 @@
 // Reference ops covered: autograd of nn.Conv2d / nn.ConvTranspose2d weights
 // (unet.py:12,15,44,66,70 under loss.backward(), train.py:140).
 #include "common.hpp"
+#include <type_traits>
 #include "../../include/abcnet_hip.h"
 #include "capi_util.hpp"
 #include "reduce_bn.hpp"
@@ -827,12 +828,157 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
     }
 }
 
+// Four pixels of a row per thread (round 4; the forward twin is stem_conv4_kernel in stem.hip).  The form above stages the image rows
+// of ONE row of dY between two barriers and reads one LDS value per CPT FMAs: 172 us for unet2's 25-tap stem (b16 at 384 x 384)
+// where the FMAs need ~35.  Here a workgroup stages the image rows of up to 8 rows of dY at once (16-byte loads, four in flight),
+// a thread owns CPT channels of FOUR neighbouring pixels, a kernel row's taps read one 8-pixel window kept as register pairs, and an
+// FMA is half of a v_pk_fma_f32 over a channel pair of dY with the pixel value broadcast by op_sel (common.hpp).
+// KW x KW taps in row-major order (checked on the host), W a multiple of 4.
+template <typename PT, int KW, int CPT, bool DUAL>
+__global__ __launch_bounds__(256) void wgrad_c1q_kernel(const C1K a) {
+    constexpr int NT = KW * KW, R = KW / 2, SROWS = 8, NR = SROWS + 2 * R, NP = CPT / 2;
+    constexpr int RC = 16 * 320;                 // floats of the cross-row reduction buffer (it aliases the image rows)
+    static_assert(NR * 520 >= RC, "the reduction buffer fits in the image rows");
+    __shared__ __attribute__((aligned(16))) float sx[NR][512 + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncg = a.Ca / CPT;               // channel groups (a power of two <= 16)
+    const int cg = tid % ncg, slot = tid / ncg;
+    const int nslot = 256 / ncg;
+    const int nrows = a.B * a.H;
+    const int r0 = (int)((long long)blockIdx.x * nrows / a.nsplit), r1 = (int)((long long)(blockIdx.x + 1) * nrows / a.nsplit);
+    const int NQ = a.W >> 2;
+    f32pair acc[NT][NP];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) acc[t][j] = (f32pair){0.f, 0.f};
+    float ca[DUAL ? CPT : 1], cb[DUAL ? CPT : 1], cc[DUAL ? CPT : 1];
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { ca[j] = a.ca[a.cp_off + cg * CPT + j]; cb[j] = a.cb[a.cp_off + cg * CPT + j]; cc[j] = a.cc[a.cp_off + cg * CPT + j]; }
+    }
+    for (int rc = r0; rc < r1;) {
+        const int b = rc / a.H, y0 = rc - b * a.H;
+        const int n = min(min(SROWS, r1 - rc), a.H - y0);      // rows of this pass: one image
+        const int nload = n + 2 * R, nq = nload * NQ;
+        __syncthreads();
+        for (int i0 = 0; i0 < nq; i0 += 1024) {
+            f32x4 tq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + tid + 256 * u;
+                const int rr = i / NQ, q = i - rr * NQ, yy = y0 - R + rr;
+                tq[u] = (i < nq && yy >= 0 && yy < a.H) ? *(const f32x4*)(a.x + ((size_t)b * a.H + yy) * a.W + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + tid + 256 * u;
+                const int rr = i / NQ, q = i - rr * NQ;
+                if (i < nq) *(f32x4*)&sx[rr][4 + 4 * q] = tq[u];
+            }
+        }
+        for (int i = tid; i < nload * 8; i += 256) sx[i >> 3][(i & 7) < 4 ? (i & 7) : a.W + (i & 7)] = 0.f;
+        __syncthreads();
+        const int nitems = n * NQ;
+        // the next item's dY (and y_raw) quads are in flight under this item's FMAs
+        static_assert(sizeof(PT) == 2, "bf16 dY");
+        typedef typename std::conditional<CPT == 8, bf16x8, bf16x4>::type raw_t;
+        raw_t rg[4], ry[DUAL ? 4 : 1];
+        auto issue = [&](int it) {
+            const int rl = it / NQ, x0 = (it - rl * NQ) << 2;
+            const size_t pix = (size_t)(rc + rl) * a.W + x0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                rg[p] = *(const raw_t*)((const PT*)a.p + (pix + p) * a.ldp + a.cp_off + cg * CPT);
+                if constexpr (DUAL) ry[p] = *(const raw_t*)((const PT*)a.p2 + (pix + p) * a.ld_p2 + a.cp2_off + cg * CPT);
+            }
+        };
+        if (slot < nitems) issue(slot);
+        for (int it = slot; it < nitems; it += nslot) {
+            const int rl = it / NQ, x0 = (it - rl * NQ) << 2;
+            const size_t pix = (size_t)(rc + rl) * a.W + x0;
+            f32pair g[4][NP];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float gv[CPT];
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) gv[j] = (float)rg[p][j];
+                if constexpr (DUAL) {
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j) gv[j] = fmaf(ca[j], gv[j], fmaf(cb[j], (float)ry[p][j], cc[j]));
+                    if (a.p_out != nullptr) {
+                        PT* dst = (PT*)a.p_out + (pix + p) * a.ld_pout + cg * CPT;
+                        if constexpr (sizeof(PT) == 2 && CPT == 8) *(bf16x8*)dst = pack_frag<bf16>(gv);
+                        else if constexpr (sizeof(PT) == 2 && CPT == 4) { bf16x4 o; for (int j = 0; j < 4; ++j) o[j] = (bf16)gv[j]; *(bf16x4*)dst = o; }
+                        else { for (int j = 0; j < CPT; ++j) dst[j] = (PT)gv[j]; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) g[p][j] = (f32pair){gv[2 * j], gv[2 * j + 1]};
+            }
+            if (it + nslot < nitems) issue(it + nslot);
+#pragma unroll
+            for (int dy = 0; dy < KW; ++dy) {
+                const float* rp = &sx[rl + dy][x0 + 2];     // pixels x0 - 2 .. x0 + 5 of image row (dY row + dy - R)
+                const f32x4 mid = *(const f32x4*)(rp + 2);
+                const f32pair win[4] = {*(const f32pair*)rp, (f32pair){mid[0], mid[1]}, (f32pair){mid[2], mid[3]}, *(const f32pair*)(rp + 6)};
+#pragma unroll
+                for (int dx = 0; dx < KW; ++dx)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int j = 0; j < NP; ++j) {
+                            const int e = p + dx + 2 - R;     // (compile-time after unrolling)
+                            if (e & 1) pk_fma_hi(acc[dy * KW + dx][j], win[e >> 1], g[p][j]); else pk_fma_lo(acc[dy * KW + dx][j], win[e >> 1], g[p][j]);
+                        }
+            }
+        }
+        rc += n;
+    }
+    // fold the pixel slots: the lanes of a 16-lane row that share a channel group by DPP rotations, then the 16 rows of the workgroup
+    // through LDS in row order, a chunk of taps at a time (the image rows are dead)
+    __syncthreads();
+    float* redf = &sx[0][0];
+    const int tch = 320 / a.Ca;                           // taps per chunk
+    for (int t0 = 0; t0 < NT; t0 += tch) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t >= t0 && t < t0 + tch) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    float v = acc[t][j >> 1][j & 1];
+                    if (ncg < 16) v = row_sum16(v, ncg);
+                    if ((lane & 15) < ncg) redf[(wave * 4 + (lane >> 4)) * 320 + (t - t0) * a.Ca + (lane & 15) * CPT + j] = v;
+                }
+            }
+        }
+        __syncthreads();
+        const int nval = min(tch, NT - t0) * a.Ca;
+        for (int i = tid; i < nval; i += 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += redf[r * 320 + i];
+            const int t = i / a.Ca, c = i - t * a.Ca;
+            a.partial[((size_t)blockIdx.x * a.ntaps + t0 + t) * a.Ca + c] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// the four-pixel form takes: a full 3 x 3 / 5 x 5 square in row-major tap order, whole pixel quads, bf16 dY
+static bool c1_quad(const abc_wgrad_desc* d) {
+    const int kw = d->ntaps == 9 ? 3 : (d->ntaps == 25 ? 5 : 0);
+    bool square = kw != 0 && (d->Wg % 4) == 0 && d->dtype_p == ABC_BF16 && d->Ca <= 32 && d->Ca % (kw == 5 ? 4 : 8) == 0;
+    for (int t = 0; square && t < d->ntaps; ++t) square = d->tap_dy[t] == t / kw - kw / 2 && d->tap_dx[t] == t % kw - kw / 2;
+    return square;
+}
+
 static bool c1_ok(const abc_wgrad_desc* d) {
     if (abc_knob("ABC_WGRAD_NOC1")) return false;
     if (d->Cb != 1 || d->cq_off != 0 || d->q.ldx != 1 || d->dtype_q != ABC_F32 || d->q.scale || d->q.pool || d->q.planar || d->q.drop_p > 0.f) return false;
     // (a transform on P only as the BatchNorm-backward correction of abc_wgrad_desc.p_dual: bf16)
-    // (9 taps only: the 25-tap form measured 332 us fused against 157 + 113 us with the separate apply pass)
-    if (d->p.scale && !(d->p_dual && d->dtype_p == ABC_BF16 && d->ntaps <= 9 && d->p2 != nullptr && (d->ld_p2 % 8) == 0 && (d->cp2_off % 8) == 0)) return false;
+    // (25 taps on the four-pixel form only: the scalar form measured 332 us fused against 157 + 113 us with the separate apply pass)
+    if (d->p.scale && !(d->p_dual && d->dtype_p == ABC_BF16 && (d->ntaps <= 9 || c1_quad(d)) && d->p2 != nullptr && (d->ld_p2 % 8) == 0 && (d->cp2_off % 8) == 0)) return false;
     if (d->p.pool || d->p.planar || d->p.drop_p > 0.f || d->stride != 1 || d->ntaps > 25) return false;
     if (d->Ca % 8 || d->Ca > 64 || (d->Ca & (d->Ca - 1)) || d->Wg > 512 || (d->p.ldx % 8) || (d->cp_off % 8)) return false;
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
@@ -853,6 +999,19 @@ static int c1_launch(const abc_wgrad_desc* d, hipStream_t st) {
     for (int t = 0; t < d->ntaps; ++t) { k.ty[t] = (int8_t)(d->tap_dy[t] - dymin); k.tx[t] = (int8_t)d->tap_dx[t]; }
     k.p2 = d->p2; k.ld_p2 = d->ld_p2; k.cp2_off = d->cp2_off; k.p_out = d->p_out; k.ld_pout = d->ld_pout;
     k.ca = d->p.scale; k.cc = d->p.shift; k.cb = d->p.slope;     // (abc_act_src of a deferred BatchNorm backward: scale = ca, shift = cc, slope = cb)
+    // the four-pixel form
+    {
+        const int kw = d->ntaps == 9 ? 3 : 5;
+        if (c1_quad(d)) {
+            const bool dual = d->p_dual && d->p.scale;
+            if (kw == 5) {
+                if (dual) hipLaunchKernelGGL((wgrad_c1q_kernel<bf16, 5, 4, true>), dim3(d->nsplit), dim3(256), 0, st, k);
+                else hipLaunchKernelGGL((wgrad_c1q_kernel<bf16, 5, 4, false>), dim3(d->nsplit), dim3(256), 0, st, k);
+            } else if (dual) hipLaunchKernelGGL((wgrad_c1q_kernel<bf16, 3, 8, true>), dim3(d->nsplit), dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((wgrad_c1q_kernel<bf16, 3, 8, false>), dim3(d->nsplit), dim3(256), 0, st, k);
+            return abc_check_launch("wgrad_c1q");
+        }
+    }
     if (d->p_dual && d->p.scale) {
         if (d->ntaps > 9) hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 25, 4, true>), dim3(d->nsplit), dim3(256), 0, st, k);
         else hipLaunchKernelGGL((wgrad_c1_kernel<bf16, 9, 8, true>), dim3(d->nsplit), dim3(256), 0, st, k);

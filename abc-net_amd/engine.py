@@ -457,8 +457,8 @@ class Engine:
         nsplit = max(1, min(max(1, npatch // 2), 256 // per_split))
         at_, bt_ = L.i32(), L.i32()
         L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
-        if (at_.value, bt_.value) == (0, 1):   # one-channel kernel: 256-thread workgroups streaming dY, several per CU
-            nsplit = min(self.B * gh, 1024)
+        if (at_.value, bt_.value) == (0, 1):   # one-channel kernel: 256-thread workgroups streaming dY, several per CU, 8 rows per pass
+            nsplit = min(-(-self.B * gh // 8), 1024)
         elif nsplit_arg is not None and (at_.value, bt_.value) == (0, 0):
             nsplit = max(1, min(nsplit_arg, self.B * gh * gw // 128))   # the heads' kernel splits whole 128-pixel chunks
         d.nsplit = nsplit

@@ -361,20 +361,22 @@ def test_wgrad_fused_bn_apply(lib, Cout, Cin, k):
     assert U.relerr(dw.cpu().view(Cout, Cin, k, k), w.grad) < U.tol(dt)
 
 
-def test_wgrad_one_channel_fused_bn_apply(lib):
+@pytest.mark.parametrize("k,Cout,W,nsplit", [(3, 16, 72, 7), (5, 32, 72, 7), (3, 16, 70, 5), (5, 32, 40, 3), (5, 8, 64, 11), (3, 32, 384, 9)])
+def test_wgrad_one_channel_fused_bn_apply(lib, k, Cout, W, nsplit):
     """the first convolution's weight gradient (unet.py:12 with one input channel: the plain-FMA kernel) with p_dual: the
     BatchNorm-backward correction on load of g and y_raw, the corrected tensor written out -- against the explicit formula
-    followed by torch's weight gradient over the f32 image"""
+    followed by torch's weight gradient over the f32 image.  3 x 3 (unet.py) and 5 x 5 (unet2.py:135) stems; widths that are whole
+    pixel quads run the four-pixel form (splits that cross image boundaries and leave partial 8-row passes), W = 70 the scalar one"""
     dt = L.BF16
     g_ = torch.Generator().manual_seed(52)
-    B, H, W, Cout, ldy, coff = 2, 40, 72, 16, 48, 16
+    B, H, ldy, coff = 2, 40, 64, 16
     gq = q(torch.randn((B, Cout, H, W), generator=g_), dt)
     yq = q(torch.randn((B, ldy, H, W), generator=g_), dt)
     ca, cb, cc = (torch.randn(Cout, generator=g_) * s_ for s_ in (1.0, 0.3, 0.05))
     dy32 = ca.view(1, -1, 1, 1) * gq + cb.view(1, -1, 1, 1) * yq[:, coff:coff + Cout] + cc.view(1, -1, 1, 1)
     img = torch.randn((B, 1, H, W), generator=g_)
-    w = torch.zeros((Cout, 1, 3, 3), requires_grad=True)
-    F.conv2d(img, w, None, padding=1).backward(dy32)         # (the kernel multiplies the UNROUNDED corrected value)
+    w = torch.zeros((Cout, 1, k, k), requires_grad=True)
+    F.conv2d(img, w, None, padding=k // 2).backward(dy32)         # (the kernel multiplies the UNROUNDED corrected value)
     gd, yd = U.nhwc(gq, dt), U.nhwc(yq, dt)
     xd = img.reshape(B, H, W, 1).contiguous().to(U.DEV)
     pcoef = tuple(t.to(U.DEV) for t in (ca, cc, cb))
@@ -383,9 +385,8 @@ def test_wgrad_one_channel_fused_bn_apply(lib):
     U.fill_src(d.p, gd, H, W, Cout, pcoef)
     U.fill_src(d.q, xd, H, W, 1, None)
     d.dtype_p, d.dtype_q, d.dtype_c = dt, L.F32, dt
-    nsplit = 7
     d.B, d.Hg, d.Wg, d.Hq, d.Wq, d.Ca, d.Cb, d.stride, d.nsplit = B, H, W, H, W, Cout, 1, 1, nsplit
-    L.set_taps(d, taps_square(3))
+    L.set_taps(d, taps_square(k))
     d.p2, d.ld_p2, d.cp2_off, d.p_dual, d.p_out, d.ld_pout = yd.data_ptr(), ldy, coff, 1, out.data_ptr(), Cout
     assert lib.abc_wgrad_fuses_apply(C.byref(d)) == 1
     at_, bt_ = L.i32(), L.i32()
@@ -393,16 +394,16 @@ def test_wgrad_one_channel_fused_bn_apply(lib):
     assert (at_.value, bt_.value) == (0, 1), "not the one-channel kernel"
     ca_, cb_ = L.i32(), L.i32()
     L.check(lib.abc_wgrad_pads(C.byref(d), C.byref(ca_), C.byref(cb_)), "pads")
-    part = torch.zeros(nsplit * 9 * ca_.value * cb_.value, dtype=torch.float32, device=U.DEV)
+    part = torch.zeros(nsplit * k * k * ca_.value * cb_.value, dtype=torch.float32, device=U.DEV)
     d.partial = part.data_ptr()
     L.check(lib.abc_wgrad(C.byref(d), U.stream()), "wgrad")
-    dw = torch.zeros((Cout, 1, 9), dtype=torch.float32, device=U.DEV)
+    dw = torch.zeros((Cout, 1, k * k), dtype=torch.float32, device=U.DEV)
     r = L.WgradReduceDesc()
-    r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), nsplit, 9, Cout, 1, ca_.value, cb_.value, dw.data_ptr(), 0
+    r.partial, r.nsplit, r.ntaps, r.Ca, r.Cb, r.Ca_pad, r.Cb_pad, r.dw, r.accumulate = part.data_ptr(), nsplit, k * k, Cout, 1, ca_.value, cb_.value, dw.data_ptr(), 0
     L.check(lib.abc_wgrad_reduce(C.byref(r), U.stream()), "reduce")
     torch.cuda.synchronize()
     assert U.relerr(U.to_nchw(out), dy32) < 1e-2
-    assert U.relerr(dw.cpu().view(Cout, 1, 3, 3), w.grad) < 2e-3
+    assert U.relerr(dw.cpu().view(Cout, 1, k, k), w.grad) < 2e-3
 
 
 @pytest.mark.parametrize("dt", DTS)
