@@ -231,6 +231,8 @@ SYMBOLS = {
     "abc_cbam_conv7_fwd": (C.c_int, [P(CbamConv7Desc), vp]),
     "abc_cbam_conv7_blocks": (C.c_int, [P(CbamConv7Desc)]),
     "abc_cbam_conv7_bwd": (C.c_int, [P(CbamConv7Desc), vp]),
+    "abc_cbam_conv7_bwd_partial": (C.c_int, [P(CbamConv7Desc), vp]),
+    "abc_cbam_channel_bwd_c7": (C.c_int, [P(CbamChannelDesc), P(CbamConv7Desc), vp]),
     "abc_add_into": (C.c_int, [vp, i32, i32, vp, i32, i32, i32, i64, i32, vp]),
     "abc_nhwc_to_nchw_f32": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "abc_nchw_to_nhwc_f32": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),

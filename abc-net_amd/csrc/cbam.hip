@@ -33,68 +33,65 @@ __device__ inline void st8(bf16* p, const float* v) {
 __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------ channel attention (forward)
-// pass 1: global avg / max pool of z per (image, channel) from the conv epilogue's per-tile partials.  One workgroup per
-// (image, 64 channels): 4 tile groups x 64 channels, so the partial rows are read as 256-byte lines by 4 waves at once
-// (one workgroup per image with a thread per channel walked 576 tiles serially: 51 us per call).
-__global__ __launch_bounds__(256) void cbam_channel_pool_kernel(const abc_cbam_channel_desc d) {
-    __shared__ double ssum[4][64];
-    __shared__ float smax[4][64], smin[4][64];
-    const int n = blockIdx.y, cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0;
-    float vmax = -3.0e38f, vmin = 3.0e38f;
-    if (c < d.C) {
-        // (four independent chains: at the 384 x 384 levels a group walks 144 of the 576 tiles of an image, and one chain of
-        //  dependent loads and f64 adds took 51-59 us for 3.6 MB)
-        double s4[4] = {0.0, 0.0, 0.0, 0.0};
-        float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, mn4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-        int k = grp;
-        for (; k + 12 < d.tiles_per_img; k += 16) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k + 4 * u) * 4) * d.C + c;
-                s4[u] += (double)p[0];
-                mx4[u] = fmaxf(mx4[u], p[2 * d.C]);
-                mn4[u] = fminf(mn4[u], p[3 * d.C]);
-            }
-        }
-        for (; k < d.tiles_per_img; k += 4) {
-            const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k) * 4) * d.C + c;
-            s4[0] += (double)p[0];
-            mx4[0] = fmaxf(mx4[0], p[2 * d.C]);
-            mn4[0] = fminf(mn4[0], p[3 * d.C]);
-        }
-        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        vmax = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
-        vmin = fminf(fminf(mn4[0], mn4[1]), fminf(mn4[2], mn4[3]));
-    }
-    ssum[grp][cl] = s; smax[grp][cl] = vmax; smin[grp][cl] = vmin;
-    __syncthreads();
-    if (grp == 0 && c < d.C) {
-        s = (ssum[0][cl] + ssum[1][cl]) + (ssum[2][cl] + ssum[3][cl]);
-        vmax = fmaxf(fmaxf(smax[0][cl], smax[1][cl]), fmaxf(smax[2][cl], smax[3][cl]));
-        vmin = fminf(fminf(smin[0][cl], smin[1][cl]), fminf(smin[2][cl], smin[3][cl]));
-        const float sc = d.scale[c], sh = d.shift[c];
-        d.avgz[(size_t)n * d.C + c] = sc * (float)(s / d.HW) + sh;
-        d.maxz[(size_t)n * d.C + c] = (sc >= 0.f ? sc * vmax : sc * vmin) + sh;
-        d.ext[(size_t)n * d.C + c] = sc >= 0.f ? vmax : vmin;
-        d.first[(size_t)n * d.C + c] = 0x7FFFFFFF;
-    }
-}
-
-// pass 2: the shared MLP on both pooled vectors + sigmoid, one workgroup per image
+// ONE launch, one workgroup per image (round 4: the pool and the MLP were two dependent ~6 us launches per block, 26 per step):
+// pass 1: global avg / max pool of z per (image, channel) from the conv epilogue's per-tile partials, 64 channels at a time:
+// 4 tile groups x 64 channels, so the partial rows are read as 256-byte lines by 4 waves at once
+// (a thread per channel walking 576 tiles serially: 51 us per call);
+// pass 2: the shared MLP on both pooled vectors + sigmoid.
 __global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_channel_desc d) {
     extern __shared__ float sm[];
     float* av = sm;              // [C] avg(z)
     float* mx = sm + d.C;        // [C] max(z)
     float* ha = sm + 2 * d.C;    // [mid]
     float* hm = ha + d.mid;      // [mid]
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < d.C; c += 256) {
-        av[c] = d.avgz[(size_t)n * d.C + c];
-        mx[c] = d.maxz[(size_t)n * d.C + c];
+    __shared__ double ssum[4][64];
+    __shared__ float smax[4][64], smin[4][64];
+    const int n = blockIdx.x, cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int cb = 0; cb < d.C; cb += 64) {
+        const int c = cb + cl;
+        double s = 0.0;
+        float vmax = -3.0e38f, vmin = 3.0e38f;
+        if (c < d.C) {
+            // (four independent chains: at the 384 x 384 levels a group walks 144 of the 576 tiles of an image, and one chain of
+            //  dependent loads and f64 adds took 51-59 us for 3.6 MB)
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, mn4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+            int k = grp;
+            for (; k + 12 < d.tiles_per_img; k += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k + 4 * u) * 4) * d.C + c;
+                    s4[u] += (double)p[0];
+                    mx4[u] = fmaxf(mx4[u], p[2 * d.C]);
+                    mn4[u] = fminf(mn4[u], p[3 * d.C]);
+                }
+            }
+            for (; k < d.tiles_per_img; k += 4) {
+                const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k) * 4) * d.C + c;
+                s4[0] += (double)p[0];
+                mx4[0] = fmaxf(mx4[0], p[2 * d.C]);
+                mn4[0] = fminf(mn4[0], p[3 * d.C]);
+            }
+            s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            vmax = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+            vmin = fminf(fminf(mn4[0], mn4[1]), fminf(mn4[2], mn4[3]));
+        }
+        ssum[grp][cl] = s; smax[grp][cl] = vmax; smin[grp][cl] = vmin;
+        __syncthreads();
+        if (grp == 0 && c < d.C) {
+            s = (ssum[0][cl] + ssum[1][cl]) + (ssum[2][cl] + ssum[3][cl]);
+            vmax = fmaxf(fmaxf(smax[0][cl], smax[1][cl]), fmaxf(smax[2][cl], smax[3][cl]));
+            vmin = fminf(fminf(smin[0][cl], smin[1][cl]), fminf(smin[2][cl], smin[3][cl]));
+            const float sc = d.scale[c], sh = d.shift[c];
+            const float a_ = sc * (float)(s / d.HW) + sh, m_ = (sc >= 0.f ? sc * vmax : sc * vmin) + sh;
+            d.avgz[(size_t)n * d.C + c] = a_;
+            d.maxz[(size_t)n * d.C + c] = m_;
+            d.ext[(size_t)n * d.C + c] = sc >= 0.f ? vmax : vmin;
+            d.first[(size_t)n * d.C + c] = 0x7FFFFFFF;
+            av[c] = a_; mx[c] = m_;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // hidden unit j: 256 / mid lanes share the dot products (mid <= 32 is a power of two)
     {
         const int per = 256 / d.mid;                  // lanes per hidden unit (>= 8)
@@ -394,19 +391,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // one workgroup per output (98 weights + bias): 256 lanes stride the per-workgroup partials, fixed tree -> reproducible
 // (one THREAD per output walking 9216 partials serially cost 6 ms per step)
+__device__ __forceinline__ void conv7_reduce_body(const float* partial, int nblk, float* dw7, float* db7, int t);
 __global__ __launch_bounds__(256) void cbam_conv7_reduce_kernel(const float* partial, int nblk, float* dw7, float* db7) {
-    __shared__ double red[4];
-    const int t = blockIdx.x;
-    double s = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += 256) s += (double)partial[(size_t)k * 99 + t];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-        if (t < 98) dw7[t] = (float)tot; else db7[0] = (float)tot;
-    }
+    conv7_reduce_body(partial, nblk, dw7, db7, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------ apply (forward): out = relu(sa*ca*z + r)
@@ -585,31 +572,50 @@ __global__ __launch_bounds__(256) void cbam_bwd2_kernel(const abc_cbam_pix_desc 
 //         gradients, partitioned over the grid; the intermediates come from `work` into LDS.
 // (8 lanes per (image, channel), each summing every 8th partial: one thread walking up to 128 partials was a 32-43 us chain
 //  of dependent f64 adds for a few KB of data; the combination order is fixed -- lanes 0..7, then the xor tree)
-__global__ __launch_bounds__(256) void cbam_channel_bwd_pre1_kernel(const abc_cbam_channel_desc d) {
-    const int gt = blockIdx.x * 256 + threadIdx.x;
-    const int idx = gt >> 3, sub = gt & 7;
-    const bool ok = idx < d.B * d.C;
-    const int n = ok ? idx / d.C : 0, c = ok ? idx - n * d.C : 0;
-    const int T = d.tiles_per_img;
+// pre (= pre1 + pre2 as one launch, one workgroup per image; round 4): a (image, channel) pair per 8 lanes, 32 channels per sweep,
+// dt kept in LDS for the hidden-unit sums that follow.  Workgroups past the B images reduce the 7x7 convolution's weight-gradient
+// partials of the SAME block (cbam_conv7_reduce_kernel's body: independent of everything here, it used to be a launch of its own).
+__device__ __forceinline__ void conv7_reduce_body(const float* partial, int nblk, float* dw7, float* db7, int t) {
+    __shared__ double red7[4];
     double s = 0.0;
-    if (ok)
-        for (int k = sub; k < T; k += 8) s += (double)d.partial[((size_t)n * T + k) * d.C + c];
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-    if (ok && sub == 0) {
-        const float ca = d.ca[idx];
-        d.work[idx] = (float)s * ca * (1.f - ca);
+    for (int k = threadIdx.x; k < nblk; k += 256) s += (double)partial[(size_t)k * 99 + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red7[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (red7[0] + red7[1]) + (red7[2] + red7[3]);
+        if (t < 98) dw7[t] = (float)tot; else db7[0] = (float)tot;
     }
 }
 
-__global__ __launch_bounds__(256) void cbam_channel_bwd_pre2_kernel(const abc_cbam_channel_desc d) {
+__global__ __launch_bounds__(256) void cbam_channel_bwd_pre_kernel(const abc_cbam_channel_desc d, const float* c7_partial, int c7_nblk,
+                                                                     float* c7_dw, float* c7_db) {
+    if ((int)blockIdx.x >= d.B) { conv7_reduce_body(c7_partial, c7_nblk, c7_dw, c7_db, (int)blockIdx.x - d.B); return; }
+    extern __shared__ float sm[];      // dt[C]
     const int n = blockIdx.x;
+    const int T = d.tiles_per_img;
+    const int sub = threadIdx.x & 7;
+    for (int c = threadIdx.x >> 3; c < ((d.C + 31) & ~31); c += 32) {
+        const bool ok = c < d.C;
+        double s = 0.0;
+        if (ok)
+            for (int k = sub; k < T; k += 8) s += (double)d.partial[((size_t)n * T + k) * d.C + c];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (ok && sub == 0) {
+            const float ca = d.ca[(size_t)n * d.C + c];
+            const float v = (float)s * ca * (1.f - ca);
+            d.work[(size_t)n * d.C + c] = v;
+            sm[c] = v;
+        }
+    }
+    __syncthreads();
     const int per = 256 / d.mid;
-    const int j = threadIdx.x / per, sub = threadIdx.x % per;
-    const float* dt = d.work + (size_t)n * d.C;
+    const int j = threadIdx.x / per, sub2 = threadIdx.x % per;
     float s = 0.f;
-    for (int c = sub; c < d.C; c += per) s += d.w2[(size_t)c * d.mid + j] * dt[c];
+    for (int c = sub2; c < d.C; c += per) s += d.w2[(size_t)c * d.mid + j] * sm[c];
     for (int o = 1; o < per && o < 64; o <<= 1) s += __shfl_xor(s, o);
-    if (sub == 0) {
+    if (sub2 == 0) {
         const int idx = n * d.mid + j;
         d.work[(size_t)d.B * d.C + idx] = d.hid_avg[idx] > 0.f ? s : 0.f;
         d.work[(size_t)d.B * d.C + d.B * d.mid + idx] = d.hid_max[idx] > 0.f ? s : 0.f;
@@ -753,12 +759,11 @@ extern "C" int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t
     if (rc) return rc;
     if (d->ext == nullptr || d->first == nullptr) return abc_fail(ABC_EINVAL, "cbam_channel_fwd: ext / first (arg-max of the global max-pool) required");
     const size_t sh = (size_t)(2 * d->C + 2 * d->mid) * sizeof(float);
-    hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(abc_cdiv(d->C, 64), d->B), dim3(256), 0, (hipStream_t)stream, *d);
     hipLaunchKernelGGL(cbam_channel_fwd_kernel, dim3(d->B), dim3(256), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_fwd");
 }
 
-extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream) {
+static int channel_bwd_launch(const abc_cbam_channel_desc* d, const abc_cbam_conv7_desc* c7, abc_stream_t stream) {
     int rc = check_channel(d);
     if (rc) return rc;
     if (d->work == nullptr) return abc_fail(ABC_EINVAL, "cbam_channel_bwd: work buffer of B * (C + 2 mid) floats required");
@@ -770,10 +775,22 @@ extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t
     // dependent global loads, so width beats depth (8 elements per thread cost 50 us per call)
     const int want = abc_cdiv(d->C * d->mid, 256);
     const int nb = want < 1 ? 1 : (want > 64 ? 64 : want);
-    hipLaunchKernelGGL(cbam_channel_bwd_pre1_kernel, dim3(abc_cdiv(d->B * d->C * 8, 256)), dim3(256), 0, (hipStream_t)stream, *d);
-    hipLaunchKernelGGL(cbam_channel_bwd_pre2_kernel, dim3(d->B), dim3(256), 0, (hipStream_t)stream, *d);
+    if (c7 != nullptr)
+        hipLaunchKernelGGL(cbam_channel_bwd_pre_kernel, dim3(d->B + 99), dim3(256), (size_t)d->C * sizeof(float), (hipStream_t)stream, *d,
+                           (const float*)c7->dw_partial, abc_cbam_conv7_blocks(c7), c7->dw7, c7->db7);
+    else
+        hipLaunchKernelGGL(cbam_channel_bwd_pre_kernel, dim3(d->B), dim3(256), (size_t)d->C * sizeof(float), (hipStream_t)stream, *d,
+                           (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(nb), dim3(256), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_bwd");
+}
+
+extern "C" int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream) { return channel_bwd_launch(d, nullptr, stream); }
+
+extern "C" int abc_cbam_channel_bwd_c7(const abc_cbam_channel_desc* d, const abc_cbam_conv7_desc* c7, abc_stream_t stream) {
+    if (c7 == nullptr || c7->dw_partial == nullptr || c7->dw7 == nullptr || c7->db7 == nullptr)
+        return abc_fail(ABC_EINVAL, "cbam_channel_bwd_c7: the 7x7 convolution's partials and gradient pointers are required");
+    return channel_bwd_launch(d, c7, stream);
 }
 
 // workgroups per image of the per-pixel passes: enough to fill the chip a few times over, few enough that the
@@ -868,12 +885,21 @@ extern "C" int abc_cbam_conv7_blocks(const abc_cbam_conv7_desc* d) {
     return ntiles < 512 ? ntiles : 512;   // persistent: 2 workgroups per CU (178 registers), all resident
 }
 
-extern "C" int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream) {
+static void conv7_bwd_main(const abc_cbam_conv7_desc* d, abc_stream_t stream) {
     if (conv7_px(d) == 4) hipLaunchKernelGGL(cbam_conv7_bwd_kernel<4>, dim3(abc_cbam_conv7_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d);
     else hipLaunchKernelGGL(cbam_conv7_bwd_kernel<1>, dim3(abc_cbam_conv7_blocks(d)), dim3(256), 0, (hipStream_t)stream, *d);
+}
+
+extern "C" int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream) {
+    conv7_bwd_main(d, stream);
     hipLaunchKernelGGL(cbam_conv7_reduce_kernel, dim3(99), dim3(256), 0, (hipStream_t)stream, (const float*)d->dw_partial,
                        abc_cbam_conv7_blocks(d), d->dw7, d->db7);
     return abc_check_launch("cbam_conv7_bwd");
+}
+
+extern "C" int abc_cbam_conv7_bwd_partial(const abc_cbam_conv7_desc* d, abc_stream_t stream) {
+    conv7_bwd_main(d, stream);
+    return abc_check_launch("cbam_conv7_bwd_partial");
 }
 
 extern "C" int abc_add_into(void* dst, int32_t ld_dst, int32_t cdst_off, const void* src, int32_t ld_src, int32_t csrc_off, int32_t C,

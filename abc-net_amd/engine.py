@@ -1636,7 +1636,8 @@ class Engine:
             nb7 = lib.abc_cbam_conv7_blocks(C.byref(c7))
             part7 = self.f32buf(nb7, 99)
             c7.dw_partial, c7.dw7, c7.db7 = part7.data_ptr(), self.G(sp + ".weight"), self.G(sp + ".bias")
-            self._emit(ops, lib.abc_cbam_conv7_bwd, c7, "cbam_conv7_bwd " + blk.prefix, writes=(sp + ".weight", sp + ".bias"))
+            # (the reduction of part7 rides in the first launch of this block's channel-attention backward below)
+            self._emit(ops, lib.abc_cbam_conv7_bwd_partial, c7, "cbam_conv7_bwd " + blk.prefix)
             d2 = pix()
             nb2 = lib.abc_cbam_bwd2_blocks(C.byref(d2))
             part2 = self.f32buf(B, nb2, Cc)
@@ -1652,8 +1653,11 @@ class Engine:
             ch.dw1, ch.db1, ch.dw2, ch.db2 = self.G(m + ".0.weight"), self.G(m + ".0.bias"), self.G(m + ".2.weight"), self.G(m + ".2.bias")
             ch.d_avgz, ch.d_maxz = d_avgz.data_ptr(), d_maxz.data_ptr()
             ch.work = self.f32buf(B * (Cc + 2 * blk.mid)).data_ptr()
-            self._emit(ops, lib.abc_cbam_channel_bwd, ch, "cbam_channel_bwd " + blk.prefix,
-                       writes=(m + ".0.weight", m + ".0.bias", m + ".2.weight", m + ".2.bias"))
+            self.keep += [ch, c7]
+            ops.append((lambda _r, st, a=(ch, c7): lib.abc_cbam_channel_bwd_c7(C.byref(a[0]), C.byref(a[1]), st), None,
+                        "cbam_channel_bwd " + blk.prefix + " + conv7 reduce",
+                        (m + ".0.weight", m + ".0.bias", m + ".2.weight", m + ".2.bias", sp + ".weight", sp + ".bias"),
+                        {"kernel": "cbam_channel_bwd", "flops": 0, "bytes": 0}))
             d3 = pix()
             nb3 = lib.abc_cbam_bwd3_blocks(C.byref(d3))
             part3 = self.f32buf(nb3, 2, Cc)

@@ -521,6 +521,9 @@ typedef struct abc_cbam_channel_desc { /* ChannelAttentionModule (unet2.py:6-22)
 } abc_cbam_channel_desc;
 int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
 int abc_cbam_channel_bwd(const abc_cbam_channel_desc* d, abc_stream_t stream);
+/* abc_cbam_channel_bwd + the pending reduction of c7->dw_partial into c7->dw7 / c7->db7 (see abc_cbam_conv7_bwd_partial) */
+struct abc_cbam_conv7_desc;
+int abc_cbam_channel_bwd_c7(const abc_cbam_channel_desc* d, const struct abc_cbam_conv7_desc* c7, abc_stream_t stream);
 
 typedef struct abc_cbam_pix_desc { /* per-pixel passes of SpatialAttentionModule / CBAM / residual (unet2.py:24-74) */
     const void* y; int32_t ld_y, cy_off;               /* raw second-conv output y2 */
@@ -553,6 +556,9 @@ typedef struct abc_cbam_conv7_desc { /* SpatialAttentionModule.conv2d 7x7 (2->1)
 int abc_cbam_conv7_fwd(const abc_cbam_conv7_desc* d, abc_stream_t stream);
 int abc_cbam_conv7_blocks(const abc_cbam_conv7_desc* d); /* dw_partial = [blocks][99] */
 int abc_cbam_conv7_bwd(const abc_cbam_conv7_desc* d, abc_stream_t stream);
+/* the same without the reduction of dw_partial: abc_cbam_channel_bwd_c7 of the same block performs it inside its first launch
+ * (the reduction is independent of the channel attention's backward and was a ~5 us launch of its own, 13 per step of unet2.py) */
+int abc_cbam_conv7_bwd_partial(const abc_cbam_conv7_desc* d, abc_stream_t stream);
 
 /* dst[.., cdst_off + c] += src[.., csrc_off + c] (identity residual gradient, unet2.py:62) */
 int abc_add_into(void* dst, int32_t ld_dst, int32_t cdst_off, const void* src, int32_t ld_src, int32_t csrc_off, int32_t C,
