@@ -136,7 +136,7 @@ class MetricsDesc(C.Structure):
 class ExtractDesc(C.Structure):
     _fields_ = [("atom_mask", vp), ("bond_mask", vp), ("types", vp), ("charges", vp), ("hs", vp), ("btypes", vp), ("rho", vp),
                 ("omega", vp), ("B", i32), ("h", i32), ("w", i32), ("cap_atoms", i32), ("cap_bonds", i32), ("counts", vp),
-                ("atoms", vp), ("bonds", vp), ("bond_rho", vp), ("work", vp), ("work_masks", vp)]
+                ("atoms", vp), ("bonds", vp), ("bond_rho", vp), ("work", vp), ("work_masks", vp), ("btype_idx", vp)]
 
 
 class RasterDesc(C.Structure):

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(XT) void extract_kernel(const abc_extract_desc d) {
             if (slot < d.cap_bonds) {
                 int* o = d.bonds + ((size_t)b * d.cap_bonds + slot) * 4;
                 o[0] = x; o[1] = y; o[2] = lane;
-                o[3] = argmax_plane<6>(d.btypes + ((size_t)b * 360 + lane) * hw + p, (size_t)60 * hw);
+                o[3] = d.btype_idx != nullptr ? (int)d.btype_idx[((size_t)b * 60 + lane) * hw + p]
+                                              : argmax_plane<6>(d.btypes + ((size_t)b * 360 + lane) * hw + p, (size_t)60 * hw);
                 d.bond_rho[(size_t)b * d.cap_bonds + slot] = fabsf(d.rho[((size_t)b * 60 + lane) * hw + p]);
             }
         }

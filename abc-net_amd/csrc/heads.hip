@@ -28,7 +28,7 @@ struct HeadFwdK {
     int f8;                // e4m3 features and weights (the fp8 inference graph): oscale[co] = s_x * s_w[co]
     const float* oscale;
     float* aux;            // abc_conv_desc.head_aux: [B][Cout][HW]
-    int aux_mode;          // 1: |v|; 2: circular 3-tap local maximum along the channel axis and v > -1
+    int aux_mode;          // 1: |v|; 2: circular 3-tap local maximum along the channel axis and v > -1; 3: arg max over six channel groups (uint8)
 };
 
 // e4m3 form (fp8 inference graph: finished features, no transform on load): a pixel's 128 channels are 128 bytes = two K = 64
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdK a) { head_
 // after the other.  The lane (pixel r, half h) holds the channels 32 mt + (k & 3) + 8 (k >> 2) + 4 h of its pixel; the partner lane
 // r + 32 the other half of every group of eight (one cross-lane exchange).  mask = (max(prev, cur, next) == cur && cur > -1) over
 // the circular channel axis -- on the very f32 values that are stored as the raw map (when y is given).
-__global__ __launch_bounds__(256) void head_fwd_omega_kernel(const HeadFwdK a) {
+template <bool F8>
+__global__ __launch_bounds__(256, 2) void head_fwd_omega_kernel(const HeadFwdK a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int pair = blockIdx.x * 4 + wave;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void head_fwd_omega_kernel(const HeadFwdK a) {
     for (int t = 0; t < 2; ++t) {
         const uint32_t pix = (uint32_t)pair * 64u + t * 32 + r;
         float v[2][16];
-        if (a.f8) {
+        if constexpr (F8) {
             const uint32_t e0 = pix * (uint32_t)a.ldx + (uint32_t)a.cin_off + 32 * h;
             i32x8 fb[2];
 #pragma unroll
@@ -272,6 +273,211 @@ __global__ __launch_bounds__(256) void head_fwd_omega_kernel(const HeadFwdK a) {
             }
         }
     }
+}
+
+// ---- a head whose maps are consumed as an arg-max over GROUPS of channel planes (abc_conv_desc.head_aux_mode == 3; the bond-type head:
+// img2smiles2.py:71 views its 360 channels as 6 types x 60 omega bins and :112 takes argmax over the 6): the raw maps are not stored at
+// all (1.5 GB of f32 per batch of 64 at 512 x 512 that only ever feed six-way comparisons), one byte per (bin, pixel) is.  A wave owns
+// 64 pixels as in the plain form and walks m-tiles made of the SAME 32 bins of each of the six groups one after the other (row
+// g * nb + 32 bb + r of the packed weights; a row past the bins of the last block reads zeros), so the six candidates of a
+// (bin, pixel) arrive in the same accumulator register of the same lane: a running (max, arg) pair per register, first maximum wins
+// as in torch.argmax.  The values compared are the f32 values the plain form would have stored.
+// Persistent 8-wave workgroups with the head's packed weights in LDS (98 KB bf16 / 49 KB e4m3: every wave of the plain form
+// re-fetches them from the L2 per 64 pixels, and with two waves per SIMD each of the twelve m-tile steps then waits out an L2 round
+// trip: that form ran this head at 1.1 TB/s, 319 us per batch of 64).  The 64-byte rows are stored with their four 16-byte slots
+// XOR-ed by (row >> 2) & 3: the 16 lanes of a ds_read_b128 group (rows c .. c+3, c+12 .. c+15, c+20 .. c+27) then hit 16 banks.
+template <bool F8>
+__global__ __launch_bounds__(512, 1) void head_fwd_group_kernel(const HeadFwdK a) {
+    extern __shared__ __attribute__((aligned(16))) char wl[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX), rsW = abc_make_rsrc(a.w, a.bytesW);
+    const int nb = a.Cout / 6, nbb = (nb + 31) >> 5;
+    const bool tr = a.sc != nullptr;
+    constexpr int ROWB = 64;                      // bytes of a packed weight row of one chunk: 64 e4m3 / 32 bf16
+    constexpr int SLOTS = ROWB / 16;
+    // bias / dequantisation factor per (group, bin), bins padded to whole blocks of 32: [6][64] floats each behind the weights
+    float* sbias = (float*)(wl + a.bytesW);
+    float* sosc = sbias + 6 * 64;
+    {
+        // packed weights [chunk][Cout_pad][ROWB] -> LDS, 16 bytes at a time, slot s of row co at s ^ ((co >> 2) & 3)
+        const int nseg = (int)(a.bytesW / 16);
+        for (int i = threadIdx.x; i < nseg; i += 512) {
+            const int row = i / SLOTS, sl = i - row * SLOTS;
+            const int co = row % a.Cout_pad;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, (unsigned)i * 16u, 0, 0);
+            *(u32x4*)(wl + row * ROWB + ((sl ^ ((co >> 2) & 3)) * 16)) = v;
+        }
+        for (int i = threadIdx.x; i < 6 * 64; i += 512) {
+            const int g = i >> 6, bin = i & 63;
+            const bool ok = bin < nb;
+            sbias[i] = (a.bias && ok) ? a.bias[g * nb + bin] : 0.f;
+            sosc[i] = (F8 && ok) ? a.oscale[g * nb + bin] : 0.f;
+        }
+    }
+    __syncthreads();
+    // the arg-max map through a buffer descriptor: a lane's part of the address is its pixel, the (image, bin) plane a scalar offset
+    const __amdgpu_buffer_rsrc_t rsO = abc_make_rsrc(a.aux, (unsigned)((size_t)(a.npairs * 64 / a.HW) * nb * a.HW));
+    for (int pair = blockIdx.x * 8 + wave; pair < a.npairs; pair += gridDim.x * 8) {
+        const int b = (pair * 64) / a.HW, pp = pair * 64 - b * a.HW;
+        bf16x8 fb[F8 ? 1 : 2][F8 ? 1 : 8];
+        i32x8 fq[F8 ? 2 : 1][F8 ? 2 : 1];
+        if constexpr (F8) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t pix = (uint32_t)pair * 64u + t * 32 + r;
+                const uint32_t e0 = pix * (uint32_t)a.ldx + (uint32_t)a.cin_off + 32 * h;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    fq[t][s] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsX, e0 + 64 * s, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsX, e0 + 64 * s + 16, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t pix = (uint32_t)pair * 64u + t * 32 + r;
+                const uint32_t e0 = pix * (uint32_t)a.ldx + (uint32_t)a.cin_off + 8 * h;
+                u32x4 raw[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) raw[kk] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (e0 + 16 * kk) * 2u, 0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    if (tr) {
+                        float f[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(raw[kk][j] << 16); f[2 * j + 1] = __uint_as_float(raw[kk][j] & 0xFFFF0000u); }
+                        const int c = a.cin_off + 16 * kk + 8 * h;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] = abc_act(f[j], a.sc[c + j], a.sh[c + j], a.sl[c + j]);
+                        fb[t][kk] = pack_frag<bf16>(f);      // (no dropout: an evaluation-time output)
+                    } else {
+                        fb[t][kk] = *(const bf16x8*)&raw[kk];
+                    }
+                }
+            }
+        }
+        for (int bb = 0; bb < nbb; ++bb) {
+            float best[2][16];
+            int arg[2][16];
+            const bool row_ok = bb * 32 + r < nb;
+            // one m-tile: the 32 bins of block bb of group g, both pixel tiles -> acc (the f32 values the plain form would store)
+            auto tile = [&](int g, f32x16* acc) {
+                const int co = row_ok ? g * nb + bb * 32 + r : a.Cout_pad - 1;   // this lane's weight row (a zero padding row past the bins)
+                const int sw = (co >> 2) & 3;
+                float bvv[16], osc[16];
+                const float* bp = sbias + g * 64 + bb * 32 + 4 * h;
+                const float* op = sosc + g * 64 + bb * 32 + 4 * h;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 b4 = *(const f32x4*)(bp + 8 * k4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bvv[4 * k4 + j] = b4[j];
+                    if constexpr (F8) {
+                        const f32x4 o4 = *(const f32x4*)(op + 8 * k4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) osc[4 * k4 + j] = o4[j];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[t][k] = F8 ? 0.f : bvv[k];
+                if constexpr (F8) {
+                    i32x8 fa[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const char* rowp = wl + (s2 * a.Cout_pad + co) * 64;      // bytes 32 h .. 32 h + 32 of the row: slots 2 h, 2 h + 1
+                        fa[s2] = abc_join32B(*(const u32x4*)(rowp + (((2 * h) ^ sw) * 16)), *(const u32x4*)(rowp + (((2 * h + 1) ^ sw) * 16)));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) mma32B_f8(acc[t], fa[s2], fq[t][s2]);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[t][k] = fmaf(acc[t][k], osc[k], bvv[k]);
+                    }
+                } else {
+                    bf16x8 fa[8];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)      // packed byte offset ((kk >> 1) Cout_pad + co) 64 + 32 (kk & 1) + 16 h: slot 2 (kk & 1) + h
+                        fa[kk] = *(const bf16x8*)(wl + ((kk >> 1) * a.Cout_pad + co) * 64 + (((2 * (kk & 1) + h) ^ sw) * 16));
+                    // (the bias as the accumulators' initial value: acc + bias in the plain form is the same f32 sum order up to the
+                    //  position of the bias term -- NOT bit-identical; keep the plain form's order: add it afterwards)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[t][kk], acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[t][k] += bvv[k];
+                    }
+                }
+            };
+            {
+                f32x16 acc[2];
+                tile(0, acc);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { best[t][k] = acc[t][k]; arg[t][k] = 0; }
+            }
+#pragma unroll 1
+            for (int g = 1; g < 6; ++g) {
+                f32x16 acc[2];
+                tile(g, acc);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool gt = acc[t][k] > best[t][k];
+                        best[t][k] = gt ? acc[t][k] : best[t][k];
+                        arg[t][k] = gt ? g : arg[t][k];
+                    }
+            }
+            // Stores.  Registers k = 4 q .. 4 q + 3 of a lane are four consecutive bins of ONE pixel; a dword of the map is four
+            // consecutive PIXELS (the lanes of a quad) of one bin: a 4 x 4 byte transpose inside the quad (two butterfly steps of one
+            // DPP move + one v_perm each), after which lane j of the quad holds bin 4 q' + j for the quad's four pixels and every lane
+            // stores one dword per register group.  (Byte stores are not merged on their way to the L2; a broadcast per byte cost
+            // 7 VALU instructions per value.)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    unsigned w = (unsigned)arg[t][4 * q4] | ((unsigned)arg[t][4 * q4 + 1] << 8) | ((unsigned)arg[t][4 * q4 + 2] << 16) | ((unsigned)arg[t][4 * q4 + 3] << 24);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    {   // step 1: exchange with lane ^ 1 -- even lanes keep bytes 0, 2 and take the partner's 0, 2 into 1, 3; odd lanes the mirror
+                        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+                        w = (lane & 1) ? __builtin_amdgcn_perm(w, o, 0x07030501u) : __builtin_amdgcn_perm(o, w, 0x06020400u);
+                    }
+                    {   // step 2: exchange with lane ^ 2 on 16-bit halves
+                        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+                        w = (lane & 2) ? __builtin_amdgcn_perm(w, o, 0x07060302u) : __builtin_amdgcn_perm(o, w, 0x05040100u);
+                    }
+#endif
+                    // this lane now holds bin 32 bb + 8 q4 + 4 h + (lane & 3) for pixels pp + 32 t + (r & ~3) .. + 3
+                    const int bin = bb * 32 + 8 * q4 + 4 * h + (lane & 3);
+                    const unsigned voff = bin < nb ? (unsigned)(bin * a.HW + pp + t * 32 + (r & ~3)) : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b32(w, rsO, voff, (unsigned)(b * nb) * (unsigned)a.HW, 0);
+                }
+        }
+    }
+}
+
+// (dynamic LDS of the group kernel: the head's packed weights)
+static int group_launch(const HeadFwdK& k, hipStream_t st) {
+    static unsigned long long ok8 = 0, ok16 = 0;
+    const int lds = (int)k.bytesW + 2 * 6 * 64 * 4;
+    if (lds > 150 * 1024) return abc_fail(ABC_EUNSUPPORTED, "head_fwd (arg-max form): the head's packed weights exceed the LDS");
+    const int want = abc_cdiv(k.npairs, 8);
+    const int grid = want < 256 ? want : 256;
+    if (k.f8) {
+        if (int rc = abc_allow_lds((const void*)head_fwd_group_kernel<true>, 160 * 1024, &ok8)) return rc;
+        hipLaunchKernelGGL(head_fwd_group_kernel<true>, dim3(grid), dim3(512), lds, st, k);
+    } else {
+        if (int rc = abc_allow_lds((const void*)head_fwd_group_kernel<false>, 160 * 1024, &ok16)) return rc;
+        hipLaunchKernelGGL(head_fwd_group_kernel<false>, dim3(grid), dim3(512), lds, st, k);
+    }
+    return 0;
 }
 
 // All heads of the network in ONE launch (blockIdx.y = head): eight back-to-back launches each drained the chip before the
@@ -433,7 +639,8 @@ int abc_head_fwd_ok(const abc_conv_desc* d) {
     if (d->src.pool || d->src.planar || d->accumulate || d->stats != nullptr || d->out_act) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || (d->Hg * d->Wg) % 64) return 0;
     if ((d->src.ldx % 8) || (d->cin_off % 8) || d->Cout_pad % 32) return 0;
-    if (d->head_aux != nullptr && !(d->head_aux_mode == 1 || (d->head_aux_mode == 2 && d->Cout == 60 && d->Cout_pad == 64 && d->src.drop_p <= 0.f))) return 0;
+    if (d->head_aux != nullptr && !(d->head_aux_mode == 1 || (d->head_aux_mode == 2 && d->Cout == 60 && d->Cout_pad == 64 && d->src.drop_p <= 0.f) ||
+                                    (d->head_aux_mode == 3 && d->Cout % 6 == 0 && d->Cout / 6 <= 64 && d->y == nullptr && d->src.drop_p <= 0.f))) return 0;
     if (d->y == nullptr && d->head_aux == nullptr) return 0;
     // (all offsets in the kernel are unsigned 32-bit bytes: a batch-64 512x512 feature buffer of 8 x 128 channels is 2^31)
     const int64_t bx = (int64_t)d->B * d->Hg * d->Wg * d->src.ldx * (f8 ? 1 : 2);
@@ -443,7 +650,9 @@ int abc_head_fwd_ok(const abc_conv_desc* d) {
 int abc_head_fwd_launch(const abc_conv_desc* d, abc_stream_t stream) {
     HeadFwdK k;
     fill_fwd(k, d);
-    if (k.aux_mode == 2) hipLaunchKernelGGL(head_fwd_omega_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+    if (k.aux_mode == 2 && k.f8) hipLaunchKernelGGL(head_fwd_omega_kernel<true>, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+    else if (k.aux_mode == 2) hipLaunchKernelGGL(head_fwd_omega_kernel<false>, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+    else if (k.aux_mode == 3) { if (int rc = group_launch(k, (hipStream_t)stream)) return rc; }
     else hipLaunchKernelGGL(head_fwd_kernel, dim3(abc_cdiv(k.npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
     return abc_check_launch("head_fwd");
 }
@@ -482,7 +691,9 @@ extern "C" int abc_heads_batch(const abc_conv_desc* descs, int32_t n, int32_t wh
         for (int i = 0; i < n; ++i) {
             HeadFwdK k;
             fill_fwd(k, descs + i);
-            if (k.aux_mode == 2) hipLaunchKernelGGL(head_fwd_omega_kernel, dim3(abc_cdiv(npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+            if (k.aux_mode == 2 && k.f8) hipLaunchKernelGGL(head_fwd_omega_kernel<true>, dim3(abc_cdiv(npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+            else if (k.aux_mode == 2) hipLaunchKernelGGL(head_fwd_omega_kernel<false>, dim3(abc_cdiv(npairs, 4)), dim3(256), 0, (hipStream_t)stream, k);
+            else if (k.aux_mode == 3) { if (int rc = group_launch(k, (hipStream_t)stream)) return rc; }
             else bt.k[m++] = k;
         }
         if (m > 0) {

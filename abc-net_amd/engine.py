@@ -110,7 +110,7 @@ class Engine:
 
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
-                 guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True, nms_heads=False):
+                 guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True, nms_heads=False, decode=False):
         """merge_reduce=False: every slab reduction and every BatchNorm-backward finaliser a launch of its own;
         actbwd_epilogue=False: every act_bwd pass as a launch of its own (the form the fused epilogue is tested against);
         batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
@@ -151,6 +151,11 @@ class Engine:
         # (abc_conv_desc.head_aux) -- nms_rho / nms_omega; the NMS kernel then reads the two one-channel centre maps only
         self.nms_heads = bool(nms_heads) and not train
         self.nms_rho = self.nms_omega = None
+        # decode (with nms_heads): the maps the decoder of img2smiles2.py:104-191 never reads as such are not stored -- the raw rho map
+        # (only |rho| is used, :73) and the 360 bond-type planes (only their six-way arg max per omega bin, :71,112: a uint8 map,
+        # abc_conv_desc.head_aux_mode 3); logits[5] / logits[6] are then None
+        self.decode = bool(decode) and self.nms_heads
+        self.btype_idx = None
         # training: the activation / BatchNorm-statistics backward pass of a layer in the epilogue of the data gradient that produces
         # its input (abc_conv_desc.actbwd_*), where the layer has that one reader (_actbwd_target)
         self.actbwd_epilogue = bool(actbwd_epilogue)
@@ -967,6 +972,19 @@ class Engine:
                 self.nms_rho, self.nms_omega = rho, om
                 head_convs[7][2]["bytes"] += float(self.B * 60 * h * w * 4)
                 head_convs[6][2]["bytes"] += float(self.B * 60 * h * w * 4)
+                if self.decode:
+                    d5 = head_convs[5][0]
+                    idx = self.new((self.B, 60, h, w), torch.uint8)
+                    y5, y6 = d5.y, d6.y
+                    d5.head_aux, d5.head_aux_mode, d5.y, d6.y = idx.data_ptr(), 3, None, None
+                    if self.lib.abc_conv_variant(C.byref(d5)) == 3 and self.lib.abc_conv_variant(C.byref(d6)) == 3:
+                        self.btype_idx = idx
+                        head_convs[5][2]["bytes"] -= float(self.B * 360 * h * w * 4 - self.B * 60 * h * w)
+                        head_convs[6][2]["bytes"] -= float(self.B * 60 * h * w * 4)
+                        self.logits[5] = self.logits[6] = None
+                    else:
+                        d5.head_aux, d5.head_aux_mode, d5.y, d6.y = None, 0, y5, y6
+                        self.decode = False
             else:
                 d6.head_aux = d7.head_aux = None
                 d6.head_aux_mode = d7.head_aux_mode = 0

@@ -20,7 +20,7 @@ from . import _lib as L
 
 class InferenceRunner:
     def __init__(self, model, batch, height, width, use_graph=True, device=None, extract=False, cap_atoms=512, cap_bonds=16384,
-                 fold_bn=None, fp8=False, fp8_margin=1.0, guards=False, heads_epilogue=False, nms_in_heads=True):
+                 fold_bn=None, fp8=False, fp8_margin=1.0, guards=False, heads_epilogue=False, nms_in_heads=True, decode=False):
         """fp8: the e4m3 form of the BatchNorm-folded graph (unet.py, bf16 model): the 128-channel 3x3 convolutions at the output
         resolution on the block-scaled MFMA over e4m3 activations and weights (Engine(fp8=True)); the per-tensor activation scales
         are calibrated on the FIRST batch loaded (calibrate(); again on demand) by running the bf16 folded graph on it.
@@ -29,7 +29,11 @@ class InferenceRunner:
         unet.py, off for unet2.py (whose CBAM reads the un-activated BatchNorm output)
         nms_in_heads (default): |rho| and the omega-bin mask of img2smiles2.py:73-79 are second outputs of the heads' 1x1 kernel
         (computed from the very f32 values it stores: bit-identical to the NMS kernel reading the maps back), and the NMS kernel
-        does the two 3x3 centre masks only -- 0.5 GB less read per batch of 64; False: the round-3 plan"""
+        does the two 3x3 centre masks only -- 0.5 GB less read per batch of 64; False: the round-3 plan
+        decode (with nms_in_heads): store only what the decoder of img2smiles2.py:104-191 reads -- |rho| instead of the raw rho map
+        (:73) and, for the 360 bond-type planes, their six-way arg max per omega bin as a uint8 map (:71,112; .btype_idx);
+        .logits[5] and .logits[6] are then None, the candidate lists (extract=True) are unchanged bit for bit.  1.7 GB less written
+        per batch of 64 at 512 x 512"""
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("InferenceRunner needs an MI355X; abcnet_amd has no CPU fallback")
         self.model = model
@@ -52,18 +56,22 @@ class InferenceRunner:
             # heads_epilogue (folded graph, opt-in: exact but slower than the default plan): the heads' 1x1
             # convolutions in the epilogue of the convolution that makes their features
             self.eng = eng = model._engine_for(x0, False, fold_bn=self.fold_bn, fp8=self.fp8, guards=guards, heads_epilogue=heads_epilogue,
-                                               nms_heads=bool(nms_in_heads) and not heads_epilogue)
+                                               nms_heads=bool(nms_in_heads) and not heads_epilogue,
+                                               decode=bool(decode) and bool(nms_in_heads) and not heads_epilogue)
             # (bf16 graph with its feature tensor materialised: calibration only)
             self._ref = model._engine_for(x0, False, fold_bn=True, heads_epilogue=False) if self.fp8 else None
         lg = eng.logits
         self.atom_mask, self.bond_mask = torch.empty_like(lg[0]), torch.empty_like(lg[4])
         self.nms_in_heads = eng.nms_rho is not None
+        self.decode = bool(getattr(eng, "decode", False)) and eng.btype_idx is not None
+        self.btype_idx = eng.btype_idx
         if self.nms_in_heads:
             self.rho_abs, self.omega_mask = eng.nms_rho, eng.nms_omega      # (written by the forward plan itself)
         else:
             self.rho_abs, self.omega_mask = torch.empty_like(lg[6]), torch.empty_like(lg[7])
         d = L.NmsDesc()
-        d.atom, d.bond, d.rho, d.omega = lg[0].data_ptr(), lg[4].data_ptr(), lg[6].data_ptr(), lg[7].data_ptr()
+        d.atom, d.bond, d.omega = lg[0].data_ptr(), lg[4].data_ptr(), lg[7].data_ptr()
+        d.rho = None if lg[6] is None else lg[6].data_ptr()      # (decode: not stored, and not read -- n_omega = 0)
         d.B, d.h, d.w, d.n_omega = eng.B, eng.h, eng.w, (0 if self.nms_in_heads else lg[7].shape[1])
         d.atom_mask, d.bond_mask = self.atom_mask.data_ptr(), self.bond_mask.data_ptr()
         d.rho_abs, d.omega_mask = self.rho_abs.data_ptr(), self.omega_mask.data_ptr()
@@ -72,7 +80,8 @@ class InferenceRunner:
         self.extractor = None
         if extract:
             from .ops import PeakExtractor
-            self.extractor = PeakExtractor(lg, self.atom_mask, self.bond_mask, cap_atoms=cap_atoms, cap_bonds=cap_bonds)
+            self.extractor = PeakExtractor(lg, self.atom_mask, self.bond_mask, cap_atoms=cap_atoms, cap_bonds=cap_bonds,
+                                           btype_idx=self.btype_idx if self.decode else None, rho_abs=self.rho_abs if self.decode else None)
         self.use_graph = use_graph
         self._graph = None
         self.steps = 0

@@ -181,18 +181,27 @@ class PeakExtractor:
     format into the unchanged CPU graph-assembly stage).  Static buffers, one launch, graph-capture safe; `lists()` is the
     only host sync (one small D2H per batch instead of hundreds of .item() calls per image)."""
 
-    def __init__(self, logits, atom_mask, bond_mask, cap_atoms=512, cap_bonds=16384):
+    def __init__(self, logits, atom_mask, bond_mask, cap_atoms=512, cap_bonds=16384, btype_idx=None, rho_abs=None):
+        """btype_idx / rho_abs (decode mode, InferenceRunner(decode=True)): the uint8 arg-max map of the bond-type head and the |rho| map
+        the heads kernel wrote instead of the raw maps logits[5] / logits[6] (which may then be None)"""
         lib = L.load()
         self.lib = lib
         B, _, h, w = logits[0].shape
-        for t in list(logits) + [atom_mask, bond_mask]:
-            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+        need = [t for i, t in enumerate(logits) if not ((i == 5 and btype_idx is not None) or (i == 6 and rho_abs is not None))]
+        for t in need + [atom_mask, bond_mask] + ([rho_abs] if rho_abs is not None else []):
+            if t is None or not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
                 raise L.AbcNetHipError("PeakExtractor wants contiguous f32 device tensors (no CPU fallback)")
+        if btype_idx is not None and not (btype_idx.is_cuda and btype_idx.is_contiguous() and btype_idx.dtype == torch.uint8 and
+                                          tuple(btype_idx.shape) == (B, 60, h, w)):
+            raise L.AbcNetHipError("PeakExtractor: btype_idx must be a contiguous uint8 device tensor [B, 60, h, w]")
         dev = logits[0].device
         d = L.ExtractDesc()
         d.atom_mask, d.bond_mask = atom_mask.data_ptr(), bond_mask.data_ptr()
         d.types, d.charges, d.hs = logits[1].data_ptr(), logits[2].data_ptr(), logits[3].data_ptr()
-        d.btypes, d.rho, d.omega = logits[5].data_ptr(), logits[6].data_ptr(), logits[7].data_ptr()
+        d.btypes = None if btype_idx is not None else logits[5].data_ptr()
+        d.btype_idx = None if btype_idx is None else btype_idx.data_ptr()
+        d.rho = rho_abs.data_ptr() if rho_abs is not None else logits[6].data_ptr()
+        d.omega = logits[7].data_ptr()
         d.B, d.h, d.w, d.cap_atoms, d.cap_bonds = B, h, w, cap_atoms, cap_bonds
         self.counts = torch.zeros((B, 4), dtype=torch.int32, device=dev)
         self.atoms = torch.zeros((B, cap_atoms, 5), dtype=torch.int32, device=dev)
@@ -202,7 +211,7 @@ class PeakExtractor:
         self.work_masks = torch.zeros((lib.abc_extract_work_masks(C.byref(d)),), dtype=torch.int64, device=dev)
         d.counts, d.atoms, d.bonds, d.bond_rho = self.counts.data_ptr(), self.atoms.data_ptr(), self.bonds.data_ptr(), self.bond_rho.data_ptr()
         d.work, d.work_masks = self.work.data_ptr(), self.work_masks.data_ptr()
-        self.d, self.keep = d, (list(logits), atom_mask, bond_mask)
+        self.d, self.keep = d, (list(logits), atom_mask, bond_mask, btype_idx, rho_abs)
         self.B, self.cap_atoms, self.cap_bonds = B, cap_atoms, cap_bonds
 
     def run(self, stream=None):

@@ -162,6 +162,9 @@ def main():
                     "them), so that RCCL's kernels start at once instead of behind a draining workgroup (abc_set_reserved_cus)")
     ap.add_argument("--no-nms-in-heads", action="store_true", help="(infer) the round-3 plan: the NMS kernel reads the stored rho / omega maps back "
                     "(InferenceRunner(nms_in_heads=False)): the A/B of the heads kernel's second outputs, not the default")
+    ap.add_argument("--decode", action="store_true", help="(infer) store only what the decoder of img2smiles2.py:104-191 reads: |rho| instead of the "
+                    "raw rho map, the bond types as their six-way arg max per omega bin (uint8) instead of 360 f32 planes "
+                    "(InferenceRunner(decode=True)); candidate lists unchanged")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -229,7 +232,7 @@ def main():
     if a.mode == "infer":
         from abcnet_amd.infer import InferenceRunner
         tr = InferenceRunner(model, a.batch, a.size, a.size, use_graph=not a.no_graph, extract=a.extract, fp8=(a.dtype == "fp8"),
-                             nms_in_heads=not a.no_nms_in_heads)
+                             nms_in_heads=not a.no_nms_in_heads, decode=a.decode)
         tr.load_batch(imgs.to(dev))
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits,
@@ -304,7 +307,8 @@ def main():
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),
                    "device_rasteriser": bool(a.raster), "device_extraction": bool(a.extract),
-                   "logits_stored": bool(a.mode != "train" or a.metrics or not a.no_logits),
+                   "logits_stored": ("decoder's maps only: |rho|, bond-type arg max (uint8), the other six heads raw" if (a.mode == "infer" and a.decode)
+                                     else bool(a.mode != "train" or a.metrics or not a.no_logits)),
                    "actbwd_epilogue": bool(a.mode == "train" and not a.no_actbwd_epilogue), "env_knobs": knobs},
         ("final_loss" if a.mode == "train" else "atom_peaks"): round(loss, 4),
     }

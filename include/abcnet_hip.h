@@ -144,7 +144,11 @@ typedef struct abc_conv_desc {
      *                    (img2smiles2.py:75-79, the omega head: Cout <= 64)
      * of the value v this launch stores to y -- the lane that computed v holds its channel neighbours (or gets them by one
      * cross-lane exchange), so the maps are not read back (abc_nms_peaks with n_omega = 0 then does the two 3x3 spatial masks
-     * alone).  With head_aux set, y may be NULL: the raw map is then not stored. */
+     * alone).  With head_aux set, y may be NULL: the raw map is then not stored.
+     *   head_aux_mode 3: head_aux is a UINT8 map [B][Cout / 6][Hout][Wout] = arg max over g = 0..5 of channel g * (Cout / 6) + bin
+     *                    (first maximum, as torch.argmax: img2smiles2.py:71,112 -- bond_types_pred.view(-1, 6, 60, H, W), .argmax(0) --
+     *                    the only use the decoder makes of the 360-channel bond-type head); y must be NULL, Cout / 6 <= 64, no dropout.
+     *                    abc_extract_desc.btype_idx consumes it. */
     float* head_aux;
     int32_t head_aux_mode;
 } abc_conv_desc;
@@ -482,6 +486,10 @@ typedef struct abc_extract_desc {
     float* bond_rho;      /* [B][cap_bonds] */
     int32_t* work;        /* scratch, abc_extract_work_ints() int32 */
     uint64_t* work_masks; /* scratch, abc_extract_work_masks() uint64 */
+    /* decode mode (InferenceRunner(decode=True)): the bond type of a (bin, pixel) from the heads kernel's arg-max map
+     * (abc_conv_desc.head_aux_mode 3, uint8 [B][60][h][w]) instead of six raw planes -- btypes may then be NULL; rho may be the |rho|
+     * map (the kernel takes the absolute value either way) */
+    const uint8_t* btype_idx;
 } abc_extract_desc;
 int64_t abc_extract_work_ints(const abc_extract_desc* d);
 int64_t abc_extract_work_masks(const abc_extract_desc* d);

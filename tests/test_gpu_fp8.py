@@ -243,3 +243,34 @@ def test_nms_outputs_from_the_heads_kernel_equal_the_nms_kernel(fp8):
         p, q = getattr(a, name), getattr(b, name)
         assert torch.equal(p, q), (name, int((p != q).sum()))
     assert a.omega_mask.sum().item() > 0 and a.rho_abs.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_decode_mode_stores_what_the_decoder_reads(fp8):
+    """InferenceRunner(decode=True): the raw rho map and the 360 bond-type planes are not stored (img2smiles2.py:73 uses |rho| only,
+    :71,112 the six-way arg max per omega bin only).  Against the plan that stores all eight maps, same weights and batch: the six
+    remaining maps, the four NMS outputs, the uint8 arg-max map == torch.argmax of the stored planes viewed as (6, 60) -- first
+    maximum on ties --, and the candidate lists of the device extraction, all bit for bit; bf16 and e4m3 graphs."""
+    from abcnet_amd.infer import InferenceRunner
+    a = _runner(fp8, 3, 160)
+    x = synthetic_images(3, 160, seed=11).to(DEV)
+    full = InferenceRunner(a.model, 3, 160, 160, use_graph=True, fold_bn=True, fp8=fp8, extract=True)
+    dec = InferenceRunner(a.model, 3, 160, 160, use_graph=True, fold_bn=True, fp8=fp8, extract=True, decode=True)
+    assert dec.decode and dec.logits[5] is None and dec.logits[6] is None and dec.btype_idx.dtype == torch.uint8
+    for run in (full, dec):
+        run.load_batch(x)
+        run.step()
+        run.step()
+    torch.cuda.synchronize()
+    for i in (0, 1, 2, 3, 4, 7):
+        assert torch.equal(full.logits[i], dec.logits[i]), i
+    for name in ("atom_mask", "bond_mask", "rho_abs", "omega_mask"):
+        assert torch.equal(getattr(full, name), getattr(dec, name)), name
+    ref_idx = full.logits[5].view(3, 6, 60, 40, 40).argmax(1)
+    assert torch.equal(dec.btype_idx.long(), ref_idx), int((dec.btype_idx.long() != ref_idx).sum())
+    assert len(set(dec.btype_idx.flatten().tolist())) > 1
+    cf, cd = full.candidates(), dec.candidates()
+    for f, d in zip(cf, cd):
+        assert torch.equal(f["atoms"], d["atoms"]) and torch.equal(f["bonds"], d["bonds"]) and torch.equal(f["rho"], d["rho"])
+        assert f["counts"] == d["counts"]
+    assert sum(len(f["bonds"]) for f in cf) > 0
