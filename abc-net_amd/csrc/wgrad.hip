@@ -489,12 +489,11 @@ constexpr int HEAD_LDS = 2 * (HEAD_PBUF + HEAD_QBUF) + 3 * 128 * 4;
 // coalesced (a wave instruction = two whole 512-byte rows of dL) one chunk ahead, transformed, and written to LDS as bf16:
 // dL as [row][pixel] (the A fragment of a K-step is one ds_read_b128), the features as [pixel][channel] (read transposed).
 template <bool BLK>
-__device__ inline void head_wgrad_body(const HeadK& a) {
+__device__ inline void head_wgrad_body(const HeadK& a, const int split, const int mg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int mi = wave & 3, nh = wave >> 2;
-    const int split = blockIdx.x, mg = blockIdx.y;
     if (split >= a.nsplit || mg * 4 >= a.mtiles) return;   // (batched launch: the grid is sized for the largest head)
     const int mt = mg * 4 + mi;
     // (wave-uniform IN A SCALAR REGISTER: an MFMA under a lane-dependent branch is not safe, the instruction ignores EXEC)
@@ -696,12 +695,23 @@ __device__ inline void head_wgrad_body(const HeadK& a) {
 }
 
 // dL planar f32 (x) activated NHWC bf16 features, 1x1, 128 b-channels, whole 128-pixel chunks per image
-__global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) { head_wgrad_body<false>(a); }
+__global__ __launch_bounds__(512, 2) void head_wgrad_kernel(const HeadK a) { head_wgrad_body<false>(a, blockIdx.x, blockIdx.y); }
 // all heads in one launch (blockIdx.z = head), as abc_heads_batch does for the forward and the data gradient
-struct HeadWgBatch { HeadK k[8]; };
-__global__ __launch_bounds__(512, 2) void head_wgrad_batch_kernel(const HeadWgBatch bt) { head_wgrad_body<false>(bt.k[blockIdx.z]); }
-// ... with d(logits) from the fused heads kernel's blocked bf16 buffer (abc_heads_fused_wgrad)
-__global__ __launch_bounds__(512, 2) void head_wgrad_blocked_kernel(const HeadWgBatch bt) { head_wgrad_body<true>(bt.k[blockIdx.z]); }
+struct HeadWgBatch { HeadK k[8]; int first[9]; };
+__global__ __launch_bounds__(512, 2) void head_wgrad_batch_kernel(const HeadWgBatch bt) { head_wgrad_body<false>(bt.k[blockIdx.z], blockIdx.x, blockIdx.y); }
+// ... with d(logits) from the fused heads kernel's blocked bf16 buffer (abc_heads_fused_wgrad).  A DENSE one-dimensional grid:
+// workgroup id -> (head, K-split, m-group) through the prefix table `first` (m-groups of a split adjacent: they stage the same
+// feature chunks).  As a (split, m-group, head) box sized for the largest head the grid was half empty workgroups; every one of
+// them still claims a CU's 150 KB of LDS for its moment, the dispatcher dealt the ~256 real ones unevenly -- some CUs ran two
+// one after the other while others idled: waves alive for 82 us of a 162 us launch (SQ_WAVE_CYCLES against GRBM_GUI_ACTIVE).
+__global__ __launch_bounds__(512, 2) void head_wgrad_blocked_kernel(const HeadWgBatch bt) {
+    const int id = blockIdx.x;
+    int hd = 0;
+    while (hd < 7 && id >= bt.first[hd + 1]) ++hd;
+    const HeadK& k = bt.k[hd];
+    const int units = (k.mtiles + 3) >> 2, local = id - bt.first[hd];
+    head_wgrad_body<true>(k, local / units, local % units);
+}
 
 static bool head_ok(const abc_wgrad_desc* d) {
     if (abc_knob("ABC_WGRAD_NOHEAD")) return false;
@@ -1404,10 +1414,13 @@ extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t
         row0 += cpad;
     }
     for (int i = 3; i < 8; ++i) bt.k[i] = bt.k[0];
+    bt.first[0] = 0;
+    for (int i = 0; i < 8; ++i) bt.first[i + 1] = bt.first[i] + (i < 3 ? bt.k[i].nsplit * abc_cdiv(bt.k[i].mtiles, 4) : 0);
+    (void)gx; (void)gy;
     rk.chan_scale = d->chan_scale;
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)head_wgrad_blocked_kernel, 160 * 1024, &lds_ok)) return rc;
-    hipLaunchKernelGGL(head_wgrad_blocked_kernel, dim3(gx, gy, 3), dim3(512), HEAD_LDS, (hipStream_t)stream, bt);
+    hipLaunchKernelGGL(head_wgrad_blocked_kernel, dim3(bt.first[8]), dim3(512), HEAD_LDS, (hipStream_t)stream, bt);
     if (int rc = abc_check_launch("heads_fused_wgrad")) return rc;
     hipLaunchKernelGGL(head_fused_small_reduce_kernel, dim3(HF_SMALL_ROWS, 16), dim3(192), 0, (hipStream_t)stream, (const float*)d->wgrad_work, nchunk, (float*)rk.small2);
     hipLaunchKernelGGL(head_fused_reduce_kernel, dim3(360, HF_NH), dim3(128), 0, (hipStream_t)stream, rk);

@@ -13,6 +13,7 @@ SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAI
 for w in ${WORKLOADS:-unet unet2 infer infer8}; do
   case $w in
     unet) A="--variant unet";; unet2) A="--variant unet2";; infer) A="--mode infer";; infer8) A="--mode infer --dtype fp8";;
+    inferd) A="--mode infer --decode";; infer8d) A="--mode infer --dtype fp8 --decode";;
   esac
   # durations: the hipGraph run the benchmark times (eager launches run 10-30 % longer under the tracer)
   rocprofv3 --kernel-trace --output-format csv -d $O/${w}_trace -- $B $A --steps 6 --warmup 2 > $O/${w}_trace.log 2>&1
@@ -34,6 +35,7 @@ cd $R
 for w in ${WORKLOADS:-unet unet2 infer infer8}; do
   case $w in
     unet) A="--variant unet --steps 20 --warmup 3";; unet2) A="--variant unet2 --steps 20 --warmup 3";; infer) A="--mode infer --steps 10 --warmup 3";; infer8) A="--mode infer --dtype fp8 --steps 10 --warmup 3";;
+    inferd) A="--mode infer --decode --steps 10 --warmup 3";; infer8d) A="--mode infer --dtype fp8 --decode --steps 10 --warmup 3";;
   esac
   ABC_BENCH_TOP=400 python3 bench.py $A > $O/${TAG}_${w}_bench.json 2> $O/${TAG}_${w}_bench.err
   echo "$w bench done"
