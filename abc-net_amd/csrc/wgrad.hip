@@ -840,13 +840,13 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(const C1K a) {
 
 // Four pixels of a row per thread (round 4; the forward twin is stem_conv4_kernel in stem.hip).  The form above stages the image rows
 // of ONE row of dY between two barriers and reads one LDS value per CPT FMAs: 172 us for unet2's 25-tap stem (b16 at 384 x 384)
-// where the FMAs need ~35.  Here a workgroup stages the image rows of up to 8 rows of dY at once (16-byte loads, four in flight),
+// where the FMAs need ~35.  Here a workgroup stages the image rows of up to 12 rows of dY at once (16-byte loads, four in flight),
 // a thread owns CPT channels of FOUR neighbouring pixels, a kernel row's taps read one 8-pixel window kept as register pairs, and an
 // FMA is half of a v_pk_fma_f32 over a channel pair of dY with the pixel value broadcast by op_sel (common.hpp).
 // KW x KW taps in row-major order (checked on the host), W a multiple of 4.
 template <typename PT, int KW, int CPT, bool DUAL>
 __global__ __launch_bounds__(256) void wgrad_c1q_kernel(const C1K a) {
-    constexpr int NT = KW * KW, R = KW / 2, SROWS = 8, NR = SROWS + 2 * R, NP = CPT / 2;
+    constexpr int NT = KW * KW, R = KW / 2, SROWS = 12, NR = SROWS + 2 * R, NP = CPT / 2;
     constexpr int RC = 16 * 320;                 // floats of the cross-row reduction buffer (it aliases the image rows)
     static_assert(NR * 520 >= RC, "the reduction buffer fits in the image rows");
     __shared__ __attribute__((aligned(16))) float sx[NR][512 + 8];

@@ -462,8 +462,9 @@ class Engine:
         nsplit = max(1, min(max(1, npatch // 2), 256 // per_split))
         at_, bt_ = L.i32(), L.i32()
         L.check(self.lib.abc_wgrad_tile(C.byref(d), C.byref(at_), C.byref(bt_)), "wgrad_tile")
-        if (at_.value, bt_.value) == (0, 1):   # one-channel kernel: 256-thread workgroups streaming dY, several per CU, 8 rows per pass
-            nsplit = min(-(-self.B * gh // 8), 1024)
+        if (at_.value, bt_.value) == (0, 1):   # one-channel kernel: 256-thread workgroups streaming dY, two per CU (184-200 registers
+            # with the BatchNorm-backward apply fused): ONE round of <= 512, 12 rows per pass (768 workgroups of 8 rows ran 1.5 rounds)
+            nsplit = min(-(-self.B * gh // 12), 512)
         elif nsplit_arg is not None and (at_.value, bt_.value) == (0, 0):
             nsplit = max(1, min(nsplit_arg, self.B * gh * gw // 128))   # the heads' kernel splits whole 128-pixel chunks
         d.nsplit = nsplit
