@@ -54,6 +54,9 @@ def act(x, sc, sh, sl):
     # unet2's 5x5 stem: 25-tap one-channel kernel; 5x5 32 -> 32 on the lean kernel over many tiles
     dict(Cin=1, Cout=32, k=5, H=40, W=24, img=True),
     dict(Cin=32, Cout=32, k=5, H=128, W=192, coef=True),
+    # widths that are no multiple of 4: the scalar one-channel kernel (the four-pixel form takes whole pixel quads)
+    dict(Cin=1, Cout=16, k=3, H=24, W=30, img=True),
+    dict(Cin=1, Cout=32, k=5, H=16, W=42, img=True),
 ])
 def test_conv_forward(lib, dt, case):
     g = torch.Generator().manual_seed(3)
