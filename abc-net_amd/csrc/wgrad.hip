@@ -26,6 +26,7 @@
 #include "capi_util.hpp"
 #include "reduce_bn.hpp"
 #include "heads_fused.hpp"
+#include "conv_fast.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -1430,6 +1431,7 @@ extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t
 extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {
     if (head_ok(d)) return 0;
     if (c1_ok(d)) return (d->p_dual && d->p.scale) ? 1 : 0;     // the one-channel kernel applies the correction on load too
+    if (abc_wgrad_narrow_ok(d)) return d->p_dual ? 1 : 0;
     WGeom g;
     if (wgeom(d, &g)) return 0;
     return dual_ok(d, g) ? 1 : 0;
@@ -1438,6 +1440,7 @@ extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {
 extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t* cb_pad) {
     if (head_ok(d)) { *ca_pad = abc_cdiv(d->Ca, 32) * 32; *cb_pad = 128; return ABC_OK; }
     if (c1_ok(d)) { *ca_pad = d->Ca; *cb_pad = 1; return ABC_OK; }
+    if (abc_wgrad_narrow_ok(d)) { *ca_pad = 16; *cb_pad = 16; return ABC_OK; }
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -1449,6 +1452,7 @@ extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t*
 extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt) {
     if (head_ok(d)) { *at = 0; *bt = 0; return ABC_OK; }  // (0, 0) = the head kernel
     if (c1_ok(d)) { *at = 0; *bt = 1; return ABC_OK; }    // (0, 1) = the one-channel kernel
+    if (abc_wgrad_narrow_ok(d)) { *at = 0; *bt = 2; return ABC_OK; }   // (0, 2) = the 16-channel kernel (wgrad_narrow.hip)
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -1459,6 +1463,7 @@ extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt)
 extern "C" int abc_wgrad_blocks(const abc_wgrad_desc* d) {
     if (head_ok(d)) return abc_cdiv(abc_cdiv(d->Ca, 32), 4);
     if (c1_ok(d)) return 1;
+    if (abc_wgrad_narrow_ok(d)) return 1;
     WGeom g;
     if (wgeom(d, &g)) return -1;
     // (4-wave workgroups sit two to a CU: half as many CU-fills per split, so that the caller's nsplit doubles)
@@ -1475,6 +1480,7 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
         if (d->p.Hx != d->Hg || d->p.Wx != d->Wg || d->q.Hx != d->Hg || d->q.Wx != d->Wg) return abc_fail(ABC_EINVAL, "wgrad: dims mismatch");
         return c1_launch(d, (hipStream_t)stream);
     }
+    if (abc_wgrad_narrow_ok(d)) return abc_wgrad_narrow_launch(d, stream);      // 16 x 16 channels, 3x3: wgrad_narrow.hip
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;

@@ -465,6 +465,8 @@ class Engine:
         if (at_.value, bt_.value) == (0, 1):   # one-channel kernel: 256-thread workgroups streaming dY, two per CU (184-200 registers
             # with the BatchNorm-backward apply fused): ONE round of <= 512, 12 rows per pass (768 workgroups of 8 rows ran 1.5 rounds)
             nsplit = min(-(-self.B * gh // 12), 512)
+        elif (at_.value, bt_.value) == (0, 2):   # 16-channel kernel: a wave per 8 x 16 tile run, 256-thread workgroups two to a CU (197 registers), 9 KB slabs
+            nsplit = max(1, min(512, self.B * (gh // 8) * (gw // 16) // 8))
         elif nsplit_arg is not None and (at_.value, bt_.value) == (0, 0):
             nsplit = max(1, min(nsplit_arg, self.B * gh * gw // 128))   # the heads' kernel splits whole 128-pixel chunks
         d.nsplit = nsplit

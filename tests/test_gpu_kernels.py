@@ -320,14 +320,15 @@ def test_pool_act_materialised(lib, dt):
     assert U.relerr(U.to_nchw(out), q(ref, dt)) < (1e-6 if dt == L.F32 else 1e-2)
 
 
-@pytest.mark.parametrize("Cout,Cin,k", [(128, 128, 3), (64, 32, 3), (32, 64, 3), (32, 32, 5)])
+@pytest.mark.parametrize("Cout,Cin,k", [(128, 128, 3), (64, 32, 3), (32, 64, 3), (32, 32, 5), (16, 16, 3)])
 def test_wgrad_fused_bn_apply(lib, Cout, Cin, k):
     """abc_wgrad with p_dual: P = ca*g + cb*y_raw + cc applied on load (the BatchNorm-backward correction), the corrected
     tensor written to p_out -- against the explicit formula followed by the plain weight gradient"""
     dt = L.BF16
     g_ = torch.Generator().manual_seed(51)
-    # (k = 5: unet2's 32-channel 5x5 layers, the tap-split form of the kernel)
-    B, H, W, ldy, coff = 2, 32 if k == 5 else 24, 32, Cout + 32, 16
+    # (k = 5: unet2's 32-channel 5x5 layers, the tap-split form of the kernel; 16 x 16: the wave-per-tile kernel of wgrad_narrow.hip,
+    #  more tiles than waves so that every wave walks several, image borders on all sides)
+    B, H, W, ldy, coff = (3, 40, 48, Cout + 32, 16) if Cout == 16 else (2, 32 if k == 5 else 24, 32, Cout + 32, 16)
     gq = q(torch.randn((B, Cout, H, W), generator=g_), dt)
     yq = q(torch.randn((B, ldy, H, W), generator=g_), dt)
     ca, cb, cc = (torch.randn(Cout, generator=g_) * s_ for s_ in (1.0, 0.3, 0.05))
