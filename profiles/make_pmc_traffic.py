@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json (what bench.py reports as roofline.traffic) from the per-shape kernel tables of one round:
 
-    python profiles/make_pmc_traffic.py TAG        (reads profiles/TAG_{unet,unet2,infer,infer8}_kernel_table.json and
+    python profiles/make_pmc_traffic.py TAG [TAG2 ...]   (reads profiles/TAG_{unet,unet2,infer,infer8}_kernel_table.json and
                                                     profiles/TAG_{..}_bench.json, rewrites profiles/pmc_traffic.json)
 
 Per bench.py kernel label (one kernel instantiation; its launches of all shapes): mean HBM bytes per launch from the
@@ -28,8 +28,18 @@ def label_of(kernel):
     return None
 
 
-def main(tag):
+def main(tags):
+    """several tags: a later tag's tables replace an earlier one's entries workload by workload (e.g. `r04b r04c`: the training
+    workloads re-collected after the last kernel change, the inference ones from the full set)"""
     out = {}
+    for tag in tags:
+        collect(tag, out)
+    with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote pmc_traffic.json with %d entries" % len(out))
+
+
+def collect(tag, out):
     # (the fp8 graph keeps bf16 launches of the same instantiations as the bf16 graph: its own key space, "infer8:unet:...")
     for mode, variant, w in (("train", "unet", "unet"), ("train", "unet2", "unet2"), ("infer", "unet", "infer"), ("infer8", "unet", "infer8")):
         tp = os.path.join(HERE, "%s_%s_kernel_table.json" % (tag, w))
@@ -81,10 +91,7 @@ def main(tag):
                 e["traffic_over_algorithmic"] = round(by / n / (algo[lab][1] * 1e6), 3) if algo[lab][1] else None
                 e["algorithmic_gflop_per_launch"] = algo[lab][0]
             out["%s:%s:%s" % (mode, variant, lab)] = e
-    with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    print("wrote pmc_traffic.json with %d entries" % len(out))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1:])
