@@ -323,7 +323,7 @@ def main():
                                          "worst_head_rms_over_std": round(m["worst_rms_over_std"], 4),
                                          "atom_peaks_missed_spurious_of": [m["atom_peaks"]["missed"], m["atom_peaks"]["spurious"], m["atom_peaks"]["oracle"]],
                                          "omega_mask_rate": round(m["omega_peaks"]["rate"], 4),
-                                         "note": ("e4m3: decision-level accuracy only (atom / bond peaks and classes), the maps carry ~9 % rms noise"
+                                         "note": ("e4m3: decision-level accuracy only (atom / bond peaks within ~2 % missed + spurious), the maps carry 5-9 % rms noise"
                                                   if a.dtype == "fp8" else "bf16: maps within 1 % rms of the fp32 oracle")}
         except (OSError, KeyError, ValueError):
             pass
