@@ -375,12 +375,161 @@ __global__ __launch_bounds__(256, R == 1 ? 2 : 1) void conv_narrow_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------
+// The 16 -> 16 channel training forward (unet.py:12,15 at full resolution: previous layer's BatchNorm + activation on load, raw
+// output + BatchNorm partial sums out) on v_mfma_f32_16x16x32_bf16 (round 4).  The kernel above is bound by the bytes it keeps in
+// flight: 256 registers (64 accumulators, 36 weight registers, coefficients, one tile of prefetch) = two waves per SIMD, 6 KB
+// each -- 3.46 TB/s, 51 us for 151 MB.  With the smaller MFMA shape K = 32 is TWO taps of 16 input channels: nine taps = five
+// MFMAs per 16-pixel row (20 weight registers), a row's result is ONE 4-register accumulator that is stored before the next row
+// starts (lane = pixel, its registers = four consecutive channels: 8-byte stores, 512 contiguous bytes per row), so the kernel
+// needs ~110 registers: four waves per SIMD, each with the next tile's halo in flight.  The pixel operand is read from the plain
+// [pixel][channel] halo image (a lane's 8 k-values = 8 channels of one tap at its pixel: one aligned ds_read_b128).
+struct N16K {
+    const bf16* x; const bf16* w; const float* bias; bf16* y;
+    const float *sc, *sh, *sl;
+    float* stats;                               // [grid][2][16] or null
+    int B, H, W, ldx, cin_off, ldy, cout_off, tiles_x, tiles_y, ntiles, tpw;
+    unsigned bytesX;
+};
+
+__global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
+    // halo image per wave: [channel half][10 rows][18 columns] x 16 bytes, the second half 3072 bytes (a multiple of 256) behind the
+    // first: a ds_read_b128 lane group takes its lanes from BOTH halves (K groups 0 and 1) -- 16 consecutive pixels of a row then sit
+    // on 16 distinct 16-byte slots (interleaved [pixel][32 bytes + pad] put five of sixteen on a slot already taken)
+    constexpr int PS = 16, RS = 18 * PS, HP = 3072, HB = 2 * HP;
+    __shared__ __attribute__((aligned(16))) char smem[4 * HB];
+    __shared__ __attribute__((aligned(16))) float scoef[3][16];
+    __shared__ float sbias[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* halo = smem + wave * HB;
+    if (threadIdx.x < 48) { const int w = threadIdx.x >> 4, c = threadIdx.x & 15; scoef[w][c] = (w == 0 ? a.sc : (w == 1 ? a.sh : a.sl))[a.cin_off + c]; }
+    if (threadIdx.x >= 64 && threadIdx.x < 80) sbias[threadIdx.x - 64] = a.bias != nullptr ? a.bias[threadIdx.x - 64] : 0.f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX);
+    // compute role: pixel column n of a row, K group kg: taps (2 p, 2 p + 1) of MFMA p -- kg < 2 the first, kg >= 2 the second -- and
+    // input channels 8 (kg & 1) .. + 7; output channels 4 kg .. 4 kg + 3 of its pixel
+    const int n = lane & 15, kg = lane >> 4;
+    bf16x8 wfr[5];
+    int boff[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int t = 2 * p + (kg >> 1);
+        const int tc = t < 9 ? t : 8;
+        // A fragment: row = output channel n (lane & 15), k = (tap, input channel): packed weights [tap][32 rows][16]
+        const bf16x8 wv = *(const bf16x8*)(a.w + ((size_t)(tc * 32 + n) * 16 + 8 * (kg & 1)));
+        bf16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+        wfr[p] = t < 9 ? wv : z;
+        boff[p] = (tc / 3) * RS + (tc % 3) * PS + HP * (kg & 1);      // (the padding tap reads tap 8's finite values against zero weights)
+    }
+    float bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = sbias[4 * kg + i];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // staging role: halo segment s = lane + 64 i (s < 360): pixel s >> 1 (row / 18, column % 18), channels 8 (lane & 1) .. + 7
+    const int half = lane & 1;
+    u32x4 pre[6];
+    const int wid = blockIdx.x * 4 + wave;
+    const int t0 = wid * a.tpw, t1 = min(t0 + a.tpw, a.ntiles);
+    auto issue = [&](int tile) {
+        int id = tile;
+        const int tx = id % a.tiles_x; id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        const int b = id / a.tiles_y;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = (lane >> 1) + 32 * i;
+            const int hr = (q * 3641) >> 16, hc = q - 18 * hr;
+            const int iy = ty * 8 - 1 + hr, ix = tx * 16 - 1 + hc;
+            const bool ok = tile < t1 && q < 180 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)a.ldx + (unsigned)(a.cin_off + 8 * half)) * 2u : 0x80000000u, 0, 0);
+        }
+    };
+    if (t0 < t1) issue(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        int id = tile;
+        const int tx = id % a.tiles_x; id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        const int b = id / a.tiles_y;
+        const int y0 = ty * 8, x0 = tx * 16;
+        {
+            float csc[8], csh[8], csl[8];
+            LoadVec<float, 8>::ld(&scoef[0][8 * half], csc); LoadVec<float, 8>::ld(&scoef[1][8 * half], csh); LoadVec<float, 8>::ld(&scoef[2][8 * half], csl);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int q = (lane >> 1) + 32 * i;
+                const int hr = (q * 3641) >> 16, hc = q - 18 * hr;
+                const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+                const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(pre[i][j] << 16); v[2 * j + 1] = __uint_as_float(pre[i][j] & 0xFFFF0000u); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = in ? abc_act(v[j], csc[j], csh[j], csl[j]) : 0.f;     // (the zero padding applies to the ACTIVATED tensor)
+                if (q < 180) *(bf16x8*)(halo + HP * half + hr * RS + hc * PS) = pack_frag<bf16>(v);
+            }
+        }
+        issue(tile + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const char* base = halo + n * PS;
+        bf16* dst = a.y + ((size_t)(b * a.H + y0) * a.W + x0 + n) * a.ldy + a.cout_off + 4 * kg;
+        // two rows at a time: two independent chains of five MFMAs
+#pragma unroll 1
+        for (int r2 = 0; r2 < 8; r2 += 2) {
+            f32x4 acc0 = (f32x4){bv[0], bv[1], bv[2], bv[3]}, acc1 = acc0;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const bf16x8 f0 = *(const bf16x8*)(base + r2 * RS + boff[p]);
+                const bf16x8 f1 = *(const bf16x8*)(base + (r2 + 1) * RS + boff[p]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[p], f0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[p], f1, acc1, 0, 0, 0);
+            }
+            bf16x4 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s1[i] += acc0[i] + acc1[i];
+                s2[i] = fmaf(acc0[i], acc0[i], fmaf(acc1[i], acc1[i], s2[i]));
+                o0[i] = (bf16)acc0[i]; o1[i] = (bf16)acc1[i];
+            }
+            *(bf16x4*)(dst + (size_t)r2 * a.W * a.ldy) = o0;
+            *(bf16x4*)(dst + (size_t)(r2 + 1) * a.W * a.ldy) = o1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (a.stats != nullptr) {
+        // sums over the 16 pixel columns of a DPP row, then the four waves through LDS: ONE partial row pair per workgroup
+        __syncthreads();
+        float* red = (float*)smem;         // [4 waves][2][16]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v1 = row_sum16(s1[i]), v2 = row_sum16(s2[i]);
+            if (n == 0) { red[(wave * 2 + 0) * 16 + 4 * kg + i] = v1; red[(wave * 2 + 1) * 16 + 4 * kg + i] = v2; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
+            a.stats[((size_t)blockIdx.x * 2 + row) * 16 + c] = (red[(0 * 2 + row) * 16 + c] + red[(1 * 2 + row) * 16 + c]) + (red[(2 * 2 + row) * 16 + c] + red[(3 * 2 + row) * 16 + c]);
+        }
+    }
+}
+
 }  // namespace
 
 // geometry shared by the eligibility test, abc_conv_stat_blocks and the launch
+// the 16 -> 16 training forward (transform on load, whole tiles, the full 3x3 square in row-major tap order) goes to conv_n16_kernel
+static bool route_n16(const abc_conv_desc* d) {
+    if (d->Cin != 16 || d->Cout != 16 || d->ntaps != 9 || d->src.scale == nullptr) return false;
+    if (d->stem_x != nullptr || d->actbwd_y != nullptr || d->pool_y != nullptr || d->out_act || d->stats_rows == 4) return false;
+    if (d->Hin % 8 || d->Win % 16 || (d->ldy % 4) || (d->cout_off % 4)) return false;
+    for (int t = 0; t < 9; ++t)
+        if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) return false;
+    return abc_knob("ABC_CONV_NON16") == nullptr;
+}
+
 static void narrow_grid(const abc_conv_desc* d, int* nwg, int* tpw) {
     const int ntiles = abc_cdiv(d->Win, 16) * abc_cdiv(d->Hin, 8) * d->B;
-    int n = abc_wg_slots(d->ntaps == 9 ? 2 : 1);      // workgroups per CU: two (3x3), one (5x5: 128 KB of LDS)
+    int n = abc_wg_slots(route_n16(d) ? 4 : (d->ntaps == 9 ? 2 : 1));      // workgroups per CU: four (conv_n16), two (3x3), one (5x5: 128 KB of LDS)
     if (n * 4 > ntiles) n = abc_cdiv(ntiles, 4);
     *tpw = abc_cdiv(ntiles, n * 4);
     *nwg = abc_cdiv(ntiles, *tpw * 4);
@@ -433,6 +582,18 @@ static int narrow_launch_inst(const NarrowK& k, int nwg, int lds, hipStream_t st
 }
 
 int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
+    if (route_n16(d)) {
+        N16K q;
+        q.x = (const bf16*)d->src.x; q.w = (const bf16*)d->w; q.bias = d->bias; q.y = (bf16*)d->y;
+        q.sc = d->src.scale; q.sh = d->src.shift; q.sl = d->src.slope; q.stats = d->stats;
+        q.B = d->B; q.H = d->Hin; q.W = d->Win; q.ldx = d->src.ldx; q.cin_off = d->cin_off; q.ldy = d->ldy; q.cout_off = d->cout_off;
+        q.tiles_x = q.W / 16; q.tiles_y = q.H / 8; q.ntiles = q.tiles_x * q.tiles_y * q.B;
+        q.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
+        int nwg;
+        narrow_grid(d, &nwg, &q.tpw);
+        hipLaunchKernelGGL(conv_n16_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, q);
+        return abc_check_launch("conv_n16");
+    }
     NarrowK k;
     k.x = (const bf16*)d->src.x; k.w = (const bf16*)d->w; k.bias = d->bias; k.y = (bf16*)d->y;
     k.sc = d->src.scale; k.sh = d->src.shift; k.sl = d->src.slope; k.stats = d->stats; k.pool_y = (bf16*)d->pool_y; k.ld_pool = d->ld_pool;
