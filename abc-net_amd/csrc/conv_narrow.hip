@@ -390,8 +390,11 @@ struct N16K {
     float* stats;                               // [grid][2][16] or null
     int B, H, W, ldx, cin_off, ldy, cout_off, tiles_x, tiles_y, ntiles, tpw;
     unsigned bytesX;
+    int out_act; float out_slope;               // XF = false (the folded inference graph): activation in the epilogue ...
+    bf16* pool_y; int ld_pool;                  // ... and optionally the 2x2 max-pool of the stored tensor, [B][H/2][W/2][ld_pool]
 };
 
+template <bool XF>
 __global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
     // halo image per wave: [channel half][10 rows][18 columns] x 16 bytes, the second half 3072 bytes (a multiple of 256) behind the
     // first: a ds_read_b128 lane group takes its lanes from BOTH halves (K groups 0 and 1) -- 16 consecutive pixels of a row then sit
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
     __shared__ float sbias[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* halo = smem + wave * HB;
-    if (threadIdx.x < 48) { const int w = threadIdx.x >> 4, c = threadIdx.x & 15; scoef[w][c] = (w == 0 ? a.sc : (w == 1 ? a.sh : a.sl))[a.cin_off + c]; }
+    if (XF && threadIdx.x < 48) { const int w = threadIdx.x >> 4, c = threadIdx.x & 15; scoef[w][c] = (w == 0 ? a.sc : (w == 1 ? a.sh : a.sl))[a.cin_off + c]; }
     if (threadIdx.x >= 64 && threadIdx.x < 80) sbias[threadIdx.x - 64] = a.bias != nullptr ? a.bias[threadIdx.x - 64] : 0.f;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX);
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
         const int ty = id % a.tiles_y;
         const int b = id / a.tiles_y;
         const int y0 = ty * 8, x0 = tx * 16;
-        {
+        if constexpr (XF) {
             float csc[8], csh[8], csl[8];
             LoadVec<float, 8>::ld(&scoef[0][8 * half], csc); LoadVec<float, 8>::ld(&scoef[1][8 * half], csh); LoadVec<float, 8>::ld(&scoef[2][8 * half], csl);
 #pragma unroll
@@ -468,6 +471,14 @@ __global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = in ? abc_act(v[j], csc[j], csh[j], csl[j]) : 0.f;     // (the zero padding applies to the ACTIVATED tensor)
                 if (q < 180) *(bf16x8*)(halo + HP * half + hr * RS + hc * PS) = pack_frag<bf16>(v);
+            }
+        } else {
+            // a finished tensor: registers -> LDS untouched (out-of-image loads returned zeros = the padding)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int q = (lane >> 1) + 32 * i;
+                const int hr = (q * 3641) >> 16, hc = q - 18 * hr;
+                if (q < 180) *(u32x4*)(halo + HP * half + hr * RS + hc * PS) = pre[i];
             }
         }
         issue(tile + 1);
@@ -486,14 +497,37 @@ __global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[p], f1, acc1, 0, 0, 0);
             }
             bf16x4 o0, o1;
+            if (XF || a.stats != nullptr) {      // (the sums are of the f32 values before the activation)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s1[i] += acc0[i] + acc1[i];
-                s2[i] = fmaf(acc0[i], acc0[i], fmaf(acc1[i], acc1[i], s2[i]));
-                o0[i] = (bf16)acc0[i]; o1[i] = (bf16)acc1[i];
+                for (int i = 0; i < 4; ++i) {
+                    s1[i] += acc0[i] + acc1[i];
+                    s2[i] = fmaf(acc0[i], acc0[i], fmaf(acc1[i], acc1[i], s2[i]));
+                }
+            }
+            {
+                const float slope = (!XF && a.out_act) ? a.out_slope : 1.f;      // (max(v, 1 * v) = v)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (!XF) { acc0[i] = fmaxf(acc0[i], slope * acc0[i]); acc1[i] = fmaxf(acc1[i], slope * acc1[i]); }
+                    o0[i] = (bf16)acc0[i]; o1[i] = (bf16)acc1[i];
+                }
             }
             *(bf16x4*)(dst + (size_t)r2 * a.W * a.ldy) = o0;
             *(bf16x4*)(dst + (size_t)(r2 + 1) * a.W * a.ldy) = o1;
+            if constexpr (!XF) {
+                if (a.pool_y != nullptr) {
+                    // the 2x2 windows of these two rows: the row pair in this lane's two accumulators, the column pair in lanes n, n ^ 1
+                    // (of the values as STORED: rounded to bf16 first, as a pool over the stored tensor sees them)
+                    bf16x4 pm;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float m = fmaxf((float)o0[i], (float)o1[i]);
+                        pm[i] = (bf16)fmaxf(m, dpp_mov<0xB1>(m));       // quad_perm [1,0,3,2]
+                    }
+                    if ((n & 1) == 0)
+                        *(bf16x4*)(a.pool_y + ((size_t)(b * (a.H >> 1) + ((y0 + r2) >> 1)) * (a.W >> 1) + ((x0 + n) >> 1)) * a.ld_pool + 4 * kg) = pm;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -517,10 +551,15 @@ __global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
 }  // namespace
 
 // geometry shared by the eligibility test, abc_conv_stat_blocks and the launch
-// the 16 -> 16 training forward (transform on load, whole tiles, the full 3x3 square in row-major tap order) goes to conv_n16_kernel
+// 16 -> 16 channels over whole tiles with the full 3x3 square in row-major tap order go to conv_n16_kernel
 static bool route_n16(const abc_conv_desc* d) {
-    if (d->Cin != 16 || d->Cout != 16 || d->ntaps != 9 || d->src.scale == nullptr) return false;
-    if (d->stem_x != nullptr || d->actbwd_y != nullptr || d->pool_y != nullptr || d->out_act || d->stats_rows == 4) return false;
+    if (d->Cin != 16 || d->Cout != 16 || d->ntaps != 9) return false;
+    if (d->stem_x != nullptr || d->actbwd_y != nullptr || d->stats_rows == 4) return false;
+    // training forward: transform on load, raw output (+ statistics); folded inference graph: a finished input, activation in the
+    // epilogue, optionally the pooled second output, no statistics
+    // (must not depend on the statistics POINTER: abc_conv_stat_blocks is asked before that buffer exists)
+    if (d->src.scale != nullptr && (d->pool_y != nullptr || d->out_act)) return false;
+    if (d->pool_y != nullptr && (d->ld_pool % 4)) return false;
     if (d->Hin % 8 || d->Win % 16 || (d->ldy % 4) || (d->cout_off % 4)) return false;
     for (int t = 0; t < 9; ++t)
         if (d->tap_dy[t] != t / 3 - 1 || d->tap_dx[t] != t % 3 - 1) return false;
@@ -589,9 +628,11 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         q.B = d->B; q.H = d->Hin; q.W = d->Win; q.ldx = d->src.ldx; q.cin_off = d->cin_off; q.ldy = d->ldy; q.cout_off = d->cout_off;
         q.tiles_x = q.W / 16; q.tiles_y = q.H / 8; q.ntiles = q.tiles_x * q.tiles_y * q.B;
         q.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
+        q.out_act = d->out_act; q.out_slope = d->out_slope; q.pool_y = (bf16*)d->pool_y; q.ld_pool = d->ld_pool;
         int nwg;
         narrow_grid(d, &nwg, &q.tpw);
-        hipLaunchKernelGGL(conv_n16_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, q);
+        if (d->src.scale != nullptr) hipLaunchKernelGGL(conv_n16_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL(conv_n16_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, q);
         return abc_check_launch("conv_n16");
     }
     NarrowK k;
