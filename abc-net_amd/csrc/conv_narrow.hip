@@ -551,6 +551,202 @@ __global__ __launch_bounds__(256, 4) void conv_n16_kernel(const N16K a) {
 }  // namespace
 
 // geometry shared by the eligibility test, abc_conv_stat_blocks and the launch
+// ---------------------------------------------------------------------------
+// unet2's 5x5 32 -> 32 convolutions at full resolution (unet2.py:52-58 and their data gradients) on v_mfma_f32_16x16x32_bf16 (round 4).
+// K = 32 is ONE tap of 32 input channels: 25 taps x 2 output-channel tiles = 50 MFMAs per 16-pixel row (121 GFLOP per layer at
+// b16, 384 x 384: 48 us of matrix time; the kernels above ran them in 128-139 us, one 4-wave workgroup per CU with 128 KB of LDS).
+// Here the 25 x 32 x 32 weights sit in LDS once per workgroup (50 KB, rows swizzled like head_fwd_group_kernel's), a wave owns a
+// 4 x 16 pixel tile (halo 8 x 20 pixels, planar by channel quarter: 10 KB), eight waves per workgroup: per kernel ROW of five
+// taps a wave reads the ten weight fragments once and walks its four output rows (five pixel fragments each, shared by the two
+// channel tiles) -- 150 LDS reads per 200 MFMAs.  A lane ends up with four consecutive output channels of one pixel per tile:
+// 8-byte stores, 64 contiguous bytes per pixel.  XF: the producer's BatchNorm + activation on load; statistics when asked for.
+struct N32K {
+    const bf16* x; const bf16* w; const float* bias; bf16* y;
+    const float *sc, *sh, *sl;
+    float* stats;                               // [grid][2][32] or null
+    int B, H, W, ldx, cin_off, ldy, cout_off, tiles_x, tiles_y, ntiles;
+    unsigned bytesX, bytesW;
+    int out_act; float out_slope;
+    int mirror;                                 // the tap list runs (+2, +2) .. (-2, -2): a data gradient (weight block 24 - t at offset t)
+};
+
+template <bool XF>
+__global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
+    constexpr int QS = 2560;                    // a channel quarter's plane of the halo image: 8 x 20 pixels x 16 bytes
+    constexpr int HB = 4 * QS;                  // per wave: 10 KB
+    constexpr int WB = 25 * 32 * 64;            // weights: [tap][32 rows][64 bytes]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;
+    float* scoef = (float*)(smem + WB);         // [sc | sh | sl][32]
+    float* sbias = scoef + 96;                  // [32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* halo = smem + WB + 512 + wave * HB;
+    {
+        const __amdgpu_buffer_rsrc_t rsW = abc_make_rsrc(a.w, a.bytesW);
+        // packed weights [tap][32 rows][32 channels] -> LDS, 16 bytes at a time, slot s of row co at (s + 2 (co >> 2)) & 3: a
+        // ds_read_b128 lane group holds rows c .. c + 3, c + 12 .. c + 15 of one K group and c + 4 .. c + 11 of the next -- with this
+        // rotation its 16 lanes hit 16 distinct 16-byte slots (an XOR by (co >> 2) & 3 left 40 % of the LDS cycles bank conflicts)
+        for (int i = threadIdx.x; i < WB / 16; i += 512) {
+            const int row = i >> 2, sl = i & 3, co = row & 31;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, (unsigned)i * 16u, 0, 0);
+            *(u32x4*)(wl + row * 64 + (((sl + 2 * (co >> 2)) & 3) * 16)) = v;
+        }
+        if (threadIdx.x < 96) scoef[threadIdx.x] = XF ? (threadIdx.x < 32 ? a.sc : (threadIdx.x < 64 ? a.sh : a.sl))[a.cin_off + (threadIdx.x & 31)] : 0.f;
+        if (threadIdx.x >= 128 && threadIdx.x < 160) sbias[threadIdx.x - 128] = a.bias != nullptr ? a.bias[threadIdx.x - 128] : 0.f;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX);
+    // compute role: pixel column n, K group kg = input channels 8 kg .. + 7 of the tap; output channels 16 c2 + 4 kg .. + 3
+    const int n = lane & 15, kg = lane >> 4;
+    // this lane's weight-fragment address inside a tap's 2 KB block: row 16 c2 + n, slot kg (swizzled by the row)
+    int woff[2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) { const int co = 16 * c2 + n; woff[c2] = co * 64 + (((kg + 2 * (co >> 2)) & 3) * 16); }
+    float bv[2][4];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[c2][i] = sbias[16 * c2 + 4 * kg + i];
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1[c2][i] = 0.f; s2[c2][i] = 0.f; }
+    // staging role: halo segment s = lane + 64 i (i < 10): pixel s >> 2 (row / 20, column % 20), channel quarter s & 3 = lane & 3
+    const int qt = lane & 3;
+    u32x4 pre[10];
+    const int wid = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+    auto issue = [&](int tile) {
+        const bool live = tile < a.ntiles;
+        int id = tile;
+        const int tx = id % a.tiles_x; id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        const int b = id / a.tiles_y;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int q = (lane >> 2) + 16 * i;
+            const int hr = (q * 3277) >> 16, hc = q - 20 * hr;      // (q / 20 for q < 160)
+            const int iy = ty * 4 - 2 + hr, ix = tx * 16 - 2 + hc;
+            const bool ok = live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)a.ldx + (unsigned)(a.cin_off + 8 * qt)) * 2u : 0x80000000u, 0, 0);
+        }
+    };
+    issue(wid);
+    for (int tile = wid; tile < a.ntiles; tile += nw) {
+        int id = tile;
+        const int tx = id % a.tiles_x; id /= a.tiles_x;
+        const int ty = id % a.tiles_y;
+        const int b = id / a.tiles_y;
+        const int y0 = ty * 4, x0 = tx * 16;
+        if constexpr (XF) {
+            float csc[8], csh[8], csl[8];
+            LoadVec<float, 8>::ld(scoef + 8 * qt, csc); LoadVec<float, 8>::ld(scoef + 32 + 8 * qt, csh); LoadVec<float, 8>::ld(scoef + 64 + 8 * qt, csl);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int q = (lane >> 2) + 16 * i;
+                const int hr = (q * 3277) >> 16, hc = q - 20 * hr;
+                const int iy = y0 - 2 + hr, ix = x0 - 2 + hc;
+                const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(pre[i][j] << 16); v[2 * j + 1] = __uint_as_float(pre[i][j] & 0xFFFF0000u); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = in ? abc_act(v[j], csc[j], csh[j], csl[j]) : 0.f;     // (the zero padding applies to the ACTIVATED tensor)
+                *(bf16x8*)(halo + QS * qt + (hr * 20 + hc) * 16) = pack_frag<bf16>(v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int q = (lane >> 2) + 16 * i;
+                const int hr = (q * 3277) >> 16, hc = q - 20 * hr;
+                *(u32x4*)(halo + QS * qt + (hr * 20 + hc) * 16) = pre[i];
+            }
+        }
+        issue(tile + nw);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) acc[r][c2] = (f32x4){bv[c2][0], bv[c2][1], bv[c2][2], bv[c2][3]};
+        const char* hb = halo + QS * kg + n * 16;
+        const char* wbase = wl + (a.mirror ? 24 * 2048 : 0);
+        // software-pipelined by one tap: the four pixel fragments of tap (dy, dx + 1) -- and, at the end of a kernel row, the ten weight
+        // fragments of the next row -- are issued in front of the eight MFMAs of tap (dy, dx) (two named fragment sets; the fences keep
+        // the compiler from sinking the reads to their uses: 89 lgkmcnt waits with two MFMAs between them otherwise)
+        bf16x8 wa[5][2], wb[5][2], fb0[4], fb1[4];
+        auto load_w = [&](bf16x8 (&w)[5][2], int dy) {
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) w[dx][c2] = *(const bf16x8*)(wbase + (a.mirror ? -(dy * 5 + dx) : dy * 5 + dx) * 2048 + woff[c2]);
+        };
+        auto load_b = [&](bf16x8 (&f)[4], int dy, int dx) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[r] = *(const bf16x8*)(hb + ((r + dy) * 20 + dx) * 16);
+        };
+        auto mma = [&](const bf16x8 (&w)[5][2], const bf16x8 (&f)[4], int dx) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[dx][0], f[r], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[dx][1], f[r], acc[r][1], 0, 0, 0);
+            }
+        };
+        load_w(wa, 0);
+        load_b(fb0, 0, 0);
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            // (kernel rows alternate between the weight sets wa / wb; taps between fb0 / fb1: 25 taps, so the parity of a tap is (5 dy + dx) & 1)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                const int t = dy * 5 + dx;
+                const bool last = t == 24;
+                const int ndy = dx == 4 ? dy + 1 : dy, ndx = dx == 4 ? 0 : dx + 1;
+                if (!last) { if (t & 1) load_b(fb0, ndy, ndx); else load_b(fb1, ndy, ndx); }
+                if (dx == 0 && dy < 4) { if (dy & 1) load_w(wa, dy + 1); else load_w(wb, dy + 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dy & 1) { if (t & 1) mma(wb, fb1, dx); else mma(wb, fb0, dx); }
+                else { if (t & 1) mma(wa, fb1, dx); else mma(wa, fb0, dx); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        bf16* dst = a.y + ((size_t)(b * a.H + y0) * a.W + x0 + n) * a.ldy + a.cout_off + 4 * kg;
+        const float slope = a.out_act ? a.out_slope : 1.f;      // (max(v, 1 * v) = v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                bf16x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[r][c2][i];
+                    s1[c2][i] += v; s2[c2][i] = fmaf(v, v, s2[c2][i]);
+                    o[i] = (bf16)fmaxf(v, slope * v);
+                }
+                *(bf16x4*)(dst + (size_t)r * a.W * a.ldy + 16 * c2) = o;
+            }
+    }
+    if (a.stats != nullptr) {
+        __syncthreads();
+        float* red = (float*)(smem + WB + 512);    // [8 waves][2][32] (the halo images are dead)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v1 = row_sum16(s1[c2][i]), v2 = row_sum16(s2[c2][i]);
+                if (n == 0) { red[(wave * 2 + 0) * 32 + 16 * c2 + 4 * kg + i] = v1; red[(wave * 2 + 1) * 32 + 16 * c2 + 4 * kg + i] = v2; }
+            }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int row = threadIdx.x >> 5, c = threadIdx.x & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[(w * 2 + row) * 32 + c];
+            a.stats[((size_t)blockIdx.x * 2 + row) * 32 + c] = v;
+        }
+    }
+}
+
 // 16 -> 16 channels over whole tiles with the full 3x3 square in row-major tap order go to conv_n16_kernel
 static bool route_n16(const abc_conv_desc* d) {
     if (d->Cin != 16 || d->Cout != 16 || d->ntaps != 9) return false;
@@ -566,7 +762,29 @@ static bool route_n16(const abc_conv_desc* d) {
     return abc_knob("ABC_CONV_NON16") == nullptr;
 }
 
+// 32 -> 32 channels, the full 5x5 square in row-major tap order, whole 4 x 16 tiles go to conv_n32r2_kernel
+static bool route_n32r2(const abc_conv_desc* d) {
+    if (d->Cin != 32 || d->Cout != 32 || d->ntaps != 25) return false;
+    if (d->stem_x != nullptr || d->actbwd_y != nullptr || d->pool_y != nullptr || d->stats_rows == 4) return false;
+    if (d->src.scale != nullptr && d->out_act) return false;
+    if (d->Hin % 4 || d->Win % 16 || (d->ldy % 4) || (d->cout_off % 4)) return false;
+    bool fwd = true, mir = true;
+    for (int t = 0; t < 25; ++t) {
+        fwd = fwd && d->tap_dy[t] == t / 5 - 2 && d->tap_dx[t] == t % 5 - 2;
+        mir = mir && d->tap_dy[t] == 2 - t / 5 && d->tap_dx[t] == 2 - t % 5;
+    }
+    if (!fwd && !mir) return false;
+    return abc_knob("ABC_CONV_NON32R2") == nullptr;
+}
+static int n32r2_grid(const abc_conv_desc* d) {
+    const int ntiles = (d->Win / 16) * (d->Hin / 4) * d->B;
+    const int want = abc_cdiv(ntiles, 8);
+    const int slots = abc_wg_slots(1);
+    return want < slots ? want : slots;
+}
+
 static void narrow_grid(const abc_conv_desc* d, int* nwg, int* tpw) {
+    if (route_n32r2(d)) { *nwg = n32r2_grid(d); *tpw = 0; return; }
     const int ntiles = abc_cdiv(d->Win, 16) * abc_cdiv(d->Hin, 8) * d->B;
     int n = abc_wg_slots(route_n16(d) ? 4 : (d->ntaps == 9 ? 2 : 1));      // workgroups per CU: four (conv_n16), two (3x3), one (5x5: 128 KB of LDS)
     if (n * 4 > ntiles) n = abc_cdiv(ntiles, 4);
@@ -593,11 +811,11 @@ int abc_conv_narrow_ok(const abc_conv_desc* d) {
                                    d->out_act || d->stats_rows != 2 || d->actbwd_ld % 8 || d->actbwd_coff % 8 || !d->actbwd_scale || !d->actbwd_shift ||
                                    !d->actbwd_slope || !d->actbwd_mean || !d->actbwd_invstd ||
                                    (int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2 >= (int64_t(1) << 31))) return 0;
-    if (d->src.scale != nullptr && d->Cin == 32) return 0;             // transform + sums + 72 weight registers do not fit
+    if (d->src.scale != nullptr && d->Cin == 32 && !route_n32r2(d)) return 0;             // transform + sums + 72 weight registers do not fit
     if (d->src.scale != nullptr && abc_knob("ABC_CONV_NONARROW_XF")) return 0;
     if (d->stem_x != nullptr && (d->Cin != 16 || d->ntaps != 9 || d->src.scale != nullptr || d->stats != nullptr || !d->stem_w || !d->stem_scale || !d->stem_bias)) return 0;
     const int R = d->ntaps == 9 ? 1 : 2;
-    if (R == 2 && (d->Cin != 32 || d->src.scale != nullptr || abc_knob("ABC_CONV_NONARROW5"))) return 0;
+    if (R == 2 && (d->Cin != 32 || (d->src.scale != nullptr && !route_n32r2(d)) || abc_knob("ABC_CONV_NONARROW5"))) return 0;
     for (int t = 0; t < d->ntaps; ++t)
         if (d->tap_dy[t] < -R || d->tap_dy[t] > R || d->tap_dx[t] < -R || d->tap_dx[t] > R) return 0;
     return (int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2 < (int64_t(1) << 31);
@@ -621,6 +839,28 @@ static int narrow_launch_inst(const NarrowK& k, int nwg, int lds, hipStream_t st
 }
 
 int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
+    if (route_n32r2(d)) {
+        N32K q;
+        q.x = (const bf16*)d->src.x; q.w = (const bf16*)d->w; q.bias = d->bias; q.y = (bf16*)d->y;
+        q.sc = d->src.scale; q.sh = d->src.shift; q.sl = d->src.slope; q.stats = d->stats;
+        q.B = d->B; q.H = d->Hin; q.W = d->Win; q.ldx = d->src.ldx; q.cin_off = d->cin_off; q.ldy = d->ldy; q.cout_off = d->cout_off;
+        q.tiles_x = q.W / 16; q.tiles_y = q.H / 4; q.ntiles = q.tiles_x * q.tiles_y * q.B;
+        q.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
+        q.bytesW = 25u * 32u * 64u;
+        q.out_act = d->out_act; q.out_slope = d->out_slope;
+        q.mirror = d->tap_dy[0] == 2 ? 1 : 0;
+        const int lds = 25 * 32 * 64 + 512 + 8 * 4 * 2560;
+        const int nwg = n32r2_grid(d);
+        static unsigned long long ok_x = 0, ok_p = 0;
+        if (d->src.scale != nullptr) {
+            if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<true>, 160 * 1024, &ok_x)) return rc;
+            hipLaunchKernelGGL(conv_n32r2_kernel<true>, dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);
+        } else {
+            if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<false>, 160 * 1024, &ok_p)) return rc;
+            hipLaunchKernelGGL(conv_n32r2_kernel<false>, dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);
+        }
+        return abc_check_launch("conv_n32r2");
+    }
     if (route_n16(d)) {
         N16K q;
         q.x = (const bf16*)d->src.x; q.w = (const bf16*)d->w; q.bias = d->bias; q.y = (bf16*)d->y;
