@@ -173,6 +173,15 @@ __device__ inline float row_sum16(float v, int m = 1) {
     return v;
 }
 
+__device__ inline float row_max16(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
+    return v;
+}
+__device__ inline float row_min16(float v) {
+    v = fminf(v, dpp_mov<0x128>(v)); v = fminf(v, dpp_mov<0x124>(v)); v = fminf(v, dpp_mov<0x122>(v)); v = fminf(v, dpp_mov<0x121>(v));
+    return v;
+}
+
 template <typename InT, int NV> struct LoadVec;
 template <> struct LoadVec<float, 4> {
     __device__ static inline void ld(const float* p, float* v) {

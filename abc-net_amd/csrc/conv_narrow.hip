@@ -568,6 +568,8 @@ struct N32K {
     unsigned bytesX, bytesW;
     int out_act; float out_slope;
     int mirror;                                 // the tap list runs (+2, +2) .. (-2, -2): a data gradient (weight block 24 - t at offset t)
+    int wpi, rows4;                             // workgroups per image (a workgroup's tiles belong to ONE image: grid = B x wpi); rows4: the
+                                                // statistics rows are [grid][4][32] = sum, sum of squares, max, min (of the values as stored) -- CBAM's
 };
 
 template <bool XF>
@@ -615,13 +617,13 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
     // staging role: halo segment s = lane + 64 i (i < 10): pixel s >> 2 (row / 20, column % 20), channel quarter s & 3 = lane & 3
     const int qt = lane & 3;
     u32x4 pre[10];
-    const int wid = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+    // this workgroup's image and its waves' tile run inside it
+    const int b = blockIdx.x / a.wpi;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int wid = (blockIdx.x - b * a.wpi) * 8 + wave, nw = a.wpi * 8;
     auto issue = [&](int tile) {
-        const bool live = tile < a.ntiles;
-        int id = tile;
-        const int tx = id % a.tiles_x; id /= a.tiles_x;
-        const int ty = id % a.tiles_y;
-        const int b = id / a.tiles_y;
+        const bool live = tile < tpi;
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             const int q = (lane >> 2) + 16 * i;
@@ -631,12 +633,14 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
             pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)a.ldx + (unsigned)(a.cin_off + 8 * qt)) * 2u : 0x80000000u, 0, 0);
         }
     };
+    float smx[2][4], smn[2][4];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { smx[c2][i] = -3.0e38f; smn[c2][i] = 3.0e38f; }
     issue(wid);
-    for (int tile = wid; tile < a.ntiles; tile += nw) {
-        int id = tile;
-        const int tx = id % a.tiles_x; id /= a.tiles_x;
-        const int ty = id % a.tiles_y;
-        const int b = id / a.tiles_y;
+    for (int tile = wid; tile < tpi; tile += nw) {
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * 4, x0 = tx * 16;
         if constexpr (XF) {
             float csc[8], csh[8], csl[8];
@@ -674,39 +678,36 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
         // software-pipelined by one tap: the four pixel fragments of tap (dy, dx + 1) -- and, at the end of a kernel row, the ten weight
         // fragments of the next row -- are issued in front of the eight MFMAs of tap (dy, dx) (two named fragment sets; the fences keep
         // the compiler from sinking the reads to their uses: 89 lgkmcnt waits with two MFMAs between them otherwise)
-        bf16x8 wa[5][2], wb[5][2], fb0[4], fb1[4];
-        auto load_w = [&](bf16x8 (&w)[5][2], int dy) {
+        bf16x8 wa[5][2], fb0[4], fb1[4];
+        auto load_w1 = [&](int dy, int dx) {
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx)
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) w[dx][c2] = *(const bf16x8*)(wbase + (a.mirror ? -(dy * 5 + dx) : dy * 5 + dx) * 2048 + woff[c2]);
+            for (int c2 = 0; c2 < 2; ++c2) wa[dx][c2] = *(const bf16x8*)(wbase + (a.mirror ? -(dy * 5 + dx) : dy * 5 + dx) * 2048 + woff[c2]);
         };
         auto load_b = [&](bf16x8 (&f)[4], int dy, int dx) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) f[r] = *(const bf16x8*)(hb + ((r + dy) * 20 + dx) * 16);
         };
-        auto mma = [&](const bf16x8 (&w)[5][2], const bf16x8 (&f)[4], int dx) {
+        auto mma = [&](const bf16x8 (&f)[4], int dx) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[dx][0], f[r], acc[r][0], 0, 0, 0);
-                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[dx][1], f[r], acc[r][1], 0, 0, 0);
+                acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[dx][0], f[r], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[dx][1], f[r], acc[r][1], 0, 0, 0);
             }
         };
-        load_w(wa, 0);
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) load_w1(0, dx);
         load_b(fb0, 0, 0);
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
-            // (kernel rows alternate between the weight sets wa / wb; taps between fb0 / fb1: 25 taps, so the parity of a tap is (5 dy + dx) & 1)
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) {
                 const int t = dy * 5 + dx;
-                const bool last = t == 24;
                 const int ndy = dx == 4 ? dy + 1 : dy, ndx = dx == 4 ? 0 : dx + 1;
-                if (!last) { if (t & 1) load_b(fb0, ndy, ndx); else load_b(fb1, ndy, ndx); }
-                if (dx == 0 && dy < 4) { if (dy & 1) load_w(wa, dy + 1); else load_w(wb, dy + 1); }
+                if (t < 24) { if (t & 1) load_b(fb0, ndy, ndx); else load_b(fb1, ndy, ndx); }
                 __builtin_amdgcn_sched_barrier(0);
-                if (dy & 1) { if (t & 1) mma(wb, fb1, dx); else mma(wb, fb0, dx); }
-                else { if (t & 1) mma(wa, fb1, dx); else mma(wa, fb0, dx); }
+                if (t & 1) mma(fb1, dx); else mma(fb0, dx);
+                // this tap's two weight fragments are free: the next kernel row's take their place (needed five taps from now)
+                if (dy < 4) load_w1(dy + 1, dx);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -722,27 +723,36 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
                     const float v = acc[r][c2][i];
                     s1[c2][i] += v; s2[c2][i] = fmaf(v, v, s2[c2][i]);
                     o[i] = (bf16)fmaxf(v, slope * v);
+                    // (max / min of the values AS STORED: CBAM's global max-pool and its backward see the tensor, unet2.py:10,20)
+                    smx[c2][i] = fmaxf(smx[c2][i], (float)o[i]); smn[c2][i] = fminf(smn[c2][i], (float)o[i]);
                 }
                 *(bf16x4*)(dst + (size_t)r * a.W * a.ldy + 16 * c2) = o;
             }
     }
     if (a.stats != nullptr) {
         __syncthreads();
-        float* red = (float*)(smem + WB + 512);    // [8 waves][2][32] (the halo images are dead)
+        float* red = (float*)(smem + WB + 512);    // [8 waves][4][32] (the halo images are dead)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v1 = row_sum16(s1[c2][i]), v2 = row_sum16(s2[c2][i]);
-                if (n == 0) { red[(wave * 2 + 0) * 32 + 16 * c2 + 4 * kg + i] = v1; red[(wave * 2 + 1) * 32 + 16 * c2 + 4 * kg + i] = v2; }
+                const float v1 = row_sum16(s1[c2][i]), v2 = row_sum16(s2[c2][i]), v3 = row_max16(smx[c2][i]), v4 = row_min16(smn[c2][i]);
+                if (n == 0) {
+                    const int c = 16 * c2 + 4 * kg + i;
+                    red[(wave * 4 + 0) * 32 + c] = v1; red[(wave * 4 + 1) * 32 + c] = v2; red[(wave * 4 + 2) * 32 + c] = v3; red[(wave * 4 + 3) * 32 + c] = v4;
+                }
             }
         __syncthreads();
-        if (threadIdx.x < 64) {
+        const int rows = a.rows4 ? 4 : 2;
+        if (threadIdx.x < 32 * rows) {
             const int row = threadIdx.x >> 5, c = threadIdx.x & 31;
-            float v = 0.f;
+            float v = red[row * 32 + c];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[(w * 2 + row) * 32 + c];
-            a.stats[((size_t)blockIdx.x * 2 + row) * 32 + c] = v;
+            for (int w = 1; w < 8; ++w) {
+                const float u = red[(w * 4 + row) * 32 + c];
+                v = row < 2 ? v + u : (row == 2 ? fmaxf(v, u) : fminf(v, u));
+            }
+            a.stats[((size_t)blockIdx.x * rows + row) * 32 + c] = v;
         }
     }
 }
@@ -765,9 +775,9 @@ static bool route_n16(const abc_conv_desc* d) {
 // 32 -> 32 channels, the full 5x5 square in row-major tap order, whole 4 x 16 tiles go to conv_n32r2_kernel
 static bool route_n32r2(const abc_conv_desc* d) {
     if (d->Cin != 32 || d->Cout != 32 || d->ntaps != 25) return false;
-    if (d->stem_x != nullptr || d->actbwd_y != nullptr || d->pool_y != nullptr || d->stats_rows == 4) return false;
+    if (d->stem_x != nullptr || d->actbwd_y != nullptr || d->pool_y != nullptr) return false;
     if (d->src.scale != nullptr && d->out_act) return false;
-    if (d->Hin % 4 || d->Win % 16 || (d->ldy % 4) || (d->cout_off % 4)) return false;
+    if (d->Hin % 4 || d->Win % 16 || (d->ldy % 4) || (d->cout_off % 4) || d->B > 256) return false;
     bool fwd = true, mir = true;
     for (int t = 0; t < 25; ++t) {
         fwd = fwd && d->tap_dy[t] == t / 5 - 2 && d->tap_dx[t] == t % 5 - 2;
@@ -776,12 +786,14 @@ static bool route_n32r2(const abc_conv_desc* d) {
     if (!fwd && !mir) return false;
     return abc_knob("ABC_CONV_NON32R2") == nullptr;
 }
-static int n32r2_grid(const abc_conv_desc* d) {
-    const int ntiles = (d->Win / 16) * (d->Hin / 4) * d->B;
-    const int want = abc_cdiv(ntiles, 8);
-    const int slots = abc_wg_slots(1);
-    return want < slots ? want : slots;
+// workgroups per image (a workgroup's tiles belong to one image: the four-row statistics of unet2's CBAM are per image); grid = B x this
+static int n32r2_wpi(const abc_conv_desc* d) {
+    const int tpi = (d->Win / 16) * (d->Hin / 4);
+    int w = abc_wg_slots(1) / d->B;
+    if (w > abc_cdiv(tpi, 8)) w = abc_cdiv(tpi, 8);
+    return w < 1 ? 1 : w;
 }
+static int n32r2_grid(const abc_conv_desc* d) { return d->B * n32r2_wpi(d); }
 
 static void narrow_grid(const abc_conv_desc* d, int* nwg, int* tpw) {
     if (route_n32r2(d)) { *nwg = n32r2_grid(d); *tpw = 0; return; }
@@ -805,7 +817,7 @@ int abc_conv_narrow_ok(const abc_conv_desc* d) {
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || d->src.Hx != d->Hin || d->src.Wx != d->Win) return 0;
     if ((d->src.ldx | d->cin_off | d->ldy | d->cout_off) % 8) return 0;
     // (must not depend on the statistics POINTER: abc_conv_stat_blocks is asked before that buffer exists)
-    if (d->stats_rows == 4) return 0;                                   // unet2's CBAM rows: per image, per tile
+    if (d->stats_rows == 4 && !route_n32r2(d)) return 0;                // unet2's CBAM rows: per image, per tile
     // act_bwd in the epilogue: the plain 16 -> <= 16 channel 3x3 data gradient only
     if (d->actbwd_y != nullptr && (d->Cin != 16 || d->ntaps != 9 || d->Cout > 16 || d->src.scale != nullptr || d->stem_x != nullptr || d->pool_y != nullptr ||
                                    d->out_act || d->stats_rows != 2 || d->actbwd_ld % 8 || d->actbwd_coff % 8 || !d->actbwd_scale || !d->actbwd_shift ||
@@ -849,6 +861,7 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         q.bytesW = 25u * 32u * 64u;
         q.out_act = d->out_act; q.out_slope = d->out_slope;
         q.mirror = d->tap_dy[0] == 2 ? 1 : 0;
+        q.wpi = n32r2_wpi(d); q.rows4 = d->stats_rows == 4 ? 1 : 0;
         const int lds = 25 * 32 * 64 + 512 + 8 * 4 * 2560;
         const int nwg = n32r2_grid(d);
         static unsigned long long ok_x = 0, ok_p = 0;
