@@ -32,3 +32,5 @@ int abc_head_dgrad_launch(const abc_conv_desc* d, abc_stream_t stream);
 // 16-channel 3x3 weight gradient (wgrad_narrow.hip)
 int abc_wgrad_narrow_ok(const abc_wgrad_desc* d);
 int abc_wgrad_narrow_launch(const abc_wgrad_desc* d, abc_stream_t stream);
+int abc_wgrad_n32r2_ok(const abc_wgrad_desc* d);
+int abc_wgrad_n32r2_launch(const abc_wgrad_desc* d, abc_stream_t stream);

@@ -1431,7 +1431,7 @@ extern "C" int abc_heads_fused_wgrad(const abc_heads_fused_desc* d, abc_stream_t
 extern "C" int abc_wgrad_fuses_apply(const abc_wgrad_desc* d) {
     if (head_ok(d)) return 0;
     if (c1_ok(d)) return (d->p_dual && d->p.scale) ? 1 : 0;     // the one-channel kernel applies the correction on load too
-    if (abc_wgrad_narrow_ok(d)) return d->p_dual ? 1 : 0;
+    if (abc_wgrad_narrow_ok(d) || abc_wgrad_n32r2_ok(d)) return d->p_dual ? 1 : 0;
     WGeom g;
     if (wgeom(d, &g)) return 0;
     return dual_ok(d, g) ? 1 : 0;
@@ -1441,6 +1441,7 @@ extern "C" int abc_wgrad_pads(const abc_wgrad_desc* d, int32_t* ca_pad, int32_t*
     if (head_ok(d)) { *ca_pad = abc_cdiv(d->Ca, 32) * 32; *cb_pad = 128; return ABC_OK; }
     if (c1_ok(d)) { *ca_pad = d->Ca; *cb_pad = 1; return ABC_OK; }
     if (abc_wgrad_narrow_ok(d)) { *ca_pad = 16; *cb_pad = 16; return ABC_OK; }
+    if (abc_wgrad_n32r2_ok(d)) { *ca_pad = 32; *cb_pad = 32; return ABC_OK; }
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -1453,6 +1454,7 @@ extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt)
     if (head_ok(d)) { *at = 0; *bt = 0; return ABC_OK; }  // (0, 0) = the head kernel
     if (c1_ok(d)) { *at = 0; *bt = 1; return ABC_OK; }    // (0, 1) = the one-channel kernel
     if (abc_wgrad_narrow_ok(d)) { *at = 0; *bt = 2; return ABC_OK; }   // (0, 2) = the 16-channel kernel (wgrad_narrow.hip)
+    if (abc_wgrad_n32r2_ok(d)) { *at = 0; *bt = 3; return ABC_OK; }    // (0, 3) = the 5x5 32-channel kernel (wgrad_narrow.hip)
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;
@@ -1463,7 +1465,7 @@ extern "C" int abc_wgrad_tile(const abc_wgrad_desc* d, int32_t* at, int32_t* bt)
 extern "C" int abc_wgrad_blocks(const abc_wgrad_desc* d) {
     if (head_ok(d)) return abc_cdiv(abc_cdiv(d->Ca, 32), 4);
     if (c1_ok(d)) return 1;
-    if (abc_wgrad_narrow_ok(d)) return 1;
+    if (abc_wgrad_narrow_ok(d) || abc_wgrad_n32r2_ok(d)) return 1;
     WGeom g;
     if (wgeom(d, &g)) return -1;
     // (4-wave workgroups sit two to a CU: half as many CU-fills per split, so that the caller's nsplit doubles)
@@ -1481,6 +1483,7 @@ extern "C" int abc_wgrad(const abc_wgrad_desc* d, abc_stream_t stream) {
         return c1_launch(d, (hipStream_t)stream);
     }
     if (abc_wgrad_narrow_ok(d)) return abc_wgrad_narrow_launch(d, stream);      // 16 x 16 channels, 3x3: wgrad_narrow.hip
+    if (abc_wgrad_n32r2_ok(d)) return abc_wgrad_n32r2_launch(d, stream);        // 32 x 32 channels, 5x5: wgrad_narrow.hip
     WGeom g;
     int rc = wgeom(d, &g);
     if (rc) return rc;

@@ -467,6 +467,8 @@ class Engine:
             nsplit = min(-(-self.B * gh // 12), 512)
         elif (at_.value, bt_.value) == (0, 2):   # 16-channel kernel: a wave per 8 x 16 tile run, 256-thread workgroups two to a CU (197 registers), 9 KB slabs
             nsplit = max(1, min(512, self.B * (gh // 8) * (gw // 16) // 8))
+        elif (at_.value, bt_.value) == (0, 3):   # 5x5 32-channel kernel: five-wave workgroups two to a CU, one 8 x 16 tile at a time, 100 KB slabs
+            nsplit = max(1, min(512, self.B * (gh // 8) * (gw // 16) // 4))
         elif nsplit_arg is not None and (at_.value, bt_.value) == (0, 0):
             nsplit = max(1, min(nsplit_arg, self.B * gh * gw // 128))   # the heads' kernel splits whole 128-pixel chunks
         d.nsplit = nsplit

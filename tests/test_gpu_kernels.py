@@ -320,15 +320,16 @@ def test_pool_act_materialised(lib, dt):
     assert U.relerr(U.to_nchw(out), q(ref, dt)) < (1e-6 if dt == L.F32 else 1e-2)
 
 
-@pytest.mark.parametrize("Cout,Cin,k", [(128, 128, 3), (64, 32, 3), (32, 64, 3), (32, 32, 5), (16, 16, 3)])
-def test_wgrad_fused_bn_apply(lib, Cout, Cin, k):
+@pytest.mark.parametrize("Cout,Cin,k,qt", [(128, 128, 3, True), (64, 32, 3, True), (32, 64, 3, True), (32, 32, 5, True), (32, 32, 5, False), (16, 16, 3, True)])
+def test_wgrad_fused_bn_apply(lib, Cout, Cin, k, qt):
     """abc_wgrad with p_dual: P = ca*g + cb*y_raw + cc applied on load (the BatchNorm-backward correction), the corrected
     tensor written to p_out -- against the explicit formula followed by the plain weight gradient"""
     dt = L.BF16
     g_ = torch.Generator().manual_seed(51)
-    # (k = 5: unet2's 32-channel 5x5 layers, the tap-split form of the kernel; 16 x 16: the wave-per-tile kernel of wgrad_narrow.hip,
-    #  more tiles than waves so that every wave walks several, image borders on all sides)
-    B, H, W, ldy, coff = (3, 40, 48, Cout + 32, 16) if Cout == 16 else (2, 32 if k == 5 else 24, 32, Cout + 32, 16)
+    # (k = 5: unet2's 32-channel 5x5 layers, wgrad_n32r2_kernel of wgrad_narrow.hip: 4 x 3 tiles per image, border tiles on all sides
+    #  and interior ones, three workgroups walking eight tiles each, with and without the transform of X; 16 x 16: the wave-per-tile
+    #  kernel of wgrad_narrow.hip, more tiles than waves so that every wave walks several, image borders on all sides)
+    B, H, W, ldy, coff = (3, 40, 48, Cout + 32, 16) if Cout == 16 else (2, 32 if k == 5 else 24, 48 if k == 5 else 32, Cout + 32, 16)
     gq = q(torch.randn((B, Cout, H, W), generator=g_), dt)
     yq = q(torch.randn((B, ldy, H, W), generator=g_), dt)
     ca, cb, cc = (torch.randn(Cout, generator=g_) * s_ for s_ in (1.0, 0.3, 0.05))
@@ -336,12 +337,12 @@ def test_wgrad_fused_bn_apply(lib, Cout, Cin, k):
     x = q(torch.randn((B, Cin, H, W), generator=g_), dt)
     sc, sh = torch.rand(Cin, generator=g_) * 2 - 0.6, torch.randn(Cin, generator=g_) * 0.3
     sl = torch.zeros(Cin)
-    a = q(act(x, sc, sh, sl), dt)
+    a = q(act(x, sc, sh, sl), dt) if qt else x
     w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
     F.conv2d(a, w, None, padding=k // 2).backward(dy)
     gd, yd, xd = U.nhwc(gq, dt), U.nhwc(yq, dt), U.nhwc(x, dt)
     pcoef = tuple(t.to(U.DEV) for t in (ca, cc, cb))   # (scale, shift, slope) = (ca, cc, cb)
-    qcoef = tuple(t.to(U.DEV) for t in (sc, sh, sl))
+    qcoef = tuple(t.to(U.DEV) for t in (sc, sh, sl)) if qt else None
     out = torch.zeros((B, H, W, Cout), dtype=U.tdt(dt), device=U.DEV)
     d = L.WgradDesc()
     U.fill_src(d.p, gd, H, W, Cout, pcoef)
