@@ -570,19 +570,27 @@ struct N32K {
     int mirror;                                 // the tap list runs (+2, +2) .. (-2, -2): a data gradient (weight block 24 - t at offset t)
     int wpi, rows4;                             // workgroups per image (a workgroup's tiles belong to ONE image: grid = B x wpi); rows4: the
                                                 // statistics rows are [grid][4][32] = sum, sum of squares, max, min (of the values as stored) -- CBAM's
+    // ACTB (abc_conv_desc.actbwd_*, plain input only): this data gradient is d(activation output) of the producing 32-channel layer; the
+    // epilogue stores g = dA * (BatchNorm(y_raw) > 0 ? 1 : slope) and the statistics rows are that layer's BatchNorm-backward sums
+    // (sum g, sum g (y_raw - mean) / std): bn_act.hip's act_bwd pass over the 384 x 384 tensor (three tensor passes) is not run
+    const bf16* ab_y; int ab_ld; unsigned bytesY;
+    const float *ab_sc, *ab_sh, *ab_sl, *ab_mu, *ab_is;
 };
+constexpr int N32_CF = 1024;                    // coefficient tables between the weights and the halo images: [sc | sh | sl][32], bias [32], ACTB's mean [32]
 
-template <bool XF>
+template <bool XF, bool ACTB = false>
 __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
+    static_assert(!(XF && ACTB), "act_bwd in the epilogue: plain inputs only");
     constexpr int QS = 2560;                    // a channel quarter's plane of the halo image: 8 x 20 pixels x 16 bytes
     constexpr int HB = 4 * QS;                  // per wave: 10 KB
     constexpr int WB = 25 * 32 * 64;            // weights: [tap][32 rows][64 bytes]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;
-    float* scoef = (float*)(smem + WB);         // [sc | sh | sl][32]
+    float* scoef = (float*)(smem + WB);         // [sc | sh | sl][32] (XF: of the input's channels; ACTB: of the producer's = output channels)
     float* sbias = scoef + 96;                  // [32]
+    float* smu = scoef + 128;                   // [32] (ACTB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* halo = smem + WB + 512 + wave * HB;
+    char* halo = smem + WB + N32_CF + wave * HB;
     {
         const __amdgpu_buffer_rsrc_t rsW = abc_make_rsrc(a.w, a.bytesW);
         // packed weights [tap][32 rows][32 channels] -> LDS, 16 bytes at a time, slot s of row co at (s + 2 (co >> 2)) & 3: a
@@ -593,11 +601,14 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, (unsigned)i * 16u, 0, 0);
             *(u32x4*)(wl + row * 64 + (((sl + 2 * (co >> 2)) & 3) * 16)) = v;
         }
-        if (threadIdx.x < 96) scoef[threadIdx.x] = XF ? (threadIdx.x < 32 ? a.sc : (threadIdx.x < 64 ? a.sh : a.sl))[a.cin_off + (threadIdx.x & 31)] : 0.f;
+        if (threadIdx.x < 96)
+            scoef[threadIdx.x] = XF ? (threadIdx.x < 32 ? a.sc : (threadIdx.x < 64 ? a.sh : a.sl))[a.cin_off + (threadIdx.x & 31)]
+                                    : (ACTB ? (threadIdx.x < 32 ? a.ab_sc : (threadIdx.x < 64 ? a.ab_sh : a.ab_sl))[threadIdx.x & 31] : 0.f);
         if (threadIdx.x >= 128 && threadIdx.x < 160) sbias[threadIdx.x - 128] = a.bias != nullptr ? a.bias[threadIdx.x - 128] : 0.f;
+        if (ACTB && threadIdx.x >= 192 && threadIdx.x < 224) smu[threadIdx.x - 192] = a.ab_mu[threadIdx.x - 192];
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX);
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX), rsYR = abc_make_rsrc(ACTB ? a.ab_y : a.x, ACTB ? a.bytesY : 0u);
     // compute role: pixel column n, K group kg = input channels 8 kg .. + 7 of the tap; output channels 16 c2 + 4 kg .. + 3
     const int n = lane & 15, kg = lane >> 4;
     // this lane's weight-fragment address inside a tap's 2 KB block: row 16 c2 + n, slot kg (swizzled by the row)
@@ -667,6 +678,16 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
             }
         }
         issue(tile + nw);
+        // ACTB: the producer's raw output at this lane's 4 pixels x 8 channels (the accumulator layout), in flight under the MFMAs
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 yq[ACTB ? 4 : 1][2];
+        if constexpr (ACTB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+                    yq[r][c2] = __builtin_amdgcn_raw_buffer_load_b64(rsYR, (unsigned)(((b * a.H + y0 + r) * a.W + x0 + n) * a.ab_ld + 16 * c2 + 4 * kg) * 2u, 0, 0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         f32x4 acc[4][2];
 #pragma unroll
@@ -713,6 +734,28 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
         }
         bf16* dst = a.y + ((size_t)(b * a.H + y0) * a.W + x0 + n) * a.ldy + a.cout_off + 4 * kg;
         const float slope = a.out_act ? a.out_slope : 1.f;      // (max(v, 1 * v) = v)
+        if constexpr (ACTB) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                float csc[4], csh[4], csl[4], cmu[4];
+                LoadVec<float, 4>::ld(scoef + 16 * c2 + 4 * kg, csc); LoadVec<float, 4>::ld(scoef + 32 + 16 * c2 + 4 * kg, csh);
+                LoadVec<float, 4>::ld(scoef + 64 + 16 * c2 + 4 * kg, csl); LoadVec<float, 4>::ld(smu + 16 * c2 + 4 * kg, cmu);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // g = dA where BatchNorm(y_raw) > 0, slope * dA elsewhere (unet2.py:54,57 backward); sums of g and g (y_raw - mean)
+                        const unsigned w = i < 2 ? yq[r][c2].x : yq[r][c2].y;
+                        const float x = (i & 1) ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
+                        const float gg = acc[r][c2][i] * (fmaf(x, csc[i], csh[i]) > 0.f ? 1.f : csl[i]);
+                        s1[c2][i] += gg; s2[c2][i] = fmaf(gg, x - cmu[i], s2[c2][i]);
+                        o[i] = (bf16)gg;
+                    }
+                    *(bf16x4*)(dst + (size_t)r * a.W * a.ldy + 16 * c2) = o;
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -728,10 +771,11 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
                 }
                 *(bf16x4*)(dst + (size_t)r * a.W * a.ldy + 16 * c2) = o;
             }
+        }
     }
     if (a.stats != nullptr) {
         __syncthreads();
-        float* red = (float*)(smem + WB + 512);    // [8 waves][4][32] (the halo images are dead)
+        float* red = (float*)(smem + WB + N32_CF);    // [8 waves][4][32] (the halo images are dead)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
@@ -752,6 +796,7 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
                 const float u = red[(w * 4 + row) * 32 + c];
                 v = row < 2 ? v + u : (row == 2 ? fmaxf(v, u) : fminf(v, u));
             }
+            if constexpr (ACTB) { if (row == 1) v *= a.ab_is[c]; }      // (the row act_bwd writes: sum of g (y_raw - mean) / std)
             a.stats[((size_t)blockIdx.x * rows + row) * 32 + c] = v;
         }
     }
@@ -775,8 +820,11 @@ static bool route_n16(const abc_conv_desc* d) {
 // 32 -> 32 channels, the full 5x5 square in row-major tap order, whole 4 x 16 tiles go to conv_n32r2_kernel
 static bool route_n32r2(const abc_conv_desc* d) {
     if (d->Cin != 32 || d->Cout != 32 || d->ntaps != 25) return false;
-    if (d->stem_x != nullptr || d->actbwd_y != nullptr || d->pool_y != nullptr) return false;
+    if (d->stem_x != nullptr || d->pool_y != nullptr) return false;
     if (d->src.scale != nullptr && d->out_act) return false;
+    // act_bwd in the epilogue: plain input, the two BatchNorm-backward rows
+    if (d->actbwd_y != nullptr && (d->src.scale != nullptr || d->out_act || d->stats_rows == 4 || (d->actbwd_ld % 4) || (d->actbwd_coff % 4) ||
+                                   (int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2 >= (int64_t(1) << 31))) return false;
     if (d->Hin % 4 || d->Win % 16 || (d->ldy % 4) || (d->cout_off % 4) || d->B > 256) return false;
     bool fwd = true, mir = true;
     for (int t = 0; t < 25; ++t) {
@@ -818,7 +866,10 @@ int abc_conv_narrow_ok(const abc_conv_desc* d) {
     if ((d->src.ldx | d->cin_off | d->ldy | d->cout_off) % 8) return 0;
     // (must not depend on the statistics POINTER: abc_conv_stat_blocks is asked before that buffer exists)
     if (d->stats_rows == 4 && !route_n32r2(d)) return 0;                // unet2's CBAM rows: per image, per tile
-    // act_bwd in the epilogue: the plain 16 -> <= 16 channel 3x3 data gradient only
+    // act_bwd in the epilogue: the plain 16 -> <= 16 channel 3x3 data gradient, and the 5x5 32 -> 32 one of conv_n32r2_kernel
+    if (d->actbwd_y != nullptr && route_n32r2(d)) {
+        if (d->stats_rows != 2 || !d->actbwd_scale || !d->actbwd_shift || !d->actbwd_slope || !d->actbwd_mean || !d->actbwd_invstd) return 0;
+    } else
     if (d->actbwd_y != nullptr && (d->Cin != 16 || d->ntaps != 9 || d->Cout > 16 || d->src.scale != nullptr || d->stem_x != nullptr || d->pool_y != nullptr ||
                                    d->out_act || d->stats_rows != 2 || d->actbwd_ld % 8 || d->actbwd_coff % 8 || !d->actbwd_scale || !d->actbwd_shift ||
                                    !d->actbwd_slope || !d->actbwd_mean || !d->actbwd_invstd ||
@@ -862,10 +913,17 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         q.out_act = d->out_act; q.out_slope = d->out_slope;
         q.mirror = d->tap_dy[0] == 2 ? 1 : 0;
         q.wpi = n32r2_wpi(d); q.rows4 = d->stats_rows == 4 ? 1 : 0;
-        const int lds = 25 * 32 * 64 + 512 + 8 * 4 * 2560;
+        q.ab_y = d->actbwd_y ? (const bf16*)d->actbwd_y + d->actbwd_coff : nullptr; q.ab_ld = d->actbwd_ld;
+        q.bytesY = d->actbwd_y ? (unsigned)((int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2) : 0u;
+        q.ab_sc = d->actbwd_scale; q.ab_sh = d->actbwd_shift; q.ab_sl = d->actbwd_slope; q.ab_mu = d->actbwd_mean; q.ab_is = d->actbwd_invstd;
+        const int lds = 25 * 32 * 64 + N32_CF + 8 * 4 * 2560;
         const int nwg = n32r2_grid(d);
-        static unsigned long long ok_x = 0, ok_p = 0;
-        if (d->src.scale != nullptr) {
+        static unsigned long long ok_x = 0, ok_p = 0, ok_a = 0;
+        if (d->actbwd_y != nullptr) {
+            if (d->stats == nullptr) return abc_fail(ABC_EINVAL, "conv: actbwd_y needs stats (the BatchNorm-backward partial sums)");
+            if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<false, true>, 160 * 1024, &ok_a)) return rc;
+            hipLaunchKernelGGL((conv_n32r2_kernel<false, true>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);
+        } else if (d->src.scale != nullptr) {
             if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<true>, 160 * 1024, &ok_x)) return rc;
             hipLaunchKernelGGL(conv_n32r2_kernel<true>, dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);
         } else {

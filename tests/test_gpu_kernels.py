@@ -770,19 +770,22 @@ def test_pack_layout_for_the_weights_direct_loop(lib):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,slope", [(2, 48, 48, 128, 128, 0.0), (3, 24, 32, 64, 64, 0.01), (2, 32, 16, 128, 256, 0.2),
                                                   (1, 32, 48, 256, 96, 0.0), (5, 96, 96, 128, 128, 0.0),
-                                                  (2, 64, 64, 16, 16, 0.0), (3, 40, 56, 16, 16, 0.01), (16, 96, 96, 16, 16, 0.0)])
+                                                  (2, 64, 64, 16, 16, 0.0), (3, 40, 56, 16, 16, 0.01), (16, 96, 96, 16, 16, 0.0),
+                                                  (2, 32, 48, 32, 32, 0.01), (3, 64, 64, 32, 32, 0.0)])
 def test_act_bwd_in_the_data_gradient_epilogue(lib, B, H, W, Cin, Cout, slope):
     """abc_conv_desc.actbwd_*: a 3x3 data-gradient convolution that stores g = dA * act'(BatchNorm(y_raw)) and the BatchNorm-backward
     partial sums of the layer it differentiates (autograd of unet.py:12-17) -- against the same convolution followed by abc_act_bwd
     (g within one bf16 rounding of it: the fused form rounds once; sums against f64 sums of the device's own g) and against torch.
     Shapes: whole 192/128/64-pixel tiles of 128- and 64-channel blocks, a 96-channel block with padding lanes, several rounds of
-    persistent workgroups (5 x 96 x 96), the 16-channel levels (conv_narrow.hip: whole and ragged tiles, runs of tiles per wave); a
-    ragged shape of the lean kernel must be refused (abc_conv_actbwd_ok == 0) and then runs the plain convolution."""
+    persistent workgroups (5 x 96 x 96), the 16-channel levels (conv_narrow.hip: whole and ragged tiles, runs of tiles per wave), the
+    5x5 32 -> 32 form of unet2.py's first level (conv_n32r2_kernel); a ragged shape of the lean kernel must be refused
+    (abc_conv_actbwd_ok == 0) and then runs the plain convolution."""
     dt = L.BF16
+    k = 5 if Cin == 32 else 3
     g = torch.Generator().manual_seed(11)
     dy = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(U.DEV)          # gradient entering the convolution
-    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3.0 * Cin ** 0.5)
-    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, 3, -(-Cout // 32) * 32, Cin)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (k * Cin ** 0.5)
+    wp = U.pack(lib, w.to(U.DEV), 0, dt, Cout, Cin, k, -(-Cout // 32) * 32, Cin)
     yraw = (torch.randn((B, H, W, Cout), generator=g) * 1.5 + 0.3).to(torch.bfloat16).to(U.DEV)
     sc = (torch.rand(Cout, generator=g) + 0.5) * (torch.randint(0, 2, (Cout,), generator=g) * 2 - 1).float()      # (both signs)
     sh = torch.randn(Cout, generator=g) * 0.5
@@ -790,16 +793,16 @@ def test_act_bwd_in_the_data_gradient_epilogue(lib, B, H, W, Cin, Cout, slope):
     istd = torch.rand(Cout, generator=g) + 0.5
     sl = torch.full((Cout,), slope)
     scd, shd, sld, mud, isd = (t.to(U.DEV) for t in (sc, sh, sl, mu, istd))
-    taps = taps_square(3)
+    taps = taps_square(k)
     gfused, part = U.conv(lib, dy, dt, dt, B, H, W, Cin, 0, Cin, wp, None, Cout, taps, H, W, stats=True,
                           actbwd=(yraw, Cout, 0, scd, shd, sld, mud, isd))
-    # (16 -> 16 channels: the narrow-level kernel, whose accumulator layout -- lane = pixel -- needs no staging for y_raw and serves
-    #  ragged shapes too; everything else: the lean kernel, whole tiles)
-    assert U.conv.last_actbwd_ok and U.conv.last_variant == (5 if Cin == 16 else 1)
+    # (16 -> 16 and 5x5 32 -> 32 channels: the narrow-level kernels, whose accumulator layout -- lane = pixel -- needs no staging for
+    #  y_raw (the 16-channel one serves ragged shapes too); everything else: the lean kernel, whole tiles)
+    assert U.conv.last_actbwd_ok and U.conv.last_variant == (5 if Cin in (16, 32) else 1)
     dA, _ = U.conv(lib, dy, dt, dt, B, H, W, Cin, 0, Cin, wp, None, Cout, taps, H, W)
     torch.cuda.synchronize()
     # torch on the device's own tensors
-    dA_ref = F.conv2d(dy.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1)
+    dA_ref = F.conv2d(dy.float().cpu().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=k // 2).permute(0, 2, 3, 1)
     ybn = yraw.float().cpu() * sc + sh
     fac = torch.where(ybn > 0, torch.ones(()), sl)
     g_ref = dA_ref * fac
