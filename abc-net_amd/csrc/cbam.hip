@@ -576,12 +576,14 @@ __global__ __launch_bounds__(256) void cbam_bwd2_kernel(const abc_cbam_pix_desc 
 // dt kept in LDS for the hidden-unit sums that follow.  Workgroups past the B images reduce the 7x7 convolution's weight-gradient
 // partials of the SAME block (cbam_conv7_reduce_kernel's body: independent of everything here, it used to be a launch of its own).
 __device__ __forceinline__ void conv7_reduce_body(const float* partial, int nblk, float* dw7, float* db7, int t) {
+    // (the first 256 threads of the workgroup, whatever its size: the summation order is part of the result)
     __shared__ double red7[4];
     double s = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += 256) s += (double)partial[(size_t)k * 99 + t];
+    if (threadIdx.x < 256)
+        for (int k = threadIdx.x; k < nblk; k += 256) s += (double)partial[(size_t)k * 99 + t];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) red7[threadIdx.x >> 6] = s;
+    if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) red7[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         const double tot = (red7[0] + red7[1]) + (red7[2] + red7[3]);
@@ -589,39 +591,64 @@ __device__ __forceinline__ void conv7_reduce_body(const float* partial, int nblk
     }
 }
 
-__global__ __launch_bounds__(256) void cbam_channel_bwd_pre_kernel(const abc_cbam_channel_desc d, const float* c7_partial, int c7_nblk,
-                                                                     float* c7_dw, float* c7_db) {
+// 1024 threads per image: CL channel lanes x KG tile groups, every thread's loads independent of one another and eight in flight (the
+// 8-lanes-per-channel form walked C / 32 sweeps of T / 8 dependent round trips: 9-39 us per call for <= 64 KB of partials)
+__global__ __launch_bounds__(1024) void cbam_channel_bwd_pre_kernel(const abc_cbam_channel_desc d, const float* c7_partial, int c7_nblk,
+                                                                      float* c7_dw, float* c7_db) {
     if ((int)blockIdx.x >= d.B) { conv7_reduce_body(c7_partial, c7_nblk, c7_dw, c7_db, (int)blockIdx.x - d.B); return; }
     extern __shared__ float sm[];      // dt[C]
+    __shared__ double sd[1024];
     const int n = blockIdx.x;
     const int T = d.tiles_per_img;
-    const int sub = threadIdx.x & 7;
-    for (int c = threadIdx.x >> 3; c < ((d.C + 31) & ~31); c += 32) {
+    int CL = 32;
+    while (CL < d.C && CL < 512) CL <<= 1;
+    const int KG = 1024 / CL;
+    const int cl = threadIdx.x & (CL - 1), kg = threadIdx.x / CL;
+    for (int c0 = 0; c0 < d.C; c0 += CL) {
+        const int c = c0 + cl;
         const bool ok = c < d.C;
-        double s = 0.0;
-        if (ok)
-            for (int k = sub; k < T; k += 8) s += (double)d.partial[((size_t)n * T + k) * d.C + c];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-        if (ok && sub == 0) {
+        double acc = 0.0;
+        if (ok) {
+            const float* p = d.partial + (size_t)n * T * d.C + c;
+            int k = kg;
+            for (; k + 7 * KG < T; k += 8 * KG) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u * KG) * d.C];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (double)v[u];
+            }
+            for (; k < T; k += KG) acc += (double)p[(size_t)k * d.C];
+        }
+        sd[kg * CL + cl] = acc;
+        __syncthreads();
+        if (kg == 0 && ok) {
+            double s = sd[cl];
+            for (int g = 1; g < KG; ++g) s += sd[g * CL + cl];
             const float ca = d.ca[(size_t)n * d.C + c];
             const float v = (float)s * ca * (1.f - ca);
             d.work[(size_t)n * d.C + c] = v;
             sm[c] = v;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    const int per = 256 / d.mid;
+    // hidden unit j: min(1024 / mid, 64) lanes of ONE wave share its dot product
+    const int per = 1024 / d.mid < 64 ? 1024 / d.mid : 64;
     const int j = threadIdx.x / per, sub2 = threadIdx.x % per;
-    float s = 0.f;
-    for (int c = sub2; c < d.C; c += per) s += d.w2[(size_t)c * d.mid + j] * sm[c];
-    for (int o = 1; o < per && o < 64; o <<= 1) s += __shfl_xor(s, o);
-    if (sub2 == 0) {
-        const int idx = n * d.mid + j;
-        d.work[(size_t)d.B * d.C + idx] = d.hid_avg[idx] > 0.f ? s : 0.f;
-        d.work[(size_t)d.B * d.C + d.B * d.mid + idx] = d.hid_max[idx] > 0.f ? s : 0.f;
+    if (j < d.mid) {
+        float s = 0.f;
+        for (int c = sub2; c < d.C; c += per) s += d.w2[(size_t)c * d.mid + j] * sm[c];
+        for (int o = 1; o < per; o <<= 1) s += __shfl_xor(s, o);
+        if (sub2 == 0) {
+            const int idx = n * d.mid + j;
+            d.work[(size_t)d.B * d.C + idx] = d.hid_avg[idx] > 0.f ? s : 0.f;
+            d.work[(size_t)d.B * d.C + d.B * d.mid + idx] = d.hid_max[idx] > 0.f ? s : 0.f;
+        }
     }
 }
 
+// grid = 5 x nb workgroups: the five result groups (dw2 | dw1 | db2 | db1 | the per-image pool gradients) are independent of one another and
+// each is a chain of B (or mid) loads per element: run side by side they take one chain, not five (11-15 us per call before)
 __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_channel_desc d) {
     extern __shared__ float sm[];
     float* dt = sm;                      // [B][C]
@@ -629,37 +656,46 @@ __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_ch
     float* dhm = dha + d.B * d.mid;      // [B][mid]
     const int tid = threadIdx.x;
     const int C_ = d.C, mid = d.mid, B = d.B;
-    for (int idx = tid; idx < B * (C_ + 2 * mid); idx += 256) sm[idx] = d.work[idx];
+    const int nbp = gridDim.x / 5, phase = blockIdx.x / nbp;
+    // (what the group reads of the intermediates: dt for dw2 / db2, the hidden-unit gradients for the others)
+    if (phase == 0 || phase == 2) { for (int idx = tid; idx < B * C_; idx += 256) sm[idx] = d.work[idx]; }
+    else { for (int idx = B * C_ + tid; idx < B * (C_ + 2 * mid); idx += 256) sm[idx] = d.work[idx]; }
     __syncthreads();
-    const int gsz = gridDim.x * 256, gt = blockIdx.x * 256 + tid;
-    for (int i = gt; i < C_ * mid; i += gsz) {
-        const int c = i / mid, j = i - c * mid;
-        float s = 0.f;
-        for (int n = 0; n < B; ++n) s += dt[n * C_ + c] * (d.hid_avg[n * mid + j] + d.hid_max[n * mid + j]);
-        d.dw2[i] = s;
-    }
-    for (int i = gt; i < mid * C_; i += gsz) {
-        const int j = i / C_, c = i - j * C_;
-        float s = 0.f;
-        for (int n = 0; n < B; ++n) s += dha[n * mid + j] * d.avgz[(size_t)n * C_ + c] + dhm[n * mid + j] * d.maxz[(size_t)n * C_ + c];
-        d.dw1[i] = s;
-    }
-    for (int c = gt; c < C_; c += gsz) {
-        float s = 0.f;
-        for (int n = 0; n < B; ++n) s += 2.f * dt[n * C_ + c];
-        d.db2[c] = s;
-    }
-    for (int j = gt; j < mid; j += gsz) {
-        float s = 0.f;
-        for (int n = 0; n < B; ++n) s += dha[n * mid + j] + dhm[n * mid + j];
-        d.db1[j] = s;
-    }
-    for (int idx = gt; idx < B * C_; idx += gsz) {
-        const int n = idx / C_, c = idx - n * C_;
-        float a = 0.f, m = 0.f;
-        for (int j = 0; j < mid; ++j) { const float w = d.w1[(size_t)j * C_ + c]; a += w * dha[n * mid + j]; m += w * dhm[n * mid + j]; }
-        d.d_avgz[idx] = a;
-        d.d_maxz[idx] = m;
+    const int gsz = nbp * 256, gt = (blockIdx.x - phase * nbp) * 256 + tid;
+    if (phase == 0) {
+        for (int i = gt; i < C_ * mid; i += gsz) {
+            const int c = i / mid, j = i - c * mid;
+            float s = 0.f;
+            for (int n = 0; n < B; ++n) s += dt[n * C_ + c] * (d.hid_avg[n * mid + j] + d.hid_max[n * mid + j]);
+            d.dw2[i] = s;
+        }
+    } else if (phase == 1) {
+        for (int i = gt; i < mid * C_; i += gsz) {
+            const int j = i / C_, c = i - j * C_;
+            float s = 0.f;
+            for (int n = 0; n < B; ++n) s += dha[n * mid + j] * d.avgz[(size_t)n * C_ + c] + dhm[n * mid + j] * d.maxz[(size_t)n * C_ + c];
+            d.dw1[i] = s;
+        }
+    } else if (phase == 2) {
+        for (int c = gt; c < C_; c += gsz) {
+            float s = 0.f;
+            for (int n = 0; n < B; ++n) s += 2.f * dt[n * C_ + c];
+            d.db2[c] = s;
+        }
+    } else if (phase == 3) {
+        for (int j = gt; j < mid; j += gsz) {
+            float s = 0.f;
+            for (int n = 0; n < B; ++n) s += dha[n * mid + j] + dhm[n * mid + j];
+            d.db1[j] = s;
+        }
+    } else {
+        for (int idx = gt; idx < B * C_; idx += gsz) {
+            const int n = idx / C_, c = idx - n * C_;
+            float a = 0.f, m = 0.f;
+            for (int j = 0; j < mid; ++j) { const float w = d.w1[(size_t)j * C_ + c]; a += w * dha[n * mid + j]; m += w * dhm[n * mid + j]; }
+            d.d_avgz[idx] = a;
+            d.d_maxz[idx] = m;
+        }
     }
 }
 
@@ -776,12 +812,12 @@ static int channel_bwd_launch(const abc_cbam_channel_desc* d, const abc_cbam_con
     const int want = abc_cdiv(d->C * d->mid, 256);
     const int nb = want < 1 ? 1 : (want > 64 ? 64 : want);
     if (c7 != nullptr)
-        hipLaunchKernelGGL(cbam_channel_bwd_pre_kernel, dim3(d->B + 99), dim3(256), (size_t)d->C * sizeof(float), (hipStream_t)stream, *d,
+        hipLaunchKernelGGL(cbam_channel_bwd_pre_kernel, dim3(d->B + 99), dim3(1024), (size_t)d->C * sizeof(float), (hipStream_t)stream, *d,
                            (const float*)c7->dw_partial, abc_cbam_conv7_blocks(c7), c7->dw7, c7->db7);
     else
-        hipLaunchKernelGGL(cbam_channel_bwd_pre_kernel, dim3(d->B), dim3(256), (size_t)d->C * sizeof(float), (hipStream_t)stream, *d,
+        hipLaunchKernelGGL(cbam_channel_bwd_pre_kernel, dim3(d->B), dim3(1024), (size_t)d->C * sizeof(float), (hipStream_t)stream, *d,
                            (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(nb), dim3(256), sh, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(5 * nb), dim3(256), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_bwd");
 }
 
