@@ -38,35 +38,36 @@ __device__ inline float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // 4 tile groups x 64 channels, so the partial rows are read as 256-byte lines by 4 waves at once
 // (a thread per channel walking 576 tiles serially: 51 us per call);
 // pass 2: the shared MLP on both pooled vectors + sigmoid.
-__global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_channel_desc d) {
+__global__ __launch_bounds__(1024) void cbam_channel_fwd_kernel(const abc_cbam_channel_desc d) {
     extern __shared__ float sm[];
     float* av = sm;              // [C] avg(z)
     float* mx = sm + d.C;        // [C] max(z)
     float* ha = sm + 2 * d.C;    // [mid]
     float* hm = ha + d.mid;      // [mid]
-    __shared__ double ssum[4][64];
-    __shared__ float smax[4][64], smin[4][64];
+    constexpr int NG = 16;       // tile groups (waves) per 64 channel lanes
+    __shared__ double ssum[NG][64];
+    __shared__ float smax[NG][64], smin[NG][64];
     const int n = blockIdx.x, cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     for (int cb = 0; cb < d.C; cb += 64) {
         const int c = cb + cl;
         double s = 0.0;
         float vmax = -3.0e38f, vmin = 3.0e38f;
         if (c < d.C) {
-            // (four independent chains: at the 384 x 384 levels a group walks 144 of the 576 tiles of an image, and one chain of
-            //  dependent loads and f64 adds took 51-59 us for 3.6 MB)
+            // (sixteen groups x four independent chains: at the 384 x 384 levels an image has 576 tiles, and one chain of dependent
+            //  loads and f64 adds took 51-59 us for 3.6 MB; four groups of 256 threads still 23 us)
             double s4[4] = {0.0, 0.0, 0.0, 0.0};
             float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f}, mn4[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
             int k = grp;
-            for (; k + 12 < d.tiles_per_img; k += 16) {
+            for (; k + 3 * NG < d.tiles_per_img; k += 4 * NG) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k + 4 * u) * 4) * d.C + c;
+                    const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k + NG * u) * 4) * d.C + c;
                     s4[u] += (double)p[0];
                     mx4[u] = fmaxf(mx4[u], p[2 * d.C]);
                     mn4[u] = fminf(mn4[u], p[3 * d.C]);
                 }
             }
-            for (; k < d.tiles_per_img; k += 4) {
+            for (; k < d.tiles_per_img; k += NG) {
                 const float* p = d.partial + ((size_t)(n * d.tiles_per_img + k) * 4) * d.C + c;
                 s4[0] += (double)p[0];
                 mx4[0] = fmaxf(mx4[0], p[2 * d.C]);
@@ -79,9 +80,9 @@ __global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_ch
         ssum[grp][cl] = s; smax[grp][cl] = vmax; smin[grp][cl] = vmin;
         __syncthreads();
         if (grp == 0 && c < d.C) {
-            s = (ssum[0][cl] + ssum[1][cl]) + (ssum[2][cl] + ssum[3][cl]);
-            vmax = fmaxf(fmaxf(smax[0][cl], smax[1][cl]), fmaxf(smax[2][cl], smax[3][cl]));
-            vmin = fminf(fminf(smin[0][cl], smin[1][cl]), fminf(smin[2][cl], smin[3][cl]));
+            s = ssum[0][cl]; vmax = smax[0][cl]; vmin = smin[0][cl];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) { s += ssum[g][cl]; vmax = fmaxf(vmax, smax[g][cl]); vmin = fminf(vmin, smin[g][cl]); }
             const float sc = d.scale[c], sh = d.shift[c];
             const float a_ = sc * (float)(s / d.HW) + sh, m_ = (sc >= 0.f ? sc * vmax : sc * vmin) + sh;
             d.avgz[(size_t)n * d.C + c] = a_;
@@ -94,12 +95,14 @@ __global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_ch
     }
     // hidden unit j: 256 / mid lanes share the dot products (mid <= 32 is a power of two)
     {
+        // (the first 256 threads, as when the workgroup had no more)
         const int per = 256 / d.mid;                  // lanes per hidden unit (>= 8)
-        const int j = threadIdx.x / per, sub = threadIdx.x % per;
+        const int j = (threadIdx.x & 255) / per, sub = (threadIdx.x & 255) % per;
         float sa = 0.f, sb = 0.f;
-        for (int c = sub; c < d.C; c += per) { const float w = d.w1[(size_t)j * d.C + c]; sa += w * av[c]; sb += w * mx[c]; }
+        if (threadIdx.x < 256)
+            for (int c = sub; c < d.C; c += per) { const float w = d.w1[(size_t)j * d.C + c]; sa += w * av[c]; sb += w * mx[c]; }
         for (int o = 1; o < per && o < 64; o <<= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
-        if (sub == 0) {
+        if (sub == 0 && threadIdx.x < 256) {
             sa = fmaxf(sa + d.b1[j], 0.f); sb = fmaxf(sb + d.b1[j], 0.f);
             ha[j] = sa; hm[j] = sb;
             d.hid_avg[(size_t)n * d.mid + j] = sa;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void cbam_channel_fwd_kernel(const abc_cbam_ch
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < d.C; c += 256) {
+    for (int c = threadIdx.x; c < d.C; c += 1024) {
         float t = 2.f * d.b2[c];
         for (int j = 0; j < d.mid; ++j) t += d.w2[(size_t)c * d.mid + j] * (ha[j] + hm[j]);
         d.ca[(size_t)n * d.C + c] = sigmoidf_(t);
@@ -648,24 +651,21 @@ __global__ __launch_bounds__(1024) void cbam_channel_bwd_pre_kernel(const abc_cb
 }
 
 // grid = 5 x nb workgroups: the five result groups (dw2 | dw1 | db2 | db1 | the per-image pool gradients) are independent of one another and
-// each is a chain of B (or mid) loads per element: run side by side they take one chain, not five (11-15 us per call before)
+// each is a chain of B (or mid) loads per element: run side by side they take one chain, not five (11-15 us per call before), and the
+// intermediates come straight from `work` (every workgroup staging all of them in LDS first was a second chain in front of the first)
 __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_channel_desc d) {
-    extern __shared__ float sm[];
-    float* dt = sm;                      // [B][C]
-    float* dha = sm + d.B * d.C;         // [B][mid]
-    float* dhm = dha + d.B * d.mid;      // [B][mid]
     const int tid = threadIdx.x;
     const int C_ = d.C, mid = d.mid, B = d.B;
+    const float* dt = d.work;                      // [B][C]
+    const float* dha = d.work + (size_t)B * C_;    // [B][mid]
+    const float* dhm = dha + B * mid;              // [B][mid]
     const int nbp = gridDim.x / 5, phase = blockIdx.x / nbp;
-    // (what the group reads of the intermediates: dt for dw2 / db2, the hidden-unit gradients for the others)
-    if (phase == 0 || phase == 2) { for (int idx = tid; idx < B * C_; idx += 256) sm[idx] = d.work[idx]; }
-    else { for (int idx = B * C_ + tid; idx < B * (C_ + 2 * mid); idx += 256) sm[idx] = d.work[idx]; }
-    __syncthreads();
     const int gsz = nbp * 256, gt = (blockIdx.x - phase * nbp) * 256 + tid;
     if (phase == 0) {
         for (int i = gt; i < C_ * mid; i += gsz) {
             const int c = i / mid, j = i - c * mid;
             float s = 0.f;
+#pragma unroll 8
             for (int n = 0; n < B; ++n) s += dt[n * C_ + c] * (d.hid_avg[n * mid + j] + d.hid_max[n * mid + j]);
             d.dw2[i] = s;
         }
@@ -673,18 +673,21 @@ __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_ch
         for (int i = gt; i < mid * C_; i += gsz) {
             const int j = i / C_, c = i - j * C_;
             float s = 0.f;
+#pragma unroll 8
             for (int n = 0; n < B; ++n) s += dha[n * mid + j] * d.avgz[(size_t)n * C_ + c] + dhm[n * mid + j] * d.maxz[(size_t)n * C_ + c];
             d.dw1[i] = s;
         }
     } else if (phase == 2) {
         for (int c = gt; c < C_; c += gsz) {
             float s = 0.f;
+#pragma unroll 8
             for (int n = 0; n < B; ++n) s += 2.f * dt[n * C_ + c];
             d.db2[c] = s;
         }
     } else if (phase == 3) {
         for (int j = gt; j < mid; j += gsz) {
             float s = 0.f;
+#pragma unroll 8
             for (int n = 0; n < B; ++n) s += dha[n * mid + j] + dhm[n * mid + j];
             d.db1[j] = s;
         }
@@ -692,6 +695,7 @@ __global__ __launch_bounds__(256) void cbam_channel_bwd_kernel(const abc_cbam_ch
         for (int idx = gt; idx < B * C_; idx += gsz) {
             const int n = idx / C_, c = idx - n * C_;
             float a = 0.f, m = 0.f;
+#pragma unroll 8
             for (int j = 0; j < mid; ++j) { const float w = d.w1[(size_t)j * C_ + c]; a += w * dha[n * mid + j]; m += w * dhm[n * mid + j]; }
             d.d_avgz[idx] = a;
             d.d_maxz[idx] = m;
@@ -795,7 +799,7 @@ extern "C" int abc_cbam_channel_fwd(const abc_cbam_channel_desc* d, abc_stream_t
     if (rc) return rc;
     if (d->ext == nullptr || d->first == nullptr) return abc_fail(ABC_EINVAL, "cbam_channel_fwd: ext / first (arg-max of the global max-pool) required");
     const size_t sh = (size_t)(2 * d->C + 2 * d->mid) * sizeof(float);
-    hipLaunchKernelGGL(cbam_channel_fwd_kernel, dim3(d->B), dim3(256), sh, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(cbam_channel_fwd_kernel, dim3(d->B), dim3(1024), sh, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_fwd");
 }
 
@@ -803,10 +807,6 @@ static int channel_bwd_launch(const abc_cbam_channel_desc* d, const abc_cbam_con
     int rc = check_channel(d);
     if (rc) return rc;
     if (d->work == nullptr) return abc_fail(ABC_EINVAL, "cbam_channel_bwd: work buffer of B * (C + 2 mid) floats required");
-    const size_t sh = (size_t)d->B * (d->C + 2 * d->mid) * sizeof(float);
-    if (sh > 150 * 1024) return abc_fail(ABC_EUNSUPPORTED, "cbam_channel_bwd: B * (C + 2 mid) floats exceed the LDS");
-    static unsigned long long lds_ok = 0;
-    if (int rc = abc_allow_lds((const void*)cbam_channel_bwd_kernel, 160 * 1024, &lds_ok)) return rc;
     // one (c, j) weight-gradient element per thread where possible: the per-element loops over the images are chains of
     // dependent global loads, so width beats depth (8 elements per thread cost 50 us per call)
     const int want = abc_cdiv(d->C * d->mid, 256);
@@ -817,7 +817,7 @@ static int channel_bwd_launch(const abc_cbam_channel_desc* d, const abc_cbam_con
     else
         hipLaunchKernelGGL(cbam_channel_bwd_pre_kernel, dim3(d->B), dim3(1024), (size_t)d->C * sizeof(float), (hipStream_t)stream, *d,
                            (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(5 * nb), dim3(256), sh, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(cbam_channel_bwd_kernel, dim3(5 * nb), dim3(256), 0, (hipStream_t)stream, *d);
     return abc_check_launch("cbam_channel_bwd");
 }
 
