@@ -578,12 +578,20 @@ struct N32K {
 };
 constexpr int N32_CF = 1024;                    // coefficient tables between the weights and the halo images: [sc | sh | sl][32], bias [32], ACTB's mean [32]
 
-template <bool XF, bool ACTB = false>
+// R: tap radius (2: unet2.py's 5x5 layers, the kernel's first use; 1: unet.py's 3x3 32 -> 32 layer at 192 x 192, forward with the
+// transform on load + statistics and data gradient with act_bwd in the epilogue, were conv_fast's BN = 32 tiles at 44 / 24 us)
+template <bool XF, bool ACTB = false, int R = 2>
 __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
     static_assert(!(XF && ACTB), "act_bwd in the epilogue: plain inputs only");
-    constexpr int QS = 2560;                    // a channel quarter's plane of the halo image: 8 x 20 pixels x 16 bytes
-    constexpr int HB = 4 * QS;                  // per wave: 10 KB
-    constexpr int WB = 25 * 32 * 64;            // weights: [tap][32 rows][64 bytes]
+    constexpr int KW = 2 * R + 1, TAPS = KW * KW;
+    constexpr int HR = 4 + 2 * R, HC = 16 + 2 * R;      // halo rows / columns of a 4 x 16 tile
+    // a channel quarter's plane of the halo image: HR x HC pixels x 16 bytes, a multiple of 256 bytes (the lane groups of a
+    // ds_read_b128 span two planes: their 16 slots stay distinct only if planes start on the same bank)
+    constexpr int QS = (HR * HC * 16 + 255) / 256 * 256;
+    constexpr int HB = 4 * QS;                  // per wave: 10 KB (R = 2), 7 KB (R = 1)
+    constexpr int NSEG = (HR * HC * 4 + 63) / 64;       // halo segments per lane
+    constexpr int DIVM = R == 2 ? 3277 : 3641;  // (q * DIVM) >> 16 = q / HC for q < HR * HC
+    constexpr int WB = TAPS * 32 * 64;          // weights: [tap][32 rows][64 bytes]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;
     float* scoef = (float*)(smem + WB);         // [sc | sh | sl][32] (XF: of the input's channels; ACTB: of the producer's = output channels)
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
         for (int i = 0; i < 4; ++i) { s1[c2][i] = 0.f; s2[c2][i] = 0.f; }
     // staging role: halo segment s = lane + 64 i (i < 10): pixel s >> 2 (row / 20, column % 20), channel quarter s & 3 = lane & 3
     const int qt = lane & 3;
-    u32x4 pre[10];
+    u32x4 pre[NSEG];
     // this workgroup's image and its waves' tile run inside it
     const int b = blockIdx.x / a.wpi;
     const int tpi = a.tiles_x * a.tiles_y;
@@ -636,11 +644,11 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
         const bool live = tile < tpi;
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
+        for (int i = 0; i < NSEG; ++i) {
             const int q = (lane >> 2) + 16 * i;
-            const int hr = (q * 3277) >> 16, hc = q - 20 * hr;      // (q / 20 for q < 160)
-            const int iy = ty * 4 - 2 + hr, ix = tx * 16 - 2 + hc;
-            const bool ok = live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const int hr = (q * DIVM) >> 16, hc = q - HC * hr;
+            const int iy = ty * 4 - R + hr, ix = tx * 16 - R + hc;
+            const bool ok = live && q < HR * HC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((unsigned)((b * a.H + iy) * a.W + ix) * (unsigned)a.ldx + (unsigned)(a.cin_off + 8 * qt)) * 2u : 0x80000000u, 0, 0);
         }
     };
@@ -657,24 +665,25 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
             float csc[8], csh[8], csl[8];
             LoadVec<float, 8>::ld(scoef + 8 * qt, csc); LoadVec<float, 8>::ld(scoef + 32 + 8 * qt, csh); LoadVec<float, 8>::ld(scoef + 64 + 8 * qt, csl);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
+            for (int i = 0; i < NSEG; ++i) {
                 const int q = (lane >> 2) + 16 * i;
-                const int hr = (q * 3277) >> 16, hc = q - 20 * hr;
-                const int iy = y0 - 2 + hr, ix = x0 - 2 + hc;
+                if (HR * HC % 16 != 0 && q >= HR * HC) continue;
+                const int hr = (q * DIVM) >> 16, hc = q - HC * hr;
+                const int iy = y0 - R + hr, ix = x0 - R + hc;
                 const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(pre[i][j] << 16); v[2 * j + 1] = __uint_as_float(pre[i][j] & 0xFFFF0000u); }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = in ? abc_act(v[j], csc[j], csh[j], csl[j]) : 0.f;     // (the zero padding applies to the ACTIVATED tensor)
-                *(bf16x8*)(halo + QS * qt + (hr * 20 + hc) * 16) = pack_frag<bf16>(v);
+                *(bf16x8*)(halo + QS * qt + (hr * HC + hc) * 16) = pack_frag<bf16>(v);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
+            for (int i = 0; i < NSEG; ++i) {
                 const int q = (lane >> 2) + 16 * i;
-                const int hr = (q * 3277) >> 16, hc = q - 20 * hr;
-                *(u32x4*)(halo + QS * qt + (hr * 20 + hc) * 16) = pre[i];
+                if (HR * HC % 16 != 0 && q >= HR * HC) continue;
+                *(u32x4*)(halo + QS * qt + q * 16) = pre[i];
             }
         }
         issue(tile + nw);
@@ -695,18 +704,18 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) acc[r][c2] = (f32x4){bv[c2][0], bv[c2][1], bv[c2][2], bv[c2][3]};
         const char* hb = halo + QS * kg + n * 16;
-        const char* wbase = wl + (a.mirror ? 24 * 2048 : 0);
+        const char* wbase = wl + (a.mirror ? (TAPS - 1) * 2048 : 0);
         // software-pipelined by one tap: the four pixel fragments of tap (dy, dx + 1) -- and, at the end of a kernel row, the ten weight
         // fragments of the next row -- are issued in front of the eight MFMAs of tap (dy, dx) (two named fragment sets; the fences keep
         // the compiler from sinking the reads to their uses: 89 lgkmcnt waits with two MFMAs between them otherwise)
-        bf16x8 wa[5][2], fb0[4], fb1[4];
+        bf16x8 wa[KW][2], fb0[4], fb1[4];
         auto load_w1 = [&](int dy, int dx) {
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) wa[dx][c2] = *(const bf16x8*)(wbase + (a.mirror ? -(dy * 5 + dx) : dy * 5 + dx) * 2048 + woff[c2]);
+            for (int c2 = 0; c2 < 2; ++c2) wa[dx][c2] = *(const bf16x8*)(wbase + (a.mirror ? -(dy * KW + dx) : dy * KW + dx) * 2048 + woff[c2]);
         };
         auto load_b = [&](bf16x8 (&f)[4], int dy, int dx) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) f[r] = *(const bf16x8*)(hb + ((r + dy) * 20 + dx) * 16);
+            for (int r = 0; r < 4; ++r) f[r] = *(const bf16x8*)(hb + ((r + dy) * HC + dx) * 16);
         };
         auto mma = [&](const bf16x8 (&f)[4], int dx) {
 #pragma unroll
@@ -716,19 +725,19 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
             }
         };
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) load_w1(0, dx);
+        for (int dx = 0; dx < KW; ++dx) load_w1(0, dx);
         load_b(fb0, 0, 0);
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy) {
+        for (int dy = 0; dy < KW; ++dy) {
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx) {
-                const int t = dy * 5 + dx;
-                const int ndy = dx == 4 ? dy + 1 : dy, ndx = dx == 4 ? 0 : dx + 1;
-                if (t < 24) { if (t & 1) load_b(fb0, ndy, ndx); else load_b(fb1, ndy, ndx); }
+            for (int dx = 0; dx < KW; ++dx) {
+                const int t = dy * KW + dx;
+                const int ndy = dx == KW - 1 ? dy + 1 : dy, ndx = dx == KW - 1 ? 0 : dx + 1;
+                if (t < TAPS - 1) { if (t & 1) load_b(fb0, ndy, ndx); else load_b(fb1, ndy, ndx); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (t & 1) mma(fb1, dx); else mma(fb0, dx);
-                // this tap's two weight fragments are free: the next kernel row's take their place (needed five taps from now)
-                if (dy < 4) load_w1(dy + 1, dx);
+                // this tap's two weight fragments are free: the next kernel row's take their place (needed KW taps from now)
+                if (dy < KW - 1) load_w1(dy + 1, dx);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -819,7 +828,8 @@ static bool route_n16(const abc_conv_desc* d) {
 
 // 32 -> 32 channels, the full 5x5 square in row-major tap order, whole 4 x 16 tiles go to conv_n32r2_kernel
 static bool route_n32r2(const abc_conv_desc* d) {
-    if (d->Cin != 32 || d->Cout != 32 || d->ntaps != 25) return false;
+    if (d->Cin != 32 || d->Cout != 32 || (d->ntaps != 25 && d->ntaps != 9)) return false;
+    if (d->ntaps == 9 && (d->stats_rows == 4 || abc_knob("ABC_CONV_NON32R1"))) return false;
     if (d->stem_x != nullptr || d->pool_y != nullptr) return false;
     if (d->src.scale != nullptr && d->out_act) return false;
     // act_bwd in the epilogue: plain input, the two BatchNorm-backward rows
@@ -827,9 +837,10 @@ static bool route_n32r2(const abc_conv_desc* d) {
                                    (int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2 >= (int64_t(1) << 31))) return false;
     if (d->Hin % 4 || d->Win % 16 || (d->ldy % 4) || (d->cout_off % 4) || d->B > 256) return false;
     bool fwd = true, mir = true;
-    for (int t = 0; t < 25; ++t) {
-        fwd = fwd && d->tap_dy[t] == t / 5 - 2 && d->tap_dx[t] == t % 5 - 2;
-        mir = mir && d->tap_dy[t] == 2 - t / 5 && d->tap_dx[t] == 2 - t % 5;
+    const int kw = d->ntaps == 25 ? 5 : 3, rr = kw / 2;
+    for (int t = 0; t < d->ntaps; ++t) {
+        fwd = fwd && d->tap_dy[t] == t / kw - rr && d->tap_dx[t] == t % kw - rr;
+        mir = mir && d->tap_dy[t] == rr - t / kw && d->tap_dx[t] == rr - t % kw;
     }
     if (!fwd && !mir) return false;
     return abc_knob("ABC_CONV_NON32R2") == nullptr;
@@ -909,27 +920,30 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         q.B = d->B; q.H = d->Hin; q.W = d->Win; q.ldx = d->src.ldx; q.cin_off = d->cin_off; q.ldy = d->ldy; q.cout_off = d->cout_off;
         q.tiles_x = q.W / 16; q.tiles_y = q.H / 4; q.ntiles = q.tiles_x * q.tiles_y * q.B;
         q.bytesX = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->src.ldx * 2);
-        q.bytesW = 25u * 32u * 64u;
+        q.bytesW = (unsigned)d->ntaps * 32u * 64u;
         q.out_act = d->out_act; q.out_slope = d->out_slope;
-        q.mirror = d->tap_dy[0] == 2 ? 1 : 0;
+        q.mirror = d->tap_dy[0] > 0 ? 1 : 0;
         q.wpi = n32r2_wpi(d); q.rows4 = d->stats_rows == 4 ? 1 : 0;
         q.ab_y = d->actbwd_y ? (const bf16*)d->actbwd_y + d->actbwd_coff : nullptr; q.ab_ld = d->actbwd_ld;
         q.bytesY = d->actbwd_y ? (unsigned)((int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2) : 0u;
         q.ab_sc = d->actbwd_scale; q.ab_sh = d->actbwd_shift; q.ab_sl = d->actbwd_slope; q.ab_mu = d->actbwd_mean; q.ab_is = d->actbwd_invstd;
-        const int lds = 25 * 32 * 64 + N32_CF + 8 * 4 * 2560;
         const int nwg = n32r2_grid(d);
-        static unsigned long long ok_x = 0, ok_p = 0, ok_a = 0;
-        if (d->actbwd_y != nullptr) {
-            if (d->stats == nullptr) return abc_fail(ABC_EINVAL, "conv: actbwd_y needs stats (the BatchNorm-backward partial sums)");
-            if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<false, true>, 160 * 1024, &ok_a)) return rc;
-            hipLaunchKernelGGL((conv_n32r2_kernel<false, true>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);
-        } else if (d->src.scale != nullptr) {
-            if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<true>, 160 * 1024, &ok_x)) return rc;
-            hipLaunchKernelGGL(conv_n32r2_kernel<true>, dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);
+        if (d->actbwd_y != nullptr && d->stats == nullptr) return abc_fail(ABC_EINVAL, "conv: actbwd_y needs stats (the BatchNorm-backward partial sums)");
+        const int form = d->actbwd_y != nullptr ? 2 : (d->src.scale != nullptr ? 1 : 0);
+        static unsigned long long okf[6] = {0, 0, 0, 0, 0, 0};
+#define ABC_N32_LAUNCH(XF_, AB_, R_, SLOT)                                                                                        \
+        do {                                                                                                                       \
+            constexpr int qs_ = ((4 + 2 * R_) * (16 + 2 * R_) * 16 + 255) / 256 * 256;                                             \
+            const int lds = (2 * R_ + 1) * (2 * R_ + 1) * 32 * 64 + N32_CF + 8 * 4 * qs_;                                          \
+            if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<XF_, AB_, R_>, 160 * 1024, &okf[SLOT])) return rc;           \
+            hipLaunchKernelGGL((conv_n32r2_kernel<XF_, AB_, R_>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);              \
+        } while (0)
+        if (d->ntaps == 25) {
+            if (form == 2) ABC_N32_LAUNCH(false, true, 2, 0); else if (form == 1) ABC_N32_LAUNCH(true, false, 2, 1); else ABC_N32_LAUNCH(false, false, 2, 2);
         } else {
-            if (int rc = abc_allow_lds((const void*)conv_n32r2_kernel<false>, 160 * 1024, &ok_p)) return rc;
-            hipLaunchKernelGGL(conv_n32r2_kernel<false>, dim3(nwg), dim3(512), lds, (hipStream_t)stream, q);
+            if (form == 2) ABC_N32_LAUNCH(false, true, 1, 3); else if (form == 1) ABC_N32_LAUNCH(true, false, 1, 4); else ABC_N32_LAUNCH(false, false, 1, 5);
         }
+#undef ABC_N32_LAUNCH
         return abc_check_launch("conv_n32r2");
     }
     if (route_n16(d)) {

@@ -343,8 +343,8 @@ def test_rank_dropout_seeds_differ_and_rank0_keeps_the_base():
 
 
 def test_act_bwd_epilogue_plan_and_its_refusals():
-    """Engine._actbwd_target / abc_conv_actbwd_ok (host logic only): at the benchmarked shape the bf16 training plan lets 14 of
-    unet.py's 26 act_bwd passes (9 of unet2.py's 14: two of them in the 5x5 32 -> 32 kernel of its first level) ride in the epilogue of the data gradient in front of them -- the first BatchNorm
+    """Engine._actbwd_target / abc_conv_actbwd_ok (host logic only): at the benchmarked shape the bf16 training plan lets 15 of
+    unet.py's 26 act_bwd passes (10 of unet2.py's 14: three of them in the 32 -> 32 kernel of its first levels) ride in the epilogue of the data gradient in front of them -- the first BatchNorm
     of a DoubleConv, a trunk layer, the trunk's last layer behind the heads' merged data gradient: layers whose activated output has
     exactly one reader (unet.py:12-17); layers
     with a skip or a pooled reader, the narrow levels (another kernel) and the 24 x 24 / 12 x 12 levels (no whole 16-pixel tile
@@ -364,13 +364,13 @@ def test_act_bwd_epilogue_plan_and_its_refusals():
         return e, [n for n in names if "+ act_bwd" in n], [n for n in names if n.startswith("act_bwd")]
 
     e, fused, plain = plan(UNet, "unet", "bf16", fused_heads=True)
-    assert len(fused) == 14 and len(plain) == 12, (fused, plain)
+    assert len(fused) == 15 and len(plain) == 11, (fused, plain)
     for n in fused:
         # "dgrad X.double_conv.3 + act_bwd X.double_conv.1" (inside a DoubleConv) or "dgrad Y.double_conv.0 + act_bwd X.double_conv.4"
         assert n.endswith("double_conv.1") or n.endswith("double_conv.4"), n
     assert fused[0] == "dgrad heads.conv1 + act_bwd dconv2.double_conv.4"
     tg = [r for r in e.recs if getattr(r, "fused_g", None) is not None]
-    assert len(tg) == 14 and all(r.ld == r.cout and r.coff == 0 and r.grad_pool is None for r in tg)
+    assert len(tg) == 15 and all(r.ld == r.cout and r.coff == 0 and r.grad_pool is None for r in tg)
     assert not any("down4" in n or "down5" in n or "up1" in n for n in fused)
     assert sum(("inc1" in n or "inc2" in n) and "inc3" not in n.split(" + ")[0] for n in fused) == 3      # (the 16-channel levels: conv_narrow.hip's own epilogue)
     _e, fused0, plain0 = plan(UNet, "unet", "bf16", fused_heads=True, actbwd_epilogue=False)
@@ -378,7 +378,7 @@ def test_act_bwd_epilogue_plan_and_its_refusals():
     _e, fused32, _p = plan(UNet, "unet", "fp32")
     assert not fused32
     _e, fused2, plain2 = plan(UNet2, "unet2", "bf16")
-    assert len(fused2) == 9 and len(plain2) == 5, (fused2, plain2)
+    assert len(fused2) == 10 and len(plain2) == 4, (fused2, plain2)
     assert sum("inc1" in n.split(" + ")[1] or "inc2" in n.split(" + ")[1] for n in fused2) == 2, fused2
     # the library's own answer for single descriptors
     lib = L.load()
@@ -403,6 +403,7 @@ def test_act_bwd_epilogue_plan_and_its_refusals():
     assert ok(16, 24, 24, 512, 512)[0] == 0          # 24 columns: no whole 16-pixel tiles
     assert ok(1, 30, 48, 64, 64)[0] == 0             # 30 rows: no tile height divides it
     assert ok(16, 384, 384, 16, 16) == (1, 5) and ok(3, 40, 56, 16, 16) == (1, 5)      # the narrow-level kernel: ragged shapes too
-    assert ok(16, 192, 192, 32, 32)[0] == 0          # the narrow-level kernel's 32-channel form has no such epilogue
+    assert ok(16, 192, 192, 32, 32) == (1, 5)        # whole 4 x 16 tiles of the 32 -> 32 kernel (conv_n32r2_kernel, R = 1)
+    assert ok(3, 42, 48, 32, 32)[0] == 0             # ... ragged rows: the general narrow-level kernel's 32-channel form has no such epilogue
     assert ok(16, 96, 96, 128, 128, dtype_out=L.F32)[0] == 0 and ok(16, 96, 96, 128, 128, accumulate=1)[0] == 0
     assert ok(16, 96, 96, 128, 128, stats=None)[0] == 0 and ok(16, 96, 96, 128, 128, actbwd_ld=100)[0] == 0

@@ -102,6 +102,10 @@ def test_conv_forward(lib, dt, case):
     dict(Cin=16, Cout=32, H=20, W=40, slope=0.01),            # ragged tiles: 20 = 2 x 8 + 4 rows, 40 = 2 x 16 + 8 columns
     dict(Cin=16, Cout=16, H=72, W=88, ld=48, coff=16, ldy=40, ycoff=8),   # channel slices of wider tensors
     dict(Cin=32, Cout=32, H=256, W=384, slope=0.0),           # every wave walks several tiles
+    # the 3x3 form of the 32 -> 32 kernel (conv_n32r2_kernel, R = 1: unet.py's 192 x 192 level): training forward, data gradient
+    dict(Cin=32, Cout=32, H=40, W=48, coef=True, stats=True),
+    dict(Cin=32, Cout=32, H=192, W=192, coef=True, stats=True),
+    dict(Cin=32, Cout=32, H=40, W=48, mirror=True),
     # training forward: the producer's BatchNorm + activation on load, BatchNorm partial sums of the outputs
     dict(Cin=16, Cout=16, H=64, W=96, coef=True, stats=True),
     dict(Cin=16, Cout=16, H=200, W=136, coef=True, stats=True),   # ragged tiles, several tiles per wave
@@ -771,7 +775,7 @@ def test_pack_layout_for_the_weights_direct_loop(lib):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,slope", [(2, 48, 48, 128, 128, 0.0), (3, 24, 32, 64, 64, 0.01), (2, 32, 16, 128, 256, 0.2),
                                                   (1, 32, 48, 256, 96, 0.0), (5, 96, 96, 128, 128, 0.0),
                                                   (2, 64, 64, 16, 16, 0.0), (3, 40, 56, 16, 16, 0.01), (16, 96, 96, 16, 16, 0.0),
-                                                  (2, 32, 48, 32, 32, 0.01), (3, 64, 64, 32, 32, 0.0)])
+                                                  (2, 32, 48, 32, 32, 0.01), (3, 64, 64, 32, 32, 0.0), (2, 36, 48, 32, 32, 0.2)])
 def test_act_bwd_in_the_data_gradient_epilogue(lib, B, H, W, Cin, Cout, slope):
     """abc_conv_desc.actbwd_*: a 3x3 data-gradient convolution that stores g = dA * act'(BatchNorm(y_raw)) and the BatchNorm-backward
     partial sums of the layer it differentiates (autograd of unet.py:12-17) -- against the same convolution followed by abc_act_bwd
@@ -781,7 +785,7 @@ def test_act_bwd_in_the_data_gradient_epilogue(lib, B, H, W, Cin, Cout, slope):
     5x5 32 -> 32 form of unet2.py's first level (conv_n32r2_kernel); a ragged shape of the lean kernel must be refused
     (abc_conv_actbwd_ok == 0) and then runs the plain convolution."""
     dt = L.BF16
-    k = 5 if Cin == 32 else 3
+    k = 5 if Cin == 32 and H != 36 else 3           # (H = 36: the 3x3 form of the 32 -> 32 kernel)
     g = torch.Generator().manual_seed(11)
     dy = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(U.DEV)          # gradient entering the convolution
     w = torch.randn((Cout, Cin, k, k), generator=g) / (k * Cin ** 0.5)
