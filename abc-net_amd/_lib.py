@@ -206,6 +206,7 @@ SYMBOLS = {
     "abc_wgrad_reduce_batch": (C.c_int, [vp, i32, vp]),
     "abc_colsum_blocks": (C.c_int, [i64]),
     "abc_colsum": (C.c_int, [vp, i32, i64, i32, i32, i32, vp, vp, vp, vp]),
+    "abc_colsum_w1": (C.c_int, [vp, i32, i64, i32, i32, i32, vp, vp, vp, vp, vp]),
     "abc_loss_blocks": (C.c_int, [P(LossDesc)]),
     "abc_loss_fwd_bwd": (C.c_int, [P(LossDesc), vp]),
     "abc_loss_finalize": (C.c_int, [P(LossFinDesc), vp]),

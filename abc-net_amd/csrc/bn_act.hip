@@ -396,6 +396,58 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* work, i
     s = block_sum_f64(s, sm);
     if (threadIdx.x == 0) out[c] = (float)s;
 }
+// column sums of x and of x * w[pixel] in one pass (w: one f32 value per pixel): bias and weight gradient of a 1x1 convolution over a
+// ONE-channel input (unet2.py:62 res_conv of the first block, unet2.py:135): work = [blocks][2][C]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_w1_kernel(const T* x, int64_t npix, int ld, int c_off, int C, const float* w, float* work) {
+    constexpr int N = VecOf<T>::N;
+    __shared__ float red[256][2 * N + 1];
+    const int ncv = C / N;                 // divides 256 (checked on the host)
+    const int cv = threadIdx.x % ncv, pl = threadIdx.x / ncv, PL = 256 / ncv;
+    float acc[N], accw[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { acc[j] = 0.f; accw[j] = 0.f; }
+    const T* base = x + c_off + cv * N;
+    int64_t p = (int64_t)blockIdx.x * PL + pl;
+    const int64_t step = (int64_t)gridDim.x * PL;
+    for (; p + 3 * step < npix; p += 4 * step) {   // four loads in flight
+        float a[4][N], wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ldv<T, N>(base + (p + u * step) * ld, a[u]); wv[u] = w[p + u * step]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < N; ++j) { acc[j] += a[u][j]; accw[j] = fmaf(a[u][j], wv[u], accw[j]); }
+    }
+    for (; p < npix; p += step) {
+        float a[N];
+        ldv<T, N>(base + p * ld, a);
+        const float wv = w[p];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { acc[j] += a[j]; accw[j] = fmaf(a[j], wv, accw[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { red[threadIdx.x][j] = acc[j]; red[threadIdx.x][N + j] = accw[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int row = c / C, cc = c - row * C;
+        const int v = cc / N, j = cc % N;
+        float s = 0.f;
+        for (int q = 0; q < PL; ++q) s += red[q * ncv + v][row * N + j];
+        work[((size_t)blockIdx.x * 2 + row) * C + cc] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_w1_reduce_kernel(const float* work, int nblk, int C, float* out_sum, float* out_w) {
+    __shared__ double sm[4];
+    const int c = blockIdx.x, row = blockIdx.y;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 256) s += (double)work[((size_t)k * 2 + row) * C + c];
+    s = block_sum_f64(s, sm);
+    if (threadIdx.x == 0) {
+        if (row == 0) { if (out_sum != nullptr) out_sum[c] = (float)s; }
+        else out_w[c] = (float)s;
+    }
+}
 
 __global__ void fill_kernel(float* p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
@@ -564,6 +616,21 @@ extern "C" int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld
         hipLaunchKernelGGL(colsum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, npix, ld, c_off, C, chan_scale, work, CW);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3(C), dim3(256), 0, st, (const float*)work, nb, C, out);
     return abc_check_launch("colsum");
+}
+
+extern "C" int abc_colsum_w1(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C, const float* w,
+                             float* work, float* out_sum, float* out_w, abc_stream_t stream) {
+    const int nb = abc_colsum_blocks(npix);
+    const int N = dtype == ABC_BF16 ? 8 : 4;
+    const int ncv = C / N;
+    if (x == nullptr || w == nullptr || work == nullptr || out_w == nullptr) return abc_fail(ABC_EINVAL, "colsum_w1: x, w, work and out_w are required");
+    if (C % N || ncv < 1 || ncv > 256 || 256 % ncv || ld % N || c_off % N)
+        return abc_fail(ABC_EUNSUPPORTED, "colsum_w1: C / vector width must divide 256, ld and c_off be multiples of the vector width");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == ABC_BF16) hipLaunchKernelGGL(colsum_w1_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, npix, ld, c_off, C, w, work);
+    else hipLaunchKernelGGL(colsum_w1_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, npix, ld, c_off, C, w, work);
+    hipLaunchKernelGGL(colsum_w1_reduce_kernel, dim3(C, 2), dim3(256), 0, st, (const float*)work, nb, C, out_sum, out_w);
+    return abc_check_launch("colsum_w1");
 }
 
 // 2x2 max-pool of the activated tensor, 8 channels (16 / 32 bytes) per thread

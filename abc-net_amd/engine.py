@@ -568,6 +568,20 @@ class Engine:
 
         ops.append((fn, None, what, (bname,), {"kernel": "colsum", "flops": 0, "bytes": float(npix * Cn * self._esz(dt))}))
 
+    def emit_colsum_w1(self, ops, t, dt, npix, ld, c_off, Cn, img, bname, wname, what):
+        """bias AND weight gradient of a 1x1 convolution over a one-channel f32 image in one pass over d(out) (abc_colsum_w1):
+        unet2's first res_conv (unet2.py:62,135)"""
+        nb = self.lib.abc_colsum_blocks(npix)
+        self._colsum_need = max(self._colsum_need, 2 * nb * Cn)
+        args = [t.data_ptr(), dt, npix, ld, c_off, Cn, img.data_ptr(), None, self.G(bname), self.G(wname)]
+        self._colsum_users.append(args)
+        lib = self.lib
+
+        def fn(_ref, stream, a=args):
+            return lib.abc_colsum_w1(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], stream)
+
+        ops.append((fn, None, what, (bname, wname), {"kernel": "colsum_w1", "flops": 0, "bytes": float(npix * (Cn * self._esz(dt) + 4))}))
+
     # ------------------------------------------------------------------ layers
     def conv_bn(self, cname, bname, src: Src, cout, k, dst, slope, recname=None, stats_rows=2, force_stats=False, stat_out=None,
                 collect_fin=None, shared=None):
@@ -1702,8 +1716,14 @@ class Engine:
             gsrc = Src(g, self.dt, H, W, Cc, 0, Cc)
             if blk.cin != blk.cout:
                 rname = blk.prefix + ".res_conv"
-                self.emit_wgrad(ops, gsrc, xin, blk.cout, blk.cin, [(0, 0)], 1, rname + ".weight", "wgrad " + rname)
-                self.emit_colsum(ops, g, self.dt, npx, Cc, 0, Cc, None, rname + ".bias", "dbias " + rname)
+                nv = 8 if self.dt == L.BF16 else 4
+                if blk.cin == 1 and xin.dt == L.F32 and xin.coef is None and not xin.pool and xin.ld == 1 and xin.coff == 0 and \
+                        Cc % nv == 0 and 256 % (Cc // nv) == 0:
+                    # the one-channel image: the 1x1 weight gradient is a second, pixel-weighted row of the bias gradient's column sums
+                    self.emit_colsum_w1(ops, g, self.dt, npx, Cc, 0, Cc, xin.t, rname + ".bias", rname + ".weight", "wgrad + dbias " + rname)
+                else:
+                    self.emit_wgrad(ops, gsrc, xin, blk.cout, blk.cin, [(0, 0)], 1, rname + ".weight", "wgrad " + rname)
+                    self.emit_colsum(ops, g, self.dt, npx, Cc, 0, Cc, None, rname + ".bias", "dbias " + rname)
                 if has_prod:
                     rows_pad = -(-blk.cin // 32) * 32
                     wd = self.packed(1, blk.cout, rows_pad)

@@ -347,6 +347,12 @@ int abc_wgrad_reduce_batch(const abc_wgrad_reduce_desc* descs, int32_t n, abc_st
 int abc_colsum_blocks(int64_t npix);
 int abc_colsum(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C,
                const float* chan_scale, float* work /* [abc_colsum_blocks(npix)][C] */, float* out, abc_stream_t stream);
+/* The same pass with a second row of sums weighted by a one-channel f32 image w[npix]: out_sum[c] = sum x[p][c] (may be NULL),
+ * out_w[c] = sum x[p][c] * w[p] -- bias and weight gradient of a 1x1 convolution over a one-channel input, i.e. autograd of
+ * unet2.DoubleConv's res_conv in the first block (unet2.py:62,72,135: nn.Conv2d(1, 32, 1)) in ONE pass over d(out).
+ * work: [abc_colsum_blocks(npix)][2][C] floats. */
+int abc_colsum_w1(const void* x, int32_t dtype, int64_t npix, int32_t ld, int32_t c_off, int32_t C, const float* w,
+                  float* work, float* out_sum, float* out_w, abc_stream_t stream);
 
 /* Fused activation + loss + dlogits (train.py:95-137).  Logits and dlogits are the 8 NCHW f32
  * head maps of unet.forward (unet.py:119), targets the reference's NCHW tensors

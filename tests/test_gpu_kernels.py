@@ -693,6 +693,40 @@ def test_colsum(lib, dt, case):
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-4
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C,ld,off,npix", [(32, 32, 0, 2 * 48 * 40), (32, 64, 32, 3 * 72 * 88 + 5), (64, 64, 0, 777)])
+def test_colsum_weighted_by_a_one_channel_image(lib, dt, C, ld, off, npix):
+    """abc_colsum_w1: column sums of d(out) and of d(out) * image[pixel] in one pass = bias and weight gradient of a 1x1 convolution
+    over a one-channel input (unet2.py:62,135: res_conv of the first block), against torch's conv2d autograd and f64 sums"""
+    g = torch.Generator().manual_seed(23)
+    x = q(torch.randn((npix, ld), generator=g), dt)
+    img = torch.rand(npix, generator=g)
+    xs = x[:, off:off + C]
+    w = torch.zeros((C, 1, 1, 1), requires_grad=True)
+    b = torch.zeros(C, requires_grad=True)
+    F.conv2d(img.view(1, 1, 1, npix), w, b).backward(xs.t().reshape(1, C, 1, npix).float())
+    xd = x.to(U.tdt(dt)).to(U.DEV)
+    nb = lib.abc_colsum_blocks(npix)
+    work = torch.zeros(nb * 2 * C, dtype=torch.float32, device=U.DEV)
+    osum = torch.zeros(C, dtype=torch.float32, device=U.DEV)
+    ow = torch.zeros(C, dtype=torch.float32, device=U.DEV)
+    imgd = img.to(U.DEV)
+    L.check(lib.abc_colsum_w1(xd.data_ptr(), dt, npix, ld, off, C, imgd.data_ptr(), work.data_ptr(), osum.data_ptr(), ow.data_ptr(), U.stream()),
+            "colsum_w1")
+    torch.cuda.synchronize()
+    r_sum = xs.double().sum(0)
+    r_w = (xs.double() * img.double().view(-1, 1)).sum(0)
+    scale = xs.abs().double().sum(0).max().item()
+    assert (osum.cpu().double() - r_sum).abs().max().item() <= 1e-5 * scale + 1e-4
+    assert (ow.cpu().double() - r_w).abs().max().item() <= 1e-5 * scale + 1e-4
+    assert (ow.cpu() - w.grad.view(-1)).abs().max().item() <= 1e-4 * scale + 1e-3 and (osum.cpu() - b.grad).abs().max().item() <= 1e-4 * scale + 1e-3
+    # the bias row is optional
+    ow2 = torch.zeros_like(ow)
+    L.check(lib.abc_colsum_w1(xd.data_ptr(), dt, npix, ld, off, C, imgd.data_ptr(), work.data_ptr(), None, ow2.data_ptr(), U.stream()), "colsum_w1")
+    torch.cuda.synchronize()
+    assert torch.equal(ow2, ow)
+
+
 def test_conv_rows_packed_side_by_side_and_concat(lib):
     """abc_pack_desc.rows_total / rows_off + abc_concat_f32: three convolutions over the same input as ONE convolution whose
     packed weight holds their rows one below the other (how the eight heads' conv1, unet.py:66,116-118, run), per-block
