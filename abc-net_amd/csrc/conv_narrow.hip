@@ -575,6 +575,9 @@ struct N32K {
     // (sum g, sum g (y_raw - mean) / std): bn_act.hip's act_bwd pass over the 384 x 384 tensor (three tensor passes) is not run
     const bf16* ab_y; int ab_ld; unsigned bytesY;
     const float *ab_sc, *ab_sh, *ab_sl, *ab_mu, *ab_is;
+    int accumulate;                             // y += result (abc_conv_desc.accumulate; plain form): the identity residual's gradient of unet2.DoubleConv
+                                                // (unet2.py:72) summed into the tensor that already holds d(out) -- bn_act.hip's add_into pass is not run
+    unsigned bytesO;
 };
 constexpr int N32_CF = 1024;                    // coefficient tables between the weights and the halo images: [sc | sh | sl][32], bias [32], ACTB's mean [32]
 
@@ -616,7 +619,9 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
         if (ACTB && threadIdx.x >= 192 && threadIdx.x < 224) smu[threadIdx.x - 192] = a.ab_mu[threadIdx.x - 192];
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX), rsYR = abc_make_rsrc(ACTB ? a.ab_y : a.x, ACTB ? a.bytesY : 0u);
+    // (the second resource: ACTB's y_raw, or the output tensor itself where the result is added to it)
+    const __amdgpu_buffer_rsrc_t rsX = abc_make_rsrc(a.x, a.bytesX),
+                                 rsYR = abc_make_rsrc(ACTB ? a.ab_y : (const bf16*)a.y, ACTB ? a.bytesY : (!XF && a.accumulate ? a.bytesO : 0u));
     // compute role: pixel column n, K group kg = input channels 8 kg .. + 7 of the tap; output channels 16 c2 + 4 kg .. + 3
     const int n = lane & 15, kg = lane >> 4;
     // this lane's weight-fragment address inside a tap's 2 KB block: row 16 c2 + n, slot kg (swizzled by the row)
@@ -689,7 +694,16 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
         issue(tile + nw);
         // ACTB: the producer's raw output at this lane's 4 pixels x 8 channels (the accumulator layout), in flight under the MFMAs
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 yq[ACTB ? 4 : 1][2];
+        u32x2 yq[XF ? 1 : 4][2];
+        if constexpr (!XF && !ACTB) {
+            if (a.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+                        yq[r][c2] = __builtin_amdgcn_raw_buffer_load_b64(rsYR, (unsigned)(((b * a.H + y0 + r) * a.W + x0 + n) * a.ldy + a.cout_off + 16 * c2 + 4 * kg) * 2u, 0, 0);
+            }
+        }
         if constexpr (ACTB) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -772,7 +786,13 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
                 bf16x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v = acc[r][c2][i];
+                    float v = acc[r][c2][i];
+                    if constexpr (!XF) {
+                        if (a.accumulate) {
+                            const unsigned w = i < 2 ? yq[r][c2].x : yq[r][c2].y;
+                            v += (i & 1) ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
+                        }
+                    }
                     s1[c2][i] += v; s2[c2][i] = fmaf(v, v, s2[c2][i]);
                     o[i] = (bf16)fmaxf(v, slope * v);
                     // (max / min of the values AS STORED: CBAM's global max-pool and its backward see the tensor, unet2.py:10,20)
@@ -871,7 +891,10 @@ int abc_conv_narrow_ok(const abc_conv_desc* d) {
     if (abc_knob("ABC_CONV_NONARROW")) return 0;
     if (d->dtype_in != ABC_BF16 || d->dtype_c != ABC_BF16 || d->dtype_out != ABC_BF16) return 0;
     if (d->src.pool || d->src.planar || d->src.drop_p > 0.f || d->planar_out) return 0;
-    if (d->accumulate || d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
+    if (d->stride != 1 || d->om != 1 || d->oy0 || d->ox0) return 0;
+    // y += result: the plain form of the 32 -> 32 kernel only
+    if (d->accumulate && !(route_n32r2(d) && d->src.scale == nullptr && d->actbwd_y == nullptr && !d->out_act && d->stats_rows != 4 &&
+                           (int64_t)d->B * d->Hin * d->Win * d->ldy * 2 < (int64_t(1) << 31))) return 0;
     if ((d->Cin != 16 && d->Cin != 32) || d->Cout_pad != 32 || d->Cout % 8 || (d->ntaps != 9 && d->ntaps != 25)) return 0;
     if (d->Hg != d->Hin || d->Wg != d->Win || d->Hout != d->Hg || d->Wout != d->Wg || d->src.Hx != d->Hin || d->src.Wx != d->Win) return 0;
     if ((d->src.ldx | d->cin_off | d->ldy | d->cout_off) % 8) return 0;
@@ -927,6 +950,7 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         q.ab_y = d->actbwd_y ? (const bf16*)d->actbwd_y + d->actbwd_coff : nullptr; q.ab_ld = d->actbwd_ld;
         q.bytesY = d->actbwd_y ? (unsigned)((int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2) : 0u;
         q.ab_sc = d->actbwd_scale; q.ab_sh = d->actbwd_shift; q.ab_sl = d->actbwd_slope; q.ab_mu = d->actbwd_mean; q.ab_is = d->actbwd_invstd;
+        q.accumulate = d->accumulate; q.bytesO = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->ldy * 2);
         const int nwg = n32r2_grid(d);
         if (d->actbwd_y != nullptr && d->stats == nullptr) return abc_fail(ABC_EINVAL, "conv: actbwd_y needs stats (the BatchNorm-backward partial sums)");
         const int form = d->actbwd_y != nullptr ? 2 : (d->src.scale != nullptr ? 1 : 0);

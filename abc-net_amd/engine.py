@@ -327,8 +327,9 @@ class Engine:
     def emit_conv(self, ops, src: Src, w, bias, y, y_dt, Hout, Wout, ldy, cout_off, Cout, taps, stats=None, stride=1,
                   grid=None, om=1, oy0=0, ox0=0, cin_off=None, Cin=None, what="conv", planar_out=False, stats_rows=2,
                   accumulate=False, collect=None, out_slope=None, cdt=None, out_scale=None, out_quant=None, out_quant_stride=0, heads_epi=None,
-                  actbwd=None):
+                  actbwd=None, only_variant=None):
         """collect: a list -- the launch is not emitted but appended as (desc, what, meta) for emit_heads_batch;
+        only_variant: emit only if abc_conv_variant says this kernel family serves the descriptor (else return None, emitting nothing);
         actbwd: the Rec of the layer whose activation output this data gradient differentiates -> abc_conv_desc.actbwd_* (the
         epilogue stores d(BatchNorm output) and that layer's BatchNorm-backward partial sums); returns None, emitting nothing, when
         the library does not serve it for this shape;
@@ -366,6 +367,8 @@ class Engine:
             stats = True
             if not self.lib.abc_conv_actbwd_ok(C.byref(d)):
                 return None
+        if only_variant is not None and self.lib.abc_conv_variant(C.byref(d)) != only_variant:
+            return None
         nblk = self.lib.abc_conv_stat_blocks(C.byref(d))
         st = None
         if stats:
@@ -1147,8 +1150,10 @@ class Engine:
             return Src(g, self.dt, rec.H, rec.W, C_, 0, C_, coef=(ca, cc, cb)), emit_apply
         return emit_apply()
 
-    def _conv_backward(self, ops, rec, dY, want_dgrad=True):
+    def _conv_backward(self, ops, rec, dY, want_dgrad=True, into=None):
         """wgrad (+ dgrad into a fresh buffer registered with the producer of rec.src).
+        into: a [B, H, W, cin] tensor the data gradient may be ADDED to instead (abc_conv_desc.accumulate, where the narrow-level
+        kernel serves that: rec.dsrc_accumulated tells) -- unet2's identity residual, whose gradient is the block's d(out) itself.
         dY is a plain Src, or the deferred pair of _bn_backward(defer=True): then the weight-gradient kernel applies the
         BatchNorm-backward correction on load and writes dY for the data-gradient conv (one pass less over g and y);
         layers whose weight gradient runs on another kernel fall back to the separate apply pass."""
@@ -1173,6 +1178,13 @@ class Engine:
         rows_pad = -(-rec.cin // 32) * 32
         wd = self.packed(len(rec.taps), rec.cout, rows_pad)
         self.emit_pack(rec.cname + ".weight", wd, 1, rec.cout, rec.cin, rec.k, rows_pad, rec.cout)
+        rec.dsrc_accumulated = False
+        if into is not None and self.dt == L.BF16 and tuple(into.shape) == (self.B, lh, lw, rec.cin):
+            got = self.emit_conv(ops, dY, wd, None, into, self.dt, lh, lw, rec.cin, 0, rec.cin, taps_mirror(rec.taps),
+                                 what="dgrad " + rec.cname + " (+= d(out) of the identity residual)", accumulate=True, only_variant=5)
+            if got is not None:
+                rec.dsrc, rec.dsrc_accumulated = into, True
+                return into
         dsrc = self.new((self.B, lh, lw, rec.cin))
         rec.dsrc = dsrc
         tgt = self._actbwd_target(rec)
@@ -1712,7 +1724,9 @@ class Engine:
             dY1 = self._bn_backward(ops, rec1, rec1.grad_same, None, defer=defer2)
             xin = blk.xin
             has_prod = xin.producer is not None
-            d_x = self._conv_backward(ops, rec1, dY1, want_dgrad=has_prod)
+            # (identity residual, unet2.py:72: d(x) = d(conv path) + d(out) -- where the 32 -> 32 kernel serves it the data gradient is
+            #  added into the tensor that holds d(out); nothing reads that tensor afterwards but the consumers of d(x))
+            d_x = self._conv_backward(ops, rec1, dY1, want_dgrad=has_prod, into=g if (blk.cin == blk.cout and has_prod) else None)
             gsrc = Src(g, self.dt, H, W, Cc, 0, Cc)
             if blk.cin != blk.cout:
                 rname = blk.prefix + ".res_conv"
@@ -1730,7 +1744,7 @@ class Engine:
                     self.emit_pack(rname + ".weight", wd, 1, blk.cout, blk.cin, 1, rows_pad, blk.cout)
                     self.emit_conv(ops, gsrc, wd, None, d_x, self.dt, H, W, blk.cin, 0, blk.cin, [(0, 0)], what="dgrad " + rname,
                                    accumulate=True)
-            elif has_prod:
+            elif has_prod and not rec1.dsrc_accumulated:
                 a = (d_x.data_ptr(), blk.cin, 0, g.data_ptr(), Cc, 0, Cc, npx, self.dt)
                 ops.append((lambda _r, st, a=a: lib.abc_add_into(*a, st), None, "d_x += g " + blk.prefix, (),
                             {"kernel": "add_into", "flops": 0, "bytes": float(npx * Cc * esz * 3)}))

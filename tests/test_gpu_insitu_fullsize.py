@@ -332,7 +332,9 @@ def _conv2_links(eng, rec, m, rep, sd):
         # the block's FIRST convolution: its data-gradient buffer also receives the residual branch's gradient (unet2.py:62-65,72):
         # d_x = conv^T(dY1) + g for the identity, + res_conv^T(g) for the 1x1 convolution
         blk = blk[0]
-        g = nchw(blk.bw["g"])
+        # (where the data gradient was ADDED into the tensor that held g -- abc_conv_desc.accumulate, rec.dsrc_accumulated -- that
+        #  tensor now holds d_x: g comes from its own inputs, and this check covers the cbam_bwd1 link "g = dOut * [out > 0]" too)
+        g = _block_g_ref(blk) if getattr(rec, "dsrc_accumulated", False) else nchw(blk.bw["g"])
         if blk.cin == blk.cout:
             ref = X.grad + g
         else:
@@ -343,6 +345,22 @@ def _conv2_links(eng, rec, m, rep, sd):
         rep.close(tag + " dgrad + residual", nchw(rec.dsrc), ref, 8e-3)
     else:
         rep.close(tag + _dgrad_tag(rec), nchw(rec.dsrc), _dgrad_ref(rec, X.grad), 5e-3)
+
+
+def _block_g_ref(blk):
+    """g = d(out) * [out > 0] of a unet2 block (unet2.py:73) from the gradient sources its consumers left and its own stored output"""
+    C_ = blk.cout
+    got_out = nchw(blk.out[..., blk.coff_out:blk.coff_out + C_])
+    dOut = torch.zeros_like(got_out)
+    if blk.grad_same is not None:
+        t, ld, co = blk.grad_same
+        dOut = dOut + nchw(t[..., co:co + C_])
+    if blk.grad_pool is not None:
+        t, ld, co = blk.grad_pool
+        oo = got_out.detach().clone().requires_grad_(True)
+        F.max_pool2d(oo, 2).backward(nchw(t[..., co:co + C_]))
+        dOut = dOut + oo.grad
+    return dOut * (got_out > 0).float()
 
 
 def _cbam_links(eng, blk, m, rep, sd):
@@ -399,7 +417,8 @@ def _cbam_links(eng, blk, m, rep, sd):
     mask = (got_out > 0).float()
     (sa * o1 + r).backward(dOut * mask)
     bw = blk.bw
-    rep.close(tag + " g = dOut * [out > 0]", nchw(bw["g"]), dOut * mask, 5e-3)
+    if not getattr(blk.rec1, "dsrc_accumulated", False):     # (else the tensor holds d_x by now: checked with the first convolution's data gradient)
+        rep.close(tag + " g = dOut * [out > 0]", nchw(bw["g"]), dOut * mask, 5e-3)
     # d(y2): through CBAM (both attention branches, the global and per-pixel max routes) and BatchNorm's batch statistics
     n = y2.shape[0] * y2.shape[2] * y2.shape[3]
     xh = ((y2 - mean) * invstd).detach()
