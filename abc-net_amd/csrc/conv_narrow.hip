@@ -575,6 +575,8 @@ struct N32K {
     // (sum g, sum g (y_raw - mean) / std): bn_act.hip's act_bwd pass over the 384 x 384 tensor (three tensor passes) is not run
     const bf16* ab_y; int ab_ld; unsigned bytesY;
     const float *ab_sc, *ab_sh, *ab_sl, *ab_mu, *ab_is;
+    bf16* pool_y; int ld_pool;                  // plain form, optional: the 2x2 max-pool of the stored tensor, [B][H/2][W/2][ld_pool] (unet.py:30: the
+                                                // folded inference graph's 32 -> 32 level at 256 x 256)
     int accumulate;                             // y += result (abc_conv_desc.accumulate; plain form): the identity residual's gradient of unet2.DoubleConv
                                                 // (unet2.py:72) summed into the tensor that already holds d(out) -- bn_act.hip's add_into pass is not run
     unsigned bytesO;
@@ -797,9 +799,29 @@ __global__ __launch_bounds__(512, 2) void conv_n32r2_kernel(const N32K a) {
                     o[i] = (bf16)fmaxf(v, slope * v);
                     // (max / min of the values AS STORED: CBAM's global max-pool and its backward see the tensor, unet2.py:10,20)
                     smx[c2][i] = fmaxf(smx[c2][i], (float)o[i]); smn[c2][i] = fminf(smn[c2][i], (float)o[i]);
+                    if constexpr (!XF) acc[r][c2][i] = (float)o[i];      // (the stored value, for the pooled output below)
                 }
                 *(bf16x4*)(dst + (size_t)r * a.W * a.ldy + 16 * c2) = o;
             }
+        if constexpr (!XF) {
+            if (a.pool_y != nullptr) {
+                // the 2x2 windows of the tile's two row pairs: the rows in this lane's accumulators, the column pair in lanes n, n ^ 1
+                // (of the values as STORED: rounded to bf16 first, as a pool over the stored tensor sees them)
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        bf16x4 pm;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float m = fmaxf(acc[2 * rp][c2][i], acc[2 * rp + 1][c2][i]);
+                            pm[i] = (bf16)fmaxf(m, dpp_mov<0xB1>(m));       // quad_perm [1,0,3,2]
+                        }
+                        if ((n & 1) == 0)
+                            *(bf16x4*)(a.pool_y + ((size_t)(b * (a.H >> 1) + ((y0 >> 1) + rp)) * (a.W >> 1) + ((x0 + n) >> 1)) * a.ld_pool + 16 * c2 + 4 * kg) = pm;
+                    }
+            }
+        }
         }
     }
     if (a.stats != nullptr) {
@@ -850,8 +872,10 @@ static bool route_n16(const abc_conv_desc* d) {
 static bool route_n32r2(const abc_conv_desc* d) {
     if (d->Cin != 32 || d->Cout != 32 || (d->ntaps != 25 && d->ntaps != 9)) return false;
     if (d->ntaps == 9 && (d->stats_rows == 4 || abc_knob("ABC_CONV_NON32R1"))) return false;
-    if (d->stem_x != nullptr || d->pool_y != nullptr) return false;
+    if (d->stem_x != nullptr) return false;
     if (d->src.scale != nullptr && d->out_act) return false;
+    // second output (the 2x2 max-pool of the stored tensor): the plain form
+    if (d->pool_y != nullptr && (d->src.scale != nullptr || d->actbwd_y != nullptr || d->accumulate || (d->ld_pool % 4) || d->stats_rows == 4)) return false;
     // act_bwd in the epilogue: plain input, the two BatchNorm-backward rows
     if (d->actbwd_y != nullptr && (d->src.scale != nullptr || d->out_act || d->stats_rows == 4 || (d->actbwd_ld % 4) || (d->actbwd_coff % 4) ||
                                    (int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2 >= (int64_t(1) << 31))) return false;
@@ -950,6 +974,7 @@ int abc_conv_narrow_launch(const abc_conv_desc* d, abc_stream_t stream) {
         q.ab_y = d->actbwd_y ? (const bf16*)d->actbwd_y + d->actbwd_coff : nullptr; q.ab_ld = d->actbwd_ld;
         q.bytesY = d->actbwd_y ? (unsigned)((int64_t)d->B * d->Hin * d->Win * d->actbwd_ld * 2) : 0u;
         q.ab_sc = d->actbwd_scale; q.ab_sh = d->actbwd_shift; q.ab_sl = d->actbwd_slope; q.ab_mu = d->actbwd_mean; q.ab_is = d->actbwd_invstd;
+        q.pool_y = (bf16*)d->pool_y; q.ld_pool = d->ld_pool;
         q.accumulate = d->accumulate; q.bytesO = (unsigned)((int64_t)d->B * d->Hin * d->Win * d->ldy * 2);
         const int nwg = n32r2_grid(d);
         if (d->actbwd_y != nullptr && d->stats == nullptr) return abc_fail(ABC_EINVAL, "conv: actbwd_y needs stats (the BatchNorm-backward partial sums)");
