@@ -17,884 +17,28 @@
 //
 // Reference ops covered: nn.Conv2d forward (unet.py:12,15,66,70), its data gradient, nn.ConvTranspose2d (unet.py:44)
 // as four output-parity phases; see include/abcnet_hip.h (abc_conv_desc).
-#include "common.hpp"
-#include "../../include/abcnet_hip.h"
-#include "capi_util.hpp"
-#include "conv_fast.hpp"
-#include <stdlib.h>
-#include <math.h>
+#include "conv_fast_body.hpp"
+
+using namespace abc_cf;
+
+// Round-5 experiments on the 192 x 128 weights-direct tile, compiled into the DEBUG flavour only (ABC_KERNEL_DEBUG=1 ./build_hip.sh) and
+// selected there by the hooks abc_debug_conv_nw / _lp / _var (profiles/tools/ab_conv128.py).  All three are exact (bit-identical
+// outputs); none is faster than the form below (profiles/README.md "Round 5"):
+//   conv_fast8.hip    8-wave workgroups (3 x 1 MFMA tiles per wave, 128 VGPRs, four waves per SIMD): 10-17 % SLOWER
+//   conv_fast_lp.hip  lane = pixel epilogue (MFMA operands swapped, 16-byte stores from registers, no LDS staging, no barrier at the tile's
+//                     end, statistics by a cross-lane butterfly): within 2 % either way; with act_bwd in the epilogue 15 % slower
+//                     ... and VAR: the four waves side by side along N (half the weight-fragment loads), s_setprio around the MFMA groups: +-1 %
+#ifdef ABC_KERNEL_DEBUG
+int abc_conv_fast_launch8(const FastK& k, const abc_fast_geom& g, int epi, hipStream_t st);
+int abc_conv_fast_launch_lp(const FastK& k, const abc_fast_geom& g, int epi, hipStream_t st);
+#endif
 
 namespace {
 
-constexpr int FT = 256;      // threads per workgroup
-// halo segments a thread may hold (3x3 taps, 64-byte chunks: (2*MT+2) x 18 pixels x 4 segments over 256 threads;
-// MT = 8 also takes unet2's 5x5 taps: 20 x 20 pixels x 4 segments = 6.25 per thread)
-__host__ __device__ constexpr int fa_max(int mt) { return mt >= 8 ? 7 : (mt >= 6 ? 4 : (mt >= 4 ? 3 : 2)); }
-// stride 2 (the data gradients of the transposed convolutions, unet.py:44 under autograd: a 17 x 33 pixel halo per 8 x 16 tile):
-// 9 segments per thread -- these kernels hold 64 accumulator registers, the staging fits
-__host__ __device__ constexpr int fa_stride2() { return 9; }
-// resident-weight (persistent, narrow-layer) workgroups only ever see 3x3 / 1x1 taps: 6 segments, and three of them per CU
-__host__ __device__ constexpr int fa_static(int mt) { return mt >= 8 ? 6 : fa_max(mt); }
-constexpr int SR_MAX = 256;  // weight rows per stage (tap group x BN)
-constexpr int LDS_WG = 80 * 1024;
-
-struct FastK {
-    const void* x;
-    const float *scale, *shift, *slope;
-    const void* w;
-    const float* bias;
-    void* y;
-    float* stats;
-    int B, Hin, Win, Hx, Wx, ldx, cin_off, Cin, nchunks;
-    int Hg, Wg, Hout, Wout, ldy, cout_off, Cout, Cout_pad, om, oy0, ox0;
-    int ntaps, tg, ngroups, dy_min, dx_min, HH, HW, RS, magic;
-    int tiles_x, tiles_y, nblocks_n, ntiles;
-    int sA_bytes, a_bufs, sB_off, sB_bytes, tap_off, coef_off, cstride, stats_rows, accumulate, b_static, stg_off, red_off, dbg, stagger;
-    int out_act; float out_slope;   // epilogue activation (BatchNorm folded into the weights: eval mode)
-    const float* oscale;            // fp8 compute: per output channel, accumulator -> real value (s_in * s_w[n])
-    const float* oquant;            // fp8 output: 1 / s_out (device), applied before the rounding to e4m3
-    int oq_stride;                  // 0: a scalar; 1: one per n-block (128 output channels)
-    const abc_heads_epi* hepi;      // HEPI: per n-block (= head) the 1x1 convolution computed in this tile's epilogue
-    // ACTB (abc_conv_desc.actbwd_*): this data gradient is d(activation output) of the producing layer; the epilogue turns it into
-    // d(BatchNorm output) and sums that layer's BatchNorm-backward statistics -- bn_act.hip's act_bwd pass, not run
-    const void* ab_y; int ab_ld;    // the producer's raw convolution output (already at its channel 0), its row length
-    const float *ab_sc, *ab_sh, *ab_sl, *ab_mu, *ab_is;
-    int ystg_off;                   // a second staging region (the y_raw tile's way into the accumulator layout)
-    unsigned bytesA, bytesW;
-    long long* prof;  // debugging: per-workgroup phase timestamps (null in production)
-    int8_t ty[ABC_MAX_TAPS], tx[ABC_MAX_TAPS];
-};
-
 static long long* g_prof = nullptr;
-
-__device__ inline void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// WD ("weights direct", 0 = off, else the tap count 9 or 25): the main loop below that streams the B operand from global
-// memory (see there).
-// HEPI ("heads in the epilogue", folded inference graph): the tile's 128 output channels are one head's finished features
-// (unet.py:66-69 with BatchNorm folded); the head's 1x1 convolution (unet.py:70) is computed from them right here and the f32
-// NCHW maps are stored -- the 8 x 128-channel feature tensor is never written or read (2 x 2.1 GB per batch of 64 at 512 x 512)
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
-__device__ __forceinline__ void conv_fast_body(const FastK& a) {
-    constexpr int CKB = CK * (int)sizeof(CT);
-    constexpr int PS = CKB + 16;
-    constexpr int LHB = CKB / 2;
-    constexpr int NR = LHB / 16;
-    constexpr int SEGS = CKB / 16;
-    constexpr int NT = BN / 32;
-    constexpr int WN = (NT >= 2) ? 2 : 1;
-    constexpr int WM = 4 / WN;
-    constexpr int TM = MT / WM;
-    constexpr int TN = NT / WN;
-    static_assert(TM >= 1 && TM * WM == MT && TN >= 1 && TN * WN == NT, "tile/wave layout");
-    constexpr int NB = (SR_MAX * SEGS + FT - 1) / FT;  // weight segments per thread per stage (a stage = <= SR_MAX weight rows)
-    typedef typename Frag<CT>::type frag_t;
-    constexpr bool F8C = sizeof(CT) == 1;    // e4m3 operands: one 32x32x64 MFMA per lane-half of a 64-byte chunk (weights-direct loop only)
-    constexpr bool F8O = sizeof(OutT) == 1;  // e4m3 output: v * (1 / s_out), saturating
-    static_assert(!F8C || WD == 9, "fp8 compute is served by the 9-tap weights-direct loop");
-    constexpr bool HEPI = EPI == 1;     // the heads' 1x1 convolutions in the epilogue
-    constexpr bool ACTB = EPI == 2;     // the activation / BatchNorm-statistics backward pass of the PRODUCER of this data gradient in the epilogue
-    static_assert(!HEPI || (WD == 9 && BN == 128 && MT == 6 && sizeof(CT) <= 2), "heads epilogue: the 192 x 128 weights-direct tile");
-    static_assert(!ACTB || (!STATIC && sizeof(OutT) == 2 && sizeof(CT) == 2), "act_bwd epilogue: bf16 gradients, streamed weights");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* sB = smem + a.sB_off;
-    int* sTap = (int*)(smem + a.tap_off);
-    float* sCoef = (float*)(smem + a.coef_off);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    long long* prof = ABC_PROF(a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr);
-    if (prof && tid == 0) { prof[0] = wall_clock64(); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); prof[6] = ((long long)xcc << 32) | hw; }
-
-    if (tid < a.ntaps) sTap[tid] = a.ty[tid] * a.RS + a.tx[tid] * PS;
-    const bool has_coef = a.scale != nullptr;
-    if (has_coef) {
-        for (int i = tid; i < a.Cin; i += FT) {
-            sCoef[i] = a.scale[a.cin_off + i];
-            sCoef[a.cstride + i] = a.shift[a.cin_off + i];
-            sCoef[2 * a.cstride + i] = a.slope[a.cin_off + i];
-        }
-    }
-    const float* lcoef = has_coef ? sCoef : nullptr;
-
-    int aBase[TM], bBase[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int prow = 2 * (wm * TM + i) + (r >> 4), pcol = r & 15;
-        aBase[i] = prow * STRIDE * a.RS + pcol * STRIDE * PS + h * LHB;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bBase[j] = ((wn * TN + j) * 32 + r) * PS + h * LHB;
-
-    const __amdgpu_buffer_rsrc_t rsA = abc_make_rsrc(a.x, a.bytesA), rsW = abc_make_rsrc(a.w, a.bytesW);
-    const HaloGeom gA = {a.HH, a.HW, a.magic, a.Hin, a.Win, a.Hx, a.Wx, a.ldx};
-    const int nstages = a.nchunks * a.ngroups;
-
-    // weight segments of a stage: segment i of a thread is segment 0 plus CONSTANT steps (source: scalar offset,
-    // LDS: immediate offset), so one VGPR each for source and destination.  The kernel is bound by instruction issue:
-    // the per-stage staging code must be loads / stores and nothing else.
-    constexpr int SEGS_TAP = BN * SEGS;                              // 16-byte segments per tap slice
-    constexpr int PER = SEGS_TAP >= FT ? SEGS_TAP / FT : 1;          // thread-segments per tap slice
-    constexpr int TSTEP = SEGS_TAP >= FT ? 1 : FT / SEGS_TAP;        // tap slices covered by one round of the threads
-    const unsigned tap_stride = (unsigned)(a.nchunks * a.Cout_pad * CK) * (unsigned)sizeof(CT);
-    const int tl0 = tid / SEGS_TAP, rem0 = tid % SEGS_TAP;           // (tl0 = 0 when a slice has >= FT segments)
-    const unsigned bvoff0 = (unsigned)tl0 * tap_stride + (unsigned)rem0 * 16u;
-    const int bdst0 = (tl0 * BN + rem0 / SEGS) * PS + (rem0 % SEGS) * 16;
-    u32x4 breg[2][NB];
-    HaloTile<InT, CT, CK, STATIC ? fa_static(MT) : (STRIDE == 2 ? fa_stride2() : fa_max(MT)), FT> apre;
-
-    unsigned w_n0 = 0;  // byte offset of the n-block's first weight row
-    auto b_issue = [&](u32x4* set, int c, int g) {
-        const unsigned soff = (unsigned)((g * a.tg * a.nchunks + c) * a.Cout_pad * CK) * (unsigned)sizeof(CT) + w_n0;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const unsigned step = (unsigned)((i / PER) * TSTEP) * tap_stride + (unsigned)((i % PER) * FT * 16);
-            set[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bvoff0, soff + step, 0);
-        }
-    };
-    auto b_commit = [&](const u32x4* set, int g, char* dst) {
-        const int tcnt = min(a.tg, a.ntaps - g * a.tg);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            constexpr int dummy = 0; (void)dummy;
-            const int tl = tl0 + (i / PER) * TSTEP;
-            const int doff = ((i / PER) * TSTEP * BN + (i % PER) * (FT / SEGS)) * PS;
-            if (tl < tcnt) *(u32x4*)(dst + bdst0 + doff) = set[i];
-        }
-    };
-
-    __syncthreads();  // tap offsets + coefficient table visible
-    bool first_tile = true;
-    // resident-weight (persistent, one n-block) workgroups keep the statistics of ALL their tiles in registers and write ONE
-    // partial row per workgroup: 768 rows for the finaliser instead of one per tile (9216 at 384 x 384, 17 us per finaliser)
-    float pst1 = 0.f, pst2 = 0.f;
-    // tile of this workgroup in round k (-1: none).  Full rounds: logical id + k * grid (XCD-contiguous ids).  The last,
-    // partial round is dealt out in equal contiguous runs per XCD (the grid of a persistent launch is a multiple of 8), so
-    // that it keeps all eight XCDs busy instead of filling the first ones.
-    const int lid = abc_xcd_remap(blockIdx.x, gridDim.x);
-    auto tile_of = [&](int k) -> int {
-        const int G = (int)gridDim.x, base = k * G;
-        if (base + G <= a.ntiles) return base + lid;
-        const int R = a.ntiles - base;
-        if (R <= 0) return -1;
-        if (G & 7) return lid < R ? base + lid : -1;
-        const int per = G >> 3, x = lid / per, i = lid - x * per;
-        const int q = R >> 3, rem = R & 7;
-        const int cnt = q + (x < rem ? 1 : 0), b0 = x * q + (x < rem ? x : rem);
-        return i < cnt ? base + b0 + i : -1;
-    };
-    for (int round = 0, tile = tile_of(0); tile >= 0; tile = tile_of(++round)) {
-        if (prof && tid == 0) { prof[5] = wall_clock64(); prof[7] = round; }
-        int id = tile;
-        const int nb = id % a.nblocks_n; id /= a.nblocks_n;
-        const int mblock = id;
-        const int tx_i = id % a.tiles_x; id /= a.tiles_x;
-        const int ty_i = id % a.tiles_y; id /= a.tiles_y;
-        const int b = id;
-        const int gy0 = ty_i * (2 * MT), gx0 = tx_i * 16;
-        const int n0 = nb * BN;
-        w_n0 = (unsigned)(n0 * CK) * (unsigned)sizeof(CT);
-        const int iy0 = gy0 * STRIDE + a.dy_min, ix0 = gx0 * STRIDE + a.dx_min;
-        float bv[TN];   // bias of this lane's output channels: loaded here, used in the epilogue (latency under the main loop)
-        float osc[TN];  // fp8 compute: the lane's dequantisation factors
-        bool nval[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + r;
-            nval[j] = n < a.Cout;
-            bv[j] = (a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
-            osc[j] = (F8C && nval[j]) ? a.oscale[n] : 1.f;
-        }
-        const float oq = F8O ? a.oquant[nb * a.oq_stride] : 1.f;
-        float csc[ACTB ? TN : 1], csh[ACTB ? TN : 1], csl[ACTB ? TN : 1], cmu[ACTB ? TN : 1];
-        if constexpr (ACTB) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + (wn * TN + j) * 32 + r;
-                csc[j] = nval[j] ? a.ab_sc[n] : 0.f; csh[j] = nval[j] ? a.ab_sh[n] : 0.f;
-                csl[j] = nval[j] ? a.ab_sl[n] : 0.f; cmu[j] = nval[j] ? a.ab_mu[n] : 0.f;
-            }
-        }
-
-        // ---- prologue: chunk 0 halo, first two stages of weights (the CU's other workgroup computes meanwhile).
-        // Persistent (resident-weight) workgroups prefetched this tile's halo during the previous tile.
-        // (WD workgroups are persistent too when there are more tiles than workgroup slots: the next tile's first halo chunk
-        //  is issued during the last chunk of this tile, see the main loop)
-        if (!(STATIC || WD != 0) || first_tile) {
-            apre.setup(gA, a.RS, PS, b, iy0, ix0, a.cin_off, abc_launder(tid));   // (laundered like the next-tile setup: its lane constants were spilled and came back as eight serialised scratch round trips in front of the first halo loads)
-            apre.issue(rsA, 0u);
-        }
-        int ci = 0, gi = 0;  // (chunk, tap group) of the next stage to issue
-        auto issue_next = [&](u32x4* set) {
-            b_issue(set, ci, gi);
-            if (++gi == a.ngroups) { gi = 0; ++ci; }
-        };
-        if constexpr (STATIC) {
-            // resident weights: one chunk, every tap group loaded once per workgroup, straight to its place
-            if (first_tile) {
-                for (int g = 0; g < a.ngroups; ++g) {
-                    b_issue(breg[0], 0, g);
-                    b_commit(breg[0], g, sB + g * a.sB_bytes);
-                }
-            }
-        } else if constexpr (WD == 0) {
-            issue_next(breg[0]);
-            issue_next(breg[1]);
-        }
-        // ---- WD: the packed weights [tap][chunk][Cout_pad][CK] ARE the MFMA B fragments (row n, bytes 32 h + 16 kk of a
-        // 64-byte chunk row), so each lane loads its own fragments straight from global memory (L1 / L2: the CU's waves
-        // all stream the same 295 KB) into a ring of 3 taps, 3 taps ahead of their use.  LDS then carries the
-        // activation halo only: 3 instead of 5 ds_read_b128 per 6 MFMAs (the LDS pipe was as busy as the matrix
-        // pipe), no weight staging writes, and one workgroup barrier per 64-byte chunk instead of one per tap pair.
-        constexpr int WNT = WD ? WD : 1;              // taps (static: the loop is fully unrolled)
-        constexpr int RING = WD == 25 ? 5 : 3;        // taps in flight; divides the tap count
-        static_assert(WNT % RING == 0 || !WD, "ring must divide the tap count");
-        u32x4 bq[(WD && !F8C) ? RING : 1][TN][2];
-        i32x8 bq8[F8C ? RING : 1][TN];     // e4m3: a tile's B operand is one 8-register tuple (both 16-byte halves)
-        const unsigned chunk_stride = (unsigned)(a.Cout_pad * CK) * (unsigned)sizeof(CT);
-        // (the wave's n-offset sits in the VGPR part: everything in the scalar offset must be provably wave-uniform, or
-        //  the compiler wraps every load in a readfirstlane loop)
-        // (abc_pack_desc.layout 1: a 32-row block is [kk][h][r][16 bytes] -- the 64 lanes of one load read 1 KB back to back)
-        const unsigned bq_voff = (unsigned)(wn * TN * 32 * CKB + h * 512 + r * 16);
-        auto bq_load = [&](int slot, int c, int t) {
-            const unsigned soff = w_n0 + (unsigned)t * tap_stride + (unsigned)c * chunk_stride;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (F8C) {
-                    bq8[slot][j] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB), soff, 0),
-                                               __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + 1024), soff, 0));
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-                        bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 1024), soff, 0);
-                }
-            }
-        };
-        if constexpr (WD != 0) {
-#pragma unroll
-            for (int q = 0; q < RING; ++q) bq_load(q, 0, q);
-        }
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-        if (!first_tile) __syncthreads();  // previous tile's epilogue staging (aliases the halo buffer) is drained
-        apre.commit(sA, lcoef, a.cstride, tid);
-        if constexpr (!STATIC && WD == 0) b_commit(breg[0], 0, sB);
-        // (the epilogue's lane constants are waited for HERE, where the halo's vmcnt(0) has just passed: first used in the
-        //  epilogue, their wait is a vmcnt(0) there -- the counter is in order -- which also waits for the NEXT tile's halo
-        //  prefetch issued during the last chunk)
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bv[j]), "v"(osc[j]));
-        asm volatile("" :: "v"(oq));
-        if constexpr (ACTB) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(csc[j]), "v"(csh[j]), "v"(csl[j]), "v"(cmu[j]));
-        }
-#endif
-        first_tile = false;
-        __syncthreads();
-        if constexpr (STATIC) {
-            // narrow layers are bound by the latency of one tile (10 KB in, 8 KB out, 18 MFMAs per wave): start the
-            // next tile's halo now, it lands under this tile's MFMAs and stores
-            const int nt = tile_of(round + 1);
-            if (nt >= 0) {
-                int id2 = nt / a.nblocks_n;
-                const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
-                const int ty2 = id2 % a.tiles_y; id2 /= a.tiles_y;
-                apre.setup(gA, a.RS, PS, id2, ty2 * (2 * MT) * STRIDE + a.dy_min, tx2 * 16 * STRIDE + a.dx_min, a.cin_off, tid);
-                apre.issue(rsA, 0u);
-            }
-        }
-        if (prof && tid == 0) prof[1] = wall_clock64();
-
-        // ---- main loop, unrolled by 2 so that the two register sets have fixed names.  Stage s: its weights sit in
-        // sB[s & 1]; set s & 1 is free (committed at the end of stage s-1) and takes the loads of stage s + 2; the next
-        // chunk's halo is issued when a chunk opens and committed when it closes.
-        if constexpr (WD != 0) {
-            static_assert(NR == 2 && !STATIC, "WD: 64-byte chunks, streamed weights");
-            for (int c = 0; c < a.nchunks; ++c) {
-                const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
-                const bool more = c + 1 < a.nchunks;
-                if (more) {
-                    apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
-                } else {
-                    // last chunk: the staging registers are free -> the NEXT tile's first halo chunk lands under this
-                    // chunk's MFMAs and the epilogue (a workgroup's prologue measured 5 of its 30 us, with no MFMA issued)
-                    const int nt = tile_of(round + 1);
-                    if (nt >= 0) {
-                        int id2 = nt / a.nblocks_n;
-                        const int tx2 = id2 % a.tiles_x; id2 /= a.tiles_x;
-                        const int ty2 = id2 % a.tiles_y; id2 /= a.tiles_y;
-                        apre.setup(gA, a.RS, PS, id2, ty2 * (2 * MT) * STRIDE + a.dy_min, tx2 * 16 * STRIDE + a.dx_min, a.cin_off, abc_launder(tid));   // (laundered: hoisted out of the tile loop, the lane-constant part of the setup was SPILLED and its reload waited for the whole weight ring)
-                        apre.issue(rsA, 0u);
-                    }
-                }
-                if constexpr (F8C) {
-                    // e4m3: a tap of a 64-byte chunk is ONE MFMA per tile pair (both 16-byte halves of the lane's 32 bytes at once);
-                    // the fragments of tap t + 1 are read while the MFMAs of tap t run (two register sets, static after unrolling)
-                    // (one A set: the CU's other waves -- two per SIMD, two workgroups -- cover the LDS latency; a second set of 24
-                    //  registers spilled)
-#pragma unroll
-                    for (int t = 0; t < WNT; ++t) {
-                        const int slot = t % RING;
-                        const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
-                        i32x8 fq[TM];
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            fq[i] = abc_join32B(*(const u32x4*)(sAc + aBase[i] + aoff), *(const u32x4*)(sAc + aBase[i] + aoff + 16));
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) mma32B_f8(acc[i][j], fq[i], bq8[slot][j]);
-                        // hipcc treats the scaled MFMA as freely sinkable: without a use here it moved all 54 of a chunk behind the
-                        // halo commit at the end of the chunk, with the nine taps' fragments (216 registers) spilled to scratch on
-                        // the way.  An empty asm that READS the accumulators pins each tap's MFMAs to its place (no instruction, no stall).
-                        // (device pass only: on the host pass a 64-byte "v" operand is not a valid x86 constraint, and clang then drops
-                        //  the whole kernel stub without a diagnostic)
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
-                        bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
-                    }
-                } else {
-                frag_t fa0[TM], fa1[TM];
-                // (tap offsets from the kernel arguments: scalar registers, no LDS round trip in front of the fragment reads)
-                {
-                    const int aoff = a.ty[0] * a.RS + a.tx[0] * PS;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff);
-                }
-#pragma unroll
-                for (int t = 0; t < WNT; ++t) {
-                    const int slot = t % RING;
-                    const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
-                    const int aoff_n = a.ty[t < WNT - 1 ? t + 1 : WNT - 1] * a.RS + a.tx[t < WNT - 1 ? t + 1 : WNT - 1] * PS;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa1[i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa0[i], *(const frag_t*)&bq[slot][j][0]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (t < WNT - 1) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff_n);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa1[i], *(const frag_t*)&bq[slot][j][1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the slot is free: tap t + RING (of this chunk or the next; past the last chunk the offsets run off
-                    // the buffer and the loads return zeros -- unconditional, so that vmcnt stays exact)
-                    bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
-                }
-                }
-                if (more) {
-                    if (a.a_bufs == 2) {
-                        apre.commit(sA + ((c + 1) & 1) * a.sA_bytes, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
-                    } else {
-                        __syncthreads();
-                        apre.commit(sA, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
-                    }
-                }
-                __syncthreads();   // next chunk's halo visible; after the last chunk: the halo is dead (the epilogue aliases it)
-            }
-        } else {
-        int c = 0, g = 0;
-        for (int s0 = 0; s0 < nstages; s0 += 2) {
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const int s = s0 + d;
-                if (s < nstages) {
-                    int gn = g + 1, cn = c;
-                    if (gn == a.ngroups) { gn = 0; cn = c + 1; }
-                    const bool has_next = (s + 1 < nstages);
-                    const bool closes = has_next && (gn == 0);  // last stage of a chunk that has a successor
-                    // (unconditional: past the last stage the offsets run off the buffer and the loads return zeros;
-                    //  a conditional issue would make the compiler drain ALL loads before every commit)
-                    if constexpr (!STATIC) issue_next(breg[d]);
-                    if (g == 0 && c + 1 < a.nchunks && !(ABC_DBG(a.dbg) & 2)) apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
-
-                    {
-                        const char* sAc = sA + ((a.a_bufs == 2) ? (c & 1) * a.sA_bytes : 0);
-                        const char* sBc = STATIC ? sB + g * a.sB_bytes : sB + d * a.sB_bytes;
-                        const int t0 = g * a.tg;
-                        const int tcnt = min(a.tg, a.ntaps - t0);
-                        // fragment reads software-pipelined one K-step ahead of the MFMAs (two named register sets;
-                        // every read unconditional -- the step after the last re-reads the last tap -- so that the
-                        // compiler can count lgkmcnt exactly instead of draining the LDS queue before each MFMA group)
-                        const int ntl = (ABC_DBG(a.dbg) & 4) ? 0 : tcnt;
-                        if constexpr (NR == 2) {
-                            frag_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-                            int aoff = sTap[t0];
-#pragma unroll
-                            for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff);
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) fb0[j] = *(const frag_t*)(sBc + bBase[j]);
-                            for (int tl = 0; tl < ntl; ++tl) {
-                                const int tn = min(tl + 1, tcnt - 1);
-                                const int boff = tl * BN * PS;
-                                const int aoff_n = sTap[t0 + tn];
-#pragma unroll
-                                for (int i = 0; i < TM; ++i) fa1[i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16);
-#pragma unroll
-                                for (int j = 0; j < TN; ++j) fb1[j] = *(const frag_t*)(sBc + bBase[j] + boff + 16);
-                                __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of the MFMA group (the scheduler sinks them otherwise)
-#pragma unroll
-                                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                    for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa0[i], fb0[j]);
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int i = 0; i < TM; ++i) fa0[i] = *(const frag_t*)(sAc + aBase[i] + aoff_n);
-#pragma unroll
-                                for (int j = 0; j < TN; ++j) fb0[j] = *(const frag_t*)(sBc + bBase[j] + tn * BN * PS);
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                    for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa1[i], fb1[j]);
-                                __builtin_amdgcn_sched_barrier(0);
-                                aoff = aoff_n;
-                            }
-                        } else {
-                            for (int tl = 0; tl < ntl; ++tl) {
-                                const int aoff = sTap[t0 + tl];
-                                const int boff = tl * BN * PS;
-                                frag_t fa[TM], fb[TN];
-#pragma unroll
-                                for (int i = 0; i < TM; ++i) fa[i] = *(const frag_t*)(sAc + aBase[i] + aoff);
-#pragma unroll
-                                for (int j = 0; j < TN; ++j) fb[j] = *(const frag_t*)(sBc + bBase[j] + boff);
-#pragma unroll
-                                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                    for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fa[i], fb[j]);
-                            }
-                        }
-                    }
-
-                    if constexpr (!STATIC) {
-                        if (has_next && !(ABC_DBG(a.dbg) & 8)) b_commit(breg[1 - d], gn, sB + (1 - d) * a.sB_bytes);
-                    }
-                    if (closes && !(ABC_DBG(a.dbg) & 16)) {
-                        if (a.a_bufs == 2) {
-                            apre.commit(sA + (cn & 1) * a.sA_bytes, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
-                        } else {
-                            __syncthreads();  // every wave is done reading this chunk's halo
-                            apre.commit(sA, lcoef ? lcoef + cn * CK : nullptr, a.cstride, tid);
-                        }
-                    }
-                    if constexpr (!STATIC) __syncthreads();  // (resident weights + single halo chunk: nothing changes hands)
-                    c = cn; g = gn;
-                }
-            }
-        }
-        }
-
-        if (prof && tid == 0) prof[2] = wall_clock64();
-        if constexpr (HEPI) {
-            // ---- 1. the tile's activated features, [pixel][128 channels] in the compute type, into LDS (the halo buffers are dead)
-            constexpr int FROW = 128 * (int)sizeof(CT) + 16;
-            char* F = smem;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const float v = F8C ? fmaf(acc[i][j][k], osc[j], bv[j]) : acc[i][j][k] + bv[j];
-                        float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
-                        if constexpr (F8C) vo *= oq;
-                        const int p = 32 * (wm * TM + i) + (k & 3) + 8 * (k >> 2) + 4 * h;
-                        *(CT*)(F + p * FROW + ((wn * TN + j) * 32 + r) * (int)sizeof(CT)) = (CT)vo;
-                    }
-            __syncthreads();
-            // ---- 2. the head's 1x1 convolution: logits[co][p] = b[co] + sum_c W2[co][c] F[p][c].  Work items = (m-tile of 32 output
-            // rows) x (one of the tile's six 32-pixel n-tiles), dealt to the four waves: m-tile-major when the head has >= 4 m-tiles
-            // (the weight fragments of an m-tile are fetched once and serve its six n-tiles), item by item for the narrow heads (one or
-            // two m-tiles: otherwise one wave would do all the work).  Stores: one raw buffer store per accumulator register -- the
-            // lane's part of the address (image, its pixel, its row half) is ONE offset per n-tile, the register's output row a
-            // scalar offset; rows past Cout and pixels past the map get the out-of-range offset and are dropped by the hardware.
-            // MEASURED (b64 at 512 x 512, same box): exact, and slower than conv1 + the separate heads kernel in both forms tried --
-            // 64-bit address per store, items dealt round-robin: 7.86 -> 9.02 ms bf16, 6.09 -> 7.68 ms e4m3; this form: 10.4 / 9.6 ms.
-            // The epilogue is a serial chain on the tile's critical path (head record -> weight fragments -> MFMAs -> 4-byte-per-lane
-            // stores in 64-byte runs) in a kernel with two workgroups per CU and nothing to cover it, and its arrays cost the main
-            // loop registers (25 / 92 spilled).  The engine therefore plans it only on request (Engine(heads_epilogue=True)).
-            const abc_heads_epi& he = a.hepi[nb];
-            const int mtiles = he.Cout_pad >> 5;
-            const unsigned HWp = (unsigned)(a.Hg * a.Wg);
-            const __amdgpu_buffer_rsrc_t rsW2 = abc_make_rsrc(he.w2, (unsigned)(128 * he.Cout_pad * (int)sizeof(CT)));
-            const __amdgpu_buffer_rsrc_t rsY = abc_make_rsrc(he.y, (unsigned)a.B * (unsigned)he.Cout * HWp * 4u);
-            const int nitems = mtiles * 6;
-            const bool mt_major = mtiles >= 4;
-            int last_mt = -1;
-            float bvv[16], os2[16];
-            i32x8 fa8[F8C ? 2 : 1];
-            bf16x8 fa16[F8C ? 1 : 8];
-            for (int it = mt_major ? wave * 6 : wave; it < nitems; it += mt_major ? (((it + 1) % 6) ? 1 : 19) : 4) {
-                const int mt = it / 6, nt = it - mt * 6;
-                if (mt != last_mt) {
-                    last_mt = mt;
-                    const int co = mt * 32 + r;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int oc = mt * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
-                        const bool ok = oc < he.Cout;
-                        bvv[k] = (he.bias && ok) ? he.bias[oc] : 0.f;
-                        os2[k] = (F8C && ok) ? he.oscale[oc] : 1.f;
-                    }
-                    if constexpr (F8C) {
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const unsigned off = (unsigned)((s2 * he.Cout_pad + co) * 64 + 32 * h);
-                            fa8[s2] = abc_join32B(__builtin_amdgcn_raw_buffer_load_b128(rsW2, off, 0, 0), __builtin_amdgcn_raw_buffer_load_b128(rsW2, off + 16, 0, 0));
-                        }
-                    } else {
-#pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) {
-                            const unsigned off = (unsigned)((((kk >> 1) * he.Cout_pad + co) * 32 + 16 * (kk & 1) + 8 * h) * 2);
-                            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsW2, off, 0, 0);
-                            fa16[kk] = *(const bf16x8*)&t;
-                        }
-                    }
-                }
-                f32x16 c2;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) c2[k] = 0.f;
-                if constexpr (F8C) {
-                    const char* fp = F + (32 * nt + r) * FROW + 32 * h;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-                        mma32B_f8(c2, fa8[s2], abc_join32B(*(const u32x4*)(fp + 64 * s2), *(const u32x4*)(fp + 64 * s2 + 16)));
-                } else {
-                    const char* fp = F + (32 * nt + r) * FROW + 16 * h;
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa16[kk], *(const bf16x8*)(fp + 32 * kk), c2, 0, 0, 0);
-                }
-                const int pp = 32 * nt + r, gy = gy0 + (pp >> 4), gx = gx0 + (pp & 15);
-                // lane part: image b, output row 4 h of the m-tile's first row, pixel (gy, gx); register part: row (k & 3) + 8 (k >> 2)
-                const unsigned vlane = ((unsigned)(b * he.Cout + mt * 32 + 4 * h) * HWp + (unsigned)(gy * a.Wg + gx)) * 4u;
-                const bool pix_ok = gy < a.Hg && gx < a.Wg;
-                const bool full = mt * 32 + 32 <= he.Cout;     // (wave-uniform: only a head's last m-tile can be partial)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int rowk = (k & 3) + 8 * (k >> 2);
-                    const bool ok = pix_ok && (full || mt * 32 + rowk + 4 * h < he.Cout);
-                    const float v = F8C ? fmaf(c2[k], os2[k], bvv[k]) : c2[k] + bvv[k];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, ok ? vlane : 0xFFFFFFFCu, (unsigned)rowk * HWp * 4u, 0);
-                }
-            }
-            continue;      // (the next tile's prologue synchronises before it re-uses the LDS; no statistics in the folded graph)
-        }
-        // ---- epilogue: bias, statistics of the f32 values, store through a wave-private LDS transpose
-        // (a lane of the accumulator layout holds ONE channel of 16 pixels; the transpose turns that into 16-byte
-        // stores of consecutive channels of one pixel).  The staging region aliases the halo / weight buffers: every
-        // wave passed the barrier that ended the last stage, so they are dead (resident weights are kept clear of it).
-        OutT* yo = (OutT*)a.y;
-        float s1[TN], s2[TN], smx[TN], smn[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; smx[j] = -3.0e38f; smn[j] = 3.0e38f; }
-        constexpr int TW = TN * 32;
-        constexpr int ROWB = TW * (int)sizeof(OutT) + 16;
-        constexpr int EV = 16 / (int)sizeof(OutT);
-        constexpr int SEG_PER_ROW = TW / EV;
-        char* stg = smem + a.stg_off + wave * (32 * ROWB);
-        const int cbase = n0 + wn * TW;
-        const bool vec_ok = ((a.ldy | a.cout_off) % EV) == 0;
-        // The epilogue is VALU work per output value (narrow layers are bound by it: 16 instructions per value cost
-        // 39 us on the 16-channel 384x384 layers).  Fast path for whole tiles with plain 16-byte stores: add bias,
-        // sum, sum of squares, convert, one ds_write per value with an immediate offset; max / min in a second sweep
-        // only when unet2's CBAM asks for them; the general path keeps every check.
-        // (ACTB launches consist of whole tiles only, checked on the host: the general path below is not compiled into them)
-        // (tiles that are short in ROWS only -- the last tile row of a 128 x 128 map under 12-row tiles, one tile in eleven of the
-        //  inference graph -- take the fast path too when no statistics are asked for: their missing rows get the dropped offset)
-        const bool rows_ok = gy0 + 2 * MT <= a.Hg;
-        const bool whole = ACTB || ((rows_ok || a.stats == nullptr) && (gx0 + 16 <= a.Wg) && (a.Cout % EV == 0) && !a.accumulate && vec_ok);
-        if (ABC_DBG(a.dbg) & 64) {
-        } else if (whole) {
-            // (laundered: computed from the plain thread index, the lane parts of the staging addresses and store offsets are hoisted
-            //  out of the tile loop, live through the main loop, get spilled, and come back as scratch round trips in front of the
-            //  stores -- each a vmcnt(0) wait that also drains the next tile's halo prefetch)
-            const int tl = abc_launder(tid), ll = tl & 63, wl = tl >> 6;
-            char* stgw = smem + a.stg_off + wl * (32 * ROWB);
-            char* wbase = stgw + 4 * (ll >> 5) * ROWB + (ll & 31) * (int)sizeof(OutT);
-            const int lrow = ll / SEG_PER_ROW, lsg = ll % SEG_PER_ROW;         // this lane's (pixel row, segment) in the store sweep
-            constexpr int RSTEP = 64 / SEG_PER_ROW;                            // pixel rows covered per sweep step
-            constexpr int NST = 32 / RSTEP;
-            const bool seg_ok = n0 + (wl % WN) * TW + lsg * EV < a.Cout;
-            // Stores: the tile's first pixel (wave-uniform) is the base of a buffer descriptor; a lane's part of the address is ONE
-            // 32-bit offset per sweep step for the whole tile (segments past Cout get an offset the hardware drops), the M-tile's
-            // two rows a scalar offset.  (64-bit address arithmetic and a predicated branch per store kept every
-            // ds_read -> global_store pair a serial LDS round trip: 12 per wave and tile.)
-            const OutT* ytile = yo + (((size_t)(b * a.Hout + gy0 * a.om + a.oy0) * a.Wout + gx0 * a.om + a.ox0) * a.ldy + a.cout_off + n0);
-            const __amdgpu_buffer_rsrc_t rsY = abc_make_rsrc(ytile, 0x80000000u);
-            const unsigned istep = (unsigned)(2 * a.om * a.Wout * a.ldy) * (unsigned)sizeof(OutT);   // bytes per M-tile (two pixel rows)
-            unsigned voff[NST];
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const int rit = lrow + RSTEP * st;       // pixel of the wave's 32: patch row (rit >> 4) of the M-tile, column rit & 15
-                voff[st] = seg_ok ? (unsigned)((wl / WN) * TM) * istep + (unsigned)((((rit >> 4) * a.Wout + (rit & 15)) * a.om * a.ldy + (wl % WN) * TW + lsg * EV) * (int)sizeof(OutT))
-                                  : 0xFFFFFFF0u;
-            }
-            // Values two at a time (accumulator registers k, k + 1 = two pixel rows of one channel): packed f32 add / multiply / fma,
-            // one conversion per pair.  Per M-tile: 32 writes, a wait for them, then the sweep's reads back to back and its stores
-            // behind them (the stores consume the reads, so the next M-tile's writes cannot overtake them).
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            f32x2 s1v[TN], s2v[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) { s1v[j] = (f32x2){0.f, 0.f}; s2v[j] = (f32x2){0.f, 0.f}; }
-            const float slope = a.out_act ? a.out_slope : 1.f;      // (max(v, 1 * v) = v: no select per value)
-            const int rlim = (ACTB || rows_ok) ? 0x7FFFFFFF : a.Hg - gy0;    // rows of this tile inside the map
-            // ACTB: the producer's raw output y_raw at this tile -- per M-tile the sweep's 16-byte loads (the stores' lane mapping),
-            // through a second staging region, read back in the accumulator layout (lane = channel, like the sums).
-            // The loads of M-tile i + 1 fly under the arithmetic of M-tile i.
-            // (the y_raw tile is staged TRANSPOSED, [channel][32 pixels + pad]: sixteen-bit writes need no answer, and a lane reads the four
-            //  consecutive pixels of an accumulator-register group with one ds_read_b64 -- 8 reads per M-tile instead of 32 ds_read_u16)
-            constexpr int YROW = 32 * 2 + 8;
-            static_assert(!ACTB || TW * YROW <= 32 * ROWB, "the transposed y_raw tile fits the staging region");
-            char* ystg = smem + a.ystg_off + wl * (32 * ROWB);
-            const char* yrd = ystg + (ll & 31) * YROW + 8 * (ll >> 5);
-            __amdgpu_buffer_rsrc_t rsYR = rsY;
-            unsigned voffy[ACTB ? NST : 1], istep_y = 0;
-            u32x4 yq[ACTB ? NST : 1];
-            if constexpr (ACTB) {
-                const bf16* yrt = (const bf16*)a.ab_y + (((size_t)(b * a.Hg + gy0) * a.Wg + gx0) * a.ab_ld + n0);
-                rsYR = abc_make_rsrc(yrt, 0x80000000u);
-                istep_y = (unsigned)(2 * a.Wg * a.ab_ld) * 2u;
-#pragma unroll
-                for (int st = 0; st < NST; ++st) {
-                    const int rit = lrow + RSTEP * st;
-                    voffy[st] = seg_ok ? (unsigned)((wl / WN) * TM) * istep_y + (unsigned)((((rit >> 4) * a.Wg + (rit & 15)) * a.ab_ld + (wl % WN) * TW + lsg * EV) * 2)
-                                       : 0xFFFFFFF0u;
-                    yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], 0u, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (ACTB) {
-#pragma unroll
-                    for (int st = 0; st < NST; ++st) {
-                        char* w0 = ystg + (lsg * EV) * YROW + (lrow + RSTEP * st) * 2;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            *(unsigned short*)(w0 + (2 * c) * YROW) = (unsigned short)(yq[st][c] & 0xFFFFu);
-                            *(unsigned short*)(w0 + (2 * c + 1) * YROW) = (unsigned short)(yq[st][c] >> 16);
-                        }
-                    }
-                    if (i + 1 < TM) {
-#pragma unroll
-                        for (int st = 0; st < NST; ++st) yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], (unsigned)(i + 1) * istep_y, 0);
-                    }
-                    lds_wave_sync();      // (the 16-bit writes have landed before other lanes' 8-byte reads)
-                }
-                // (ACTB: the M-tile's y_raw values read back in ONE batch, two bf16 per register -- read pair by pair between the
-                //  staging writes, which the compiler must keep in program order, every pair was a serial LDS round trip)
-                unsigned xq[ACTB ? TN : 1][ACTB ? 8 : 1];
-                if constexpr (ACTB) {
-                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            // pixels 8 g4 + 4 h + (0..3) of channel 32 j + r = accumulator registers 4 g4 .. 4 g4 + 3
-                            const u32x2 t = *(const u32x2*)(yrd + j * 32 * YROW + 16 * g4);
-                            xq[j][2 * g4] = t[0]; xq[j][2 * g4 + 1] = t[1];
-                        }
-                    asm volatile("" ::: "memory");
-#if defined(__HIP_DEVICE_COMPILE__)
-                    // (all eight reads issued back to back, ONE wait: left to itself the compiler sinks each read to its use)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(xq[j][q]));
-#endif
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const f32x2 b2 = {bv[j], bv[j]};
-#pragma unroll
-                    for (int k = 0; k < 16; k += 2) {
-                        f32x2 v = {acc[i][j][k], acc[i][j][k + 1]};
-                        if constexpr (F8C) v = __builtin_elementwise_fma(v, (f32x2){osc[j], osc[j]}, b2); else v += b2;
-                        char* p = wbase + ((k & 3) + 8 * (k >> 2)) * ROWB + j * 32 * (int)sizeof(OutT);
-                        if constexpr (ACTB) {
-                            // g = dA where BatchNorm(y_raw) > 0, slope * dA elsewhere (unet.py:14,17 backward); sums of g and g (y_raw - mean)
-                            const f32x2 x = {__uint_as_float(xq[j][k >> 1] << 16), __uint_as_float(xq[j][k >> 1] & 0xFFFF0000u)};
-                            const f32x2 yv = __builtin_elementwise_fma(x, (f32x2){csc[j], csc[j]}, (f32x2){csh[j], csh[j]});
-                            const f32x2 f = {yv.x > 0.f ? 1.f : csl[j], yv.y > 0.f ? 1.f : csl[j]};
-                            const f32x2 gg = v * f;
-                            s1v[j] += gg; s2v[j] = __builtin_elementwise_fma(gg, x - (f32x2){cmu[j], cmu[j]}, s2v[j]);
-                            abc_put2<OutT>(p, p + ROWB, gg.x, gg.y);
-                        } else {
-                            s1v[j] += v; s2v[j] = __builtin_elementwise_fma(v, v, s2v[j]);
-                            const f32x2 m = v * slope;
-                            f32x2 vo = {fmaxf(v.x, m.x), fmaxf(v.y, m.y)};
-                            if constexpr (F8O) vo *= oq;
-                            abc_put2<OutT>(p, p + ROWB, vo.x, vo.y);
-                        }
-                    }
-                }
-                // (the sums are pinned to their M-tile and the scheduler barriers keep the M-tiles apart: left free, the compiler
-                //  sinks the 2 x 96 accumulations behind the last store and hoists the bias adds to the front -- the biased values
-                //  of the whole tile live beside the accumulators, ~50 lane constants of the main loop spilled)
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(s1v[j]), "+v"(s2v[j]));
-#endif
-                // (a wait, not program order alone: the rows are read by other lanes than wrote them)
-                lds_wave_sync();
-                __builtin_amdgcn_sched_barrier(0);
-                u32x4 rd[NST];
-#pragma unroll
-                for (int st = 0; st < NST; ++st) rd[st] = *(const u32x4*)(stgw + (lrow + RSTEP * st) * ROWB + lsg * 16);
-#pragma unroll
-                for (int st = 0; st < NST; ++st) {
-                    const int prow = 2 * ((wl / WN) * TM + i) + ((lrow + RSTEP * st) >> 4);      // pixel row of the tile
-                    __builtin_amdgcn_raw_buffer_store_b128(rd[st], rsY, prow < rlim ? voff[st] : 0xFFFFFFF0u, (unsigned)i * istep, 0);
-                }
-                // HAZARD (seen on gfx950, ROCm 7.2): a VALU write to the first data register of a 16-byte buffer store IN THE NEXT
-                // INSTRUCTION reaches the stored data -- the compiler had picked that register for the next store's offset select
-                // (`buffer_store_dwordx4 v[98:101], ..; v_cndmask_b32 v98, ..`: intermittently two channels of a pixel came out as
-                // the bits of an offset); LLVM's hazard recogniser covers this only for stores without a scalar offset register.
-                // Keep the data registers live past the last store and two wait states behind it.
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-                for (int st = 0; st < NST; ++st) asm volatile("" :: "v"(rd[st]));
-                asm volatile("s_nop 1");
-#endif
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) { s1[j] = s1v[j].x + s1v[j].y; s2[j] = s2v[j].x + s2v[j].y; }
-            if (a.stats_rows == 4) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            // (max / min of the values AS STORED, i.e. after the rounding to OutT: CBAM's global max-pool and its backward,
-                            //  unet2.py:10,20, see the tensor -- taken before the rounding, the backward's "is this pixel the maximum"
-                            //  never found it in bf16 and the max branch's gradient was lost)
-                            const float v = (float)(OutT)(acc[i][j][k] + bv[j]); smx[j] = fmaxf(smx[j], v); smn[j] = fminf(smn[j], v);
-                        }
-            }
-            // channels past Cout (padding lanes of the last n-block) carry bias-free zeros: keep them out of the sums
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (!nval[j]) { s1[j] = 0.f; s2[j] = 0.f; }
-        } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int rit = (k & 3) + 8 * (k >> 2) + 4 * h;
-                    const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
-                    const float v = F8C ? fmaf(acc[i][j][k], osc[j], bv[j]) : acc[i][j][k] + bv[j];
-                    if (nval[j] && gy < a.Hg && gx < a.Wg) {
-                        const float vr = (float)(OutT)v;
-                        s1[j] += v; s2[j] += v * v; smx[j] = fmaxf(smx[j], vr); smn[j] = fminf(smn[j], vr);
-                    }
-                    float vo = a.out_act ? fmaxf(v, a.out_slope * v) : v;
-                    if constexpr (F8O) vo *= oq;
-                    *(OutT*)(stg + rit * ROWB + (j * 32 + r) * (int)sizeof(OutT)) = (OutT)vo;
-                }
-            }
-            lds_wave_sync();
-#pragma unroll
-            for (int e = lane; e < 32 * SEG_PER_ROW; e += 64) {
-                const int rit = e / SEG_PER_ROW, sg = e - rit * SEG_PER_ROW;
-                const int gy = gy0 + 2 * (wm * TM + i) + (rit >> 4), gx = gx0 + (rit & 15);
-                const int cch = cbase + sg * EV;
-                if (gy < a.Hg && gx < a.Wg && cch < a.Cout) {
-                    const size_t o = ((size_t)(b * a.Hout + gy * a.om + a.oy0) * a.Wout + gx * a.om + a.ox0) * a.ldy + a.cout_off + cch;
-                    const char* src = stg + rit * ROWB + sg * 16;
-                    if (a.accumulate) {
-                        for (int q = 0; q < EV && cch + q < a.Cout; ++q)
-                            yo[o + q] = (OutT)((float)yo[o + q] + (float)*(const OutT*)(src + q * (int)sizeof(OutT)));
-                    } else if (cch + EV <= a.Cout && vec_ok) {
-                        *(f32x4*)(yo + o) = *(const f32x4*)src;
-                    } else {
-                        for (int q = 0; q < EV && cch + q < a.Cout; ++q) yo[o + q] = *(const OutT*)(src + q * (int)sizeof(OutT));
-                    }
-                }
-            }
-            lds_wave_sync();
-        }
-        }
-        if (prof && tid == 0) prof[3] = wall_clock64();
-        if (a.stats != nullptr) {
-            float* red = (float*)(smem + a.red_off);  // [WM][4][BN], clear of the transpose regions
-            const int rows = a.stats_rows == 4 ? 4 : 2;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float v1 = s1[j] + __shfl_xor(s1[j], 32);
-                const float v2 = s2[j] + __shfl_xor(s2[j], 32);
-                const float v3 = fmaxf(smx[j], __shfl_xor(smx[j], 32));
-                const float v4 = fminf(smn[j], __shfl_xor(smn[j], 32));
-                if (h == 0) {
-                    const int nl = (wn * TN + j) * 32 + r;
-                    red[(wm * 4 + 0) * BN + nl] = v1;
-                    red[(wm * 4 + 1) * BN + nl] = v2;
-                    red[(wm * 4 + 2) * BN + nl] = v3;
-                    red[(wm * 4 + 3) * BN + nl] = v4;
-                }
-            }
-            __syncthreads();
-            if (tid < BN && n0 + tid < a.Cout) {
-                float v1 = 0.f, v2 = 0.f, v3 = -3.0e38f, v4 = 3.0e38f;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) {
-                    v1 += red[(w * 4 + 0) * BN + tid]; v2 += red[(w * 4 + 1) * BN + tid];
-                    v3 = fmaxf(v3, red[(w * 4 + 2) * BN + tid]); v4 = fminf(v4, red[(w * 4 + 3) * BN + tid]);
-                }
-                if constexpr (ACTB) v2 *= a.ab_is[n0 + tid];      // (the row act_bwd writes: sum of g (y_raw - mean) / std)
-                if (STATIC && rows == 2) {      // (unet2's CBAM needs its four rows PER IMAGE: those stay per tile)
-                    pst1 += v1; pst2 += v2;
-                } else {
-                    a.stats[((size_t)mblock * rows + 0) * a.Cout + n0 + tid] = v1;
-                    a.stats[((size_t)mblock * rows + 1) * a.Cout + n0 + tid] = v2;
-                    if (rows == 4) {
-                        a.stats[((size_t)mblock * rows + 2) * a.Cout + n0 + tid] = v3;
-                        a.stats[((size_t)mblock * rows + 3) * a.Cout + n0 + tid] = v4;
-                    }
-                }
-            }
-        }
-        if (prof && tid == 0) prof[4] = wall_clock64();
-    }
-    if constexpr (STATIC) {
-        if (a.stats != nullptr && a.stats_rows != 4 && tid < BN && tid < a.Cout) {
-            a.stats[((size_t)blockIdx.x * 2 + 0) * a.Cout + tid] = pst1;
-            a.stats[((size_t)blockIdx.x * 2 + 1) * a.Cout + tid] = pst2;
-        }
-    }
-}
-
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
-__global__ __launch_bounds__(256, (STATIC ? 3 : 2)) void conv_fast_kernel(const FastK a) {
-    conv_fast_body<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI>(a);
-}
+static int g_force_var = 0;     // measurement hook (abc_debug_conv_var): VAR of conv_fast_body.hpp for the 192 x 128 weights-direct tile
+static int g_force_lp = 0;      // measurement hook (abc_debug_conv_lp, DEBUG flavour): 1 = plan the lane = pixel form (conv_fast_lp.hip) where it applies
+static int g_force_nw = 0;     // measurement hook (abc_debug_conv_nw): 8 = plan the 8-wave form (conv_fast8.hip) where it applies
 
 // Up to four convolutions of ONE geometry as one launch, blockIdx.y picks the descriptor: the four output-parity phases of a
 // ConvTranspose2d(k3, s2) forward (unet.py:44) -- each a 1 / 2 / 2 / 4-tap convolution over the same input into interleaved output
@@ -905,15 +49,6 @@ __global__ __launch_bounds__(256, 2) void conv_fast_batch_kernel(const FastKB b)
     conv_fast_body<InT, CT, OutT, CK, BN, 1, MT, false, 0, 0>(b.k[blockIdx.y]);
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0>
-int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
-    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI>;
-    static unsigned long long lds_ok = 0;
-    if (int rc = abc_allow_lds((const void*)fn, LDS_WG, &lds_ok)) return rc;
-    hipLaunchKernelGGL(fn, dim3(g.nwg), dim3(FT), g.lds, st, k);
-    return abc_check_launch("conv_fast");
-}
-
 template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, int EPI = 0>
 int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     if constexpr (BN == 32 && EPI == 0) {  // resident weights exist for the narrow layers only
@@ -921,6 +56,12 @@ int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
     }
     if constexpr (BN >= 64 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2) {
         // 3x3 (any 9-tap list) over 64-byte chunks: weights straight from global memory into the MFMA operands
+#ifdef ABC_KERNEL_DEBUG
+        if constexpr (BN == 128 && MT == 6 && sizeof(InT) == 2 && sizeof(OutT) == 2 && (EPI == 0 || EPI == 2)) {
+            if (g.wd == 9 && g.nw == 8) return abc_conv_fast_launch8(k, g, EPI, st);
+            if (g.wd == 9 && (g.lp || g.var)) return abc_conv_fast_launch_lp(k, g, EPI, st);
+        }
+#endif
         if (g.wd == 9) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9, EPI>(k, g, st);
     }
     if constexpr (BN == 32 && MT == 8 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2 && EPI == 0) {
@@ -960,6 +101,13 @@ int launch_bn(const FastK& k, const abc_fast_geom& g, int stride, hipStream_t st
 
 // debugging hook (not part of the public ABI): device buffer of 8 x int64 per workgroup for phase timestamps
 extern "C" void abc_debug_conv_prof(void* p) { g_prof = (long long*)p; }
+// measurement hook (not part of the public ABI; profiles/tools/ab_conv128.py): 8 = plan the 8-wave form (conv_fast8.hip: measured SLOWER, profiles/README.md round 5) where it applies, 0 = default.
+// Process-wide and read at plan AND launch time: set it before any plan is built, never between a plan and its launches.
+#ifdef ABC_KERNEL_DEBUG
+extern "C" void abc_debug_conv_nw(int nw) { g_force_nw = nw; }
+extern "C" void abc_debug_conv_lp(int lp) { g_force_lp = lp; }
+extern "C" void abc_debug_conv_var(int var) { g_force_var = var; }
+#endif
 
 // Geometry of the lean kernel for this descriptor, or eligible = 0 (-> the general kernel of conv_igemm.hip).
 int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
@@ -1041,9 +189,10 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     g->MT = best;
     g->BN = best_bn;
     g->nbn = d->Cout_pad / g->BN;
-    const int tn = g->BN >= 64 ? g->BN / 64 : 1;
-    const int stg = 4 * 32 * (tn * 32 * osz + 16);
-    const int red = 4 * 4 * g->BN * 4;
+    g->nw = 4;
+    int tn = g->BN >= 64 ? g->BN / 64 : 1;
+    int stg = 4 * 32 * (tn * 32 * osz + 16);
+    int red = 4 * 4 * g->BN * 4;
     const int prow = 2 * g->MT;
     g->HH = (prow - 1) * d->stride + (dymax - dymin) + 1;
     g->HW = 15 * d->stride + (dxmax - dxmin) + 1;
@@ -1078,6 +227,22 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         if (csz == 2 && g->CK == 32 && g->BN == 32 && g->MT == 8 && d->stride == 1 && d->ntaps == 25 && abc_knob("ABC_CONV_WD25")) g->wd = 25;
     }
     if (g->wd) g->sB_bytes = 0;
+    // eight waves per workgroup (conv_fast8.hip): the bf16 192 x 128 weights-direct tile, plain or with act_bwd in the epilogue
+    if (g->wd == 9 && g->BN == 128 && g->MT == 6 && !f8 && d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16 && d->dtype_out == ABC_BF16 &&
+        d->heads_epi == nullptr && g_force_nw == 8) {
+        g->nw = 8; tn = 1;
+        stg = 8 * 32 * (tn * 32 * osz + 16);
+    }
+    // lane = pixel epilogue (conv_fast_lp.hip): the bf16 192 x 128 weights-direct tile storing whole channel octets, sums and squares only
+    g->lp = (g->wd == 9 && g->nw == 4 && g->BN == 128 && g->MT == 6 && !f8 && d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16 && d->dtype_out == ABC_BF16 &&
+             d->heads_epi == nullptr && d->stats_rows != 4 && !d->accumulate && d->Cout % 8 == 0 && (d->ldy | d->cout_off) % 8 == 0 && g_force_lp == 1) ? 1 : 0;
+    if (g->lp) { stg = 0; red = 0; }       // (no staging, no reduction through LDS)
+    g->var = 0;
+    if (g_force_var && g->wd == 9 && g->nw == 4 && g->BN == 128 && g->MT == 6 && !f8 && d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16 && d->dtype_out == ABC_BF16 &&
+        d->heads_epi == nullptr) {
+        g->var = g_force_var & 3;
+        if ((g->var & 1) && !g->lp) stg = 4 * 32 * (32 * osz + 16);      // (1 x 4 waves: 32-channel staging rows)
+    }
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
     g->b_static = (!actb && !g->wd && g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget &&
                    abc_cdiv(g->HH * g->HW * segs, FT) <= fa_static(g->MT)) ? 1 : 0;
@@ -1102,6 +267,8 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     if (g->lds < g->red_off + red) g->lds = g->red_off + red;
     g->ystg_off = abc_roundup(g->lds, 256);      // (behind everything: the tap and coefficient tables outlive the tile)
     if (actb) g->lds = g->ystg_off + stg;
+    g->epi_off = abc_roundup(g->lds, 256);       // LP: [2][1 or 6][BN] floats
+    if (g->lp) g->lds = g->epi_off + 2 * (actb ? 6 : 1) * g->BN * 4;
     if (g->lds > LDS_WG) return ABC_OK;
     g->tiles_x = abc_cdiv(d->Wg, 16);
     g->tiles_y = abc_cdiv(d->Hg, prow);
@@ -1141,8 +308,10 @@ static void fill_fastk(const abc_conv_desc* d, const abc_fast_geom& g, FastK& k)
     k.ab_y = d->actbwd_y ? (const char*)d->actbwd_y + (size_t)d->actbwd_coff * 2 : nullptr; k.ab_ld = d->actbwd_ld;
     k.ab_sc = d->actbwd_scale; k.ab_sh = d->actbwd_shift; k.ab_sl = d->actbwd_slope; k.ab_mu = d->actbwd_mean; k.ab_is = d->actbwd_invstd;
     k.ystg_off = g.ystg_off;
+    k.epi_off = g.epi_off;
     { const char* e = abc_knob("ABC_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }  // timing ablations only (results invalid)
     k.prof = g_prof;
+    { const char* e = abc_knob("ABC_CONV_PROF_ROUND"); k.prof_round = e ? atoi(e) : -1; }
     { const char* e = abc_knob("ABC_CONV_STAGGER"); k.stagger = e ? atoi(e) : 0; }
     k.bytesA = (unsigned)((int64_t)d->B * d->src.Hx * d->src.Wx * d->src.ldx * abc_dsize(d->dtype_in));
     k.bytesW = (unsigned)((int64_t)d->ntaps * k.nchunks * d->Cout_pad * g.CK * abc_dsize(d->dtype_c));

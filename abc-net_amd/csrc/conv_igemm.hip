@@ -561,7 +561,7 @@ extern "C" int abc_conv_stat_blocks(const abc_conv_desc* d) {
         if (abc_conv_narrow_ok(d)) return abc_conv_narrow_stat_blocks(d);
     }
     abc_fast_geom f;
-    if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return (f.b_static && d->stats_rows != 4) ? f.nwg : f.tiles_x * f.tiles_y * d->B;   // (resident weights: one row per workgroup)
+    if (abc_conv_fast_geom(d, &f) == ABC_OK && f.eligible) return (f.b_static && d->stats_rows != 4) ? f.nwg : f.tiles_x * f.tiles_y * d->B * (f.lp ? 2 : 1);   // (resident weights: one row per workgroup; lane = pixel epilogue: one row per wave row, WM = 2)
     Geom g;
     if (conv_geom(d, &g)) return -1;
     return g.tiles_x * g.tiles_y * d->B;

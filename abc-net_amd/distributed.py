@@ -217,6 +217,10 @@ class GradReducer:
         self.dev = flat_grad.device
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self._pending = []
+        # measure_exposed = True: finish() brackets the launch stream's wait for the communication stream with two events; their
+        # distance is the part of the exchange that backward did NOT hide (exposed_ms(): one value per step since it was switched on)
+        self.measure_exposed = False
+        self._exposed = []
         self.by_ready = {}
         for b in buckets:
             self.by_ready.setdefault(b[2], []).append(b)
@@ -296,11 +300,28 @@ class GradReducer:
         if not self.active:
             return
         if self.cuda:
-            torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+            main = torch.cuda.current_stream(self.dev)
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                main.wait_stream(self.comm_stream)
+                e1.record(main)
+                self._exposed.append((e0, e1))
+            else:
+                main.wait_stream(self.comm_stream)
         else:
             for w in self._pending:
                 w.wait()
             self._pending = []
+
+    def exposed_ms(self):
+        """per step since measure_exposed was set: milliseconds the launch stream spent waiting for the communication stream after
+        the last backward kernel (host sync)"""
+        if self.cuda:
+            torch.cuda.synchronize(self.dev)
+        out = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return out
 
 
 def broadcast_parameters(flat_params, flat_buffers=None, src=0, group=None, counters=None):

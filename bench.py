@@ -38,9 +38,10 @@ SURVEY_ROOFLINE = {
 }
 
 
-def cpu_baseline(size, seconds_budget=25.0, variant="unet"):
+def cpu_baseline(size, seconds_budget=40.0, variant="unet"):
     """oracle = torch-CPU restatement of the reference train step (bitwise-pinned to the reference import);
-    bounded sample: fwd+loss+bwd of batch 4 at the benchmark resolution, median of up to 3 timed iterations"""
+    bounded sample: fwd+loss+bwd of batch 4 at the benchmark resolution, median of 5 warm iterations (SURVEY.md section 8d;
+    fewer only when the host is so slow that five would take more than `seconds_budget`, and the sample string says how many)"""
     from abcnet_amd.synthetic import synthetic_images, synthetic_targets
     from oracle import loss_oracle
     from oracle import unet_oracle as uo
@@ -50,7 +51,7 @@ def cpu_baseline(size, seconds_budget=25.0, variant="unet"):
     sd0 = uo.filled_state(variant, 1, HEADS, seed=0)
     times = []
     t_start = time.time()
-    for it in range(4):
+    for it in range(6):
         sd = uo.clone_state(sd0, requires_grad=True)
         t0 = time.time()
         preds = uo.forward(variant, sd, x, train=True)
@@ -67,7 +68,7 @@ def cpu_baseline(size, seconds_budget=25.0, variant="unet"):
             "sample": "oracle fwd+loss+bwd (no optimiser), fp32, batch %d at %dx%d, median of %d warm iterations" % (B, size, size, len(times))}
 
 
-def cpu_baseline_infer(size, seconds_budget=25.0, variant="unet"):
+def cpu_baseline_infer(size, seconds_budget=40.0, variant="unet"):
     """oracle eval forward + oracle NMS (img2smiles2.py:56-79 restated) on the host, batch 4 at the benchmark resolution"""
     from abcnet_amd.synthetic import synthetic_images
     from oracle import nms_oracle
@@ -78,7 +79,7 @@ def cpu_baseline_infer(size, seconds_budget=25.0, variant="unet"):
     times = []
     t_start = time.time()
     with torch.no_grad():
-        for it in range(4):
+        for it in range(6):
             t0 = time.time()
             p = uo.forward(variant, sd, x, train=False)
             nms_oracle.nms(p[0], p[4], p[6], p[7])
@@ -105,6 +106,74 @@ def pmc_traffic(kernel, mode="train", variant="unet"):
         return None
     rec = table.get("%s:%s:%s" % (mode, variant, kernel))
     return None if rec is None else rec["bytes_per_launch"]
+
+
+def dominant_family(prof):
+    """(label, record) of the kernel FAMILY with the largest share of the step among those that do arithmetic.  A convolution kernel
+    with the producing layer's act_bwd pass in its epilogue ("conv_fast+act_bwd<...>", abc_conv_desc.actbwd_*) is the same tile and
+    main loop as the plain instantiation -- one row, priced on the convolution's flops alone (the epilogue's extra work counts against
+    it); both labels stay in the breakdown."""
+    fam = {}
+    for k, v in prof.items():
+        f = fam.setdefault(k.replace("+act_bwd<", "<"), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "labels": []})
+        for q in ("calls", "ms", "flops", "bytes"):
+            f[q] += v[q]
+        f["labels"].append(k)
+    dom = max((k for k in fam if fam[k]["flops"] > 0), key=lambda k: fam[k]["ms"])
+    return dom, fam[dom]
+
+
+def other_configs(dev, steps=20, warmup=5):
+    """BASELINE.json's configs 3 and 5 through the same harness, AFTER the headline's timed region and report (nothing here can
+    perturb it): unet2.py train step b16 @ 384x384 (unet2.py:129-173) and the img2smiles2.py heat-map path b64 @ 512x512 in bf16
+    (img2smiles2.py:42-79), each on its own model / Trainer / InferenceRunner, freed afterwards.  One record per config: the same
+    wall-clock measurement as the headline (K steps between synchronisations) and the dominant kernel family's fraction of the
+    dense bf16 MFMA peak from an instrumented eager pass."""
+    import gc
+    from abcnet_amd.synthetic import synthetic_images, synthetic_targets
+    from abcnet_amd.train import Trainer
+    from abcnet_amd.infer import InferenceRunner
+    recs = []
+    for mode, variant, size, batch in (("train", "unet2", 384, 16), ("infer", "unet", 512, 64)):
+        t_cfg = time.perf_counter()
+        if variant == "unet2":
+            from abcnet_amd.unet2 import UNet
+        else:
+            from abcnet_amd.unet import UNet
+        model = UNet(1, HEADS, dtype="bf16")
+        model.reset_parameters(seed=1234)
+        model = model.to(dev)
+        imgs = synthetic_images(batch, size, seed=7)
+        if mode == "infer":
+            tr = InferenceRunner(model, batch, size, size)
+            tr.load_batch(imgs.to(dev))
+            workload = "img2smiles2.py heat-map path on unet.py (eval forward + peak NMS), %dx%d, batch %d/GPU" % (size, size, batch)
+        else:
+            tr = Trainer(model, batch, size, size)
+            tr.load_batch(imgs.to(dev), [t.to(dev) for t in synthetic_targets(batch, size // 4, seed=1)])
+            workload = variant + ".py train step (pack+fwd+fused loss+bwd+Adam), %dx%d, batch %d/GPU, dropout 0.2" % (size, size, batch)
+        torch.cuda.synchronize()
+        for _ in range(warmup):
+            tr.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        dom, r = dominant_family(tr.profile(iters=2))
+        ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        sr = SURVEY_ROOFLINE[(mode, variant, size)]
+        val = batch * steps / el
+        recs.append({"workload": workload, "value": round(val, 2), "unit": "images/sec", "ms_per_step": round(1000 * el / steps, 3), "steps": steps,
+                     "warmup": warmup, "dtype": "bf16", "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK["bf16"],
+                                                                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK["bf16"], 4)},
+                     "survey_roofline_frac": round(val / sr["R_img_s"], 4), "wall_s": None})
+        del tr, model, imgs
+        gc.collect()
+        torch.cuda.empty_cache()
+        recs[-1]["wall_s"] = round(time.perf_counter() - t_cfg, 1)
+    return recs
 
 
 def experiment_knobs():
@@ -168,6 +237,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="the default single-GPU headline run also times BASELINE.json's configs 3 (unet2.py "
+                    "train) and 5 (inference heat-map path, bf16) after the headline and reports them as other_configs; this skips them")
     ap.add_argument("--allow-knobs", action="store_true", help="run although ABC_* experiment switches are set (they are echoed)")
     a = ap.parse_args()
     knobs = experiment_knobs()
@@ -275,6 +346,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
     loss = tr.loss_value()["total"] if a.mode == "train" else float(tr.atom_mask.sum().item())
+    # N > 1: how much of the gradient exchange backward did NOT hide -- three extra steps AFTER the timed region with the launch
+    # stream's wait for the communication stream (GradReducer.finish) bracketed by HIP events
+    exposed = None
+    if a.mode == "train" and world > 1:
+        tr.reducer.measure_exposed = True
+        for _ in range(3):
+            tr.step()
+        ex = tr.reducer.exposed_ms()
+        tr.reducer.measure_exposed = False
+        t = torch.tensor([sum(ex) / max(len(ex), 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed = round(t.item(), 4)
     # what makes a multi-GPU line checkable from the line alone: who joined, on which device, over which backend and
     # exchange, and that the replicas hold identical parameters after the averaged updates (after the clock stopped)
     chk = model._flat.double().sum().item()
@@ -302,7 +385,7 @@ def main():
         "exchange": (tr.reducer.mode if (a.mode == "train" and world > 1) else None),
         "exchange_fallback": (tr.reducer.fallback_reason if (a.mode == "train" and world > 1) else None),
         "bucket_mb": (a.bucket_mb if (a.mode == "train" and world > 1) else None), "n_buckets": (len(tr.buckets) if (a.mode == "train" and world > 1) else None),
-        "reserved_cus": a.reserve_cus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
+        "exposed_exchange_ms": exposed, "reserved_cus": a.reserve_cus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * el / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "graph": not a.no_graph, "device_meters": bool(a.metrics),
@@ -340,17 +423,7 @@ def main():
         if rank == 0 and not a.no_profile:
             prof = tr.profile(iters=3)
             tot = sum(r["ms"] for r in prof.values())
-            # the dominant kernel FAMILY: a convolution kernel with the producing layer's act_bwd pass in its epilogue
-            # ("conv_fast+act_bwd<...>", abc_conv_desc.actbwd_*) is the same tile and main loop as the plain instantiation -- one row,
-            # priced on the convolution's flops alone (the epilogue's extra work counts against it); both labels stay in the breakdown
-            fam = {}
-            for k, v in prof.items():
-                f = fam.setdefault(k.replace("+act_bwd<", "<"), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "labels": []})
-                for q in ("calls", "ms", "flops", "bytes"):
-                    f[q] += v[q]
-                f["labels"].append(k)
-            dom = max((k for k in fam if fam[k]["flops"] > 0), key=lambda k: fam[k]["ms"])
-            r = fam[dom]
+            dom, r = dominant_family(prof)
             ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
             # (a mixed graph: the dominant kernel is priced against the peak of ITS operand type)
             peak = MFMA_PEAK["fp8" if "<fp8,fp8," in dom else ("bf16" if a.dtype == "fp8" else a.dtype)]
@@ -376,6 +449,14 @@ def main():
             out["whole_step"] = {"algorithmic_tflop": round(flops_step / 1e12, 3), "algorithmic_gb": round(bytes_step / 1e9, 3),
                                  "mfma_frac": round(flops_step / (el / a.steps) / 1e12 / MFMA_PEAK["bf16" if a.dtype == "fp8" else a.dtype], 4),
                                  "hbm_frac": round(bytes_step / (el / a.steps) / 1e9 / HBM_PEAK, 4)}
+        headline = (a.mode, a.variant, a.size, a.batch, a.dtype) == ("train", "unet", 384, 16, "bf16") and not (a.metrics or a.raster or a.no_graph)
+        if rank == 0 and world == 1 and headline and not a.no_other_configs:
+            # (the headline's objects are released first: the other configs start from the state a fresh process would give them)
+            del tr, model
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(dev)
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline if a.mode == "train" else cpu_baseline_infer)(a.size, variant=a.variant)
 

@@ -76,7 +76,38 @@ def rank_runs(tmp_path_factory):
     assert codes == [0], "rccl world-1 worker: exit codes %s" % codes
     import json
     runs["rccl1"] = json.load(open(out))
+    # the exact command the driver runs for the scaling bench, at N = 2, end to end: `bench.py --gpus 2` (without a launcher: it
+    # starts its own two ranks, multi_gpu_train.py:30-37) at the benchmark workload.  RCCL with a GPU per rank; on a one-GPU box
+    # both ranks on device 0 over gloo (bench.py's testing hooks).
+    import subprocess
+    env2 = dict(os.environ)
+    if ndev < WORLD:
+        env2.update(ABC_BENCH_DEVICE="0", ABC_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env2, stdout=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, "bench.py --gpus 2: exit code %d" % p.returncode
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "bench.py --gpus 2 must print ONE JSON line, got %d" % len(lines)
+    runs["bench2"] = json.loads(lines[0])
     return runs, ndev
+
+
+def test_bench_py_gpus_2_end_to_end(rank_runs):
+    """the driver's SCALE command at N = 2: one JSON line from rank 0, both ranks joined, the default all-reduce exchange with no
+    fallback, several buckets launched between graph segments, replicas identical after the averaged updates (bench.py exits non-zero
+    when their checksums differ), whole-job throughput, and how much of the exchange backward did not hide"""
+    runs, ndev = rank_runs
+    b = runs["bench2"]
+    print("bench.py --gpus 2:", {k: b[k] for k in ("value", "ms_per_step", "backend", "exchange", "n_buckets", "exposed_exchange_ms", "rank_devices")}, file=sys.stderr)
+    assert b["n_gpus"] == b["ranks_joined"] == 2 and b["steps"] == 3 and b["warmup"] == 1
+    assert b["backend"] == ("nccl" if ndev >= 2 else "gloo")
+    assert b["exchange"] == "all_reduce" and b["exchange_fallback"] is None and b["n_buckets"] >= 3
+    assert b["scaling"] == "weak" and b["config"]["global_batch"] == 32 and b["config"]["parallelism"] == "dp2"
+    assert b["value"] > 0 and abs(b["value"] - 2 * 16 * 1000.0 / b["ms_per_step"]) <= 1e-2 * b["value"]
+    assert isinstance(b["replica_checksum"], float) and b["exposed_exchange_ms"] is not None and b["exposed_exchange_ms"] >= 0.0
+    assert len(b["rank_devices"]) == 2 and (ndev < 2 or sorted(b["rank_devices"]) == [0, 1])
+    assert "other_configs" not in b and "cpu_baseline" not in b        # (N = 1 legs only)
+    assert "roofline" in b                                             # the instrumented pass runs on rank 0 at any N
 
 
 def test_rccl_exchanges_between_graph_segments_are_the_identity_at_world_1(rank_runs):
