@@ -14,6 +14,7 @@ PyTorch is used here only to own device memory and the stream.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -105,13 +106,35 @@ class Rec:
         self.__dict__.update(kw)
 
 
+def set_reserved_cus(n):
+    """abc_set_reserved_cus for Python callers: leave n of the 256 CUs out of the persistent convolution grids (PROCESS-wide).  The plans
+    of this process bake the value into grid sizes and BatchNorm partial-row buffers, so it can only change while no plan is alive:
+    raises otherwise.  Setting the value it already has is always fine."""
+    lib = L.load()
+    n = (int(n) + 3) & ~3
+    if n == lib.abc_get_reserved_cus():
+        return n
+    alive = [e for e in Engine._live]
+    if alive:
+        raise L.AbcNetHipError("cannot change the reserved-CU count from %d to %d: %d plan(s) built under the current value are alive "
+                               "(it is a process-wide setting baked into their grids; build every Trainer / InferenceRunner of this "
+                               "process with the same reserve_cus, or drop the old ones first)" % (lib.abc_get_reserved_cus(), n, len(alive)))
+    L.check(lib.abc_set_reserved_cus(n), "set_reserved_cus")
+    return n
+
+
 class Engine:
-    DUAL_WGRAD = True      # class-wide measurement switch (profiles/tools): False = BatchNorm-backward apply as a pass of its own
+    # every plan alive in this process (weak references): the reserved-CU count is a PROCESS-wide setting of the library that plans bake
+    # into their grids and buffer sizes, so it may only change while no plan exists (set_reserved_cus below)
+    _live = weakref.WeakSet()
 
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
-                 guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True, nms_heads=False, decode=False):
+                 guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True, nms_heads=False, decode=False,
+                 dual_wgrad=True):
         """merge_reduce=False: every slab reduction and every BatchNorm-backward finaliser a launch of its own;
+        dual_wgrad=False: the BatchNorm-backward apply as a pass of its own instead of on the weight gradient's load (the A/B of that
+        fusion; part of the engine cache key like the other plan switches);
         actbwd_epilogue=False: every act_bwd pass as a launch of its own (the form the fused epilogue is tested against);
         batched_heads=False: one launch per head instead of the batched / merged heads launches (kept as the plain form the
         batched one is tested against, tests/test_gpu_model.py::test_batched_heads_equal_one_by_one_launches)"""
@@ -123,6 +146,11 @@ class Engine:
             raise ValueError("in_channels must be positive")
         self.in_channels = in_channels
         self.lib = L.load()
+        # the persistent convolution grids -- and the BatchNorm partial-row buffers sized after them -- follow the library's
+        # process-wide reserved-CU count AT PLAN TIME; the launches re-derive their grids from the current value, so it must
+        # not move while this plan lives (checked before every run_*; set_reserved_cus refuses to move it)
+        self.reserved_cus = self.lib.abc_get_reserved_cus()
+        self.dual_wgrad = bool(dual_wgrad)
         self.variant, self.heads, self.B, self.H, self.W = variant, list(heads), B, H, W
         self.train = train
         # eval-mode graph with every BatchNorm folded into the convolution in front of it: the weights are
@@ -189,6 +217,7 @@ class Engine:
         self._colsum_need = 0
         self._colsum_users = []
         self._build()
+        Engine._live.add(self)      # (a plan that was built: half-constructed ones hold no launches)
 
     def dropout_seed(self, nth_forward):
         """the hash seed the nth train-mode forward of this engine (1-based) draws its mask with (tests mirror the mask
@@ -985,7 +1014,7 @@ class Engine:
             self.keep.append(epi_items)
             return
         # (the eight conv1 launches above write the eight slices of hfeat; the eight 1x1 convolutions go as one launch)
-        if self.nms_heads and self.heads == [1, 14, 3, 2, 1, 360, 60, 60] and len(head_convs) == 8 and self.drop_p >= 0:
+        if self.nms_heads and self.heads == [1, 14, 3, 2, 1, 360, 60, 60] and len(head_convs) == 8:
             d6, d7 = head_convs[6][0], head_convs[7][0]
             rho, om = self.new((self.B, 60, h, w), torch.float32), self.new((self.B, 60, h, w), torch.float32)
             d6.head_aux, d6.head_aux_mode = rho.data_ptr(), 1
@@ -1003,6 +1032,9 @@ class Engine:
                         self.btype_idx = idx
                         head_convs[5][2]["bytes"] -= float(self.B * 360 * h * w * 4 - self.B * 60 * h * w)
                         head_convs[6][2]["bytes"] -= float(self.B * 60 * h * w * 4)
+                        # (the bond-type and rho maps are neither written nor read in decode mode: release them -- 1.7 GB at b64 @ 512 x 512)
+                        for dead in (self.logits[5], self.logits[6]):
+                            self.keep[:] = [t for t in self.keep if t is not dead]
                         self.logits[5] = self.logits[6] = None
                     else:
                         d5.head_aux, d5.head_aux_mode, d5.y, d6.y = None, 0, y5, y6
@@ -1157,7 +1189,7 @@ class Engine:
         dY is a plain Src, or the deferred pair of _bn_backward(defer=True): then the weight-gradient kernel applies the
         BatchNorm-backward correction on load and writes dY for the data-gradient conv (one pass less over g and y);
         layers whose weight gradient runs on another kernel fall back to the separate apply pass."""
-        if isinstance(dY, tuple) and not Engine.DUAL_WGRAD:      # (measurement switch: the separate apply pass everywhere)
+        if isinstance(dY, tuple) and not self.dual_wgrad:      # (Engine(dual_wgrad=False): the separate apply pass everywhere)
             dY = dY[1]()
         if isinstance(dY, tuple):
             gsrc, emit_apply = dY
@@ -1806,6 +1838,10 @@ class Engine:
         data gradient, the weight gradients of the 12 x 12 .. 48 x 48 levels and the transposed convolutions (round 3,
         profiles/tools/ab_side.py history: 6.68 ms -> 6.93 ms with 16 launches forked, 6.99 ms with 46): every fork / join
         edge of the graph costs more than the 20-70 workgroup kernels it lets overlap."""
+        if self.lib.abc_get_reserved_cus() != self.reserved_cus:
+            raise L.AbcNetHipError("the library's reserved-CU count changed from %d to %d since this plan was built: its grids and "
+                                   "statistics buffers were sized for the old value (abc_set_reserved_cus is process-wide; use "
+                                   "abcnet_amd.engine.set_reserved_cus, which refuses while plans exist)" % (self.reserved_cus, self.lib.abc_get_reserved_cus()))
         for fn, ref, what, _w, m in ops:
             rc = fn(ref, stream)
             if rc != 0:

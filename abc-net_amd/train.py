@@ -22,7 +22,7 @@ class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
                  process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True, keep_logits=True,
                  batched_heads=True, exchange="all_reduce", force_exchange=False, guards=False, actbwd_epilogue=True, merge_reduce=True,
-                 reserve_cus=0):
+                 reserve_cus=None, dual_wgrad=True):
         """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
         mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
         as DDP does; "lazy" (default): when sync_buffers() is called -- evaluate() calls it; before a checkpoint of a rank
@@ -41,7 +41,10 @@ class Trainer:
         tensors of the plan's real bucket sizes when the reducer is built and fall back (reducer.fallback_reason) -- neither
         has run at world > 1 on RCCL hardware yet, which is why they are not the default.
         reserve_cus: leave this many CUs out of the persistent convolution grids so that RCCL's kernels can start beside
-        them (abc_set_reserved_cus: PROCESS-wide, applied before the plan is built; 0 = the single-GPU grids).
+        them (engine.set_reserved_cus: PROCESS-wide and baked into every plan's grids and buffer sizes, so it is applied before
+        the plan is built and REFUSED when plans built under another value are alive; None (default) = leave the process's
+        current value alone -- 0 unless somebody set it).
+        dual_wgrad=False: the BatchNorm-backward apply as passes of their own (Engine(dual_wgrad=...): the A/B of that fusion).
         force_exchange: segment the plan and run the bucket exchanges although the group has one rank (testing RCCL's launch
         mechanics between graph segments on a one-GPU box)."""
         if not torch.cuda.is_available():
@@ -64,14 +67,14 @@ class Trainer:
         # single-process stream)
         model.dropout_seed = D.rank_dropout_seed(model.dropout_seed_base, self.rank)
         model.train()
-        self.reserve_cus = int(reserve_cus)
-        L.check(L.load().abc_set_reserved_cus(self.reserve_cus), "set_reserved_cus")
+        from .engine import set_reserved_cus
+        self.reserve_cus = L.load().abc_get_reserved_cus() if reserve_cus is None else set_reserved_cus(reserve_cus)
         with torch.cuda.device(dev):
             x0 = torch.zeros((batch, model.n_channels, height, width), device=dev)
             # (fused_heads: the heads' 1x1 convolutions, the loss and the way back as one pass where the engine can -- bf16)
             # (guards: the debug plan -- every buffer between guard bands, Engine.check_guards())
             self.eng = model._engine_for(x0, True, fused_heads=fused_heads, batched_heads=batched_heads, guards=guards,
-                                         actbwd_epilogue=actbwd_epilogue, merge_reduce=merge_reduce)
+                                         actbwd_epilogue=actbwd_epilogue, merge_reduce=merge_reduce, dual_wgrad=dual_wgrad)
         eng = self.eng
         h, w = eng.h, eng.w
         B = batch

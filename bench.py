@@ -280,9 +280,8 @@ def main():
     else:
         from abcnet_amd.unet import UNet
 
-    if os.environ.get("ABC_BENCH_NODUAL"):      # (measurement hook, echoed: the BatchNorm-backward apply as passes of their own)
-        from abcnet_amd.engine import Engine
-        Engine.DUAL_WGRAD = False
+    nodual = bool(os.environ.get("ABC_BENCH_NODUAL"))      # (measurement hook, echoed: the BatchNorm-backward apply as passes of their own)
+    if nodual:
         knobs = dict(knobs, ABC_BENCH_NODUAL="1")
     backend = None
     if world > 1:
@@ -308,7 +307,7 @@ def main():
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits,
                      actbwd_epilogue=not a.no_actbwd_epilogue, merge_reduce=not a.no_merge_reduce, bucket_mb=a.bucket_mb,
-                     exchange=a.exchange or "all_reduce", reserve_cus=a.reserve_cus)
+                     exchange=a.exchange or "all_reduce", reserve_cus=a.reserve_cus, dual_wgrad=not nodual)
         if world > 1 and a.exchange is not None and tr.reducer.mode != a.exchange:
             raise SystemExit("bench.py --exchange %s: the reducer runs %r (%s)" % (a.exchange, tr.reducer.mode, tr.reducer.fallback_reason))
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)

@@ -26,6 +26,10 @@ What is produced (all float32 unless noted):
   calibrated_<variant>.npz BatchNorm running statistics after CALIB_STEPS train-mode forwards of the reference module (statistics that
                            match the activations: the eval maps then have their train-mode range), eval head maps with them at 64x64
                            (full) and for two images of the 512x512 benchmark batch (samples, statistics, NMS decisions)
+  trained_unet.npz         the FROZEN trained fixture (trained_unet_state.npz: unet.py trained on the device ONCE, parameters rounded to
+                           bf16 -- make_trained_fixture.py) loaded into the reference's UNet: eval head maps at 64x64 (full, two drawn
+                           molecules) and, for the 16 sampled images of config 5's accuracy batch (drawn_molecules(64, 512, seed=777)
+                           [0::4]), strided samples, statistics and the NMS decisions of img2smiles2.py:61-79 (bit-packed)
   meta.json                state_dict key/shape lists, parameter counts
 """
 import json
@@ -385,6 +389,49 @@ def calibrated_goldens(variant):
           [(float(res["eval512_head%d_stats" % i][0]), float(res["eval512_head%d_stats" % i][1])) for i in range(8)])
 
 
+TRAINED_SAMPLE = tuple(range(0, 64, 4))      # (tests/test_gpu_trained.py: SAMPLE)
+
+
+def trained_goldens():
+    """the frozen trained fixture through THE REFERENCE: tests/golden/trained_unet_state.npz (its parameters are bf16-representable
+    f32 values) loaded into unet.UNet with strict=True, eval mode; what the oracle has to reproduce bit for bit and what the device
+    graphs of config 5 are measured against (tests/test_gpu_trained.py)"""
+    from abcnet_amd.synthetic import drawn_molecules
+    sys.path.insert(0, HERE)
+    from make_trained_fixture import unpack_state
+    mod = ref_module("unet")
+    sd = unpack_state(os.path.join(HERE, "trained_unet_state.npz"))
+    m = mod.UNet(1, HEADS)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    res = {"sample": np.array(TRAINED_SAMPLE)}
+    with torch.no_grad():
+        x64, _ = drawn_molecules(2, 64, seed=778, n_atoms=(2, 4), margin=8, min_dist=12, max_bond=40)
+        for i, y in enumerate(m(x64)):
+            res["eval64_head%d" % i] = y.numpy()
+        x, _ = drawn_molecules(64, 512, seed=777)
+        x = x[list(TRAINED_SAMPLE)]
+        ys = [[] for _ in range(8)]
+        for b in range(0, len(TRAINED_SAMPLE), 4):      # (four images at a time: 8 GB of activations otherwise)
+            for i, y in enumerate(m(x[b:b + 4])):
+                ys[i].append(y)
+        ys = [torch.cat(t) for t in ys]
+    for i, y in enumerate(ys):
+        res["eval512_head%d_sample" % i] = np.stack([sample(y[b], 4099) for b in range(y.shape[0])])
+        res["eval512_head%d_stats" % i] = np.array([[y[b].min().item(), y[b].max().item(), y[b].double().mean().item(), y[b].double().norm().item()]
+                                                    for b in range(y.shape[0])])
+    ns = {"torch": torch, "atom_targets_pred": ys[0], "bond_targets_pred": ys[4], "bond_rhos_pred": ys[6], "bond_types_pred": ys[5],
+          "bond_omega_types_pred": ys[7]}
+    exec(slice_text(os.path.join(REF, "img2smiles2.py"), 61, 79), ns)
+    res["nms512_atom"] = np.packbits(ns["atom_targets_pred"].numpy().astype(np.uint8))
+    res["nms512_bond"] = np.packbits(ns["bond_targets_pred"].numpy().astype(np.uint8))
+    res["nms512_omega"] = np.packbits(ns["bond_omega_types_pred2"].numpy().astype(np.uint8))
+    res["nms512_counts"] = np.array([ns["atom_targets_pred"].sum().item(), ns["bond_targets_pred"].sum().item(),
+                                     ns["bond_omega_types_pred2"].sum().item()])
+    np.savez_compressed(os.path.join(HERE, "trained_unet.npz"), **res)
+    print("wrote trained", res["nms512_counts"], [(float(res["eval512_head%d_stats" % i][:, 0].min()), float(res["eval512_head%d_stats" % i][:, 1].max())) for i in range(8)])
+
+
 def meta():
     out = {}
     for variant in ("unet", "unet2"):
@@ -403,6 +450,9 @@ def meta():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trained":
+        trained_goldens()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "calibrated":
         for v in ("unet", "unet2"):
             calibrated_goldens(v)
@@ -422,3 +472,4 @@ if __name__ == "__main__":
         model_goldens(v)
         grad_goldens(v)
         calibrated_goldens(v)
+    trained_goldens()

@@ -407,3 +407,29 @@ def test_act_bwd_epilogue_plan_and_its_refusals():
     assert ok(3, 42, 48, 32, 32)[0] == 0             # ... ragged rows: the general narrow-level kernel's 32-channel form has no such epilogue
     assert ok(16, 96, 96, 128, 128, dtype_out=L.F32)[0] == 0 and ok(16, 96, 96, 128, 128, accumulate=1)[0] == 0
     assert ok(16, 96, 96, 128, 128, stats=None)[0] == 0 and ok(16, 96, 96, 128, 128, actbwd_ld=100)[0] == 0
+
+
+def test_reserved_cus_cannot_change_while_a_plan_is_alive():
+    """abc_set_reserved_cus is process-wide and plans bake it into their grids and BatchNorm partial-row buffers (the launches re-derive
+    the grids from the current value): engine.set_reserved_cus refuses to move it while any plan exists, accepts the value it already
+    has, and rounds to a multiple of four (workgroups per CU times CUs must stay a multiple of the eight XCDs)"""
+    from abcnet_amd import engine as E
+    lib = L.load()
+    assert lib.abc_get_reserved_cus() == 0
+
+    class Plan:      # (stands in for an Engine: building one needs a GPU)
+        pass
+    import weakref
+    plan = Plan()
+    saved, E.Engine._live = E.Engine._live, weakref.WeakSet([plan])      # (plans other tests of this process built stay out of it)
+    try:
+        assert E.set_reserved_cus(0) == 0
+        with pytest.raises(L.AbcNetHipError, match="plan"):
+            E.set_reserved_cus(8)
+        assert lib.abc_get_reserved_cus() == 0
+        E.Engine._live.discard(plan)
+        assert E.set_reserved_cus(6) == 8 and lib.abc_get_reserved_cus() == 8
+        assert E.set_reserved_cus(0) == 0 and lib.abc_get_reserved_cus() == 0
+    finally:
+        E.Engine._live = saved
+        L.check(lib.abc_set_reserved_cus(0), "set")

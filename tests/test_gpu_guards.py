@@ -56,3 +56,47 @@ def test_inference_plans_store_inside_their_buffers(fp8):
     run.step()
     torch.cuda.synchronize()
     assert run.eng.check_guards() > 60
+
+
+def test_a_second_trainer_cannot_move_the_reserved_cus_under_the_first():
+    """Trainer(reserve_cus=n) sets a PROCESS-wide value that the first plan's persistent grids and BatchNorm partial-row buffers were
+    sized for: a default-constructed Trainer leaves it alone (and plans for it), one that asks for another value is refused while the
+    first lives, a direct library call is caught before the next launch, and the step under reserved CUs stays inside its buffers"""
+    import gc
+    from abcnet_amd import _lib as L
+    from abcnet_amd import engine as E
+    from abcnet_amd.train import Trainer
+    lib = L.load()
+    B, S = 2, 64
+    x = synthetic_images(B, S, seed=7)
+    tg = synthetic_targets(B, S // 4, seed=1)
+    import weakref
+    gc.collect()
+    # (plans that other tests of this session keep alive -- cached fixtures -- stay out of it: they are not launched meanwhile, and the
+    #  process-wide value is back at 0 when this test ends)
+    saved, E.Engine._live = E.Engine._live, weakref.WeakSet()
+    m1 = _model("unet", "bf16")
+    t1 = Trainer(m1, B, S, S, use_graph=False, guards=True, reserve_cus=8)
+    try:
+        assert lib.abc_get_reserved_cus() == 8 and t1.eng.reserved_cus == 8
+        t1.load_batch(x.to(DEV), [t.to(DEV) for t in tg])
+        t1.step()
+        t2 = Trainer(_model("unet", "bf16"), B, S, S, use_graph=False)      # default: does not reset the process-wide value
+        assert lib.abc_get_reserved_cus() == 8 and t2.eng.reserved_cus == 8
+        with pytest.raises(L.AbcNetHipError, match="plan"):
+            Trainer(_model("unet", "bf16"), B, S, S, use_graph=False, reserve_cus=0)
+        L.check(lib.abc_set_reserved_cus(0), "set")         # behind the engine's back
+        with pytest.raises(L.AbcNetHipError, match="reserved-CU"):
+            t1.step()
+        L.check(lib.abc_set_reserved_cus(8), "set")
+        t1.step()
+        torch.cuda.synchronize()
+        assert t1.eng.check_guards() > 150
+        del t2
+    finally:
+        del t1, m1
+        gc.collect()
+        L.check(lib.abc_set_reserved_cus(0), "set")
+        left = [e for e in E.Engine._live]
+        E.Engine._live = saved
+    assert not left, "plans of this test are still alive: %d" % len(left)
