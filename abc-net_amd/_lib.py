@@ -142,7 +142,8 @@ class ExtractDesc(C.Structure):
 class RasterDesc(C.Structure):
     _fields_ = [("t_atom", vp), ("t_types", vp), ("t_charges", vp), ("t_hs", vp), ("t_bond", vp), ("t_btypes", vp), ("t_rho", vp),
                 ("t_omega", vp), ("B", i32), ("h", i32), ("w", i32), ("max_atoms", i32), ("max_bonds", i32), ("atoms", vp),
-                ("n_atoms", vp), ("bonds", vp), ("n_bonds", vp), ("rho", vp)]
+                ("n_atoms", vp), ("bonds", vp), ("n_bonds", vp), ("rho", vp), ("group_flags", vp), ("prev_atoms", vp), ("prev_bonds", vp),
+                ("prev_rho", vp), ("prev_counts", vp), ("incremental", i32)]
 
 
 class HeadsFusedDesc(C.Structure):
@@ -151,7 +152,7 @@ class HeadsFusedDesc(C.Structure):
                 ("logits", vp * 8), ("t_atom", vp), ("t_types", vp), ("t_charges", vp), ("t_hs", vp), ("t_bond", vp),
                 ("t_btypes", vp), ("t_rho", vp), ("t_omega", vp), ("dl", vp), ("g", vp), ("bn_partial", vp), ("loss_partial", vp),
                 ("B", i32), ("h", i32), ("w", i32), ("chan_scale", vp), ("chan_off", i32 * 8), ("dw2", vp * 8), ("db2", vp * 8),
-                ("wgrad_work", vp), ("keep_mask", vp)]
+                ("wgrad_work", vp), ("keep_mask", vp), ("target_flags", vp), ("zero_bytes", vp)]
 
 
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,

@@ -75,7 +75,11 @@ class TargetRasterizer:
     """device-side utils.py:83-228 for a batch; `targets` may be the Trainer's static target tensors (then `run` writes
     the loss inputs in place), otherwise fresh ones are allocated with the reference collate shapes / dtypes"""
 
-    def __init__(self, batch, h, w=None, max_atoms=256, max_bonds=256, targets=None, device="cuda"):
+    def __init__(self, batch, h, w=None, max_atoms=256, max_bonds=256, targets=None, device="cuda", sparse=False):
+        """sparse=True: the maps are zeroed ONCE; every later run() erases the pixels the previous records drew instead of zeroing
+        23 MB per image (the target tensors must not be written by anybody else in between: invalidate() after that), and
+        .group_flags says which 32-pixel groups of the batch hold targets of which head -- Trainer.use_sparse_targets(rasterizer)
+        lets the fused heads pass skip the all-zero planes (abc_raster_desc.group_flags)."""
         w = h if w is None else w
         if not torch.cuda.is_available():
             raise L.AbcNetHipError("TargetRasterizer needs an MI355X; abcnet_amd has no CPU fallback")
@@ -104,7 +108,22 @@ class TargetRasterizer:
         d.B, d.h, d.w, d.max_atoms, d.max_bonds = B, h, w, max_atoms, max_bonds
         d.atoms, d.bonds, d.rho = self.d_atoms.data_ptr(), self.d_bonds.data_ptr(), self.d_rho.data_ptr()
         d.n_atoms, d.n_bonds = self.d_cnt[0].data_ptr(), self.d_cnt[1].data_ptr()
+        self.sparse = bool(sparse)
+        self.group_flags = None
+        self._drawn = False          # sparse: do the maps hold exactly what the prev_* records say?
+        if self.sparse:
+            if (h * w) % 32:
+                raise L.AbcNetHipError("sparse rasteriser: h * w must be a multiple of 32")
+            self.group_flags = torch.zeros(B * h * w // 32, dtype=torch.int32, device=dev)
+            self.p_atoms, self.p_bonds = torch.zeros_like(self.d_atoms), torch.zeros_like(self.d_bonds)
+            self.p_rho, self.p_cnt = torch.zeros_like(self.d_rho), torch.zeros_like(self.d_cnt)
+            d.group_flags = self.group_flags.data_ptr()
+            d.prev_atoms, d.prev_bonds, d.prev_rho, d.prev_counts = (t.data_ptr() for t in (self.p_atoms, self.p_bonds, self.p_rho, self.p_cnt))
         self.d = d
+
+    def invalidate(self):
+        """sparse: somebody else wrote the target tensors -- the next run() zeroes them completely again"""
+        self._drawn = False
 
     def load(self, records):
         """records = list of B (atoms, bonds, rho) triples from parse_record; async H2D of a few KB"""
@@ -134,5 +153,8 @@ class TargetRasterizer:
     def run(self, stream=None):
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
+        if self.sparse:
+            self.d.incremental = 1 if self._drawn else 0
         L.check(self.lib.abc_rasterize_targets(C.byref(self.d), stream), "rasterize_targets")
+        self._drawn = True
         return self.targets

@@ -118,11 +118,33 @@ class Trainer:
         self._loss_acc = torch.zeros(2, dtype=torch.float64, device=dev)   # [sum of totals, count]
 
     # ------------------------------------------------------------------ data
-    def load_batch(self, imgs, targets):
-        """copy a batch into the static input buffers (what a loader's H2D copy would target directly)"""
+    def load_batch(self, imgs, targets=None):
+        """copy a batch into the static input buffers (what a loader's H2D copy would target directly); targets=None: the images
+        only (the targets come from a rasteriser that draws into self.targets)"""
         self.eng.img.copy_(imgs.reshape(self.eng.img.shape), non_blocking=True)
+        if targets is None:
+            return
+        if getattr(self, "_rasterizer", None) is not None:
+            raise L.AbcNetHipError("load_batch(dense targets) under use_sparse_targets(): the rasteriser's group flags would no longer "
+                                   "describe the maps; load records into the rasteriser, or call use_sparse_targets(None) first")
         for dst, src in zip(self.targets, targets):
             dst.copy_(src, non_blocking=True)
+
+    def use_sparse_targets(self, rasterizer):
+        """rasterizer: a TargetRasterizer(sparse=True, targets=self.targets) -- the fused heads pass then reads only the target planes of
+        the 32-pixel groups the rasteriser drew into (FusedHeadsLoss.use_target_flags); None: back to reading every plane.  The loss
+        and every gradient are unchanged bit for bit."""
+        if not hasattr(self.loss, "use_target_flags"):
+            raise L.AbcNetHipError("sparse targets need the fused heads pass (bf16, fused_heads=True)")
+        if rasterizer is None:
+            self.loss.use_target_flags(None)
+            self._rasterizer = None
+        else:
+            if not getattr(rasterizer, "sparse", False) or any(a.data_ptr() != b.data_ptr() for a, b in zip(rasterizer.targets, self.targets)):
+                raise L.AbcNetHipError("use_sparse_targets: a TargetRasterizer(sparse=True) over this Trainer's own target tensors")
+            self.loss.use_target_flags(rasterizer.group_flags)
+            self._rasterizer = rasterizer
+        self._graphs = None
 
     def reset_optimizer(self, lr):
         """train.py:84-85: a NEW Adam (moments reset) at the learning-rate drop"""

@@ -216,6 +216,8 @@ def main():
                     "img2smiles2.py:113-191 on the device inside the step")
     ap.add_argument("--raster", action="store_true", help="rasterise the targets on the device every step from compact records "
                     "(utils.py:83-228 on the GPU) instead of keeping pre-rasterised maps resident")
+    ap.add_argument("--dense-targets", action="store_true", help="(--raster) the round-4 form: zero all eight maps and draw every step, the "
+                    "fused heads pass reads every target plane (TargetRasterizer(sparse=False)): the A/B of the sparse form, not the default")
     ap.add_argument("--no-logits", action="store_true", help="(train) do not store the eight output maps: nothing reads them without "
                     "--metrics (Trainer(keep_logits=False)); NOT the default -- the headline line stores them as the reference does")
     ap.add_argument("--no-actbwd-epilogue", action="store_true", help="(train) every act_bwd pass as a launch of its own "
@@ -316,7 +318,11 @@ def main():
             # the data path a real loader would use: a few KB of records per batch, maps built where the loss reads them
             from abcnet_amd.raster import TargetRasterizer, parse_record
             from abcnet_amd.synthetic import random_annotations   # seeded annotation strings in the reference's format
-            rz = TargetRasterizer(a.batch, a.size // 4, max_atoms=64, max_bonds=64, targets=tr.targets)
+            # (sparse: the maps are zeroed once, later steps erase what the previous records drew, and the fused heads pass reads the
+            #  target planes only where the rasteriser's group flags say there is something: SURVEY K9)
+            rz = TargetRasterizer(a.batch, a.size // 4, max_atoms=64, max_bonds=64, targets=tr.targets, sparse=not a.dense_targets)
+            if rz.sparse:
+                tr.use_sparse_targets(rz)
             rz.load([parse_record(*random_annotations(30, 32, 900 + 16 * rank + i, size=a.size), h=a.size // 4) for i in range(a.batch)])
             _step = tr.step
 

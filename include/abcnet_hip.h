@@ -437,6 +437,10 @@ typedef struct abc_heads_fused_desc {
     void* keep_mask;                    /* optional, 3 * B*h*w * 16 bytes: abc_heads_fused_fwd_bwd leaves the dropout keep bits of the three
                                            wide heads' features here and abc_heads_fused_wgrad reads them instead of hashing every
                                            element again (set it for both calls, or for neither) */
+    /* optional (both or neither): abc_raster_desc.group_flags of the rasteriser that drew the target maps, and 512 zero bytes.  A wave whose
+     * 32 pixels carry no target of a head reads that head's targets from the zero bytes instead of the maps (train.py:107-125 on
+     * all-zero targets: identical arithmetic, no HBM traffic -- the maps hold ~62 non-zero 3x3 neighbourhoods per image) */
+    const uint32_t* target_flags; const void* zero_bytes;
 } abc_heads_fused_desc;
 int64_t abc_heads_fused_pack_bytes(void);
 int abc_heads_fused_chunks(const abc_heads_fused_desc* d);
@@ -470,6 +474,16 @@ typedef struct abc_raster_desc {
     const int32_t* atoms; const int32_t* n_atoms;   /* [B][max_atoms][5], [B] */
     const int32_t* bonds; const int32_t* n_bonds;   /* [B][max_bonds][5], [B] */
     const double* rho;                              /* [B][max_bonds] */
+    /* Sparse use of the maps (optional; all NULL / 0 = the plain form: zero all eight maps, draw).
+     *   group_flags  out, uint32 [B * h * w / 32]: bit i of word g set when head i's targets (atom 0, types 1, charges 2, hs 3, bond 4,
+     *                bond types 5, rho 6, omega 7) may be non-zero somewhere in pixels [32 g, 32 g + 32) of the flattened batch -- the unit a
+     *                wave of abc_heads_fused_fwd_bwd owns (abc_heads_fused_desc.target_flags); h * w a multiple of 32
+     *   prev_*       device scratch of the records' shapes (atoms, bonds, rho, counts [2][B]): the records the maps currently hold.
+     *   incremental  1: the maps hold exactly the drawing of prev_* (a previous call with the same buffers): ERASE those pixels instead of
+     *                zeroing 23 MB per image; 0: zero everything first.  Either way prev_* <- the new records. */
+    uint32_t* group_flags;
+    int32_t* prev_atoms; int32_t* prev_bonds; double* prev_rho; int32_t* prev_counts;
+    int32_t incremental;
 } abc_raster_desc;
 int abc_rasterize_targets(const abc_raster_desc* d, abc_stream_t stream);
 

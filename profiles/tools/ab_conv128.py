@@ -1,7 +1,7 @@
 """Same-process A/B of the 128-channel convolution forms (conv_fast.hip: lane = channel epilogue through LDS; conv_fast_lp.hip: lane = pixel epilogue from registers; "nw8": conv_fast8.hip, 8-wave workgroups)
 through the C ABI on the shapes that own the headline step: interleaved rounds, median and min per form, outputs compared bit for bit.
 
-  ABC_TOOL_LIB=scratch/lib_dbg.so python profiles/tools/ab_conv128.py [rounds] [nw8]      (the DEBUG flavour of the library: the forms other than
+  ABC_TOOL_LIB=scratch/lib_dbg.so python profiles/tools/ab_conv128.py [rounds] [all]      (the DEBUG flavour of the library: the forms other than
   the default exist only there)
 
 Forms are switched with the measurement hooks abc_debug_conv_lp / abc_debug_conv_nw.
@@ -27,6 +27,12 @@ lib.abc_debug_conv_lp.argtypes = [C.c_int]
 lib.abc_debug_conv_lp.restype = None
 lib.abc_debug_conv_var.argtypes = [C.c_int]
 lib.abc_debug_conv_var.restype = None
+try:      # (only in a library built with profiles/tools/conv_mixed_round_r05.patch applied: the mixed last round, measured slower)
+    lib.abc_debug_conv_mixed.argtypes = [C.c_int]
+    lib.abc_debug_conv_mixed.restype = None
+    HAVE_MIXED = True
+except AttributeError:
+    HAVE_MIXED = False
 
 
 def set_form(v):
@@ -35,6 +41,8 @@ def set_form(v):
     lib.abc_debug_conv_lp(v[0])
     lib.abc_debug_conv_var(v[1])
     lib.abc_debug_conv_nw(v[2])
+    if HAVE_MIXED:
+        lib.abc_debug_conv_mixed(0 if len(v) > 3 and v[3] == 0 else 1)      # (4th entry 0: no mixed last round -- the product's launch)
 
 
 dt = L.BF16
@@ -80,9 +88,13 @@ CASES = [
     make_case("heads conv1 data gradient 1024->128 @96 b16 + act_bwd", 16, 96, 1024, 128, "actb"),
     make_case("inference 128->128 @128 b64 folded", 64, 128, 128, 128, "infer"),
     make_case("decoder 256->128 @48 b16 fwd", 16, 48, 256, 128, "fwd"),
+    make_case("128->128 @96 b20 fwd (960 tiles: last round 448 of 512, no mixed round)", 20, 96, 128, 128, "fwd"),
+    make_case("128->128 @96 b12 fwd (576 tiles: last round 64 of 512)", 12, 96, 128, 128, "fwd"),
 ]
-FORMS = [("lc", (0, 0, 0)), ("lc 1x4", (0, 1, 0)), ("lc prio", (0, 2, 0)), ("lc 1x4 prio", (0, 3, 0)),
-         ("lp", (1, 0, 0)), ("lp 1x4", (1, 1, 0)), ("lp prio", (1, 2, 0)), ("lp 1x4 prio", (1, 3, 0))] + ([("nw8", (0, 0, 8))] if "nw8" in sys.argv else [])
+FORMS = [("product", (0, 0, 0, 0))] + ([("mixed round", (0, 0, 0, 1))] if HAVE_MIXED else [])
+if "all" in sys.argv:
+    FORMS += [("lc 1x4", (0, 1, 0, 0)), ("lc prio", (0, 2, 0, 0)), ("lc 1x4 prio", (0, 3, 0, 0)),
+              ("lp", (1, 0, 0, 0)), ("lp 1x4", (1, 1, 0, 0)), ("lp prio", (1, 2, 0, 0)), ("lp 1x4 prio", (1, 3, 0, 0)), ("nw8", (0, 0, 8, 0))]
 
 
 def graph_of(run):

@@ -76,3 +76,52 @@ def test_raster_rejects_out_of_range_and_cpu():
         parse_record("C:600,10,0;", "", h=128)
     with pytest.raises(Exception):
         TargetRasterizer(1, 32, targets=[torch.zeros(1)] * 8)
+
+
+def test_sparse_rasteriser_erases_its_own_drawing_and_flags_every_target():
+    """TargetRasterizer(sparse=True) over a SEQUENCE of batches (dense overlapping items, an empty image, batches of different sizes of
+    molecules): after every run() the eight maps equal the oracle's for THAT batch bit for bit -- i.e. the incremental form erased
+    everything the previous records had drawn, nothing else, and the first call zeroed stale contents -- and the group flags cover
+    every non-zero target: a 32-pixel group whose flag bit of a head is clear holds only zeros in that head's planes (the contract
+    abc_heads_fused_fwd_bwd relies on).  invalidate() makes the next run zero the maps completely again."""
+    B, h = 3, 96
+    shapes = [(B, 1, h, h), (B, 14, h, h), (B, 3, h, h), (B, 2, h, h), (B, 1, h, h), (B, 6, 60, h, h), (B, 60, h, h), (B, 60, h, h)]
+    dts = [torch.float32] * 6 + [torch.float64] * 2
+    targets = [torch.full(s, 5.0, dtype=dt, device=DEV) for s, dt in zip(shapes, dts)]      # stale contents
+    rz = TargetRasterizer(B, h, max_atoms=120, max_bonds=120, targets=targets, sparse=True)
+    bit_of = [0, 1, 2, 3, 4, 5, 6, 7]
+
+    def check(batch_seed, counts):
+        recs, want = [], []
+        for b in range(B):
+            na, nb = counts[b]
+            a, q = ro.random_annotations(na, nb, batch_seed + b, size=4 * h) if na + nb else ("", "")
+            recs.append(parse_record(a, q, h=h))
+            want.append(ro.rasterize(a, q, h=h))
+        rz.load(recs)
+        rz.run()
+        torch.cuda.synchronize()
+        flags = rz.group_flags.cpu().numpy().astype(np.uint32).reshape(B, h * h // 32)
+        for mi in range(8):
+            got = targets[mi].cpu().numpy()
+            for b in range(B):
+                assert np.array_equal(got[b], want[b][mi]), (batch_seed, b, mi)
+                # non-zero anywhere in the head's planes of a pixel group => the group's flag bit is set
+                nz = (got[b].reshape(-1, h * h) != 0).any(axis=0).reshape(-1, 32).any(axis=1)
+                assert not (nz & (((flags[b] >> bit_of[mi]) & 1) == 0)).any(), (batch_seed, b, mi)
+        return flags
+
+    f1 = check(100, [(100, 100), (0, 0), (30, 32)])
+    assert f1[1].sum() == 0 and f1[0].any() and f1[2].any()
+    check(200, [(5, 4), (60, 70), (0, 0)])          # fewer items than before: the old ones must be gone
+    check(300, [(30, 32), (30, 32), (30, 32)])
+    check(300, [(30, 32), (30, 32), (30, 32)])      # the same records again (what a benchmark loop does)
+    for t in targets:
+        t.fill_(9)                                  # somebody else wrote the maps
+    rz.invalidate()
+    f5 = check(400, [(10, 10), (0, 0), (1, 1)])
+    assert f5[1].sum() == 0
+    # sparsity the fused heads pass lives on: at 30 atoms + 32 bonds per 96 x 96 image (a 3 x 3 neighbourhood touches three 32-pixel
+    # groups) about a quarter of the groups carry a target of a given head
+    f = check(500, [(30, 32), (30, 32), (30, 32)])
+    assert ((f >> 5) & 1).mean() < 0.4 and (f & 1).mean() < 0.4
