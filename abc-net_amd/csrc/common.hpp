@@ -717,11 +717,13 @@ struct HaloFetch {
 // instruction issue, not by registers): voff = byte offset of the segment in chunk 0 (out-of-range marker when the
 // pixel lies outside the image -> the buffer load returns zeros), dst = LDS byte offset.  Per chunk the issue is
 // NMAX buffer loads with the chunk's byte offset in the scalar operand, nothing else.
-template <typename InT, typename CT, int CK, int NMAX, int NTHR>
+// NSET register sets for the raw data (issue<S> / commit<S>): with two, the chunk after next can be in flight while the next one waits to
+// be committed (the small tiles of the deep levels, whose chunk of matrix work is shorter than a trip to memory).
+template <typename InT, typename CT, int CK, int NMAX, int NTHR, int NSET = 1>
 struct HaloTile {
     static constexpr int NV = Frag<CT>::NV;
     static constexpr int SEGS = CK / NV;
-    RawBuf<InT, NV> raw[NMAX];
+    RawBuf<InT, NV> raw[NSET][NMAX];
     unsigned voff[NMAX];
     int dst[NMAX];  // < 0: this thread has no such segment
 
@@ -742,12 +744,12 @@ struct HaloTile {
         }
     }
     // coff = byte offset of the chunk's first channel relative to chunk 0
-    __device__ inline void issue(__amdgpu_buffer_rsrc_t rs, unsigned coff) {
+    template <int S = 0> __device__ inline void issue(__amdgpu_buffer_rsrc_t rs, unsigned coff) {
 #pragma unroll
-        for (int i = 0; i < NMAX; ++i) raw[i].ld2(rs, voff[i], coff);
+        for (int i = 0; i < NMAX; ++i) raw[S][i].ld2(rs, voff[i], coff);
     }
     // lcoef = LDS table [3][cstride] of (scale, shift, slope) at the chunk's first channel, or null
-    __device__ inline void commit(char* sA, const float* lcoef, int cstride, int tid) {
+    template <int S = 0> __device__ inline void commit(char* sA, const float* lcoef, int cstride, int tid) {
         const int cch = (tid % SEGS) * NV;
         float sc[NV], sh[NV], sl[NV];
         if (lcoef != nullptr) {
@@ -758,10 +760,10 @@ struct HaloTile {
         for (int i = 0; i < NMAX; ++i) {
             if (dst[i] >= 0) {
                 if constexpr (sizeof(InT) == sizeof(CT)) {
-                    if (lcoef == nullptr) { *(u32x4*)(sA + dst[i]) = raw[i].v; continue; }
+                    if (lcoef == nullptr) { *(u32x4*)(sA + dst[i]) = raw[S][i].v; continue; }
                 }
                 float v[NV];
-                raw[i].get(v);
+                raw[S][i].get(v);
                 if (lcoef != nullptr && !(voff[i] >> 31)) {
                     abc_act_n<NV>(v, sc, sh, sl);
                 }

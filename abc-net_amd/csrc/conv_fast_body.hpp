@@ -7,6 +7,7 @@
 #include "conv_fast.hpp"
 #include <stdlib.h>
 #include <math.h>
+#include <type_traits>
 
 namespace abc_cf {
 
@@ -169,7 +170,12 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
     const unsigned bvoff0 = (unsigned)tl0 * tap_stride + (unsigned)rem0 * 16u;
     const int bdst0 = (tl0 * BN + rem0 / SEGS) * PS + (rem0 % SEGS) * 16;
     u32x4 breg[2][NB];
-    HaloTile<InT, CT, CK, STATIC ? fa_static(MT) : (STRIDE == 2 ? fa_stride2() : (fa_max(MT) + NW / 4 - 1) / (NW / 4)), FT> apre;
+    constexpr bool DEEP = WD == 9 && !F8C && !STATIC && NW == 4 && !LP && TN == 1 && TM <= 2;      // (see the weights-direct loop)
+    // DEEP2 (measured, off): the halo of chunk c + 2 in flight while chunk c multiplies (two staging register sets, chunk k in set k & 1).
+    // It does NOT help -- 24.8 -> 26.2 us on the 24 x 24 layers, 24.3 -> 26.7 us on the 12 x 12 ones: a chunk's end waits for the commit's
+    // arithmetic and the barrier, not for the halo loads (profiles/README.md round 5)
+    constexpr bool DEEP2 = false;
+    HaloTile<InT, CT, CK, STATIC ? fa_static(MT) : (STRIDE == 2 ? fa_stride2() : (fa_max(MT) + NW / 4 - 1) / (NW / 4)), FT, DEEP2 ? 2 : 1> apre;
 
     unsigned w_n0 = 0;  // byte offset of the n-block's first weight row
     auto b_issue = [&](u32x4* set, int c, int g) {
@@ -297,7 +303,13 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         // activation halo only: 3 instead of 5 ds_read_b128 per 6 MFMAs (the LDS pipe was as busy as the matrix
         // pipe), no weight staging writes, and one workgroup barrier per 64-byte chunk instead of one per tap pair.
         constexpr int WNT = WD ? WD : 1;              // taps (static: the loop is fully unrolled)
-        constexpr int RING = WD == 25 ? 5 : 3;        // taps in flight; divides the tap count
+        // DEEP (small wave tiles: one or two MFMAs per 16-byte K-slice -- the 64-channel blocks of the 24 x 24 and 12 x 12 levels): a tap's
+        // matrix work is 64-128 cycles, far less than an LDS round trip (~130) or a trip to the L2 (500-900).  The three-tap weight ring
+        // and the half-tap fragment prefetch of the big tile leave every K-slice waiting on its operands (measured: these launches keep
+        // the matrix pipe 10-20 % busy).  So: the weight fragments of a WHOLE chunk in flight (ring of 9: TN = 1, 72 registers -- these
+        // instantiations use 120-150 of their 256) and the pixel fragments of tap t + 2 read while tap t multiplies.
+        // Measured (same box, rocprofv3 of the graph run): the 64-channel blocks at 24 x 24 26.4 -> 24.8 us, at 12 x 12 29.3 -> 24.3 us.
+        constexpr int RING = WD == 25 ? 5 : (DEEP ? 9 : 3);        // taps in flight; divides the tap count
         static_assert(WNT % RING == 0 || !WD, "ring must divide the tap count");
         u32x4 bq[(WD && !F8C) ? RING : 1][TN][2];
         i32x8 bq8[F8C ? RING : 1][TN];     // e4m3: a tile's B operand is one 8-register tuple (both 16-byte halves)
@@ -323,6 +335,9 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         if constexpr (WD != 0) {
 #pragma unroll
             for (int q = 0; q < RING; ++q) bq_load(q, 0, q);
+        }
+        if constexpr (DEEP2) {
+            if (a.nchunks > 1) apre.template issue<1>(rsA, (unsigned)CK * (unsigned)sizeof(InT));
         }
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -376,12 +391,14 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         // chunk's halo is issued when a chunk opens and committed when it closes.
         if constexpr (WD != 0) {
             static_assert(NR == 2 && !STATIC, "WD: 64-byte chunks, streamed weights");
-            for (int c = 0; c < a.nchunks; ++c) {
+            auto chunk = [&](auto PARV, const int c) {
+                constexpr int PAR = decltype(PARV)::value;      // DEEP2: c & 1, the staging set that held this chunk and takes chunk c + 2
                 const char* sAc = sA + ((a.a_bufs == 2) ? ((c + cpar) & 1) * a.sA_bytes : 0);
                 const bool more = c + 1 < a.nchunks;
-                if (more) {
-                    apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
-                } else {
+                if (DEEP2 ? (c + 2 < a.nchunks) : more) {
+                    if constexpr (DEEP2) apre.template issue<PAR>(rsA, (unsigned)((c + 2) * CK) * (unsigned)sizeof(InT));
+                    else apre.issue(rsA, (unsigned)((c + 1) * CK) * (unsigned)sizeof(InT));
+                } else if (!more) {
                     // last chunk: the staging registers are free -> the NEXT tile's first halo chunk lands under this
                     // chunk's MFMAs and the epilogue (a workgroup's prologue measured 5 of its 30 us, with no MFMA issued)
                     const int nt = tile_of(round + 1);
@@ -423,6 +440,33 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
 #endif
                         __builtin_amdgcn_sched_barrier(0);
                         bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
+                    }
+                } else if constexpr (DEEP) {
+                    // pixel fragments: a ring of three taps (both 16-byte halves), two taps ahead of the MFMAs
+                    frag_t fr[3][2][TM];
+                    auto fr_read = [&](int t) {
+                        const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) fr[t % 3][kk][i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16 * kk);
+                    };
+                    fr_read(0);
+                    fr_read(1);
+#pragma unroll
+                    for (int t = 0; t < WNT; ++t) {
+                        if (t + 2 < WNT) fr_read(t + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fr[t % 3][kk][i], *(const frag_t*)&bq[t][j][kk]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // the slot is free: the same tap of the NEXT chunk (past the last chunk the offsets run off the buffer and the loads
+                        // return zeros -- unconditional, so that vmcnt stays exact)
+                        bq_load(t, c + 1, t);
                     }
                 } else {
                 frag_t fa0[TM], fa1[TM];
@@ -471,16 +515,26 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
                 }
                 }
                 if (more) {
+                    constexpr int CS = DEEP2 ? 1 - PAR : 0;      // the set that holds chunk c + 1
                     if (a.a_bufs == 2) {
-                        apre.commit(sA + ((c + 1 + cpar) & 1) * a.sA_bytes, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
+                        apre.template commit<CS>(sA + ((c + 1 + cpar) & 1) * a.sA_bytes, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
                     } else {
                         __syncthreads();
-                        apre.commit(sA, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
+                        apre.template commit<CS>(sA, lcoef ? lcoef + (c + 1) * CK : nullptr, a.cstride, tid);
                     }
                 }
                 // next chunk's halo visible; after the last chunk: the halo is dead (the epilogue aliases it) -- LP's epilogue uses no
                 // LDS staging, and with two halo buffers the next tile's first chunk goes into the OTHER buffer: no barrier there
                 if (!(LP && !more && a.a_bufs == 2)) __syncthreads();
+            };
+            if constexpr (DEEP2) {
+                // (two chunks per trip: the staging set of a chunk is a compile-time index)
+                for (int c = 0; c < a.nchunks; c += 2) {
+                    chunk(std::integral_constant<int, 0>{}, c);
+                    if (c + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, c + 1);
+                }
+            } else {
+                for (int c = 0; c < a.nchunks; ++c) chunk(std::integral_constant<int, 0>{}, c);
             }
         } else {
         int c = 0, g = 0;
