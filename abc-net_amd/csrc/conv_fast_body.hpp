@@ -9,6 +9,10 @@
 #include <math.h>
 #include <type_traits>
 
+#ifndef ABC_DEEP_TM
+#define ABC_DEEP_TM 2      // deep operand pipelining (DEEP below) for wave tiles of up to this many 32-pixel M-tiles x one 32-channel N-tile
+#endif
+
 namespace abc_cf {
 
 constexpr int FT = 256;      // threads per workgroup
@@ -170,7 +174,7 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
     const unsigned bvoff0 = (unsigned)tl0 * tap_stride + (unsigned)rem0 * 16u;
     const int bdst0 = (tl0 * BN + rem0 / SEGS) * PS + (rem0 % SEGS) * 16;
     u32x4 breg[2][NB];
-    constexpr bool DEEP = WD == 9 && !F8C && !STATIC && NW == 4 && !LP && TN == 1 && TM <= 2;      // (see the weights-direct loop)
+    constexpr bool DEEP = WD == 9 && !F8C && !STATIC && NW == 4 && !LP && TN == 1 && TM <= ABC_DEEP_TM;      // (see the weights-direct loop)
     // DEEP2 (measured, off): the halo of chunk c + 2 in flight while chunk c multiplies (two staging register sets, chunk k in set k & 1).
     // It does NOT help -- 24.8 -> 26.2 us on the 24 x 24 layers, 24.3 -> 26.7 us on the 12 x 12 ones: a chunk's end waits for the commit's
     // arithmetic and the barrier, not for the halo loads (profiles/README.md round 5)
@@ -309,7 +313,7 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         // the matrix pipe 10-20 % busy).  So: the weight fragments of a WHOLE chunk in flight (ring of 9: TN = 1, 72 registers -- these
         // instantiations use 120-150 of their 256) and the pixel fragments of tap t + 2 read while tap t multiplies.
         // Measured (same box, rocprofv3 of the graph run): the 64-channel blocks at 24 x 24 26.4 -> 24.8 us, at 12 x 12 29.3 -> 24.3 us.
-        constexpr int RING = WD == 25 ? 5 : (DEEP ? 9 : 3);        // taps in flight; divides the tap count
+        constexpr int RING = WD == 25 ? 5 : ((DEEP && TM <= 2) ? 9 : 3);        // taps in flight; divides the tap count
         static_assert(WNT % RING == 0 || !WD, "ring must divide the tap count");
         u32x4 bq[(WD && !F8C) ? RING : 1][TN][2];
         i32x8 bq8[F8C ? RING : 1][TN];     // e4m3: a tile's B operand is one 8-register tuple (both 16-byte halves)
@@ -442,31 +446,32 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
                         bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
                     }
                 } else if constexpr (DEEP) {
-                    // pixel fragments: a ring of three taps (both 16-byte halves), two taps ahead of the MFMAs
-                    frag_t fr[3][2][TM];
+                    // pixel fragments: a ring of AD taps (both 16-byte halves), AD - 1 taps ahead of the MFMAs
+                    constexpr int AD = TM <= 2 ? 3 : 2;
+                    frag_t fr[AD][2][TM];
                     auto fr_read = [&](int t) {
                         const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                            for (int i = 0; i < TM; ++i) fr[t % 3][kk][i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16 * kk);
+                            for (int i = 0; i < TM; ++i) fr[t % AD][kk][i] = *(const frag_t*)(sAc + aBase[i] + aoff + 16 * kk);
                     };
-                    fr_read(0);
-                    fr_read(1);
+#pragma unroll
+                    for (int t = 0; t < AD - 1; ++t) fr_read(t);
 #pragma unroll
                     for (int t = 0; t < WNT; ++t) {
-                        if (t + 2 < WNT) fr_read(t + 2);
+                        if (t + AD - 1 < WNT) fr_read(t + AD - 1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                                for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fr[t % 3][kk][i], *(const frag_t*)&bq[t][j][kk]);
+                                for (int j = 0; j < TN; ++j) mma16B(acc[i][j], fr[t % AD][kk][i], *(const frag_t*)&bq[t % RING][j][kk]);
                         __builtin_amdgcn_sched_barrier(0);
-                        // the slot is free: the same tap of the NEXT chunk (past the last chunk the offsets run off the buffer and the loads
-                        // return zeros -- unconditional, so that vmcnt stays exact)
-                        bq_load(t, c + 1, t);
+                        // the slot is free: tap t + RING (of this chunk or the next; past the last chunk the offsets run off the buffer and
+                        // the loads return zeros -- unconditional, so that vmcnt stays exact)
+                        bq_load(t % RING, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
                     }
                 } else {
                 frag_t fa0[TM], fa1[TM];

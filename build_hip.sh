@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/abc-net_amd/csrc"
 OUT=../libabcnet_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $ABC_EXTRA_FLAGS"   # (ABC_EXTRA_FLAGS: -D switches of measured A/B builds, e.g. -DABC_DEEP_TM=4)
 [ -n "$ABC_RESOURCE_USAGE" ] && FLAGS="$FLAGS -Rpass-analysis=kernel-resource-usage"
 # debug build (ABC_KERNEL_DEBUG=1 ./build_hip.sh): phase-skipping ablations, in-kernel phase timestamps and the
 # environment-driven experiment switches (abc_knob in common.hpp); the production library reads no environment variable

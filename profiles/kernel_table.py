@@ -53,7 +53,7 @@ def short(name):
                 break
             except (OSError, subprocess.SubprocessError):
                 continue
-    out = out.replace("(anonymous namespace)::", "").replace("void ", "")
+    out = out.replace("(anonymous namespace)::", "").replace("abc_cf::", "").replace("void ", "")
     depth = 0
     for i, ch in enumerate(out):       # cut the argument list: the first '(' outside the template brackets
         if ch == "<":

@@ -6,6 +6,8 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import torch
 import abcnet_amd
 from abcnet_amd import _lib as L
+if os.environ.get("ABC_TOOL_LIB"):
+    L.LIB_PATH = os.path.abspath(os.environ["ABC_TOOL_LIB"])
 import hiputil as U
 from abcnet_amd.engine import taps_square
 lib = L.load()
@@ -43,9 +45,14 @@ for H, Cin, Cout in SHAPES:
                 run = lambda: L.check(lib.abc_conv_fwd(C.byref(d), U.stream()), "conv")
                 for _ in range(5): run()
                 torch.cuda.synchronize()
+                # (40 launches as ONE hipGraph: launched one by one from Python, 20-us kernels are bound by the host)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    for _ in range(40): run()
+                gr.replay(); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(40): run()
+                gr.replay()
                 e1.record(); torch.cuda.synchronize()
                 res.append((form, "default" if bn is None else "forced", bn_.value, mt_.value, e0.elapsed_time(e1) / 40 * 1000))
     for form in ("fwd", "plain"):
