@@ -155,14 +155,21 @@ class HeadsFusedDesc(C.Structure):
                 ("wgrad_work", vp), ("keep_mask", vp), ("target_flags", vp), ("zero_bytes", vp)]
 
 
+class ConvTDesc(C.Structure):
+    _fields_ = [("src", ActSrc), ("w", vp), ("bias", vp), ("y", vp), ("dtype", i32), ("B", i32), ("Hin", i32), ("Win", i32), ("cin_off", i32),
+                ("Cin", i32), ("Hout", i32), ("Wout", i32), ("ldy", i32), ("cout_off", i32), ("Cout", i32), ("Cout_pad", i32)]
+
+
 _STRUCTS = [ActSrc, ConvDesc, PackDesc, BnFwdDesc, ActBwdDesc, BnBwdDesc, BnApplyDesc, WgradDesc, WgradReduceDesc,
             LossDesc, LossFinDesc, AdamDesc, NmsDesc, CbamChannelDesc, CbamPixDesc, CbamConv7Desc, MetricsDesc, ExtractDesc, RasterDesc,
-            HeadsFusedDesc, HeadsEpi]
+            HeadsFusedDesc, HeadsEpi, ConvTDesc]
 
 # every symbol include/abcnet_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
 SYMBOLS = {
     "abc_conv_stat_blocks": (C.c_int, [P(ConvDesc)]),
+    "abc_convt_fused_ok": (C.c_int, [P(ConvTDesc)]),
+    "abc_convt_fused_fwd": (C.c_int, [P(ConvTDesc), vp]),
     "abc_conv_actbwd_ok": (C.c_int, [P(ConvDesc)]),
     "abc_conv_fwd_batch": (C.c_int, [P(ConvDesc), C.c_int32, C.c_void_p]),
     "abc_conv_batch_ok": (C.c_int, [P(ConvDesc), C.c_int32]),

@@ -590,6 +590,7 @@ extern "C" int abc_sizeof(int which) {
         case 18: return (int)sizeof(abc_raster_desc);
         case 19: return (int)sizeof(abc_heads_fused_desc);
         case 20: return (int)sizeof(abc_heads_epi);
+        case 21: return (int)sizeof(abc_convt_desc);
         default: return -1;
     }
 }

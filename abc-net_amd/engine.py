@@ -131,7 +131,7 @@ class Engine:
     def __init__(self, variant, in_channels, heads, params, grads, buffers, counters, layout, B, H, W, dtype, train,
                  dropout_p=0.2, device="cuda", drop_seed=0x1234ABCD, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False,
                  guards=False, heads_epilogue=False, actbwd_epilogue=True, merge_reduce=True, nms_heads=False, decode=False,
-                 dual_wgrad=True):
+                 dual_wgrad=True, fused_convt=True):
         """merge_reduce=False: every slab reduction and every BatchNorm-backward finaliser a launch of its own;
         dual_wgrad=False: the BatchNorm-backward apply as a pass of its own instead of on the weight gradient's load (the A/B of that
         fusion; part of the engine cache key like the other plan switches);
@@ -151,6 +151,7 @@ class Engine:
         # not move while this plan lives (checked before every run_*; set_reserved_cus refuses to move it)
         self.reserved_cus = self.lib.abc_get_reserved_cus()
         self.dual_wgrad = bool(dual_wgrad)
+        self.fused_convt = bool(fused_convt)      # False: the ConvTranspose forward as four batched phase convolutions (the A/B of convt_fused.hip)
         self.variant, self.heads, self.B, self.H, self.W = variant, list(heads), B, H, W
         self.train = train
         # eval-mode graph with every BatchNorm folded into the convolution in front of it: the weights are
@@ -823,9 +824,31 @@ class Engine:
         crop_y, crop_x = Hs == 2 * lh, Ws == 2 * lw
         rows_pad = -(-half // 32) * 32
         phases, items = [], []
+        # all four phases in ONE pass over the input where the library serves it (abc_convt_fused_fwd: bf16, both axes cropped): the nine
+        # weight slices of the phases one after the other in one buffer, fragment-contiguous (abc_pack_desc.layout 1)
+        fused = None
+        if self.fused_convt and crop_y and crop_x and self.dt == L.BF16 and low.dt == L.BF16:
+            dT = L.ConvTDesc()
+            low.fill(dT.src)
+            dT.bias, dT.y, dT.dtype = self.P(name + ".up.bias"), cat.data_ptr(), L.BF16
+            dT.B, dT.Hin, dT.Win, dT.cin_off, dT.Cin = self.B, lh, lw, low.coff, cin
+            dT.Hout, dT.Wout, dT.ldy, dT.cout_off, dT.Cout, dT.Cout_pad = Hs, Ws, Ctot, half, half, rows_pad
+            if self.lib.abc_convt_fused_ok(C.byref(dT)):
+                fused = dT
+                wall = self.packed(9, cin, rows_pad)
+                dT.w = wall.data_ptr()
+                slice_elems = wall.numel() // 9
+                first_slice = {(0, 0): 0, (0, 1): 1, (1, 0): 3, (1, 1): 5}
         for py in (0, 1):
             for px in (0, 1):
                 taps = convT_phase_taps(py, px, crop_y, crop_x)
+                if fused is not None:
+                    wp = wall[first_slice[(py, px)] * slice_elems:(first_slice[(py, px)] + len(taps)) * slice_elems]
+                    self._w_layout[wp.data_ptr()] = 1
+                    self.emit_pack(name + ".up.weight", wp, 2, half, cin, 3, rows_pad, cin, py=convT_pack_parity(py, crop_y),
+                                   px=convT_pack_parity(px, crop_x))
+                    phases.append(wp)
+                    continue
                 wp = self.packed(len(taps), cin, rows_pad)
                 self.emit_pack(name + ".up.weight", wp, 2, half, cin, 3, rows_pad, cin, py=convT_pack_parity(py, crop_y),
                                px=convT_pack_parity(px, crop_x))
@@ -834,7 +857,14 @@ class Engine:
                 self.emit_conv(self.fwd_ops, low, wp, self.P(name + ".up.bias"), cat, self.dt, Hs, Ws, Ctot, half, half, taps,
                                grid=(gh, gw), om=2, oy0=py, ox0=px, what="fwd %s.up phase %d%d" % (name, py, px), collect=items)
                 phases.append(wp)
-        self.emit_conv_batch(self.fwd_ops, items, "fwd %s.up (4 phases)" % name)
+        if fused is not None:
+            self.keep.append(fused)
+            lib = self.lib
+            meta = {"kernel": "convt_fused<bf16>", "flops": 2.0 * self.B * lh * lw * cin * half * 9,
+                    "bytes": float(self.B * lh * lw * cin * 2 + self.B * Hs * Ws * half * 2)}
+            self.fwd_ops.append((lambda _r, st, d=fused: lib.abc_convt_fused_fwd(C.byref(d), st), None, "fwd %s.up (4 phases, one pass)" % name, (), meta))
+        else:
+            self.emit_conv_batch(self.fwd_ops, items, "fwd %s.up (4 phases)" % name)
         rec = Rec(kind="convT", cname=name + ".up", src=low, cin=cin, cout=half, H=Hs, W=Ws, ld=Ctot, coff=half, y=cat,
                   taps_bwd=convT_dgrad_taps(crop_y, crop_x))
         self.recs.append(rec)

@@ -278,7 +278,7 @@ class UNetBase(nn.Module):
 
     # ------------------------------------------------------------------ engines
     def _engine_for(self, x, train, fold_bn=False, fused_heads=False, batched_heads=True, fp8=False, guards=False, heads_epilogue=False,
-                    actbwd_epilogue=True, merge_reduce=True, nms_heads=False, decode=False, dual_wgrad=True):
+                    actbwd_epilogue=True, merge_reduce=True, nms_heads=False, decode=False, dual_wgrad=True, fused_convt=True):
         if not x.is_cuda:
             raise L.AbcNetHipError("abcnet_amd runs on an MI355X only (got a %s tensor); there is no CPU fallback" % x.device)
         if x.device != self._flat.device:
@@ -290,7 +290,7 @@ class UNetBase(nn.Module):
         if Cc != self.n_channels:
             raise ValueError("expected %d input channels, got %d" % (self.n_channels, Cc))
         key = (B, H, W, bool(train), self.compute_dtype, self.dropout_seed, bool(fold_bn), bool(fused_heads), bool(batched_heads), bool(fp8), bool(guards), bool(heads_epilogue), bool(actbwd_epilogue), bool(merge_reduce),
-               bool(nms_heads), bool(decode), bool(dual_wgrad), L.load().abc_get_reserved_cus())     # (grid sizes and statistics rows follow abc_set_reserved_cus)
+               bool(nms_heads), bool(decode), bool(dual_wgrad), bool(fused_convt), L.load().abc_get_reserved_cus())     # (grid sizes and statistics rows follow abc_set_reserved_cus)
         eng = self._engines.get(key)
         if eng is None or eng.params.data_ptr() != self._flat.data_ptr():
             if self._flat_grad is None or self._flat_grad.device != x.device:
@@ -304,7 +304,7 @@ class UNetBase(nn.Module):
                              self._counters, (self._lay_p, self._lay_b, self._lay_c), B, H, W, self.compute_dtype, train,
                              dropout_p=self.dropout_p, device=x.device, drop_seed=self.dropout_seed, fold_bn=fold_bn,
                              fused_heads=fused_heads, batched_heads=batched_heads, fp8=fp8, guards=guards, heads_epilogue=heads_epilogue, nms_heads=nms_heads,
-                             actbwd_epilogue=actbwd_epilogue, merge_reduce=merge_reduce, decode=decode, dual_wgrad=dual_wgrad)
+                             actbwd_epilogue=actbwd_epilogue, merge_reduce=merge_reduce, decode=decode, dual_wgrad=dual_wgrad, fused_convt=fused_convt)
             self._engines[key] = eng
         return eng
 

@@ -22,7 +22,7 @@ class Trainer:
     def __init__(self, model, batch, height, width, lr=2.5e-4, weight_decay=1e-8, use_graph=True, bucket_mb=8.0,
                  process_group=None, device=None, metrics=False, broadcast_buffers="lazy", fused_heads=True, keep_logits=True,
                  batched_heads=True, exchange="all_reduce", force_exchange=False, guards=False, actbwd_epilogue=True, merge_reduce=True,
-                 reserve_cus=None, dual_wgrad=True):
+                 reserve_cus=None, dual_wgrad=True, fused_convt=True):
         """broadcast_buffers: how DDP's per-forward buffer broadcast (multi_gpu_train.py:52, broadcast_buffers=True) is
         mirrored when world > 1 -- "step": rank 0's BatchNorm buffers are broadcast at the start of every step, literally
         as DDP does; "lazy" (default): when sync_buffers() is called -- evaluate() calls it; before a checkpoint of a rank
@@ -45,6 +45,7 @@ class Trainer:
         the plan is built and REFUSED when plans built under another value are alive; None (default) = leave the process's
         current value alone -- 0 unless somebody set it).
         dual_wgrad=False: the BatchNorm-backward apply as passes of their own (Engine(dual_wgrad=...): the A/B of that fusion).
+        fused_convt=False: the ConvTranspose forward as four batched phase convolutions (Engine(fused_convt=...): the A/B of convt_fused.hip).
         force_exchange: segment the plan and run the bucket exchanges although the group has one rank (testing RCCL's launch
         mechanics between graph segments on a one-GPU box)."""
         if not torch.cuda.is_available():
@@ -74,7 +75,7 @@ class Trainer:
             # (fused_heads: the heads' 1x1 convolutions, the loss and the way back as one pass where the engine can -- bf16)
             # (guards: the debug plan -- every buffer between guard bands, Engine.check_guards())
             self.eng = model._engine_for(x0, True, fused_heads=fused_heads, batched_heads=batched_heads, guards=guards,
-                                         actbwd_epilogue=actbwd_epilogue, merge_reduce=merge_reduce, dual_wgrad=dual_wgrad)
+                                         actbwd_epilogue=actbwd_epilogue, merge_reduce=merge_reduce, dual_wgrad=dual_wgrad, fused_convt=fused_convt)
         eng = self.eng
         h, w = eng.h, eng.w
         B = batch

@@ -222,6 +222,8 @@ def main():
                     "--metrics (Trainer(keep_logits=False)); NOT the default -- the headline line stores them as the reference does")
     ap.add_argument("--no-actbwd-epilogue", action="store_true", help="(train) every act_bwd pass as a launch of its own "
                     "(Trainer(actbwd_epilogue=False)): the A/B of the fused data-gradient epilogue, not the default")
+    ap.add_argument("--no-fused-convt", action="store_true", help="(train) the ConvTranspose forward as four batched phase convolutions "
+                    "(Trainer(fused_convt=False)): the A/B of the one-pass kernel, not the default")
     ap.add_argument("--no-merge-reduce", action="store_true", help="(train) slab reductions and BatchNorm-backward finalisers as launches of "
                     "their own (Trainer(merge_reduce=False)): the A/B of the merged launch, not the default")
     ap.add_argument("--exchange", default=None, choices=["all_reduce", "rs_ag", "direct"],
@@ -309,7 +311,7 @@ def main():
     else:
         tr = Trainer(model, a.batch, a.size, a.size, use_graph=not a.no_graph, metrics=a.metrics, keep_logits=not a.no_logits,
                      actbwd_epilogue=not a.no_actbwd_epilogue, merge_reduce=not a.no_merge_reduce, bucket_mb=a.bucket_mb,
-                     exchange=a.exchange or "all_reduce", reserve_cus=a.reserve_cus, dual_wgrad=not nodual)
+                     exchange=a.exchange or "all_reduce", reserve_cus=a.reserve_cus, dual_wgrad=not nodual, fused_convt=not a.no_fused_convt)
         if world > 1 and a.exchange is not None and tr.reducer.mode != a.exchange:
             raise SystemExit("bench.py --exchange %s: the reducer runs %r (%s)" % (a.exchange, tr.reducer.mode, tr.reducer.fallback_reason))
         tgs = synthetic_targets(a.batch, a.size // 4, seed=1 + rank)

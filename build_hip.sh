@@ -27,7 +27,7 @@ stale() {
 
 OBJS=""
 pids=""
-for f in conv_igemm conv_fast conv_fast8 conv_fast_lp conv_narrow stem heads heads_fused wgrad wgrad_narrow bn_act loss misc cbam metrics extract raster; do
+for f in conv_igemm conv_fast conv_fast8 conv_fast_lp convt_fused conv_narrow stem heads heads_fused wgrad wgrad_narrow bn_act loss misc cbam metrics extract raster; do
   if stale $f; then
     hipcc $FLAGS -MD -MF $f.d -c $f.hip -o $f.o &
     pids="$pids $!"

@@ -160,6 +160,25 @@ int abc_conv_stat_blocks(const abc_conv_desc* d);
  * interleaved output pixels) -- and one after the other otherwise: the result is that of n abc_conv_fwd calls either way.
  * abc_conv_batch_ok tells which of the two it will be (1: one launch). */
 int abc_conv_fwd_batch(const abc_conv_desc* d, int32_t n, abc_stream_t stream);
+
+/* nn.ConvTranspose2d(Cin -> Cout, kernel 3, stride 2) + the crop of the first output row and column that unet.py:51-56 applies when the
+ * skip tensor has 2n rows / columns (every level when the input size is a multiple of 32), forward, bias included: all four output-parity
+ * phases in ONE pass over the input (convt_fused.hip) -- the same result as the four abc_conv_fwd phase calls (engine.convT_phase_taps).
+ *   src          the input, NHWC bf16, with the producer's BatchNorm + activation applied on load (abc_act_src; no pool / dropout / planar)
+ *   w            the NINE packed weight slices of the four phases one after the other -- phase (0,0): 1 tap, (0,1): 2, (1,0): 2, (1,1): 4,
+ *                each packed by abc_pack_conv_weights mode 2 with layout 1 into [taps][Cin / 32][Cout_pad][32] -- i.e. phase p starts
+ *                at slice {0, 1, 3, 5}[p] of one [9][Cin / 32][Cout_pad][32] buffer
+ *   y            NHWC bf16 [B][Hout][Wout][ldy], written at channels [cout_off, cout_off + Cout); Hout = 2 Hin, Wout = 2 Win
+ * abc_convt_fused_ok: 1 when the kernel serves the descriptor (bf16, both axes cropped, Cin % 32 == 0, Cout_pad % 64 == 0, Cout % 8 == 0). */
+typedef struct abc_convt_desc {
+    abc_act_src src;
+    const void* w; const float* bias; void* y;
+    int32_t dtype;                     /* ABC_BF16 */
+    int32_t B, Hin, Win, cin_off, Cin;
+    int32_t Hout, Wout, ldy, cout_off, Cout, Cout_pad;
+} abc_convt_desc;
+int abc_convt_fused_ok(const abc_convt_desc* d);
+int abc_convt_fused_fwd(const abc_convt_desc* d, abc_stream_t stream);
 int abc_conv_batch_ok(const abc_conv_desc* d, int32_t n);
 /* 1 when abc_conv_fwd honours d->actbwd_* for this descriptor (fill everything first, `stats` included), else 0: the caller then clears
  * actbwd_y and runs abc_act_bwd as a pass of its own (the engine's fallback; same results up to the rounding of dA to bf16) */
@@ -611,7 +630,7 @@ int abc_concat_f32(const float* const* srcs, const int32_t* counts, int32_t n, f
 /* *p += inc (one thread): the per-step dropout salt */
 int abc_counter_add_u32(uint32_t* p, uint32_t inc, abc_stream_t stream);
 
-/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17, abc_raster_desc = 18, abc_heads_fused_desc = 19, abc_heads_epi = 20):
+/* sizeof(descriptor #which) in declaration order (abc_act_src = 0 ... abc_nms_desc = 12, abc_cbam_channel_desc = 13, abc_cbam_pix_desc = 14, abc_cbam_conv7_desc = 15, abc_metrics_desc = 16, abc_extract_desc = 17, abc_raster_desc = 18, abc_heads_fused_desc = 19, abc_heads_epi = 20, abc_convt_desc = 21):
  * lets a foreign-language binding check its mirror structs at load time */
 int abc_sizeof(int which);
 const char* abc_last_error(void);

@@ -69,9 +69,10 @@ def test_engine_plan_builds_without_gpu():
     assert sum(1 for op in ev.fwd_ops if "out_modules" in op[2] and "conv1" in op[2]) == 1
     assert sum(1 for op in tr.fwd_ops if "out_modules" in op[2] and "conv1" in op[2]) == 8
     # (train adds 34 BatchNorm finalisations, the heads' eight as one batched launch; fp32 keeps the 8 conv1 launches)
-    # (bf16 issues the four phases of a ConvTranspose2d as one launch where they share a tile geometry, abc_conv_fwd_batch; fp32 does not)
-    nb = sum(1 for op in ev.fwd_ops if "(4 phases)" in op[2])
-    assert 1 <= nb <= 3 and not any("(4 phases)" in op[2] for op in tr.fwd_ops)
+    # (bf16 runs the four phases of a ConvTranspose2d in ONE pass over the input, abc_convt_fused_fwd -- or, where that kernel does not serve
+    #  the layer, as one batched launch of four convolutions, abc_conv_fwd_batch; fp32 launches the four phases one by one)
+    nb = sum(1 for op in ev.fwd_ops if "(4 phases" in op[2])
+    assert nb == 3 and sum(1 for op in ev.fwd_ops if "(4 phases, one pass)" in op[2]) == 3 and not any("(4 phases" in op[2] for op in tr.fwd_ops)
     assert len(ev.bwd_ops) == 0 and len(ev.fwd_ops) + 3 * nb + 7 + (34 - 7) + 7 + 1 == len(tr.fwd_ops) > 80 and len(tr.bwd_ops) > 200
     assert tr.fwd_ops[0][2] == "dropout step"
     assert sum(op[4]["flops"] for op in ev.fwd_ops) == sum(op[4]["flops"] for op in tr.fwd_ops)

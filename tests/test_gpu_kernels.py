@@ -920,6 +920,72 @@ def test_conv_transpose_phases_as_one_launch(lib, B, H, W, Cin, Chalf):
     assert float(one[..., :Chalf].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Chalf,coef", [(16, 12, 12, 512, 256, True), (2, 24, 24, 256, 128, True), (16, 48, 48, 128, 64, False), (3, 10, 20, 64, 64, True),
+                                                  (1, 7, 33, 96, 72, True)])
+def test_conv_transpose_all_phases_in_one_pass(lib, B, H, W, Cin, Chalf, coef):
+    """abc_convt_fused_fwd (convt_fused.hip): ConvTranspose2d(k3, s2) + the reference's crop (unet.py:44,51-56) with all four output-parity
+    phases in one pass over the input -- bit-identical to the four abc_conv_fwd phase calls it replaces (the same products summed in the
+    same order per output), with and without the producer's BatchNorm + ReLU on load, on the benchmark's three up-layers, a ragged map
+    (10 x 20: tiles that stick out in both directions) and a channel count that leaves padding rows (72 of 96); torch within the bf16 bar"""
+    from abcnet_amd.engine import convT_pack_parity
+    dt = L.BF16
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(U.DEV)
+    w = torch.randn((Cin, Chalf, 3, 3), generator=g) / (2.0 * Cin ** 0.5)       # ConvTranspose2d weight layout
+    bias = torch.randn(Chalf, generator=g).to(U.DEV)
+    cf = tuple(t.to(U.DEV) for t in (torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3, torch.zeros(Cin))) if coef else None
+    Hs, Ws, Ctot = 2 * H, 2 * W, 2 * Chalf
+    rows_pad = -(-Chalf // 64) * 64
+    # reference: the four phase convolutions
+    four = torch.zeros((B, Hs, Ws, Ctot), dtype=torch.bfloat16, device=U.DEV)
+    for py in (0, 1):
+        for px in (0, 1):
+            wp = U.pack(lib, w.to(U.DEV), 2, dt, Chalf, Cin, 3, -(-Chalf // 32) * 32, Cin, py=convT_pack_parity(py, True), px=convT_pack_parity(px, True))
+            U.conv(lib, x, dt, dt, B, H, W, Cin, 0, Cin, wp, bias, Chalf, convT_phase_taps(py, px, True, True), Hs, Ws, ldy=Ctot, cout_off=Chalf,
+                   grid=((Hs - py + 1) // 2, (Ws - px + 1) // 2), om=2, oy0=py, ox0=px, out=four, coef=cf)
+    # the fused pass: nine slices in one buffer, fragment-contiguous
+    ck = lib.abc_conv_chunk(dt, Cin)
+    assert ck == 32
+    slice_elems = (Cin // ck) * rows_pad * ck
+    wall = torch.zeros(9 * slice_elems, dtype=torch.bfloat16, device=U.DEV)
+    first = {(0, 0): 0, (0, 1): 1, (1, 0): 3, (1, 1): 5}
+    for py in (0, 1):
+        for px in (0, 1):
+            n = len(convT_phase_taps(py, px, True, True))
+            pd = L.PackDesc()
+            dst = wall[first[(py, px)] * slice_elems:(first[(py, px)] + n) * slice_elems]
+            pd.w, pd.dst, pd.mode, pd.dtype_c = w.to(U.DEV).data_ptr(), dst.data_ptr(), 2, dt
+            wdev = w.to(U.DEV)
+            pd.w = wdev.data_ptr()
+            pd.Cout, pd.Cin, pd.kh, pd.kw, pd.py, pd.px = Chalf, Cin, 3, 3, convT_pack_parity(py, True), convT_pack_parity(px, True)
+            pd.rows_pad, pd.red_pad, pd.red_total, pd.red_off, pd.ck, pd.layout = rows_pad, Cin, Cin, 0, ck, 1
+            L.check(lib.abc_pack_conv_weights(C.byref(pd), U.stream()), "pack")
+            torch.cuda.synchronize()
+    one = torch.zeros((B, Hs, Ws, Ctot), dtype=torch.bfloat16, device=U.DEV)
+    d = L.ConvTDesc()
+    U.fill_src(d.src, x, H, W, Cin, cf)
+    d.w, d.bias, d.y, d.dtype = wall.data_ptr(), bias.data_ptr(), one.data_ptr(), dt
+    d.B, d.Hin, d.Win, d.cin_off, d.Cin = B, H, W, 0, Cin
+    d.Hout, d.Wout, d.ldy, d.cout_off, d.Cout, d.Cout_pad = Hs, Ws, Ctot, Chalf, Chalf, rows_pad
+    assert lib.abc_convt_fused_ok(C.byref(d)) == 1
+    L.check(lib.abc_convt_fused_fwd(C.byref(d), U.stream()), "convt_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(one, four), (one.float() - four.float()).abs().max().item()
+    xa = x.float().cpu()
+    if coef:
+        yv = xa * cf[0].cpu() + cf[1].cpu()
+        xa = torch.maximum(yv, cf[2].cpu() * yv).to(torch.bfloat16).float()
+    y = F.conv_transpose2d(xa.permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), bias.cpu(), stride=2)
+    y = y[:, :, y.shape[2] - Hs:, y.shape[3] - Ws:]
+    assert U.relerr(one[..., Chalf:].float().cpu().permute(0, 3, 1, 2), y) < 3e-2
+    assert float(one[..., :Chalf].abs().max()) == 0.0
+    # not served: an uncropped axis, f32
+    d.Hout = 2 * H + 1
+    assert lib.abc_convt_fused_ok(C.byref(d)) == 0
+    d.Hout, d.dtype = 2 * H, L.F32
+    assert lib.abc_convt_fused_ok(C.byref(d)) == 0
+
+
 @pytest.mark.parametrize("Ca,Cb,ntaps,nsplit,C_,nblk", [(128, 128, 9, 128, 128, 768), (64, 32, 9, 33, 64, 2304), (16, 16, 9, 256, 16, 512), (256, 128, 4, 17, 256, 48)])
 def test_slab_reduction_and_bn_finaliser_as_one_launch(lib, Ca, Cb, ntaps, nsplit, C_, nblk):
     """abc_wgrad_reduce_bn_bwd == abc_wgrad_reduce + abc_bn_finalize_bwd of two unrelated layers, bit for bit (vector and scalar reduction
