@@ -64,6 +64,9 @@ int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
 #endif
         if (g.wd == 9) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9, EPI>(k, g, st);
     }
+    if constexpr (BN >= 64 && STRIDE == 2 && MT == 4 && CK == 32 && sizeof(InT) == 2 && sizeof(CT) == 2 && sizeof(OutT) == 2 && EPI == 0) {
+        if (g.wd == 9) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9, EPI>(k, g, st);
+    }
     if constexpr (BN == 32 && MT == 8 && STRIDE == 1 && CK == 32 && sizeof(CT) == 2 && EPI == 0) {
         // unet2's 5x5 32 -> 32 convolutions: 25 taps, a ring of 5
         if (g.wd == 25) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 25>(k, g, st);
@@ -220,7 +223,9 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     {
         const char* e = abc_knob("ABC_CONV_NOWD");   // "1": never; "2": only the 192 x 128 tile (experiments)
         const int lim = e ? atoi(e) : 0;
-        g->wd = (csz <= 2 && CKB == 64 && g->BN >= 64 && d->stride == 1 && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 9 : 0;
+        // (stride 2, bf16 in and out: the data gradients of the transposed convolutions -- 9 taps over a 17 x 33-pixel halo per 8 x 16 tile)
+        const bool s2 = d->stride == 2 && g->MT == 4 && d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16 && d->dtype_out == ABC_BF16 && !abc_knob("ABC_CONV_NOWD_S2");
+        g->wd = (csz <= 2 && CKB == 64 && g->BN >= 64 && (d->stride == 1 || s2) && d->ntaps == 9 && lim != 1 && (lim != 2 || (g->BN == 128 && g->MT == 6))) ? 9 : 0;
         if (f8 && (g->wd != 9 || g->BN != 128 || g->MT != 6)) return ABC_OK;
         // (25-tap form for unet2's 5x5 32 -> 32 layers: measured SLOWER than the LDS-staged weights, 136 vs 121 us -- a
         //  32-channel tile has only 4 MFMAs per tap to cover the global-load latency of the ring; opt-in for experiments)
