@@ -104,6 +104,188 @@ __device__ inline double wave_sum_d(double v) {
     return v;
 }
 
+// The small heads (one row tile, <= 14 channels) also finish conv2's WEIGHT gradient in the fused pass: dW2[c][ci] = sum_p dL[c][p] a[p][ci]
+// over the workgroup's 128 pixels is 8 MFMAs per wave (wave w = feature tile w) from the four waves' d(logits) tiles and
+// their activated features in LDS -- one 32 x 128 partial per workgroup instead of a pass of the blocked weight-gradient
+// kernel over the head's features (5 of its 11 units of work went to these 21 channels).  A ones-fragment gives the row
+// sums of dL (the bias gradient) on the way.  (All four waves: two workgroup barriers.)
+template <int HEAD>
+__device__ inline void small_head_wgrad(const HFK& a, const Ctx& c, const bf16x8* fb) {
+    constexpr int CH = hf_ch(HEAD);
+    const int r = c.r, h = c.h, lane = c.lane;
+    if (ABC_DBG(a.dbg) & 32) return;
+    char* img = c.ot + WV_AIMG;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) *(bf16x8*)(img + r * AROW + (16 * kk + 8 * h) * 2) = fb[kk];
+    __syncthreads();
+    const int trow = 8 * h + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    f32x16 aw, ab;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+        const char* tw = c.ot + (w2 - c.wave) * WV;          // wave w2's region
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 fa2 = *(const bf16x8*)(tw + r * TROW + (16 * s2 + 8 * h) * 2);
+            const char* q0 = tw + WV_AIMG + (16 * s2 + trow) * AROW + (32 * c.wave + tcol) * 2;
+            const bf16x8 fb2 = tr_read8f(q0, q0 + 4 * AROW);
+            aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, fb2, aw, 0, 0, 0);
+            // (every wave: an MFMA under a lane-dependent branch -- `wave == 0` is a VGPR compare -- came out wrong,
+            //  the instruction ignores EXEC; only wave 0 stores the sums)
+            ab = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, ones, ab, 0, 0, 0);
+        }
+    }
+    if (h == 0) {
+        // register k of half 0 = packed row (k & 3) + 8 (k >> 2) = channel k (hf_chan_of_row)
+        float* dst = a.dwsmall + ((size_t)c.chunk * HF_SMALL_ROWS + hf_small_row0(HEAD)) * 129;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            dst[k * 129 + 32 * c.wave + r] = aw[k];
+            if (c.wave == 0 && r == 0) dst[k * 129 + 128] = ab[k];
+        }
+    }
+    __syncthreads();   // the tiles are read by the other waves: the epilogue reuses their space
+}
+
+// A wave NONE of whose 32 pixels carries a target of a softmax head (atom types, charges, hydrogens, bond types; known from the
+// rasteriser's group flags): every term of class_focal and every derivative is zero there (loss_math.hpp: t[k] == 0 adds nothing to
+// the numerator or the denominator and leaves a[k] = 0, so dz[k] = q[k] * (0 - 0)) -- for finite logits exactly what the full path
+// computes.  What is left of the head for this wave: its logits (when somebody reads them: hd.logits), zeros for d(logits), g and the
+// BatchNorm sums.  The exp / log / focal arithmetic of the 15-tile bond-type head is the bulk of the fused pass's instruction issue,
+// and most waves see no bond at all.
+template <int HEAD>
+__device__ inline void run_head_skip(const HFK& a, Ctx& c, double* lsum) {
+    static_assert(HEAD == 1 || HEAD == 2 || HEAD == 3 || HEAD == 5, "softmax heads");
+    constexpr int CH = hf_ch(HEAD), NT = hf_tiles(HEAD), CPAD = NT * 32;
+    const HFHead& hd = a.hd[HEAD];
+    const int slice = 128 * HEAD;
+    const int r = c.r, h = c.h, lane = c.lane;
+    const uint32_t lch = HEAD >= 5 ? 30u * h : 0u;
+    const uint32_t loff = ((uint32_t)(c.b * CH) + lch) * (uint32_t)a.HW + (uint32_t)c.yx;
+    auto at4w = [&](float* base, int chu) -> float* { return (float*)((char*)(base + (size_t)chu * a.HW) + 4u * loff); };
+    float* cf = (float*)(c.ot + WV_CF);
+    float* bl = (float*)(c.ot + WV_BIAS);
+    const uint32_t e0 = c.pix * (uint32_t)a.ld + slice + 8 * h;
+    const bool st_logits = hd.logits != nullptr;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    bf16x8 fb[8];
+    uint32_t kbits[2] = {0u, 0u};
+    if (st_logits || (HEAD >= 5 && hd.keep != nullptr)) {
+        // ---- the forward half as in run_head: features -> BN + LeakyReLU + dropout -> B fragments (and the keep bits the weight gradient takes)
+        u32x4 raw[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) raw[kk] = *(const u32x4*)(a.y1 + e0 + 16 * kk);
+        {
+            const int ch = slice + 2 * lane;
+            const float2 v0 = *(const float2*)(a.sc + ch), v1 = *(const float2*)(a.sh + ch), v2 = *(const float2*)(a.sl + ch);
+            *(float2*)(cf + 0 * 128 + 2 * lane) = v0; *(float2*)(cf + 1 * 128 + 2 * lane) = v1; *(float2*)(cf + 2 * 128 + 2 * lane) = v2;
+#pragma unroll
+            for (int i = 0; i < (CPAD + 63) / 64; ++i)
+                if (lane + 64 * i < CPAD) bl[lane + 64 * i] = hd.biasp[lane + 64 * i];
+        }
+        lds_sync();
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float v[8], sc[8], sh[8], sl[8];
+            const int cc = 16 * kk + 8 * h;
+            LoadVec<float, 8>::ld(cf + cc, sc); LoadVec<float, 8>::ld(cf + 128 + cc, sh); LoadVec<float, 8>::ld(cf + 256 + cc, sl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(raw[kk][j] << 16); v[2 * j + 1] = __uint_as_float(raw[kk][j] & 0xFFFF0000u); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = fmaf(v[j], sc[j], sh[j]);
+                const bool keep = a.drop_p > 0.f ? abc_drop_hash24(e0 + 16 * kk + j, c.dseed) >= a.drop_thr : true;
+                kbits[kk >> 2] |= (keep ? 1u : 0u) << (8 * (kk & 3) + j);
+                v[j] = keep ? fmaxf(y, sl[j] * y) * c.dscale : 0.f;
+            }
+            fb[kk] = pack_frag<bf16>(v);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) fb[kk] = __builtin_bit_cast(bf16x8, z4);
+    }
+    if (st_logits) {
+        bf16x8 fa[8];
+        auto load_fa = [&](int mt) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                fa[kk] = *(const bf16x8*)((const char*)(hd.w2f + (size_t)((kk >> 1) * CPAD + 32 * mt) * 32 + 16 * (kk & 1)) + (uint32_t)(r * 64 + h * 16));
+        };
+        load_fa(0);
+#pragma unroll 1
+        for (int mt = 0; mt < NT; ++mt) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = *(const f32x4*)(bl + 32 * mt + 8 * q + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] = b4[j];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk], acc, 0, 0, 0);
+            // (the next tile's weights ahead of this tile's stores: loads and stores retire through one in-order counter)
+            __builtin_amdgcn_sched_barrier(0);
+            load_fa(mt + 1 < NT ? mt + 1 : mt);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HEAD == 5) {
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) *at4w(hd.logits, k * 60 + 2 * mt + gi) = acc[8 * gi + k];
+            } else if (h == 0) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) *at4w(hd.logits, k) = acc[k];
+            }
+        }
+    }
+    // ---- d(logits) = 0: the blocked buffer of the weight gradient (the stores of run_head's tile loop), the wave's LDS tile (the
+    // small heads' weight gradient reads it), and for the bond types the per-bin target sums rho takes
+#pragma unroll 1
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = lane + 64 * j, row = q >> 2, part = q & 3;
+            *(u32x4*)((char*)(hd.dlb + ((size_t)c.chunk * CPAD + 32 * mt) * 128) + (uint32_t)((row * 128 + 32 * c.wave + part * 8) * 2)) = z4;
+        }
+    if constexpr (HEAD == 5) {
+#pragma unroll
+        for (int j = 0; j < 30; ++j) c.dnl[j * 64 + lane] = 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = lane + 64 * j, row = q >> 2, part = q & 3;
+            *(u32x4*)(c.ot + row * TROW + part * 16) = z4;
+        }
+        lds_sync();
+        small_head_wgrad<HEAD>(a, c, fb);
+    }
+    // ---- g = 0 and its BatchNorm sums (run_head's epilogue: dA = W2^T x 0)
+    {
+        const int sg = lane & 7, pg = lane >> 3;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                *(u32x4*)(a.g + (size_t)(c.pix0 + it * 8 + pg) * a.ld + slice + 64 * half + sg * 8) = z4;
+        float* ws = c.wsum + c.nslice * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ws[lane + 64 * i] = 0.f;
+    }
+    if constexpr (HEAD >= 5) {
+        if (hd.keep != nullptr) hd.keep[2u * c.pix + h] = make_uint2(kbits[0], kbits[1]);
+    }
+    c.nslice += 1;
+    if (lane == 0) {
+        lsum[HEAD] = 0.0;
+        lsum[8 + HEAD] = 0.0;
+        if (HEAD == 5) lsum[8 + 6] = 0.0;
+    }
+}
+
 // One head for the wave's 32 pixels; its loss numerator / denominator (summed over the wave) go to lsum[HEAD] / lsum[8 + HEAD].
 //
 // The row-tile loop is software-pipelined by hand: on this hardware loads and stores retire through ONE in-order counter, so
@@ -126,8 +308,12 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
     // ~62 non-zero 3x3 neighbourhoods per image), every target address is redirected into 512 zero bytes -- the same loads, the same
     // arithmetic on the same zeros, no HBM traffic (0.37 GB of target planes per step otherwise).  tz is wave-uniform: one scalar select of
     // the plane stride and base, one vector select of the lane's offset.
-    const uint32_t tword = a.tflags ? a.tflags[c.pix0 >> 5] : 0xFFFFFFFFu;
+    const uint32_t tword = a.tflags ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tflags[c.pix0 >> 5]) : 0xFFFFFFFFu;
     const bool tz = !((tword >> (HEAD == 6 ? 5 : HEAD)) & 1u);      // (rho reads the bond-type targets' bins: their flag)
+    if constexpr (HEAD == 1 || HEAD == 2 || HEAD == 3 || HEAD == 5) {
+        // the softmax heads contribute nothing where no pixel of the wave has a target: run_head_skip (ABC_HF_DBG bit 6: the A/B)
+        if (tz && !(ABC_DBG(a.dbg) & 64)) { run_head_skip<HEAD>(a, c, lsum); return; }
+    }
     const size_t thw = tz ? (size_t)0 : (size_t)a.HW;
     const uint32_t tloff = tz ? (uint32_t)lane : loff;
     auto tbase4 = [&](const float* base) -> const float* { return tz ? (const float*)a.tzero : base; };
@@ -368,50 +554,8 @@ __device__ inline void run_head(const HFK& a, Ctx& c, double* lsum) {
     for (int kk = 0; kk < 8; ++kk) raw[kk] = *(const u32x4*)(a.y1 + e0 + 16 * kk);
     dgrad_mfma();
 
-    // ---- the small heads (one row tile, <= 14 channels) also finish conv2's WEIGHT gradient here: dW2[c][ci] = sum_p dL[c][p] a[p][ci]
-    // over the workgroup's 128 pixels is 8 MFMAs per wave (wave w = feature tile w) from the four waves' d(logits) tiles and
-    // their activated features in LDS -- one 32 x 128 partial per workgroup instead of a pass of the blocked weight-gradient
-    // kernel over the head's features (5 of its 11 units of work went to these 21 channels).  A ones-fragment gives the row
-    // sums of dL (the bias gradient) on the way.
-    if constexpr (HEAD < 5) {
-        if (!(ABC_DBG(a.dbg) & 32)) {
-        char* img = c.ot + WV_AIMG;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) *(bf16x8*)(img + r * AROW + (16 * kk + 8 * h) * 2) = fb[kk];
-        __syncthreads();
-        const int trow = 8 * h + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-        f32x16 aw, ab;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
-        bf16x8 ones;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
-            const char* tw = c.ot + (w2 - c.wave) * WV;          // wave w2's region
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 fa2 = *(const bf16x8*)(tw + r * TROW + (16 * s2 + 8 * h) * 2);
-                const char* q0 = tw + WV_AIMG + (16 * s2 + trow) * AROW + (32 * c.wave + tcol) * 2;
-                const bf16x8 fb2 = tr_read8f(q0, q0 + 4 * AROW);
-                aw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, fb2, aw, 0, 0, 0);
-                // (every wave: an MFMA under a lane-dependent branch -- `wave == 0` is a VGPR compare -- came out wrong,
-                //  the instruction ignores EXEC; only wave 0 stores the sums)
-                ab = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, ones, ab, 0, 0, 0);
-            }
-        }
-        if (h == 0) {
-            // register k of half 0 = packed row (k & 3) + 8 (k >> 2) = channel k (hf_chan_of_row)
-            float* dst = a.dwsmall + ((size_t)c.chunk * HF_SMALL_ROWS + hf_small_row0(HEAD)) * 129;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                dst[k * 129 + 32 * c.wave + r] = aw[k];
-                if (c.wave == 0 && r == 0) dst[k * 129 + 128] = ab[k];
-            }
-        }
-        __syncthreads();   // the tiles are read by the other waves: the epilogue below reuses their space
-        }
-    }
+    // ---- the small heads also finish conv2's WEIGHT gradient here (small_head_wgrad)
+    if constexpr (HEAD < 5) small_head_wgrad<HEAD>(a, c, fb);
 
     // ---- dA -> g.  The packed W2^T puts feature channel 32 mi + 16 (k >> 3) + 8 h + (k & 7) in register k of accumulator mi:
     // element (kk = 2 mi + (k >> 3), j = k & 7) of this lane's own feature fragments.  g and g * xhat are formed here, then go
@@ -509,6 +653,7 @@ __global__ __launch_bounds__(256, 2) void heads_fused_kernel(const HFK a) {
     c.ot = smem + c.wave * WV;
     c.dnl = (float*)(smem + c.wave * WV + WV_DN);
     const int group = blockIdx.y;
+    if (ABC_DBG(a.dbg) & (256 << group)) return;    // (debug build: time the work types one by one)
     c.wsum = (float*)(smem + LDS_BSUM) + c.wave * 512;
     c.nslice = 0;
     c.dscale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;

@@ -7,6 +7,8 @@ from abcnet_amd.engine import head_offsets
 from abcnet_amd.synthetic import synthetic_targets
 HEADS = [1, 14, 3, 2, 1, 360, 60, 60]
 DEV = "cuda"
+if os.environ.get("ABC_TOOL_LIB"):
+    L.LIB_PATH = os.path.abspath(os.environ["ABC_TOOL_LIB"])
 lib = L.load()
 B, hw, ld = 16, 96, 1024
 npix = B * hw * hw
@@ -20,7 +22,7 @@ tg = [t.to(DEV) for t in synthetic_targets(B, hw, seed=1)]
 d = L.HeadsFusedDesc()
 d.feat, d.ld = feat.data_ptr(), ld
 d.scale, d.shift, d.slope, d.mean, d.invstd = sc.data_ptr(), sh.data_ptr(), sl.data_ptr(), mean.data_ptr(), invstd.data_ptr()
-d.drop_p, d.drop_seed, d.drop_salt = 0.2, 0x1234567, None
+d.drop_p, d.drop_seed, d.drop_salt = float(os.environ.get("HF_DROP_P", "0.2")), 0x1234567, None
 pack = torch.zeros(lib.abc_heads_fused_pack_bytes(), dtype=torch.uint8, device=DEV)
 logits = [torch.zeros((B, c, hw, hw), device=DEV) for c in HEADS]
 for i in range(8):
@@ -52,9 +54,20 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1000
-for dbg in [int(x) for x in (sys.argv[1:] or ["0"])]:
-    os.environ["ABC_HF_DBG"] = str(dbg & 255)
-    os.environ["ABC_HF_LDS_EXTRA"] = str(20000 if dbg & 256 else 0)
+args = sys.argv[1:]
+if args and args[0] == "--flags":
+    # the rasteriser's group flags, from the dense maps: bit i = some pixel of the 32-pixel group has a target of head i (rho: the bond types')
+    args = args[1:]
+    fl = torch.zeros(npix // 32, dtype=torch.int32, device=DEV)
+    for i, tt in enumerate(tg):
+        m = tt.reshape(B, -1, hw * hw)
+        any_ = (m != 0).any(dim=1).reshape(B * hw * hw // 32, 32).any(dim=1)
+        fl |= any_.to(torch.int32) << (5 if i == 6 else i)
+    zb = torch.zeros(512, dtype=torch.uint8, device=DEV)
+    d.target_flags, d.zero_bytes = fl.data_ptr(), zb.data_ptr()
+    print("flagged groups per head:", [round(float(((fl >> i) & 1).float().mean()), 3) for i in range(8)])
+for dbg in [int(x, 0) for x in (args or ["0"])]:
+    os.environ["ABC_HF_DBG"] = str(dbg)     # bits 0-6: phase ablations of heads_fused.hip; 256 << g: work type g not run
     print("dbg %3d: fwd_bwd %.1f us" % (dbg, t(lambda: L.check(lib.abc_heads_fused_fwd_bwd(C.byref(d), st), "f"))), flush=True)
 os.environ["ABC_HF_DBG"] = "0"
 print("wgrad %.1f us" % t(lambda: L.check(lib.abc_heads_fused_wgrad(C.byref(d), st), "w")))
