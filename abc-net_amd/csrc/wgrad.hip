@@ -28,6 +28,7 @@
 #include "heads_fused.hpp"
 #include "conv_fast.hpp"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -1172,7 +1173,15 @@ static int wgeom(const abc_wgrad_desc* d, WGeom* g) {
     // 32x32 tile pairs per workgroup (one pair per wave, the remaining waves split the patch rows).  Ragged channel
     // tails are fine (zero-filled): wide tiles are what keeps the operands from being re-staged per pair.
     static const bool no42 = abc_knob("ABC_WGRAD_NO42") != nullptr;  // (experiment switch)
-    if (!no42 && d->stride == 1 && csz == 2 && ta >= 3 && tb >= 2) { g->AT = 4; g->BT = 2; }
+    // 4 x 2 pairs where a workgroup has patches to amortise its 295 KB slab over: with one round of <= 256 workgroups (the engine's
+    // split rule: nsplit = min(patches / 2, 256 / tiles)) the 48 x 48 and smaller maps leave 2-5 patches per workgroup, the kernel is
+    // prologue + slab store, and 2 x 2 pairs halve the slabs written here and re-read by the reduction (per layer: launch +0..5 us,
+    // reduction -5..9 us; at 96 x 96 -- 9 patches per workgroup -- the wide tile wins by 10 us per launch)
+    const int patches = d->B * abc_cdiv(d->Hg, 8) * abc_cdiv(d->Wg, 16);
+    const int tiles42 = abc_cdiv(d->Ca, 128) * abc_cdiv(d->Cb, 64);
+    const int ns42 = std::max(1, std::min(std::max(1, patches / 2), 256 / std::max(1, tiles42)));
+    const bool few = patches < 6 * ns42 && !abc_knob("ABC_WGRAD_42_ALWAYS");
+    if (!no42 && !few && d->stride == 1 && csz == 2 && ta >= 3 && tb >= 2) { g->AT = 4; g->BT = 2; }
     else if (d->stride == 1 && ta >= 2 && tb >= 2) { g->AT = 2; g->BT = 2; }
     else if (d->stride == 1 && csz == 2 && ta == 1 && tb >= 4) { g->AT = 1; g->BT = 4; }
     // ConvTranspose (stride 2): two P tiles share one staging of Q's 17 x 33-pixel halo (a 32-channel halo is what the prefetch path holds;
