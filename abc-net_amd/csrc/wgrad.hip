@@ -1584,7 +1584,7 @@ extern "C" int abc_wgrad_reduce_bn_bwd(const abc_wgrad_reduce_desc* d, const abc
     }
     ReduceBn a;
     a.r = *d; a.f = *f;
-    a.vec = (d->Cb % 4 == 0 && d->Cb_pad % 4 == 0 && ((uintptr_t)d->partial & 15) == 0 && d->nsplit >= 16 && n >= 16384) ? 1 : 0;
+    a.vec = (d->Cb % 4 == 0 && d->Cb_pad % 4 == 0 && ((uintptr_t)d->partial & 15) == 0 && d->nsplit >= 16 && (n >= 16384 || d->nsplit >= 64)) ? 1 : 0;   // (few outputs over many slabs: the scalar form walks them four at a time, 32 us for 4608 x 256)
     a.nr = a.vec ? (int)((n / 4 + 63) / 64) : (int)((n + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(a.nr + f->C), dim3(256), 0, (hipStream_t)stream, a);
     return abc_check_launch("wgrad_reduce_bn_bwd");
@@ -1597,7 +1597,7 @@ extern "C" int abc_wgrad_reduce(const abc_wgrad_reduce_desc* d, abc_stream_t str
         return abc_check_launch("wgrad_reduce");
     }
     static const bool scalar_only = abc_knob("ABC_WGRAD_REDUCE_SCALAR") != nullptr;   // (A/B runs)
-    if (!scalar_only && d->Cb % 4 == 0 && d->Cb_pad % 4 == 0 && ((uintptr_t)d->partial & 15) == 0 && d->nsplit >= 16 && n >= 16384) {
+    if (!scalar_only && d->Cb % 4 == 0 && d->Cb_pad % 4 == 0 && ((uintptr_t)d->partial & 15) == 0 && d->nsplit >= 16 && (n >= 16384 || d->nsplit >= 64)) {
         hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((int)((n / 4 + 63) / 64)), dim3(256), 0, (hipStream_t)stream, *d);
         return abc_check_launch("wgrad_reduce");
     }
