@@ -124,8 +124,8 @@ def dominant_family(prof):
 
 
 def other_configs(dev, steps=20, warmup=5):
-    """BASELINE.json's configs 3 and 5 through the same harness, AFTER the headline's timed region and report (nothing here can
-    perturb it): unet2.py train step b16 @ 384x384 (unet2.py:129-173) and the img2smiles2.py heat-map path b64 @ 512x512 in bf16
+    """BASELINE.json's configs 3 and 5 (and the headline's step with the device rasteriser in it) through the same harness, AFTER the
+    headline's timed region and report (nothing here can perturb it): unet2.py train step b16 @ 384x384 (unet2.py:129-173) and the img2smiles2.py heat-map path b64 @ 512x512 in bf16
     (img2smiles2.py:42-79), each on its own model / Trainer / InferenceRunner, freed afterwards.  One record per config: the same
     wall-clock measurement as the headline (K steps between synchronisations) and the dominant kernel family's fraction of the
     dense bf16 MFMA peak from an instrumented eager pass."""
@@ -134,8 +134,9 @@ def other_configs(dev, steps=20, warmup=5):
     from abcnet_amd.train import Trainer
     from abcnet_amd.infer import InferenceRunner
     recs = []
-    for mode, variant, size, batch in (("train", "unet2", 384, 16), ("infer", "unet", 512, 64)):
+    for mode, variant, size, batch in (("train", "unet2", 384, 16), ("infer", "unet", 512, 64), ("train_raster", "unet", 384, 16)):
         t_cfg = time.perf_counter()
+        rz = None
         if variant == "unet2":
             from abcnet_amd.unet2 import UNet
         else:
@@ -152,6 +153,22 @@ def other_configs(dev, steps=20, warmup=5):
             tr = Trainer(model, batch, size, size)
             tr.load_batch(imgs.to(dev), [t.to(dev) for t in synthetic_targets(batch, size // 4, seed=1)])
             workload = variant + ".py train step (pack+fwd+fused loss+bwd+Adam), %dx%d, batch %d/GPU, dropout 0.2" % (size, size, batch)
+            if mode == "train_raster":
+                # the headline's step with the loader's half of it on the device: the eight target maps rasterised EVERY step from compact
+                # records (utils.py:83-228; 30 atoms + 32 bonds per image) instead of resident dense maps, the fused heads pass reading
+                # targets by the rasteriser's group flags -- strictly more work in the timed region than the headline
+                from abcnet_amd.raster import TargetRasterizer, parse_record
+                from abcnet_amd.synthetic import random_annotations
+                rz = TargetRasterizer(batch, size // 4, max_atoms=64, max_bonds=64, targets=tr.targets, sparse=True)
+                tr.use_sparse_targets(rz)
+                rz.load([parse_record(*random_annotations(30, 32, 900 + i, size=size), h=size // 4) for i in range(batch)])
+                _step = tr.step
+
+                def step_with_raster(_rz=rz, _s=_step):
+                    _rz.run()
+                    _s()
+                tr.step = step_with_raster
+                workload = "unet.py train step + device rasteriser every step (records -> 8 target maps + group flags; sparse target reads), %dx%d, batch %d/GPU, dropout 0.2" % (size, size, batch)
         torch.cuda.synchronize()
         for _ in range(warmup):
             tr.step()
@@ -163,13 +180,13 @@ def other_configs(dev, steps=20, warmup=5):
         el = time.perf_counter() - t0
         dom, r = dominant_family(tr.profile(iters=2))
         ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
-        sr = SURVEY_ROOFLINE[(mode, variant, size)]
+        sr = SURVEY_ROOFLINE[("train" if mode == "train_raster" else mode, variant, size)]
         val = batch * steps / el
         recs.append({"workload": workload, "value": round(val, 2), "unit": "images/sec", "ms_per_step": round(1000 * el / steps, 3), "steps": steps,
                      "warmup": warmup, "dtype": "bf16", "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK["bf16"],
                                                                     "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK["bf16"], 4)},
                      "survey_roofline_frac": round(val / sr["R_img_s"], 4), "wall_s": None})
-        del tr, model, imgs
+        del tr, model, imgs, rz
         gc.collect()
         torch.cuda.empty_cache()
         recs[-1]["wall_s"] = round(time.perf_counter() - t_cfg, 1)
