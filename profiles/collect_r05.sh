@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-profile"
+B="python3 $R/bench.py --no-cpu-baseline --no-profile --no-other-configs"
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 for w in ${WORKLOADS:-unet unet2 infer infer8}; do
   case $w in
