@@ -203,12 +203,16 @@ def test_fused_heads_pass(B, hw, drop_p, keepmask):
             assert torch.equal(bits[i - 5], wbyte), ("keep bits", i)
 
 
-def test_sparse_targets_give_the_same_step_bit_for_bit():
+@pytest.mark.parametrize("keep_logits", [True, False])
+def test_sparse_targets_give_the_same_step_bit_for_bit(keep_logits):
     """Trainer.use_sparse_targets (abc_heads_fused_desc.target_flags): the fused heads pass reads a head's target planes only in the
     32-pixel groups the rasteriser flagged; everywhere else the same loads hit 512 zero bytes.  Same records through the sparse
     rasteriser + flags and through the plain rasteriser + every plane: the loss terms, d(logits) in the stored logits' gradient
     chain -- i.e. EVERY parameter gradient -- and the parameters after three steps (three different batches: the sparse form erases
-    its previous drawing) are bit-identical; and the flags did switch reads off (most groups carry no target)."""
+    its previous drawing) are bit-identical; and the flags did switch reads off (most groups carry no target).  Since round 5 a wave
+    without a target of a softmax head also SKIPS that head's loss / data gradient / epilogue (run_head_skip: logits + zeros) -- the
+    stored logits must be the same bits too, and with keep_logits=False (nothing of the head's forward is observable) the skipped
+    waves write zeros only."""
     from abcnet_amd.raster import TargetRasterizer, parse_record
     from abcnet_amd.synthetic import random_annotations, synthetic_images
     from abcnet_amd.train import Trainer
@@ -220,13 +224,13 @@ def test_sparse_targets_give_the_same_step_bit_for_bit():
         m = UNet(1, HEADS, dtype="bf16", dropout_p=0.2)
         m.reset_parameters(seed=77)
         m = m.to(DEV)
-        tr = Trainer(m, B, S, S, use_graph=False)
+        tr = Trainer(m, B, S, S, use_graph=False, keep_logits=keep_logits)
         rz = TargetRasterizer(B, h, max_atoms=64, max_bonds=64, targets=tr.targets, sparse=sparse)
         if sparse:
             tr.use_sparse_targets(rz)
             with pytest.raises(Exception, match="sparse"):
                 tr.load_batch(synthetic_images(B, S, seed=1).to(DEV), [t.clone() for t in tr.targets])
-        grads, losses = [], []
+        grads, losses, logits = [], [], []
         for step in range(3):
             tr.load_batch(synthetic_images(B, S, seed=11 + step).to(DEV))
             rz.load([parse_record(*random_annotations(12 + 9 * step, 10 + 11 * step, 4000 + 10 * step + i, size=S), h=h) for i in range(B)])
@@ -235,14 +239,19 @@ def test_sparse_targets_give_the_same_step_bit_for_bit():
             torch.cuda.synchronize()
             grads.append(m._flat_grad.clone())
             losses.append(tr.loss.out.clone())
+            if keep_logits:
+                logits.append([t.clone() for t in tr.eng.logits])
         frac = None
         if sparse:
             f = rz.group_flags.cpu().numpy().astype("uint32")
             frac = float(((f & 0xFF) != 0).mean())
-        res.append((grads, losses, m._flat.detach().clone(), frac))
+        res.append((grads, losses, m._flat.detach().clone(), frac, logits))
         del tr, rz, m
-    (g0, l0, p0, _), (g1, l1, p1, frac) = res
+    (g0, l0, p0, _, z0), (g1, l1, p1, frac, z1) = res
     for step in range(3):
+        if keep_logits:
+            for i in range(8):
+                assert torch.equal(z0[step][i], z1[step][i]), ("stored logits", step, i)
         assert torch.equal(l0[step], l1[step]), ("loss terms", step, l0[step], l1[step])
         assert torch.equal(g0[step], g1[step]), ("gradients", step, (g0[step] - g1[step]).abs().max().item())
     assert torch.equal(p0, p1)
