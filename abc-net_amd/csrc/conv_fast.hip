@@ -62,6 +62,10 @@ int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
             if (g.wd == 9 && (g.lp || g.var)) return abc_conv_fast_launch_lp(k, g, EPI, st);
         }
 #endif
+        if constexpr (BN == 128 && MT == 6 && sizeof(InT) == 2 && sizeof(OutT) == 2 && (EPI == 0 || EPI == 2)) {
+            // the 16x16x32 form of the same tile (whole tiles, sums and squares only: abc_fast_geom.m16)
+            if (g.wd == 9 && g.m16) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9, EPI, 4, false, 0, true>(k, g, st);
+        }
         if (g.wd == 9) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9, EPI>(k, g, st);
     }
     if constexpr (BN >= 64 && STRIDE == 2 && MT == 4 && CK == 32 && sizeof(InT) == 2 && sizeof(CT) == 2 && sizeof(OutT) == 2 && EPI == 0) {
@@ -248,6 +252,10 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         g->var = g_force_var & 3;
         if ((g->var & 1) && !g->lp) stg = 4 * 32 * (32 * osz + 16);      // (1 x 4 waves: 32-channel staging rows)
     }
+    // v_mfma_f32_16x16x32_bf16 form (conv_fast_body.hpp M16): the bf16 192 x 128 weights-direct tile where every tile takes the whole-tile epilogue
+    g->m16 = (g->wd == 9 && g->nw == 4 && !g->lp && !g->var && g->BN == 128 && g->MT == 6 && d->stride == 1 && !f8 && d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16 &&
+              d->dtype_out == ABC_BF16 && d->heads_epi == nullptr && d->stats_rows != 4 && !d->accumulate && d->Cout % 8 == 0 && (d->ldy | d->cout_off) % 8 == 0 &&
+              d->Wg % 16 == 0 && (d->Hg % 12 == 0 || d->stats == nullptr) && !abc_knob("ABC_CONV_NOM16")) ? 1 : 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
     g->b_static = (!actb && !g->wd && g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget &&
                    abc_cdiv(g->HH * g->HW * segs, FT) <= fa_static(g->MT)) ? 1 : 0;
@@ -272,8 +280,8 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
     if (g->lds < g->red_off + red) g->lds = g->red_off + red;
     g->ystg_off = abc_roundup(g->lds, 256);      // (behind everything: the tap and coefficient tables outlive the tile)
     if (actb) g->lds = g->ystg_off + stg;
-    g->epi_off = abc_roundup(g->lds, 256);       // LP: [2][1 or 6][BN] floats
-    if (g->lp) g->lds = g->epi_off + 2 * (actb ? 6 : 1) * g->BN * 4;
+    g->epi_off = abc_roundup(g->lds, 256);       // LP, M16: [2][1 or 6][BN] floats
+    if (g->lp || g->m16) g->lds = g->epi_off + 2 * (actb ? 6 : 1) * g->BN * 4;
     if (g->lds > LDS_WG) return ABC_OK;
     g->tiles_x = abc_cdiv(d->Wg, 16);
     g->tiles_y = abc_cdiv(d->Hg, prow);

@@ -5,7 +5,7 @@
 struct abc_fast_geom {
     int eligible;
     int CK, BN, MT, dy_min, dx_min, HH, HW, PS, RS, tg, ngroups, sA_bytes, a_bufs, sB_bytes, tap_off, coef_off, cstride, lds,
-        tiles_x, tiles_y, nbn, ntiles, nwg, b_static, stg_off, red_off, wd, ystg_off, nw, lp, epi_off, var;
+        tiles_x, tiles_y, nbn, ntiles, nwg, b_static, stg_off, red_off, wd, ystg_off, nw, lp, epi_off, var, m16;
 };
 
 int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g);

@@ -84,7 +84,15 @@ __device__ inline float lane_reduce16(const float* v, int r) {
 // HEPI ("heads in the epilogue", folded inference graph): the tile's 128 output channels are one head's finished features
 // (unet.py:66-69 with BatchNorm folded); the head's 1x1 convolution (unet.py:70) is computed from them right here and the f32
 // NCHW maps are stored -- the 8 x 128-channel feature tensor is never written or read (2 x 2.1 GB per batch of 64 at 512 x 512)
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0, int NW = 4, bool LP = false, int VAR = 0>
+// M16 (round 5, the bf16 192-pixel x 128-channel weights-direct tile over whole tiles): the SAME tile, halo image, weight packing and
+// ring, but multiplied with v_mfma_f32_16x16x32_bf16 -- one MFMA = the 16 pixels of a patch row x 16 output channels x the WHOLE 64-byte
+// chunk of a tap (A: lane (m, q) = pixel m's bytes [16 q, 16 q + 16); B: row 16 ci + n's same bytes of the packed weights; four
+// accumulator registers: channel n, pixels 4 q .. 4 q + 3 of the row).  The same FLOPs per cycle as the 32x32x16 form on paper; on the chip
+// the long launches run power-limited (1.73-1.95 GHz) and the smaller shape costs less energy per FLOP (MI355X_MICROARCH.md: 1.15 x the
+// FLOP/s in bare loops): a timing probe that issued two 16x16x32 per 32x32x16 on the same registers read 295 -> 245 us on the heads' conv1
+// and 45 -> 41.5 us on a trunk layer before this form existed.  The epilogue differs in its lane mapping only (a lane owns two channels
+// x eight pixels of a 32 x 32 block instead of one channel x sixteen pixels); the store sweep is the same.
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0, int NW = 4, bool LP = false, int VAR = 0, bool M16 = false>
 __device__ __forceinline__ void conv_fast_body(const FastK& a) {
     // NW waves per workgroup.  8 (the 192-pixel x 128-channel weights-direct tile only): the SAME tile, halo and grid, but a wave owns
     // 3 x 1 instead of 3 x 2 MFMA tiles -- 48 accumulator registers, the kernel fits 128 VGPRs, two workgroups = FOUR waves per SIMD:
@@ -125,6 +133,8 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
     // butterfly (v_permlane16_swap + DPP mirrors: 38 instructions per 16 channels, fixed order) leaves each channel's total in one lane, and
     // every wave writes its own partial row (rows per tile = WM).  Measured: profiles/README.md round 5.
     static_assert(!LP || (WD == 9 && !STATIC && !HEPI && sizeof(OutT) == 2 && sizeof(CT) == 2 && NW == 4), "lane = pixel: the bf16 weights-direct kernels");
+    static_assert(!M16 || (WD == 9 && !STATIC && !HEPI && !LP && VAR == 0 && NW == 4 && STRIDE == 1 && sizeof(InT) == 2 && sizeof(CT) == 2 && sizeof(OutT) == 2 && BN >= 64),
+                  "16x16x32 form: the bf16 weights-direct kernels, stride 1");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -158,6 +168,13 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) bBase[j] = ((wn * TN + j) * 32 + r) * PS + h * LHB;
+    // M16: lane (m = lane % 16, q = lane / 16) reads bytes [16 q, 16 q + 16) of pixel m of patch row 2 (wm TM + i) (+ one halo row: row 1)
+    const int m16 = lane & 15, q16 = lane >> 4;
+    int aBase16[M16 ? TM : 1];
+    if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) aBase16[i] = 2 * (wm * TM + i) * a.RS + m16 * PS + 16 * q16;
+    }
 
     const __amdgpu_buffer_rsrc_t rsA = abc_make_rsrc(a.x, a.bytesA), rsW = abc_make_rsrc(a.w, a.bytesW);
     const HaloGeom gA = {a.HH, a.HW, a.magic, a.Hin, a.Win, a.Hx, a.Wx, a.ldx};
@@ -174,7 +191,7 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
     const unsigned bvoff0 = (unsigned)tl0 * tap_stride + (unsigned)rem0 * 16u;
     const int bdst0 = (tl0 * BN + rem0 / SEGS) * PS + (rem0 % SEGS) * 16;
     u32x4 breg[2][NB];
-    constexpr bool DEEP = WD == 9 && !F8C && !STATIC && NW == 4 && !LP && TN == 1 && TM <= ABC_DEEP_TM;      // (see the weights-direct loop)
+    constexpr bool DEEP = WD == 9 && !F8C && !STATIC && NW == 4 && !LP && !M16 && TN == 1 && TM <= ABC_DEEP_TM;      // (see the weights-direct loop)
     // DEEP2 (measured, off): the halo of chunk c + 2 in flight while chunk c multiplies (two staging register sets, chunk k in set k & 1).
     // It does NOT help -- 24.8 -> 26.2 us on the 24 x 24 layers, 24.3 -> 26.7 us on the 12 x 12 ones: a chunk's end waits for the commit's
     // arithmetic and the barrier, not for the halo loads (profiles/README.md round 5)
@@ -246,15 +263,18 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn * TN + j) * 32 + r;
             nval[j] = n < a.Cout;
-            bv[j] = (!LP && a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
+            bv[j] = (!LP && !M16 && a.bias != nullptr && nval[j]) ? a.bias[n] : 0.f;
             osc[j] = (F8C && nval[j]) ? a.oscale[n] : 1.f;
         }
         // LP: the epilogue reads its per-channel constants from an LDS table of the n-block (a lane owns 16 channels of every n-tile);
         // loaded here, written behind the halo commit, visible after the barrier that opens the main loop.  Two copies (round parity):
         // a wave in the next tile's prologue must not overwrite what a slower wave's epilogue still reads.
-        float etab[LP ? NTAB : 1];
-        const bool etab_fill = LP && (first_tile || a.nblocks_n > 1) && tid < BN;
-        if constexpr (LP) {
+        // (M16 too: its lanes own two channels per n-tile -- twice the lane constants of the 32x32 form, and held in registers across the main
+        //  loop they pushed its operand addresses into scratch, reloaded between the MFMA groups behind the whole weight ring)
+        constexpr bool ETAB = LP || M16;
+        float etab[ETAB ? NTAB : 1];
+        const bool etab_fill = ETAB && (first_tile || a.nblocks_n > 1) && tid < BN;
+        if constexpr (ETAB) {
             if (etab_fill) {
                 const int n = n0 + tid;
                 const bool ok = n < a.Cout;
@@ -267,7 +287,7 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         }
         const float oq = F8O ? a.oquant[nb * a.oq_stride] : 1.f;
         float csc[ACTB ? TN : 1], csh[ACTB ? TN : 1], csl[ACTB ? TN : 1], cmu[ACTB ? TN : 1];
-        if constexpr (ACTB && !LP) {
+        if constexpr (ACTB && !LP && !M16) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + (wn * TN + j) * 32 + r;
@@ -321,7 +341,10 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         // (the wave's n-offset sits in the VGPR part: everything in the scalar offset must be provably wave-uniform, or
         //  the compiler wraps every load in a readfirstlane loop)
         // (abc_pack_desc.layout 1: a 32-row block is [kk][h][r][16 bytes] -- the 64 lanes of one load read 1 KB back to back)
-        const unsigned bq_voff = (unsigned)(wn * TN * 32 * CKB + h * 512 + r * 16);
+        // (M16: the same packed block, lane (n, q): row 16 ci + n's piece q = bytes [16 q, 16 q + 16) of its chunk row, which layout 1 keeps at
+        //  (q & 1) * 1024 + (q >> 1) * 512 + row * 16; the second index of bq is ci instead of the K half)
+        const unsigned bq_voff = M16 ? (unsigned)(wn * TN * 32 * CKB + (q16 & 1) * 1024 + (q16 >> 1) * 512 + m16 * 16) : (unsigned)(wn * TN * 32 * CKB + h * 512 + r * 16);
+        constexpr int BQ_STEP = M16 ? 256 : 1024;
         auto bq_load = [&](int slot, int c, int t) {
             const unsigned soff = w_n0 + (unsigned)t * tap_stride + (unsigned)c * chunk_stride;
 #pragma unroll
@@ -332,7 +355,7 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
                 } else {
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk)
-                        bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * 1024), soff, 0);
+                        bq[slot][j][kk] = __builtin_amdgcn_raw_buffer_load_b128(rsW, bq_voff + (unsigned)(j * 32 * CKB + kk * BQ_STEP), soff, 0);
                 }
             }
         };
@@ -343,18 +366,30 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         if constexpr (DEEP2) {
             if (a.nchunks > 1) apre.template issue<1>(rsA, (unsigned)CK * (unsigned)sizeof(InT));
         }
-        f32x16 acc[TM][TN];
+        f32x16 acc[M16 ? 1 : TM][M16 ? 1 : TN];
+        f32x4 acc16[M16 ? TM : 1][2][M16 ? TN : 1][2];      // [M-tile][patch row][n-tile][channel half]
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int ci = 0; ci < 2; ++ci) acc16[i][pi][j][ci] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+        }
         if constexpr (!LP) {
             if (!first_tile) __syncthreads();  // previous tile's epilogue staging (aliases the halo buffer) is drained
         }
         apre.commit(sA + ((LP && a.a_bufs == 2) ? (cpar & 1) * a.sA_bytes : 0), lcoef, a.cstride, tid);
-        if constexpr (LP) {
+        if constexpr (ETAB) {
             if (etab_fill) {
                 float* tb = sEpi + ((a.nblocks_n > 1) ? (round & 1) : 0) * (NTAB * BN) + tid;      // (one n-block: written once, never overwritten)
 #pragma unroll
@@ -366,10 +401,12 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
         //  epilogue, their wait is a vmcnt(0) there -- the counter is in order -- which also waits for the NEXT tile's halo
         //  prefetch issued during the last chunk)
 #if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (!M16) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bv[j]), "v"(osc[j]));
+        }
         asm volatile("" :: "v"(oq));
-        if constexpr (ACTB && !LP) {
+        if constexpr (ACTB && !LP && !M16) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(csc[j]), "v"(csh[j]), "v"(csl[j]), "v"(cmu[j]));
         }
@@ -472,6 +509,36 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
                         // the slot is free: tap t + RING (of this chunk or the next; past the last chunk the offsets run off the buffer and
                         // the loads return zeros -- unconditional, so that vmcnt stays exact)
                         bq_load(t % RING, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
+                    }
+                } else if constexpr (M16) {
+                    // a step = (tap t, M-tile i): the fragments of the M-tile's two patch rows (read one step ahead: two register sets) times the
+                    // tap's 2 TN channel-half fragments: 4 TN MFMAs of 16 cycles
+                    frag_t fp[2][2];
+                    auto fp_read = [&](int set, int t, int i) {
+                        const int aoff = a.ty[t] * a.RS + a.tx[t] * PS;
+                        fp[set][0] = *(const frag_t*)(sAc + aBase16[i] + aoff);
+                        fp[set][1] = *(const frag_t*)(sAc + aBase16[i] + a.RS + aoff);
+                    };
+                    fp_read(0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < WNT; ++t) {
+                        const int slot = t % RING;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const int st = (t * TM + i) & 1;
+                            if (i + 1 < TM) fp_read(st ^ 1, t, i + 1);
+                            else if (t + 1 < WNT) fp_read(st ^ 1, t + 1, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                    for (int ci = 0; ci < 2; ++ci)
+                                        acc16[i][pi][j][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[st][pi], *(const frag_t*)&bq[slot][j][ci], acc16[i][pi][j][ci], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        bq_load(slot, t + RING < WNT ? c : c + 1, t + RING < WNT ? t + RING : t + RING - WNT);
                     }
                 } else {
                 frag_t fa0[TM], fa1[TM];
@@ -869,6 +936,194 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
             if (a.a_bufs == 2) cpar += a.nchunks;
             continue;
         }
+        if constexpr (M16) {
+            // ---- the epilogue below in the 16x16 accumulator layout: lane (m16, q16) holds, of every 32-pixel x 32-channel block (i, j),
+            // channels 16 ci + m16 (ci = 0, 1) at pixels 16 pi + 4 q16 + e (pi = patch row, e = 0..3).  Whole tiles only (host: abc_fast_geom.m16):
+            // values -> the wave's staging tile [32 pixels][TW channels], then the SAME 16-byte store sweep.
+            OutT* yo = (OutT*)a.y;
+            constexpr int TW = TN * 32;
+            constexpr int ROWB = TW * (int)sizeof(OutT) + 16;
+            constexpr int EV = 16 / (int)sizeof(OutT);
+            constexpr int SEG_PER_ROW = TW / EV;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const int tl = abc_launder(tid), ll = tl & 63, wl = tl >> 6;
+            const int cl = ll & 15, q4 = ll >> 4;
+            char* stgw = smem + a.stg_off + wl * (32 * ROWB);
+            char* wbase = stgw + 4 * q4 * ROWB + cl * (int)sizeof(OutT);      // + (16 pi + e) rows, + (32 j + 16 ci) channels
+            const int lrow = ll / SEG_PER_ROW, lsg = ll % SEG_PER_ROW;
+            constexpr int RSTEP = 64 / SEG_PER_ROW;
+            constexpr int NST = 32 / RSTEP;
+            const bool seg_ok = n0 + (wl % WN) * TW + lsg * EV < a.Cout;
+            const OutT* ytile = yo + (((size_t)(b * a.Hout + gy0 * a.om + a.oy0) * a.Wout + gx0 * a.om + a.ox0) * a.ldy + a.cout_off + n0);
+            const __amdgpu_buffer_rsrc_t rsY = abc_make_rsrc(ytile, 0x80000000u);
+            const unsigned istep = (unsigned)(2 * a.om * a.Wout * a.ldy) * (unsigned)sizeof(OutT);
+            unsigned voff[NST];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int rit = lrow + RSTEP * st;
+                voff[st] = seg_ok ? (unsigned)((wl / WN) * TM) * istep + (unsigned)((((rit >> 4) * a.Wout + (rit & 15)) * a.om * a.ldy + (wl % WN) * TW + lsg * EV) * (int)sizeof(OutT))
+                                  : 0xFFFFFFF0u;
+            }
+            f32x2 s1v[TN][2], s2v[TN][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) { s1v[j][ci] = (f32x2){0.f, 0.f}; s2v[j][ci] = (f32x2){0.f, 0.f}; }
+            // the lane's per-channel constants: rows of the n-block's LDS table (bias; act_bwd: scale, shift, slope, mean), channel (wn TN + j) 32 + 16 ci + cl
+            const float* tab = sEpi + ((a.nblocks_n > 1) ? (round & 1) : 0) * (NTAB * BN) + (wl % WN) * TW + cl;
+            float bv16[TN][2], csc16[ACTB ? TN : 1][2], csh16[ACTB ? TN : 1][2], csl16[ACTB ? TN : 1][2], cmu16[ACTB ? TN : 1][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    const float* tq = tab + j * 32 + 16 * ci;
+                    bv16[j][ci] = tq[0];
+                    if constexpr (ACTB) { csc16[j][ci] = tq[1 * BN]; csh16[j][ci] = tq[2 * BN]; csl16[j][ci] = tq[3 * BN]; cmu16[j][ci] = tq[4 * BN]; }
+                }
+            const float slope = a.out_act ? a.out_slope : 1.f;
+            const bool rows_ok = gy0 + 2 * MT <= a.Hg;
+            const int rlim = (ACTB || rows_ok) ? 0x7FFFFFFF : a.Hg - gy0;
+            constexpr int YROW = 32 * 2 + 8;
+            static_assert(!ACTB || TW * YROW <= 32 * ROWB, "the transposed y_raw tile fits the staging region");
+            char* ystg = smem + a.ystg_off + wl * (32 * ROWB);
+            const char* yrd = ystg + cl * YROW + 8 * q4;      // + (32 j + 16 ci) channels, + 32 pi bytes (16 pixels)
+            __amdgpu_buffer_rsrc_t rsYR = rsY;
+            unsigned voffy[ACTB ? NST : 1], istep_y = 0;
+            u32x4 yq[ACTB ? NST : 1];
+            if constexpr (ACTB) {
+                const bf16* yrt = (const bf16*)a.ab_y + (((size_t)(b * a.Hg + gy0) * a.Wg + gx0) * a.ab_ld + n0);
+                rsYR = abc_make_rsrc(yrt, 0x80000000u);
+                istep_y = (unsigned)(2 * a.Wg * a.ab_ld) * 2u;
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int rit = lrow + RSTEP * st;
+                    voffy[st] = seg_ok ? (unsigned)((wl / WN) * TM) * istep_y + (unsigned)((((rit >> 4) * a.Wg + (rit & 15)) * a.ab_ld + (wl % WN) * TW + lsg * EV) * 2)
+                                       : 0xFFFFFFF0u;
+                    yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], 0u, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (ACTB) {
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) {
+                        char* w0 = ystg + (lsg * EV) * YROW + (lrow + RSTEP * st) * 2;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            *(unsigned short*)(w0 + (2 * c) * YROW) = (unsigned short)(yq[st][c] & 0xFFFFu);
+                            *(unsigned short*)(w0 + (2 * c + 1) * YROW) = (unsigned short)(yq[st][c] >> 16);
+                        }
+                    }
+                    if (i + 1 < TM) {
+#pragma unroll
+                        for (int st = 0; st < NST; ++st) yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], (unsigned)(i + 1) * istep_y, 0);
+                    }
+                    lds_wave_sync();
+                }
+                unsigned xq[ACTB ? TN : 1][2][2][ACTB ? 2 : 1];      // [j][ci][pi][pixel pair]: y_raw of the lane's values
+                if constexpr (ACTB) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                            for (int pi = 0; pi < 2; ++pi) {
+                                const u32x2 t = *(const u32x2*)(yrd + (j * 32 + 16 * ci) * YROW + 32 * pi);
+                                xq[j][ci][pi][0] = t[0]; xq[j][ci][pi][1] = t[1];
+                            }
+                    asm volatile("" ::: "memory");
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                            for (int pi = 0; pi < 2; ++pi) asm volatile("" : "+v"(xq[j][ci][pi][0]), "+v"(xq[j][ci][pi][1]));
+#endif
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci) {
+                        const f32x2 b2 = {bv16[j][ci], bv16[j][ci]};
+#pragma unroll
+                        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32x2 v = (f32x2){acc16[i][pi][j][ci][e], acc16[i][pi][j][ci][e + 1]} + b2;
+                                char* p = wbase + (16 * pi + e) * ROWB + (j * 32 + 16 * ci) * (int)sizeof(OutT);
+                                if constexpr (ACTB) {
+                                    const unsigned xw = xq[j][ci][pi][e >> 1];
+                                    const f32x2 x = {__uint_as_float(xw << 16), __uint_as_float(xw & 0xFFFF0000u)};
+                                    const f32x2 yv = __builtin_elementwise_fma(x, (f32x2){csc16[j][ci], csc16[j][ci]}, (f32x2){csh16[j][ci], csh16[j][ci]});
+                                    const f32x2 f = {yv.x > 0.f ? 1.f : csl16[j][ci], yv.y > 0.f ? 1.f : csl16[j][ci]};
+                                    const f32x2 gg = v * f;
+                                    s1v[j][ci] += gg; s2v[j][ci] = __builtin_elementwise_fma(gg, x - (f32x2){cmu16[j][ci], cmu16[j][ci]}, s2v[j][ci]);
+                                    abc_put2<OutT>(p, p + ROWB, gg.x, gg.y);
+                                } else {
+                                    s1v[j][ci] += v; s2v[j][ci] = __builtin_elementwise_fma(v, v, s2v[j][ci]);
+                                    const f32x2 m = v * slope;
+                                    const f32x2 vo = {fmaxf(v.x, m.x), fmaxf(v.y, m.y)};
+                                    abc_put2<OutT>(p, p + ROWB, vo.x, vo.y);
+                                }
+                            }
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(s1v[j][0]), "+v"(s2v[j][0]), "+v"(s1v[j][1]), "+v"(s2v[j][1]));
+#endif
+                lds_wave_sync();
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 rd[NST];
+#pragma unroll
+                for (int st = 0; st < NST; ++st) rd[st] = *(const u32x4*)(stgw + (lrow + RSTEP * st) * ROWB + lsg * 16);
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int prow = 2 * ((wl / WN) * TM + i) + ((lrow + RSTEP * st) >> 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(rd[st], rsY, prow < rlim ? voff[st] : 0xFFFFFFF0u, (unsigned)i * istep, 0);
+                }
+                // (the store-data hazard of the epilogue below: keep the data registers live two wait states past the last store)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int st = 0; st < NST; ++st) asm volatile("" :: "v"(rd[st]));
+                asm volatile("s_nop 1");
+#endif
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (pr) prof[3] = wall_clock64();
+            if (a.stats != nullptr) {
+                // a channel's sums sit in the four lanes m16 + 16 q: added in the order (q0 + q1) + (q2 + q3), then the WM waves in order
+                float* red = (float*)(smem + a.red_off);  // [WM][4][BN]
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci) {
+                        const bool nok = n0 + (wn * TN + j) * 32 + 16 * ci + m16 < a.Cout;      // (padding channels of the last n-block: bias-free zeros)
+                        float v1 = nok ? s1v[j][ci].x + s1v[j][ci].y : 0.f;
+                        float v2 = nok ? s2v[j][ci].x + s2v[j][ci].y : 0.f;
+                        v1 += __shfl_xor(v1, 16); v2 += __shfl_xor(v2, 16);
+                        v1 += __shfl_xor(v1, 32); v2 += __shfl_xor(v2, 32);
+                        if (q16 == 0) {
+                            const int nl = (wn * TN + j) * 32 + 16 * ci + m16;
+                            red[(wm * 4 + 0) * BN + nl] = v1;
+                            red[(wm * 4 + 1) * BN + nl] = v2;
+                        }
+                    }
+                __syncthreads();
+                if (tid < BN && n0 + tid < a.Cout) {
+                    float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) { v1 += red[(w * 4 + 0) * BN + tid]; v2 += red[(w * 4 + 1) * BN + tid]; }
+                    if constexpr (ACTB) v2 *= a.ab_is[n0 + tid];
+                    a.stats[((size_t)mblock * 2 + 0) * a.Cout + n0 + tid] = v1;
+                    a.stats[((size_t)mblock * 2 + 1) * a.Cout + n0 + tid] = v2;
+                }
+            }
+            if (pr) prof[4] = wall_clock64();
+            continue;
+        }
         // ---- epilogue: bias, statistics of the f32 values, store through a wave-private LDS transpose
         // (a lane of the accumulator layout holds ONE channel of 16 pixels; the transpose turns that into 16-byte
         // stores of consecutive channels of one pixel).  The staging region aliases the halo / weight buffers: every
@@ -1157,14 +1412,14 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
     }
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0, int NW = 4, bool LP = false, int VAR = 0>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0, int NW = 4, bool LP = false, int VAR = 0, bool M16 = false>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : (STATIC ? 3 : 2))) void conv_fast_kernel(const FastK a) {
-    conv_fast_body<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI, NW, LP, VAR>(a);
+    conv_fast_body<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI, NW, LP, VAR, M16>(a);
 }
 
-template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0, int NW = 4, bool LP = false, int VAR = 0>
+template <typename InT, typename CT, typename OutT, int CK, int BN, int STRIDE, int MT, bool STATIC, int WD = 0, int EPI = 0, int NW = 4, bool LP = false, int VAR = 0, bool M16 = false>
 int launch_st(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
-    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI, NW, LP, VAR>;
+    auto fn = conv_fast_kernel<InT, CT, OutT, CK, BN, STRIDE, MT, STATIC, WD, EPI, NW, LP, VAR, M16>;
     static unsigned long long lds_ok = 0;
     if (int rc = abc_allow_lds((const void*)fn, LDS_WG, &lds_ok)) return rc;
     hipLaunchKernelGGL(fn, dim3(g.nwg), dim3(64 * NW), g.lds, st, k);

@@ -17,7 +17,7 @@ tot = 0
 for r in last:
     n = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000
-    if "wgrad" in n:
+    if "${FILTER:-wgrad}" in n or "${FILTER:-wgrad}" == "all":
         tot += d
         print("%7.1f us  grid %-8s %s" % (d, r.get("Grid_Size_X", "?"), n.replace("(anonymous namespace)::", "")[:110]))
 print("wgrad total of the step: %.1f us; step kernels: %.1f us" % (tot, sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000 for r in last)))

@@ -177,8 +177,18 @@ def test_heads_in_the_epilogue_equal_the_separate_heads_kernel(fp8, B, H, W):
         run.step()
         torch.cuda.synchronize()
         outs.append([t.clone() for t in run.logits] + [run.atom_mask.clone(), run.omega_mask.clone()])
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    # bf16 at 96 x 128 maps (whole 12-row tiles): the separate plan's conv1 runs the 16x16x32 MFMA form of the tile (conv_fast_body.hpp
+    # M16, round 5), the heads-epilogue kernel the 32x32x16 form -- the same products summed in a different association inside the
+    # instruction, so the features agree to a bf16 rounding instead of bit for bit: logits within 2 % of their spread, at most 1 in 10^4
+    # NMS decisions different.  Everything else (e4m3; maps without whole 12-row tiles) stays exact.
+    m16 = (not fp8) and (H // 4) % 12 == 0 and (W // 4) % 16 == 0
+    for i, (a, b) in enumerate(zip(*outs)):
+        if not m16:
+            assert torch.equal(a, b)
+        elif a.dtype.is_floating_point and i < 8:
+            assert (a - b).abs().max().item() <= 0.02 * b.float().std().item() + 1e-3, (i, (a - b).abs().max().item(), b.float().std().item())
+        else:
+            assert (a != b).float().mean().item() <= 1e-4, (i, (a != b).float().mean().item())
 
 
 def test_fp8_inference_graph_against_oracle_and_bf16_graph():
