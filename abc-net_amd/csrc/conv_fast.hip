@@ -62,7 +62,7 @@ int launch_inst(const FastK& k, const abc_fast_geom& g, hipStream_t st) {
             if (g.wd == 9 && (g.lp || g.var)) return abc_conv_fast_launch_lp(k, g, EPI, st);
         }
 #endif
-        if constexpr (BN == 128 && MT == 6 && sizeof(InT) == 2 && sizeof(OutT) == 2 && (EPI == 0 || EPI == 2)) {
+        if constexpr (((BN == 128 && (MT == 6 || MT == 4)) || (BN == 64 && MT == 8)) && sizeof(InT) == 2 && sizeof(OutT) == 2 && (EPI == 0 || EPI == 2)) {
             // the 16x16x32 form of the same tile (whole tiles, sums and squares only: abc_fast_geom.m16)
             if (g.wd == 9 && g.m16) return launch_st<InT, CT, OutT, CK, BN, STRIDE, MT, false, 9, EPI, 4, false, 0, true>(k, g, st);
         }
@@ -253,9 +253,13 @@ int abc_conv_fast_geom(const abc_conv_desc* d, abc_fast_geom* g) {
         if ((g->var & 1) && !g->lp) stg = 4 * 32 * (32 * osz + 16);      // (1 x 4 waves: 32-channel staging rows)
     }
     // v_mfma_f32_16x16x32_bf16 form (conv_fast_body.hpp M16): the bf16 192 x 128 weights-direct tile where every tile takes the whole-tile epilogue
-    g->m16 = (g->wd == 9 && g->nw == 4 && !g->lp && !g->var && g->BN == 128 && g->MT == 6 && d->stride == 1 && !f8 && d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16 &&
+    // (192 x 128 pixels x channels everywhere; 128 x 128 and 256 x 64 where the epilogue carries no statistics -- the folded inference graph:
+    //  +3 % on b64 @ 512 x 512 with them; in the training step, whose epilogues sum and square every value, they measure the same or slightly
+    //  slower in this form, 5.924 -> 5.930 ms same box)
+    const bool m16_shape = (g->BN == 128 && g->MT == 6) || (d->stats == nullptr && ((g->BN == 128 && g->MT == 4) || (g->BN == 64 && g->MT == 8)));
+    g->m16 = (g->wd == 9 && g->nw == 4 && !g->lp && !g->var && m16_shape && d->stride == 1 && !f8 && d->dtype_in == ABC_BF16 && d->dtype_c == ABC_BF16 &&
               d->dtype_out == ABC_BF16 && d->heads_epi == nullptr && d->stats_rows != 4 && !d->accumulate && d->Cout % 8 == 0 && (d->ldy | d->cout_off) % 8 == 0 &&
-              d->Wg % 16 == 0 && (d->Hg % 12 == 0 || d->stats == nullptr) && !abc_knob("ABC_CONV_NOM16")) ? 1 : 0;
+              d->Wg % 16 == 0 && (d->Hg % (2 * g->MT) == 0 || d->stats == nullptr) && !abc_knob("ABC_CONV_NOM16")) ? 1 : 0;
     // whole weight set resident (narrow layers: one chunk, one n-block): persistent workgroups
     g->b_static = (!actb && !g->wd && g->BN == 32 && nchunks == 1 && g->nbn == 1 && g->sA_bytes + g->ngroups * g->sB_bytes + stg + red <= budget &&
                    abc_cdiv(g->HH * g->HW * segs, FT) <= fa_static(g->MT)) ? 1 : 0;
