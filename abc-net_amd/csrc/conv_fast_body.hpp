@@ -1094,23 +1094,42 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
             }
             if (pr) prof[3] = wall_clock64();
             if (a.stats != nullptr) {
-                // a channel's sums sit in the four lanes m16 + 16 q: added in the order (q0 + q1) + (q2 + q3), then the WM waves in order
+                // a channel's sums sit in the four lanes m16 + 16 q: added as (own + lane ^ 16) + (lane ^ 32's same), then the WM waves in order.
+                // A halving butterfly on the VALU (v_permlane16_swap, v_permlane32_swap) instead of two ds_bpermute per value: of the lane's
+                // 4 TN values, step 1 leaves the pair sums of the even-indexed ones in even rows of 16 lanes and of the odd-indexed ones in odd
+                // rows, step 2 the quad sums of half of those in each wave half: a lane ends with TN totals, the four lanes of a channel
+                // column with all 4 TN between them.
                 float* red = (float*)(smem + a.red_off);  // [WM][4][BN]
+                float sv[4 * TN];      // index 4 j + 2 ci + (0: sum, 1: sum of squares)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int ci = 0; ci < 2; ++ci) {
                         const bool nok = n0 + (wn * TN + j) * 32 + 16 * ci + m16 < a.Cout;      // (padding channels of the last n-block: bias-free zeros)
-                        float v1 = nok ? s1v[j][ci].x + s1v[j][ci].y : 0.f;
-                        float v2 = nok ? s2v[j][ci].x + s2v[j][ci].y : 0.f;
-                        v1 += __shfl_xor(v1, 16); v2 += __shfl_xor(v2, 16);
-                        v1 += __shfl_xor(v1, 32); v2 += __shfl_xor(v2, 32);
-                        if (q16 == 0) {
-                            const int nl = (wn * TN + j) * 32 + 16 * ci + m16;
-                            red[(wm * 4 + 0) * BN + nl] = v1;
-                            red[(wm * 4 + 1) * BN + nl] = v2;
-                        }
+                        sv[4 * j + 2 * ci + 0] = nok ? s1v[j][ci].x + s1v[j][ci].y : 0.f;
+                        sv[4 * j + 2 * ci + 1] = nok ? s2v[j][ci].x + s2v[j][ci].y : 0.f;
                     }
+                // step 1: values (2 u, 2 u + 1) -> even rows keep value 2 u, odd rows value 2 u + 1 (own + the lane 16 away)
+                float s16[2 * TN];
+#pragma unroll
+                for (int u = 0; u < 2 * TN; ++u) {
+                    const u32x2 pr2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(sv[2 * u]), __float_as_uint(sv[2 * u + 1]), false, false);
+                    s16[u] = __uint_as_float(pr2[0]) + __uint_as_float(pr2[1]);
+                }
+                // step 2: values (2 w, 2 w + 1) of step 1 -> the lower wave half keeps 2 w, the upper half 2 w + 1 (own + the lane 32 away)
+                float s32[TN];
+#pragma unroll
+                for (int w2 = 0; w2 < TN; ++w2) {
+                    const u32x2 pr2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s16[2 * w2]), __float_as_uint(s16[2 * w2 + 1]), false, false);
+                    s32[w2] = __uint_as_float(pr2[0]) + __uint_as_float(pr2[1]);
+                }
+                // lane (m16, q16) now holds, for w2 = 0 .. TN - 1, the total of value index 4 w2 + 2 (q16 >> 1) + (q16 & 1):
+                // j = w2, ci = q16 >> 1, sum or sum of squares = q16 & 1
+#pragma unroll
+                for (int w2 = 0; w2 < TN; ++w2) {
+                    const int nl = (wn * TN + w2) * 32 + 16 * (q16 >> 1) + m16;
+                    red[(wm * 4 + (q16 & 1)) * BN + nl] = s32[w2];
+                }
                 __syncthreads();
                 if (tid < BN && n0 + tid < a.Cout) {
                     float v1 = 0.f, v2 = 0.f;
