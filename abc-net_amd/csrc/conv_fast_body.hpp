@@ -1003,6 +1003,11 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
                     yq[st] = __builtin_amdgcn_raw_buffer_load_b128(rsYR, voffy[st], 0u, 0);
                 }
             }
+            // (OACT: an activation in the epilogue -- the folded inference graph; without it the multiply and the two maxima per value pair are
+            //  not issued: the epilogue is VALU issue with both workgroups of a CU in the same phase)
+            auto store_tiles = [&](auto OACTV, auto WSTATV) {
+                constexpr bool OACT = decltype(OACTV)::value;
+                constexpr bool WSTAT = decltype(WSTATV)::value;      // the sums and squares are wanted (not in the inference graph)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if constexpr (ACTB) {
@@ -1062,10 +1067,13 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
                                     s1v[j][ci] += gg; s2v[j][ci] = __builtin_elementwise_fma(gg, x - (f32x2){cmu16[j][ci], cmu16[j][ci]}, s2v[j][ci]);
                                     abc_put2<OutT>(p, p + ROWB, gg.x, gg.y);
                                 } else {
-                                    s1v[j][ci] += v; s2v[j][ci] = __builtin_elementwise_fma(v, v, s2v[j][ci]);
-                                    const f32x2 m = v * slope;
-                                    const f32x2 vo = {fmaxf(v.x, m.x), fmaxf(v.y, m.y)};
-                                    abc_put2<OutT>(p, p + ROWB, vo.x, vo.y);
+                                    if constexpr (WSTAT) { s1v[j][ci] += v; s2v[j][ci] = __builtin_elementwise_fma(v, v, s2v[j][ci]); }
+                                    if constexpr (OACT) {
+                                        const f32x2 m = v * slope;
+                                        abc_put2<OutT>(p, p + ROWB, fmaxf(v.x, m.x), fmaxf(v.y, m.y));
+                                    } else {
+                                        abc_put2<OutT>(p, p + ROWB, v.x, v.y);      // (training: the raw output, the consumer applies the activation on load)
+                                    }
                                 }
                             }
                     }
@@ -1092,6 +1100,11 @@ __device__ __forceinline__ void conv_fast_body(const FastK& a) {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
+            };
+            if constexpr (ACTB) store_tiles(std::false_type{}, std::true_type{});
+            else if (!a.out_act) store_tiles(std::false_type{}, std::true_type{});
+            else if (a.stats == nullptr) store_tiles(std::true_type{}, std::false_type{});
+            else store_tiles(std::true_type{}, std::true_type{});
             if (pr) prof[3] = wall_clock64();
             if (a.stats != nullptr) {
                 // a channel's sums sit in the four lanes m16 + 16 q: added as (own + lane ^ 16) + (lane ^ 32's same), then the WM waves in order.
